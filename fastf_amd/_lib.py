@@ -1,0 +1,162 @@
+"""ctypes binding of libfastf_amd.so (the C ABI declared in include/fastf_amd.h)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_LIB = os.path.join(HERE, "lib", "libfastf_amd.so")
+_CLI = os.path.join(HERE, "bin", "fastF")
+
+
+class FastfError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB
+
+
+def cli_path():
+    return _CLI
+
+
+def build(force=False):
+    """Compile every HIP/C source for gfx950 into fastf_amd/lib + fastf_amd/bin (in-tree)."""
+    args = ["make", "-s", "-C", os.path.join(HERE, "csrc")]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args + ["all"])
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [
+        ("cell_keys", C.c_void_p), ("n_cells", C.c_uint32),
+        ("feature_keys", C.c_void_p), ("n_features", C.c_uint32),
+        ("draw_threshold", C.c_uint64), ("umi_max_bases", C.c_uint32),
+        ("mt_seed", C.c_uint32), ("mt_skip", C.c_uint64),
+        ("n_shards", C.c_uint32), ("shard_rank", C.c_uint32),
+        ("device", C.c_int32), ("batch_records", C.c_uint64), ("key_capacity", C.c_uint64),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [("cb_key", C.c_void_p), ("gx_key", C.c_void_p), ("umi", C.c_void_p),
+                ("meta", C.c_void_p), ("n", C.c_size_t)]
+
+
+class Coo(C.Structure):
+    _fields_ = [("feature", C.POINTER(C.c_uint32)), ("cell", C.POINTER(C.c_uint32)),
+                ("count", C.POINTER(C.c_uint32)), ("nnz", C.c_size_t)]
+
+
+class UmiRows(C.Structure):
+    _fields_ = [("feature", C.POINTER(C.c_uint32)), ("cell", C.POINTER(C.c_uint32)),
+                ("n_copy", C.POINTER(C.c_uint32)), ("umi", C.POINTER(C.c_uint32)),
+                ("nonnull", C.POINTER(C.c_uint8)), ("n", C.c_size_t)]
+
+
+class ListsStruct(C.Structure):
+    _fields_ = [
+        ("n_lines_barcodes", C.c_size_t), ("n_sampled_target", C.c_size_t), ("n_cells", C.c_size_t),
+        ("barcode", C.POINTER(C.c_char_p)), ("cell_key", C.POINTER(C.c_uint64)),
+        ("n_features", C.c_size_t),
+        ("feat_id", C.POINTER(C.c_char_p)), ("feat_name", C.POINTER(C.c_char_p)),
+        ("feat_type", C.POINTER(C.c_char_p)), ("feature_key", C.POINTER(C.c_uint64)),
+        ("cell_dict", C.c_void_p), ("feat_dict", C.c_void_p),
+        ("mt_skip", C.c_uint64), ("dup_barcodes", C.c_size_t), ("dup_features", C.c_size_t),
+    ]
+
+
+class MT(C.Structure):
+    _fields_ = [("s", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+_lib = None
+
+# every symbol include/fastf_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "bam2db", "_umi_copies_flag", "cmd_bam2db", "fastf_last_error", "fastf_version",
+    "fastf_mt_seed", "fastf_mt_next", "fastf_mt_fill", "fastf_mt_skip",
+    "fastf_draw_threshold", "fastf_sample_cells", "fastf_pack_umi",
+    "fastf_keydict_create", "fastf_keydict_destroy", "fastf_keydict_add", "fastf_keydict_pack",
+    "fastf_keydict_pack_many",
+    "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",
+    "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
+    "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
+    "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_kernel_names",
+]
+
+
+def lib():
+    """Load the shared library.  torch (if it is going to be used in this process) must be
+    imported BEFORE this call so both share one HIP runtime (same libamdhip64 soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise FastfError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no Python/CPU fallback for the engine)" % _LIB)
+    L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
+    vp, u64, u32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
+    L.fastf_last_error.restype = C.c_char_p
+    L.fastf_version.restype = C.c_char_p
+    L.fastf_kernel_names.restype = C.c_char_p
+    L.fastf_mt_seed.argtypes = [C.POINTER(MT), u32]
+    L.fastf_mt_next.argtypes = [C.POINTER(MT)]
+    L.fastf_mt_next.restype = u32
+    L.fastf_mt_fill.argtypes = [C.POINTER(MT), vp, sz]
+    L.fastf_mt_skip.argtypes = [C.POINTER(MT), u64]
+    L.fastf_draw_threshold.argtypes = [C.c_float]
+    L.fastf_draw_threshold.restype = u64
+    L.fastf_sample_cells.argtypes = [sz, C.c_float, C.c_uint, vp, C.POINTER(sz), C.POINTER(u64)]
+    L.fastf_pack_umi.argtypes = [C.c_char_p, sz, C.POINTER(u32)]
+    L.fastf_pack_umi.restype = u32
+    L.fastf_keydict_create.restype = vp
+    L.fastf_keydict_destroy.argtypes = [vp]
+    L.fastf_keydict_add.argtypes = [vp, C.c_char_p, sz]
+    L.fastf_keydict_add.restype = u64
+    L.fastf_keydict_pack.argtypes = [vp, C.c_char_p, sz]
+    L.fastf_keydict_pack.restype = u64
+    L.fastf_keydict_pack_many.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.fastf_keydict_pack_many.restype = None
+    L.fastf_engine_create.argtypes = [C.POINTER(EngineConfig), C.POINTER(vp)]
+    L.fastf_engine_destroy.argtypes = [vp]
+    L.fastf_engine_destroy.restype = None
+    L.fastf_engine_push.argtypes = [vp, C.POINTER(Batch)]
+    L.fastf_engine_push_draws.argtypes = [vp, C.POINTER(Batch), vp, sz]
+    L.fastf_engine_finish.argtypes = [vp, C.POINTER(Coo), C.POINTER(u64 * 3)]
+    L.fastf_engine_umi_rows.argtypes = [vp, C.POINTER(UmiRows)]
+    L.fastf_engine_reset.argtypes = [vp]
+    L.fastf_engine_reseed.argtypes = [vp, u32, u64]
+    L.fastf_engine_key_bits.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fastf_engine_set_timing.argtypes = [vp, C.c_int]
+    L.fastf_engine_get_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.fastf_dev_count_hits.argtypes = [vp, vp, u64, vp, vp]
+    L.fastf_dev_probe_pack.argtypes = [vp, vp, vp, vp, vp, u64, vp, u64, vp, u64, vp, vp, vp]
+    L.fastf_dev_sort.argtypes = [vp, vp, vp, vp, u64, u32, C.POINTER(C.c_int), vp]
+    L.fastf_dev_reduce.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp]
+    L.fastf_dev_umi_rows.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
+    L.fastf_dev_reserve.argtypes = [vp, u64, u64]
+    L.fastf_dev_error_bits.argtypes = [vp, C.POINTER(u64)]
+    L.fastf_lists_load_mem.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_float, C.c_uint, C.POINTER(ListsStruct)]
+    L.fastf_lists_load.argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_uint, C.POINTER(ListsStruct)]
+    L.fastf_lists_free.argtypes = [C.POINTER(ListsStruct)]
+    L.fastf_lists_free.restype = None
+    L.fastf_bam_open.argtypes = [C.c_char_p, C.c_int]
+    L.fastf_bam_open.restype = vp
+    L.fastf_bam_read_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz]
+    L.fastf_bam_read_batch.restype = C.c_long
+    L.fastf_bam_close.argtypes = [vp]
+    L.fastf_bam_close.restype = None
+    L.fastf_format_matrix.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(u64 * 3), sz, sz,
+                                      C.POINTER(Coo), C.POINTER(vp), C.POINTER(sz)]
+    L.fastf_format_umi_rows.argtypes = [C.POINTER(UmiRows), C.POINTER(vp), C.POINTER(sz)]
+    L.bam2db.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, C.c_uint]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc:
+        raise FastfError(lib().fastf_last_error().decode(errors="replace"))

@@ -1,0 +1,183 @@
+/*
+ * bam2db_main.c — the outer drop-in layer: bam2db(), _umi_copies_flag, cmd_bam2db().
+ *
+ *   bam2db()      same signature/return convention as the reference (bam2db_ds.h:62-70,
+ *                 bam2db_ds.c:106-573); db_file is accepted and ignored.
+ *   cmd_bam2db()  same flags as main.c:288-362 (-b -f -a -d -c -r -o -s -u), values as
+ *                 `-x v`, `-xv`, `--long v`, `--long=v`; floats via strtof, ints via
+ *                 strtol(s, &e, 0) like argparse.c:88-108.
+ * The device engine does the work; there is no CPU fallback.
+ */
+#define _GNU_SOURCE
+#include "host_io.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+int _umi_copies_flag = 0;
+
+static uint32_t bits_for(uint64_t v) { uint32_t b = 0; while (b < 64 && (v >> b)) b++; return b ? b : 1; }
+
+int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, char *features_file,
+           float rate_cell, float rate_depth, unsigned int seed)
+{
+    (void)db_file;                      /* no SQLite in this engine */
+    int rc = 1;
+    fastf_lists_t lists; memset(&lists, 0, sizeof lists);
+    fastf_bam_t *bam = NULL;
+    fastf_engine_t *eng = NULL;
+    uint64_t *cb = NULL, *gx = NULL; uint32_t *umi = NULL, *meta = NULL;
+
+    bam = fastf_bam_open(bam_file, 0);
+    if (!bam) { fprintf(stderr, "Fail to open BAM file %s (%s)\n", bam_file, fastf_last_error()); goto done; }
+    fprintf(stderr, "Opened BAM file %s successfully\n", bam_file);
+
+    if (fastf_lists_load(barcodes_file, features_file, rate_cell, seed, &lists)) {
+        fprintf(stderr, "Fail to load barcode/feature lists: %s\n", fastf_last_error());
+        goto done;
+    }
+    printf("Total number of cells: %zu\n", lists.n_lines_barcodes);
+    printf("Actual number of sampled cell barcodes: %zu\n", lists.n_sampled_target);
+    for (size_t i = 0; i < lists.dup_barcodes; i++) printf("Warning: Duplicate cell barcodes were found in %s!\n", barcodes_file);
+    for (size_t i = 0; i < lists.dup_features; i++) printf("Warning: Duplicate feature names were found in %s!\n", features_file);
+
+    fastf_engine_config_t cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.cell_keys = lists.cell_key; cfg.n_cells = (uint32_t)lists.n_cells;
+    cfg.feature_keys = lists.feature_key; cfg.n_features = (uint32_t)lists.n_features;
+    cfg.draw_threshold = fastf_draw_threshold(rate_depth);
+    cfg.mt_seed = seed; cfg.mt_skip = lists.mt_skip;
+    cfg.n_shards = 1; cfg.shard_rank = 0;
+    const char *dev = getenv("FASTF_DEVICE");
+    cfg.device = dev ? atoi(dev) : 0;
+    /* widest UMI field the 64-bit key allows (16 bases need 36 bits, 12 need 27) */
+    const char *ul = getenv("FASTF_UMI_MAX_BASES");
+    if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);
+    else cfg.umi_max_bases = (bits_for(cfg.n_cells) + bits_for(cfg.n_features) + 36 <= 64) ? 16 : 12;
+    const char *bs = getenv("FASTF_BATCH_RECORDS");
+    cfg.batch_records = bs ? strtoull(bs, NULL, 0) : (4ull << 20);
+    if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+
+    const size_t cap = (size_t)cfg.batch_records;
+    cb = (uint64_t *)malloc(cap * 8); gx = (uint64_t *)malloc(cap * 8);
+    umi = (uint32_t *)malloc(cap * 4); meta = (uint32_t *)malloc(cap * 4);
+    if (!cb || !gx || !umi || !meta) { fprintf(stderr, "out of memory\n"); goto done; }
+
+    printf("Start to convert bam file to UMI keys on the device...\n");
+    for (;;) {
+        long n = fastf_bam_read_batch(bam, lists.cell_dict, lists.feat_dict, cb, gx, umi, meta, cap);
+        if (n < 0) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+        if (n == 0) break;
+        fastf_batch_t batch = { cb, gx, umi, meta, (size_t)n };
+        if (fastf_engine_push(eng, &batch)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    }
+    fastf_coo_t coo; uint64_t counters[3];
+    if (fastf_engine_finish(eng, &coo, counters)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    printf("In %s, total fastQ reads: %zu\n", bam_file, (size_t)counters[0]);
+    printf("In %s, sampled fastQ reads: %zu\n", bam_file, (size_t)counters[1]);
+    printf("In %s, sampled and valid fastQ reads: %zu\n", bam_file, (size_t)counters[2]);
+    uint64_t no_xf = 0, no_gx = 0;
+    fastf_bam_stats(bam, NULL, &no_xf, &no_gx);
+    if (no_xf || no_gx)
+        fprintf(stderr, "Note: %llu records with a CB but no xf tag and %llu with a valid xf but no GX tag were skipped "
+                        "(the reference dereferences NULL on them).\n", (unsigned long long)no_xf, (unsigned long long)no_gx);
+
+    fastf_umi_rows_t urows; memset(&urows, 0, sizeof urows);
+    if (_umi_copies_flag && fastf_engine_umi_rows(eng, &urows)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    if (fastf_write_outputs(path_out, bam_file, rate_cell, rate_depth, counters, &lists, &coo,
+                            _umi_copies_flag ? &urows : NULL)) {
+        fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error());
+        goto done;
+    }
+    rc = 0;
+done:
+    free(cb); free(gx); free(umi); free(meta);
+    if (eng) fastf_engine_destroy(eng);
+    if (bam) fastf_bam_close(bam);
+    fastf_lists_free(&lists);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* CLI                                                                 */
+/* ------------------------------------------------------------------ */
+static void usage_bam2db(FILE *f)
+{
+    fprintf(f,
+            "Usage: fastF bam2db [options]\n\n"
+            "Filter bam file with desired cell proportion and read depth on the GPU, then summarise it into UMI matrix.\n\n"
+            "    -h, --help            show this help message and exit\n"
+            "    -b, --bam=<str>       path to bam file\n"
+            "    -f, --feature=<str>   path to feature list file\n"
+            "    -a, --barcode=<str>   path to barcode list file\n"
+            "    -d, --dbname=<str>    name of database (accepted for compatibility, ignored)\n"
+            "    -c, --cell=<flt>      rate of cell barcode (default 1.0)\n"
+            "    -r, --depth=<flt>     rate of depth (default 1.0)\n"
+            "    -o, --out=<str>       path to output directory (default .)\n"
+            "    -s, --seed=<int>      seed for random number generator (default 926)\n"
+            "    -u, --umicopies       whether to store umi.tsv.gz\n");
+}
+
+struct opt { char s; const char *l; int has_arg; };
+static const struct opt k_opts[] = {
+    {'h', "help", 0}, {'b', "bam", 1}, {'f', "feature", 1}, {'a', "barcode", 1}, {'d', "dbname", 1},
+    {'c', "cell", 1}, {'r', "depth", 1}, {'o', "out", 1}, {'s', "seed", 1}, {'u', "umicopies", 0}, {0, NULL, 0}};
+
+int cmd_bam2db(int argc, const char **argv)
+{
+    const char *bam = NULL, *feat = NULL, *bar = NULL, *db = NULL, *out = ".";
+    /* the reference leaves the two rates uninitialised when omitted (main.c:293-294); 1.0 here */
+    float rate_cell = 1.0f, rate_depth = 1.0f;
+    unsigned int seed = 926;
+
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        const struct opt *o = NULL;
+        const char *val = NULL;
+        if (a[0] != '-' || !a[1]) break;                       /* first non-option stops parsing */
+        if (a[1] == '-') {
+            if (!a[2]) break;                                  /* "--" */
+            const char *eq = strchr(a + 2, '=');
+            size_t nl = eq ? (size_t)(eq - a - 2) : strlen(a + 2);
+            for (const struct opt *k = k_opts; k->l; k++)
+                if (strlen(k->l) == nl && strncmp(k->l, a + 2, nl) == 0) { o = k; break; }
+            if (o && eq) val = eq + 1;
+        } else {
+            for (const struct opt *k = k_opts; k->l; k++) if (k->s == a[1]) { o = k; break; }
+            if (o && o->has_arg && a[2]) val = a + 2;          /* -xVALUE */
+        }
+        if (!o) { fprintf(stderr, "error: unknown option `%s`\n", a); usage_bam2db(stderr); exit(129); }
+        if (o->has_arg && !val) {
+            if (i + 1 >= argc) { fprintf(stderr, "error: option `%s` requires a value\n", a); exit(129); }
+            val = argv[++i];
+        }
+        char *end = NULL;
+        switch (o->s) {
+        case 'h': usage_bam2db(stdout); exit(0);
+        case 'b': bam = val; break;
+        case 'f': feat = val; break;
+        case 'a': bar = val; break;
+        case 'd': db = val; break;
+        case 'o': out = val; break;
+        case 'c': rate_cell = strtof(val, &end); if (!*val || *end) { fprintf(stderr, "error: option `%s` expects a numerical value\n", a); exit(129); } break;
+        case 'r': rate_depth = strtof(val, &end); if (!*val || *end) { fprintf(stderr, "error: option `%s` expects a numerical value\n", a); exit(129); } break;
+        case 's': seed = (unsigned int)strtol(val, &end, 0); if (!*val || *end) { fprintf(stderr, "error: option `%s` expects an integer value\n", a); exit(129); } break;
+        case 'u': _umi_copies_flag = 1; break;
+        }
+    }
+
+    /* existence checks of main.c:323-345 */
+    if (!bam || access(bam, F_OK) == -1) { fprintf(stderr, "\x1b[31mError:\x1b[0m bam file: %s does not exist.\n", bam ? bam : "(null)"); exit(1); }
+    if (!feat || access(feat, F_OK) == -1) { fprintf(stderr, "\x1b[31mError:\x1b[0m feature file: %s does not exist.\n", feat ? feat : "(null)"); exit(1); }
+    if (!bar || access(bar, F_OK) == -1) { fprintf(stderr, "\x1b[31mError:\x1b[0m barcode file: %s does not exist.\n", bar ? bar : "(null)"); exit(1); }
+    if (db && access(db, F_OK) != -1) {
+        fprintf(stderr, "\x1b[31mError:\x1b[0m database: %s already exists, change the name of database in -d argument!\n", db);
+        exit(1);
+    }
+    if (bam2db((char *)bam, (char *)db, (char *)out, (char *)bar, (char *)feat, rate_cell, rate_depth, seed)) {
+        fprintf(stderr, "\x1b[31mError:\x1b[0m bam2db failed.\n");
+        return 1;
+    }
+    return 0;
+}

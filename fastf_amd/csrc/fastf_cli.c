@@ -1,0 +1,23 @@
+/* fastf_cli.c — `fastF` command line: dispatch table of the reference (main.c:404-443),
+ * with the one subcommand this engine implements. */
+#include "fastf_amd.h"
+
+#include <stdio.h>
+#include <string.h>
+
+struct cmd_struct { const char *cmd; int (*fn)(int, const char **); };
+static const struct cmd_struct commands[] = { {"bam2db", cmd_bam2db} };
+
+int main(int argc, const char **argv)
+{
+    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
+        printf("Usage: fastF <command> [options]\n\nCommands:\n"
+               "    bam2db    BAM -> down-sampled, UMI-deduplicated gene x cell matrix (MI355X engine)\n\n"
+               "(%s; freq/filter/crb/extract are not part of this engine)\n", fastf_version());
+        return argc < 2 ? 1 : 0;
+    }
+    for (size_t i = 0; i < sizeof commands / sizeof commands[0]; i++)
+        if (!strcmp(commands[i].cmd, argv[1])) return commands[i].fn(argc - 1, argv + 1);
+    fprintf(stderr, "\x1b[31mError:\x1b[0m unknown command `%s`\n", argv[1]);
+    return 1;
+}

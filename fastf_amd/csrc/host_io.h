@@ -1,0 +1,68 @@
+/* host_io.h — internal host-side front/back end of bam2db (lists, BAM reader, writers).
+ * These symbols are exported from libfastf_amd.so for the tests and the CLI, but the
+ * stable ABI is include/fastf_amd.h. */
+#ifndef FASTF_HOST_IO_H
+#define FASTF_HOST_IO_H
+
+#include "fastf_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void fastf_set_error_(const char *msg);
+
+/* ---- barcode / feature lists: bam2db_ds.c:229-337 ---- */
+typedef struct fastf_lists {
+    size_t    n_lines_barcodes;    /* "Total number of cells"                    (:233-237) */
+    size_t    n_sampled_target;    /* (size_t)(n_cells * rate_cell)              (:241)     */
+    size_t    n_cells;             /* rows of the cell table = barcodes inserted (:268-280) */
+    char    **barcode;             /* [n_cells] text, file order                              */
+    uint64_t *cell_key;            /* [n_cells]                                               */
+    size_t    n_features;          /* rows of the feature table                  (:313-327) */
+    char    **feat_id, **feat_name, **feat_type;
+    uint64_t *feature_key;
+    fastf_keydict_t *cell_dict, *feat_dict;
+    uint64_t  mt_skip;             /* MT draws SampleInt consumed after the re-seed (utils.c:32,55) */
+    size_t    dup_barcodes, dup_features;
+} fastf_lists_t;
+
+int  fastf_lists_load(const char *barcodes_file, const char *features_file,
+                      float rate_cell, unsigned int seed, fastf_lists_t *out);
+int  fastf_lists_load_mem(const char *barcodes, size_t barcodes_len,
+                          const char *features, size_t features_len,
+                          float rate_cell, unsigned int seed, fastf_lists_t *out);
+void fastf_lists_free(fastf_lists_t *l);
+
+/* ---- BAM front end: replaces sam_open/sam_hdr_read/sam_read1/bam_aux_get/bam_aux2Z/
+ *      bam_aux2i (bam2db_ds.c:141,340,360-417) for BGZF-compressed BAM ---- */
+typedef struct fastf_bam fastf_bam_t;
+fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
+/* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
+long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
+                          uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap);
+/* counts of records whose reference behaviour is undefined (xf / GX missing where the
+ * reference dereferences NULL, bam2db_ds.c:394-395,403-404); they are skipped here */
+void fastf_bam_stats(const fastf_bam_t *b, uint64_t *n_records, uint64_t *n_no_xf, uint64_t *n_no_gx);
+void fastf_bam_close(fastf_bam_t *b);
+
+/* ---- writers: bam2db_ds.c:453-556, table2gz :575-650 ---- */
+int fastf_write_outputs(const char *path_out, const char *bam_label, float rate_cell, float rate_depth,
+                        const uint64_t counters[3], const fastf_lists_t *lists,
+                        const fastf_coo_t *coo, const fastf_umi_rows_t *umi_rows /* NULL unless -u */);
+/* the decompressed bytes of matrix.mtx (header + rows) into a malloc'ed buffer */
+int fastf_format_matrix(const char *bam_label, float rate_cell, float rate_depth, const uint64_t counters[3],
+                        size_t n_feature, size_t n_barcode, const fastf_coo_t *coo, char **out, size_t *out_len);
+int fastf_format_umi_rows(const fastf_umi_rows_t *rows, char **out, size_t *out_len);
+
+/* string-level records → packed SoA (flags: 1 CB, 2 xf, 4 GX, 8 UB present) */
+void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *feats, size_t n,
+                        const uint8_t *flags, const int32_t *xf,
+                        const char *cb, size_t cb_stride, const char *gx, size_t gx_stride,
+                        const char *ub, size_t ub_stride,
+                        uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,668 @@
+// umi_engine.hip — the engine behind the C ABI of include/fastf_amd.h (sections 2b and 3).
+//
+// Replaces the reference's record loop + SQLite aggregate (bam2db_ds.c:360-438, 480-483,
+// 539-542) with: H2D of packed SoA batches on a copy stream → K1 probe/filter/pack →
+// (finish) K2 LSD radix sort → K3 segmented unique/reduce → COO D2H.
+// There is NO CPU fallback: every entry point fails loudly when HIP is unusable.
+#include "umi_kernels.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "fastf_amd.h"
+}
+
+using namespace fastf;
+
+static thread_local char g_err[512] = "";
+
+static int set_err(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return 1;
+}
+extern "C" const char* fastf_last_error(void) { return g_err; }
+extern "C" const char* fastf_version(void) { return "fastf_amd 0.1 (gfx950)"; }
+extern "C" void fastf_set_error_(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+
+#define HIP_OK(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static u32 bits_for(u64 max_value) {   // bits needed to hold 0..max_value
+    u32 b = 0;
+    while (b < 64 && (max_value >> b)) b++;
+    return b ? b : 1;
+}
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        HIP_OK(hipMalloc(&p, need));
+        bytes = need;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct KernelTimer {           // optional per-kernel HIP-event timing (bench roofline leg)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+};
+
+struct fastf_engine {
+    int device = 0;
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    KeyLayout L{};
+    u32 cell_bits = 0, feat_bits = 0, n_cells = 0, n_features = 0;
+    u64 threshold = 0;
+    u32 n_shards = 1, shard_rank = 0;
+    DevBuf tab_cells, tab_feats;
+    Table cells{}, feats{};
+    // draw stream
+    fastf_mt_t mt{};
+    std::vector<u32> pending_draws;      // generated, not yet consumed
+    // staging (double buffered)
+    u64 batch_cap = 0;
+    void* h_stage[2] = {nullptr, nullptr};       // pinned: cb | gx | umi | meta | draws
+    DevBuf d_stage[2];
+    int cur = 0;
+    bool batch_in_flight = false, in_flight_external = false;
+    u64 in_flight_n = 0;
+    // key store + results
+    u64 key_cap = 0;
+    DevBuf d_keys, d_tmp;
+    DevBuf d_small;              // key_counts[8] | counters[4] | nnz | nrows_u | n_tmp  (u64 each)
+    u64* h_small = nullptr;      // pinned mirror
+    DevBuf d_feature, d_cell, d_count, d_ukeys, d_ncopy;
+    std::vector<u32> h_feature, h_cell, h_count, h_ufeature, h_ucell, h_uumi, h_ncopy;
+    std::vector<uint8_t> h_unonnull;
+    u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;
+    u64 c_sampled = 0, c_valid = 0;
+    bool finished = false; int sorted_in_tmp = 0; u64 n_sorted = 0;
+    // workspace
+    DevBuf d_status, d_ticket, d_hist, d_binbase, d_cnt;
+    bool fused_hist_valid = false;
+    // timing
+    bool timing = false;
+    hipEvent_t t_ev[2] = {nullptr, nullptr};
+    double t_scatter_ms = 0; u64 t_scatter_n = 0;
+    double t_k1_ms = 0; u64 t_k1_n = 0;
+    double t_k3_ms = 0; u64 t_k3_n = 0;
+    double t_count_ms = 0; u64 t_count_n = 0;
+};
+
+enum { SM_KEYCOUNT = 0, SM_COUNTERS = 8, SM_NNZ = 12, SM_NROWS_U = 13, SM_N = 14, SM_WORDS = 16 };
+
+static size_t scatter_smem_bytes() {
+    return (size_t)SORT_TILE * 8 + (size_t)SORT_WAVES * RADIX * 4 + RADIX * 4 * 2 + 64;
+}
+
+// ------------------------------------------------------------------------------------
+// table build (host) + upload
+// ------------------------------------------------------------------------------------
+static u64 h_mix64(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char* what) {
+    u32 cap = 64;
+    while (cap < 2ull * n) cap <<= 1;
+    std::vector<uint4> slots(cap, make_uint4(0, 0, 0, 0));
+    for (u32 i = 0; i < n; ++i) {
+        const u64 k = keys[i];
+        if (k == 0) return set_err("%s key %u is 0 (unpackable string?)", what, i);
+        u32 h = (u32)h_mix64(k) & (cap - 1);
+        for (;;) {
+            uint4& s = slots[h];
+            const u64 sk = ((u64)s.y << 32) | s.x;
+            if (sk == 0) { s.x = (u32)k; s.y = (u32)(k >> 32); s.z = i + 1; break; }
+            if (sk == k) return set_err("duplicate %s key at index %u (first occurrence wins in the reference; dedup before create)", what, i);
+            h = (h + 1) & (cap - 1);
+        }
+    }
+    if (buf.ensure((size_t)cap * sizeof(uint4))) return 1;
+    HIP_OK(hipMemcpy(buf.p, slots.data(), (size_t)cap * sizeof(uint4), hipMemcpyHostToDevice));
+    t.slots = (const uint4*)buf.p;
+    t.mask = cap - 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------
+extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engine_t** out) {
+    if (!cfg || !out) return set_err("null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev == 0)
+        return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err("device %d out of range (have %d)", cfg->device, ndev);
+    if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 16) return set_err("umi_max_bases must be 1..16");
+    if (cfg->n_shards < 1 || cfg->n_shards > 8 || cfg->shard_rank >= cfg->n_shards) return set_err("bad shard config");
+    HIP_OK(hipSetDevice(cfg->device));
+
+    fastf_engine* e = new fastf_engine();
+    e->device = cfg->device;
+    e->n_cells = cfg->n_cells; e->n_features = cfg->n_features;
+    e->cell_bits = bits_for(cfg->n_cells);
+    e->feat_bits = bits_for(cfg->n_features);
+    e->L.umi_bits = 2 * cfg->umi_max_bases;
+    e->L.umi_max_bytes = (cfg->umi_max_bases + 3) / 4;
+    e->L.len_bits = bits_for(e->L.umi_max_bytes);
+    e->L.feat_shift = 1 + e->L.umi_bits + e->L.len_bits;
+    e->L.cell_shift = e->L.feat_shift + e->feat_bits;
+    e->L.total_bits = e->L.cell_shift + e->cell_bits;
+    if (e->L.total_bits > 64) {
+        set_err("packed key needs %u bits (cell %u + feature %u + umi %u) > 64: lower umi_max_bases",
+                e->L.total_bits, e->cell_bits, e->feat_bits, 1 + e->L.umi_bits + e->L.len_bits);
+        delete e; return 1;
+    }
+    e->threshold = cfg->draw_threshold;
+    e->n_shards = cfg->n_shards; e->shard_rank = cfg->shard_rank;
+    fastf_mt_seed(&e->mt, cfg->mt_seed);
+    fastf_mt_skip(&e->mt, cfg->mt_skip);
+
+    int rc = 0;
+    do {
+        if (hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_copy[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_copy[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&e->t_ev[0]) != hipSuccess || hipEventCreate(&e->t_ev[1]) != hipSuccess) {
+            rc = set_err("stream/event creation failed"); break;
+        }
+        if ((rc = build_table((const u64*)cfg->cell_keys, cfg->n_cells, e->tab_cells, e->cells, "cell"))) break;
+        if ((rc = build_table((const u64*)cfg->feature_keys, cfg->n_features, e->tab_feats, e->feats, "feature"))) break;
+        if ((rc = e->d_small.ensure(SM_WORDS * sizeof(u64)))) break;
+        if (hipHostMalloc((void**)&e->h_small, SM_WORDS * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+            rc = set_err("hipHostMalloc failed"); break;
+        }
+        if (hipMemset(e->d_small.p, 0, SM_WORDS * sizeof(u64)) != hipSuccess) { rc = set_err("memset failed"); break; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) {
+            rc = set_err("cannot raise dynamic LDS limit to %zu bytes", scatter_smem_bytes()); break;
+        }
+        e->batch_cap = cfg->batch_records ? cfg->batch_records : (4ull << 20);
+        e->key_cap = cfg->key_capacity;
+    } while (0);
+    if (rc) { fastf_engine_destroy(e); return 1; }
+    *out = e;
+    return 0;
+}
+
+extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) {
+        if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
+        e->d_stage[i].release();
+        if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
+        if (e->t_ev[i]) (void)hipEventDestroy(e->t_ev[i]);
+    }
+    if (e->h_small) (void)hipHostFree(e->h_small);
+    DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_status, &e->d_ticket, &e->d_hist, &e->d_binbase, &e->d_cnt};
+    for (DevBuf* b : all) b->release();
+    if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
+    if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
+    delete e;
+}
+
+extern "C" int fastf_engine_key_bits(const fastf_engine_t* e, uint32_t* cell_bits, uint32_t* feature_bits,
+                                     uint32_t* umi_bits, uint32_t* total_bits) {
+    if (!e) return set_err("null engine");
+    if (cell_bits) *cell_bits = e->cell_bits;
+    if (feature_bits) *feature_bits = e->feat_bits;
+    if (umi_bits) *umi_bits = 1 + e->L.umi_bits + e->L.len_bits;
+    if (total_bits) *total_bits = e->L.total_bits;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------
+static u64 max_tiles_for(u64 n, u64 tile) { return (n + tile - 1) / tile + 1; }
+
+static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
+    const u64 t1 = max_tiles_for(max_records, K1_TILE), t3 = max_tiles_for(max_keys, K3_TILE);
+    const u64 ts = max_tiles_for(max_keys, SORT_TILE);
+    if (e->d_status.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
+    if (e->d_ticket.ensure(64)) return 1;
+    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
+    if (e->d_binbase.ensure(8 * RADIX * sizeof(u32))) return 1;
+    if (e->d_cnt.ensure(ts * RADIX * sizeof(u32))) return 1;
+    return 0;
+}
+
+extern "C" int fastf_dev_reserve(fastf_engine_t* e, uint64_t max_records, uint64_t max_keys) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    return reserve_workspace(e, max_records, max_keys);
+}
+
+// per-kernel timing helpers (only active in timing mode; adds event records to the stream)
+static void t_begin(fastf_engine* e, hipStream_t s) { if (e->timing) (void)hipEventRecord(e->t_ev[0], s); }
+static void t_end(fastf_engine* e, hipStream_t s, double* acc, u64* cnt) {
+    if (!e->timing) return;
+    (void)hipEventRecord(e->t_ev[1], s);
+    (void)hipEventSynchronize(e->t_ev[1]);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->t_ev[0], e->t_ev[1]) == hipSuccess) { *acc += ms; *cnt += 1; }
+}
+
+extern "C" int fastf_engine_set_timing(fastf_engine_t* e, int on) {
+    if (!e) return set_err("null engine");
+    e->timing = on != 0;
+    e->t_scatter_ms = e->t_k1_ms = e->t_k3_ms = e->t_count_ms = 0;
+    e->t_scatter_n = e->t_k1_n = e->t_k3_n = e->t_count_n = 0;
+    return 0;
+}
+// which: 0 = K1 probe_filter_pack, 1 = K2 scatter, 2 = K3 reduce, 3 = K2 tile_count
+extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* total_ms, uint64_t* launches) {
+    if (!e) return set_err("null engine");
+    const double ms[4] = {e->t_k1_ms, e->t_scatter_ms, e->t_k3_ms, e->t_count_ms};
+    const u64 n[4] = {e->t_k1_n, e->t_scatter_n, e->t_k3_n, e->t_count_n};
+    if (which < 0 || which > 3) return set_err("bad timer index");
+    *total_ms = ms[which]; *launches = n[which];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// device-level entry points
+// ------------------------------------------------------------------------------------
+extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key, uint64_t n,
+                                    uint64_t* d_hits_out, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s));
+    if (n == 0) return 0;
+    const u32 grid = (u32)std::min<u64>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(count_hits_kernel, dim3(grid), dim3(256), 0, s, (const u64*)d_cb_key, (u64)n, e->cells, (u64*)d_hits_out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
+                        const u32* draws, u64 n_draws, u64* keys, u64 stride, u64* key_counts, u64* counters,
+                        u32* fused_hist, hipStream_t s) {
+    if (n == 0) return 0;
+    if (reserve_workspace(e, n, 0)) return 1;
+    const u64 tiles = (n + K1_TILE - 1) / K1_TILE;
+    HIP_OK(hipMemsetAsync(e->d_status.p, 0, tiles * sizeof(u64), s));
+    HIP_OK(hipMemsetAsync(e->d_ticket.p, 0, 16, s));
+    ProbeParams p{};
+    p.cb = cb; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
+    p.draws = draws; p.n_draws = n_draws;
+    p.cells = e->cells; p.feats = e->feats;
+    p.threshold = e->threshold; p.L = e->L;
+    p.n_shards = e->n_shards;
+    p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
+    p.status = (u64*)e->d_status.p; p.ticket = (u32*)e->d_ticket.p;
+    p.digit_hist = (e->n_shards == 1) ? fused_hist : nullptr;
+    p.hist_passes = (e->L.total_bits + 7) / 8;
+    t_begin(e, s);
+    hipLaunchKernelGGL(probe_filter_pack_kernel, dim3((u32)tiles), dim3(K1_THREADS), 0, s, p);
+    HIP_OK(hipGetLastError());
+    t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
+    return 0;
+}
+
+extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key, const uint64_t* d_gx_key,
+                                    const uint32_t* d_umi, const uint32_t* d_meta, uint64_t n,
+                                    const uint32_t* d_draws, uint64_t n_draws, uint64_t* d_keys_out,
+                                    uint64_t shard_stride, uint64_t* d_key_counts, uint64_t* d_counters, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
+                        (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters, nullptr, (hipStream_t)stream);
+}
+
+static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits,
+                       bool hist_ready, int* sorted_in_tmp, hipStream_t s) {
+    const u32 passes = (key_bits + 7) / 8;
+    *sorted_in_tmp = (int)(passes & 1);
+    if (max_n == 0) return 0;
+    if (passes > 8) return set_err("key_bits %u > 64", key_bits);
+    if (max_n >= (1ull << 32)) return set_err("sort of %llu keys: limit is 2^32-1 per shard", (unsigned long long)max_n);
+    if (reserve_workspace(e, 0, max_n)) return 1;
+    const u32 T = (u32)((max_n + SORT_TILE - 1) / SORT_TILE);
+    u32* hist = (u32*)e->d_hist.p; u32* binbase = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
+    if (!hist_ready) {
+        HIP_OK(hipMemsetAsync(hist, 0, passes * RADIX * sizeof(u32), s));
+        const u32 grid = (u32)std::min<u64>((max_n + 4095) / 4096, 1024);
+        hipLaunchKernelGGL(digit_hist_kernel, dim3(grid), dim3(256), 0, s, (const u64*)keys, d_n, passes, hist);
+    }
+    hipLaunchKernelGGL(bin_base_kernel, dim3(passes), dim3(RADIX), 0, s, (const u32*)hist, binbase);
+    for (u32 q = 0; q < passes; ++q) {
+        const u64* src = (q & 1) ? tmp : keys;
+        u64* dst = (q & 1) ? keys : tmp;
+        t_begin(e, s);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt);
+        t_end(e, s, &e->t_count_ms, &e->t_count_n);
+        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, (const u32*)(binbase + q * RADIX));
+        t_begin(e, s);
+        hipLaunchKernelGGL(scatter_kernel, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(), s, src, dst, d_n, 8 * q,
+                           (const u32*)cnt);
+        t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_tmp, const uint64_t* d_n,
+                              uint64_t max_n, uint32_t key_bits, int* sorted_in_tmp, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    int dummy = 0;
+    return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits, false,
+                       sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream);
+}
+
+template <bool UMI_ROWS>
+static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u32* feature, u32* cell,
+                         u32* count, u64* ukeys, u64* nrows, u64* err, hipStream_t s) {
+    HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s));
+    if (max_n == 0) return 0;
+    if (reserve_workspace(e, 0, max_n)) return 1;
+    const u64 tiles = (max_n + K3_TILE - 1) / K3_TILE;
+    HIP_OK(hipMemsetAsync(e->d_status.p, 0, tiles * sizeof(u64), s));
+    HIP_OK(hipMemsetAsync(e->d_ticket.p, 0, 16, s));
+    HIP_OK(hipMemsetAsync(count, 0, max_n * sizeof(u32), s));
+    ReduceParams p{};
+    p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
+    p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys; p.nrows = nrows;
+    p.status = (u64*)e->d_status.p; p.ticket = (u32*)e->d_ticket.p; p.err = err;
+    t_begin(e, s);
+    hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3((u32)tiles), dim3(K3_THREADS), 0, s, p);
+    HIP_OK(hipGetLastError());
+    if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
+    return 0;
+}
+
+extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
+                                uint32_t* d_feature, uint32_t* d_cell, uint32_t* d_count, uint64_t* d_nnz, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    return launch_reduce<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, d_feature, d_cell, d_count, nullptr,
+                                (u64*)d_nnz, (u64*)e->d_small.p + SM_COUNTERS + 3, (hipStream_t)stream);
+}
+
+extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
+                                  uint64_t* d_ukeys, uint32_t* d_ncopy, uint64_t* d_nrows, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    return launch_reduce<true>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, nullptr, nullptr, d_ncopy,
+                               (u64*)d_ukeys, (u64*)d_nrows, (u64*)e->d_small.p + SM_COUNTERS + 3, (hipStream_t)stream);
+}
+
+extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(bits, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" const char* fastf_kernel_names(void) {
+    return "probe_filter_pack_kernel,digit_hist_kernel,bin_base_kernel,tile_count_kernel,row_scan_kernel,"
+           "scatter_kernel,reduce_kernel,count_hits_kernel";
+}
+
+// ------------------------------------------------------------------------------------
+// host-buffer streaming API
+// ------------------------------------------------------------------------------------
+static const char* err_bits_text(u64 bits) {
+    static thread_local char buf[256];
+    snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s", (unsigned long long)bits,
+             (bits & ERR_SPIN_TIMEOUT) ? " inter-workgroup wait timed out;" : "",
+             (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
+             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it; key must still fit 64 bits);" : "",
+             (bits & ERR_KEYS_FULL) ? " key store full;" : "");
+    return buf;
+}
+
+static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4 + 4); }
+
+static int grow_keys(fastf_engine* e, u64 need) {
+    if (need <= e->key_cap && e->d_keys.p) return 0;
+    u64 ncap = std::max<u64>(need, std::max<u64>(e->key_cap * 2, 1u << 20));
+    void* np = nullptr;
+    HIP_OK(hipMalloc(&np, ncap * sizeof(u64)));
+    if (e->d_keys.p && e->keys_so_far)
+        HIP_OK(hipMemcpy(np, e->d_keys.p, e->keys_so_far * sizeof(u64), hipMemcpyDeviceToDevice));
+    e->d_keys.release();
+    e->d_keys.p = np; e->d_keys.bytes = ncap * sizeof(u64);
+    e->key_cap = ncap;
+    return 0;
+}
+
+// wait for the batch in flight, fold its counters into the host-side running state
+static int retire_batch(fastf_engine* e) {
+    if (!e->batch_in_flight) return 0;
+    HIP_OK(hipStreamSynchronize(e->s_compute));
+    e->batch_in_flight = false;
+    const u64* c = e->h_small + SM_COUNTERS;
+    const u64 hits_total = c[0];
+    const u64 consumed = hits_total - e->hits_so_far;
+    if (!e->in_flight_external) {
+        if (consumed > e->pending_draws.size()) return set_err("internal: consumed more draws than staged");
+        e->pending_draws.erase(e->pending_draws.begin(), e->pending_draws.begin() + (size_t)consumed);
+    }
+    e->hits_so_far = hits_total;
+    e->c_sampled = c[1]; e->c_valid = c[2];
+    e->keys_so_far = e->h_small[SM_KEYCOUNT];
+    if (c[3]) return set_err("%s", err_bits_text(c[3]));
+    return 0;
+}
+
+static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_t n, const u32* draws, size_t n_draws) {
+    if (retire_batch(e)) return 1;
+    if (grow_keys(e, e->keys_so_far + n)) return 1;
+    const int cur = e->cur;
+    if (!e->h_stage[cur]) {
+        HIP_OK(hipHostMalloc(&e->h_stage[cur], stage_bytes(e->batch_cap), hipHostMallocDefault));
+        if (e->d_stage[cur].ensure(stage_bytes(e->batch_cap))) return 1;
+    }
+    const u64 cap = e->batch_cap;
+    char* hs = (char*)e->h_stage[cur];
+    char* ds = (char*)e->d_stage[cur].p;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_draw = cap * 24;
+    memcpy(hs, b->cb_key + off, n * 8);
+    memcpy(hs + o_gx, b->gx_key + off, n * 8);
+    memcpy(hs + o_umi, b->umi + off, n * 4);
+    memcpy(hs + o_meta, b->meta + off, n * 4);
+    size_t nd;
+    if (draws) { nd = std::min(n_draws, n); memcpy(hs + o_draw, draws, nd * 4); }
+    else {
+        if (e->pending_draws.size() < n) {
+            const size_t have = e->pending_draws.size();
+            e->pending_draws.resize(n);
+            fastf_mt_fill(&e->mt, e->pending_draws.data() + have, n - have);
+        }
+        nd = n;
+        memcpy(hs + o_draw, e->pending_draws.data(), n * 4);
+    }
+    hipStream_t sc = e->s_copy, sk = e->s_compute;
+    HIP_OK(hipMemcpyAsync(ds, hs, n * 8, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_gx, hs + o_gx, n * 8, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_umi, hs + o_umi, n * 4, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_meta, hs + o_meta, n * 4, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_draw, hs + o_draw, nd * 4, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipEventRecord(e->ev_copy[cur], sc));
+    HIP_OK(hipStreamWaitEvent(sk, e->ev_copy[cur], 0));
+    u64* small = (u64*)e->d_small.p;
+    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
+    if (e->total_records == 0) {
+        HIP_OK(hipMemsetAsync(e->d_hist.p, 0, 8 * RADIX * sizeof(u32), sk));
+        e->fused_hist_valid = true;
+    }
+    if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
+                     (const u32*)(ds + o_draw), nd, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
+                     small + SM_COUNTERS, (u32*)e->d_hist.p, sk))
+        return 1;
+    HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
+    e->batch_in_flight = true;
+    e->in_flight_external = draws != nullptr;
+    e->in_flight_n = n;
+    e->total_records += n;
+    e->cur ^= 1;
+    e->finished = false;
+    return 0;
+}
+
+static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws) {
+    if (!e || !batch) return set_err("null argument");
+    if (e->n_shards != 1) return set_err("fastf_engine_push drives a single shard; use the fastf_dev_* calls for sharded runs");
+    HIP_OK(hipSetDevice(e->device));
+    if (retire_batch(e)) return 1;
+    const u64 hits_start = e->hits_so_far;
+    size_t off = 0;
+    while (off < batch->n) {
+        const size_t n = std::min<size_t>(batch->n - off, e->batch_cap);
+        if (draws) {
+            // caller-supplied draws: a chunk starts at the hits consumed by the chunks before it
+            if (retire_batch(e)) return 1;
+            const size_t doff = (size_t)(e->hits_so_far - hits_start);
+            if (push_chunk(e, batch, off, n, draws + std::min(doff, n_draws), n_draws > doff ? n_draws - doff : 0)) return 1;
+        } else {
+            if (push_chunk(e, batch, off, n, nullptr, 0)) return 1;
+        }
+        off += n;
+    }
+    return 0;
+}
+
+extern "C" int fastf_engine_push(fastf_engine_t* e, const fastf_batch_t* batch) {
+    return push_impl(e, batch, nullptr, 0);
+}
+
+extern "C" int fastf_engine_push_draws(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws) {
+    if (!draws && batch && batch->n) return set_err("null draws");
+    return push_impl(e, batch, draws, n_draws);
+}
+
+extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) {
+    if (!e || !coo) return set_err("null argument");
+    HIP_OK(hipSetDevice(e->device));
+    if (retire_batch(e)) return 1;
+    hipStream_t s = e->s_compute;
+    u64* small = (u64*)e->d_small.p;
+    const u64 n = e->keys_so_far;
+    if (!e->finished) {
+        if (n) {
+            if (e->d_tmp.ensure(e->key_cap * sizeof(u64))) return 1;
+            if (e->d_feature.ensure(n * 4) || e->d_cell.ensure(n * 4) || e->d_count.ensure(n * 4)) return 1;
+            if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits,
+                            e->fused_hist_valid, &e->sorted_in_tmp, s))
+                return 1;
+            const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
+            if (launch_reduce<false>(e, sorted, small + SM_KEYCOUNT, n, (u32*)e->d_feature.p, (u32*)e->d_cell.p,
+                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, small + SM_COUNTERS + 3, s))
+                return 1;
+        } else {
+            HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
+        }
+        HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
+        const u64 nnz = e->h_small[SM_NNZ];
+        e->h_feature.resize(nnz); e->h_cell.resize(nnz); e->h_count.resize(nnz);
+        if (nnz) {
+            HIP_OK(hipMemcpy(e->h_feature.data(), e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(e->h_cell.data(), e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(e->h_count.data(), e->d_count.p, nnz * 4, hipMemcpyDeviceToHost));
+        }
+        e->n_sorted = n;
+        e->finished = true;
+        e->fused_hist_valid = false;       // histograms describe the unsorted store only once
+    }
+    coo->feature = e->h_feature.data(); coo->cell = e->h_cell.data(); coo->count = e->h_count.data();
+    coo->nnz = e->h_feature.size();
+    if (counters) { counters[0] = e->total_records; counters[1] = e->c_sampled; counters[2] = e->c_valid; }
+    return 0;
+}
+
+extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) {
+    if (!e || !rows) return set_err("null argument");
+    if (!e->finished) return set_err("call fastf_engine_finish first");
+    HIP_OK(hipSetDevice(e->device));
+    hipStream_t s = e->s_compute;
+    u64* small = (u64*)e->d_small.p;
+    const u64 n = e->n_sorted;
+    u64 nrows = 0;
+    std::vector<u64> ukeys;
+    if (n) {
+        if (e->d_ukeys.ensure(n * 8) || e->d_ncopy.ensure(n * 4)) return 1;
+        const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
+        if (launch_reduce<true>(e, sorted, small + SM_KEYCOUNT, n, nullptr, nullptr, (u32*)e->d_ncopy.p,
+                                (u64*)e->d_ukeys.p, small + SM_NROWS_U, small + SM_COUNTERS + 3, s))
+            return 1;
+        HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
+        nrows = e->h_small[SM_NROWS_U];
+        ukeys.resize(nrows);
+        e->h_ncopy.resize(nrows);
+        if (nrows) {
+            HIP_OK(hipMemcpy(ukeys.data(), e->d_ukeys.p, nrows * 8, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(e->h_ncopy.data(), e->d_ncopy.p, nrows * 4, hipMemcpyDeviceToHost));
+        }
+    } else {
+        e->h_ncopy.clear();
+    }
+    e->h_ufeature.resize(nrows); e->h_ucell.resize(nrows); e->h_uumi.resize(nrows); e->h_unonnull.resize(nrows);
+    const u32 fmask = (u32)((1ull << e->feat_bits) - 1);
+    const u64 umask = e->L.umi_bits >= 64 ? ~0ull : ((1ull << e->L.umi_bits) - 1);
+    for (u64 i = 0; i < nrows; ++i) {
+        const u64 k = ukeys[i];
+        e->h_ufeature[i] = (u32)(k >> e->L.feat_shift) & fmask;
+        e->h_ucell[i] = (u32)(k >> e->L.cell_shift);
+        e->h_unonnull[i] = (uint8_t)((k >> (e->L.umi_bits + e->L.len_bits)) & 1);
+        const u64 field = (k >> e->L.len_bits) & umask;
+        e->h_uumi[i] = (u32)(field << (32 - e->L.umi_bits));
+    }
+    rows->feature = e->h_ufeature.data(); rows->cell = e->h_ucell.data(); rows->n_copy = e->h_ncopy.data();
+    rows->umi = e->h_uumi.data(); rows->nonnull = e->h_unonnull.data(); rows->n = nrows;
+    return 0;
+}
+
+extern "C" int fastf_engine_reset(fastf_engine_t* e) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemset(e->d_small.p, 0, SM_WORDS * sizeof(u64)));
+    memset(e->h_small, 0, SM_WORDS * sizeof(u64));
+    e->batch_in_flight = false;
+    e->total_records = e->hits_so_far = e->keys_so_far = e->c_sampled = e->c_valid = 0;
+    e->finished = false; e->fused_hist_valid = false;
+    e->pending_draws.clear();
+    return 0;
+}
+
+// re-position the engine-owned draw stream (tests; bam2db() sets it through the config)
+extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t skip) {
+    if (!e) return set_err("null engine");
+    fastf_mt_seed(&e->mt, seed);
+    fastf_mt_skip(&e->mt, skip);
+    e->pending_draws.clear();
+    return 0;
+}

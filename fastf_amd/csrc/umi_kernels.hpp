@@ -1,0 +1,613 @@
+// umi_kernels.hpp — hand-written HIP kernels of the bam2db hot path for gfx950 (CDNA4).
+//
+//   K0  count_hits_kernel         CB probe only (draw-rank base of a shard)
+//   K1  probe_filter_pack_kernel  §3.3 chain E3..E11 of the reference loop
+//                                 (bam2db_ds.c:374-434) on packed SoA records
+//   K2  digit_hist / tile_count / row_scan / scatter: 64-bit LSD radix sort,
+//                                 8-bit digits — stands in for SQLite's sorter
+//                                 behind GROUP BY (bam2db_ds.c:480-483)
+//   K3  reduce_kernel             COUNT(DISTINCT umi) GROUP BY cell, feature
+//   K3u umi_rows_kernel           COUNT(*) GROUP BY cell, feature, umi (-u, :539-542)
+//
+// All of it is integer indexing: wave64 ballots/mbcnt for ranking, LDS for the
+// tile-local reorder, coalesced 8-byte streams to HBM.  No MFMA by design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fastf {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int WAVE = 64;
+constexpr u32 SPIN_LIMIT = 1u << 22;      // every inter-workgroup wait is bounded
+
+// error bits accumulated in counters[3]
+constexpr u64 ERR_SPIN_TIMEOUT = 1;
+constexpr u64 ERR_DRAWS_SHORT  = 2;
+constexpr u64 ERR_UMI_TOOLONG  = 4;
+constexpr u64 ERR_KEYS_FULL    = 8;
+
+// meta bits (mirror of fastf_amd.h)
+constexpr u32 META_XF_OK = 1, META_HAS_UB = 2, META_UMI_NONNULL = 4, META_UMI_TOOLONG = 8;
+constexpr u32 META_LEN_SHIFT = 4, META_LEN_MASK = 0x70;
+
+// ------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of m strictly below this lane
+__device__ __forceinline__ u32 rank_below(u64 m) {
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum32(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+// inclusive scan across the wave
+__device__ __forceinline__ u32 wave_incl_scan32(u32 v, int lane) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        u32 t = __shfl_up(v, o, WAVE);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+// ------------------------------------------------------------------------------------
+// device-resident open-addressed table: 16-byte slots {key lo, key hi, value, 0},
+// key 0 = empty, linear probing, load <= 0.5.  A few hundred KB: lives in L2.
+// ------------------------------------------------------------------------------------
+struct Table { const uint4* slots; u32 mask; };
+
+__device__ __forceinline__ u32 table_probe(const Table t, u64 key) {
+    if (key == 0) return 0;
+    u32 h = (u32)mix64(key) & t.mask;
+    for (u32 i = 0; i <= t.mask; ++i) {
+        const uint4 s = t.slots[h];
+        const u64 k = ((u64)s.y << 32) | s.x;
+        if (k == key) return s.z;
+        if (k == 0) return 0;
+        h = (h + 1) & t.mask;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// chained scan across tiles: 8-byte {flag:2, value:62} granules, one relaxed agent-scope
+// store / load each (the value IS the flag — no fence needed), wave-parallel look-back.
+// ------------------------------------------------------------------------------------
+constexpr u64 ST_AGG = 1ULL << 62, ST_INC = 2ULL << 62, ST_VAL = (1ULL << 62) - 1;
+
+__device__ __forceinline__ void st_store(u64* p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 st_load(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by all 64 lanes of ONE wave.  Publishes `aggregate` for `tile`, returns the sum of
+// the aggregates of tiles [0, tile).  *timeout is set if a predecessor never shows up.
+__device__ __forceinline__ u64 chained_scan_wave(u64* status, u32 tile, u64 aggregate, int lane, bool* timeout) {
+    if (lane == 0) st_store(&status[tile], (tile == 0 ? ST_INC : ST_AGG) | aggregate);
+    if (tile == 0) return 0;
+    u64 excl = 0;
+    long long base = (long long)tile - 1;       // lane 0 looks at the nearest predecessor
+    u32 spins = 0;
+    for (;;) {
+        const long long idx = base - lane;
+        const u64 s = (idx >= 0) ? st_load(&status[idx]) : ST_INC;   // tile -1: inclusive 0
+        const u32 flag = (u32)(s >> 62);
+        const u64 m_inv = __ballot(flag == 0);
+        const u64 m_inc = __ballot(flag == 2);
+        const int first_inv = m_inv ? __builtin_ctzll(m_inv) : 64;
+        const int first_inc = m_inc ? __builtin_ctzll(m_inc) : 64;
+        if (first_inc < first_inv) {                                // resolved
+            excl += wave_sum64(lane <= first_inc ? (s & ST_VAL) : 0);
+            break;
+        }
+        if (first_inv > 0) {                                        // a run of aggregates
+            excl += wave_sum64(lane < first_inv ? (s & ST_VAL) : 0);
+            base -= first_inv;
+            if (first_inv == 64) continue;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) { *timeout = true; break; }
+    }
+    if (lane == 0) st_store(&status[tile], ST_INC | (excl + aggregate));
+    return excl;
+}
+
+// ordered tile ticket: predecessors of a ticket are always running or done
+__device__ __forceinline__ u32 take_ticket(u32* counter, u32* s_slot) {
+    if (threadIdx.x == 0) *s_slot = atomicAdd(counter, 1u);
+    __syncthreads();
+    return *s_slot;
+}
+
+// ------------------------------------------------------------------------------------
+// packed sort key layout:  [cell][feature][nonnull:1][umi: 2*Lmax bits][len]
+// ------------------------------------------------------------------------------------
+struct KeyLayout {
+    u32 umi_bits;      // 2 * umi_max_bases
+    u32 len_bits;      // 2 (Lmax <= 12) or 3
+    u32 feat_shift;    // = 1 + umi_bits + len_bits
+    u32 cell_shift;    // = feat_shift + feature_bits
+    u32 total_bits;
+    u32 umi_max_bytes;
+};
+
+__device__ __forceinline__ u64 make_key(const KeyLayout L, u32 cell, u32 feat, u32 umi, u32 meta) {
+    u64 k = ((u64)cell << L.cell_shift) | ((u64)feat << L.feat_shift);
+    if (meta & META_UMI_NONNULL) {
+        const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+        k |= (1ULL << (L.umi_bits + L.len_bits)) | ((u64)(umi >> (32 - L.umi_bits)) << L.len_bits) | len;
+    }
+    return k;
+}
+
+// a UMI the chosen layout cannot hold exactly (longer than umi_max_bases with non-zero tail,
+// or more blob bytes than the length field encodes)
+__device__ __forceinline__ bool umi_overflows(const KeyLayout L, u32 umi, u32 meta) {
+    if (meta & META_UMI_TOOLONG) return true;
+    if (!(meta & META_UMI_NONNULL)) return false;
+    const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+    return len > L.umi_max_bytes || (L.umi_bits < 32 && (umi << L.umi_bits) != 0);
+}
+
+// ------------------------------------------------------------------------------------
+// K0: count CB hits
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_hits_kernel(const u64* __restrict__ cb, u64 n, Table cells, u64* out) {
+    u32 local = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        local += table_probe(cells, cb[i]) != 0;
+    local = wave_sum32(local);
+    __shared__ u32 s[4];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    if (lane == 0) s[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (u64)s[0] + s[1] + s[2] + s[3]);
+}
+
+// ------------------------------------------------------------------------------------
+// K1: probe + filter + pack
+// ------------------------------------------------------------------------------------
+struct ProbeParams {
+    const u64* cb; const u64* gx; const u32* umi; const u32* meta; u64 n;
+    const u32* draws; u64 n_draws;
+    Table cells, feats;
+    u64 threshold;                 // keep iff draw < threshold
+    KeyLayout L;
+    u32 n_shards;
+    u64* keys; u64 shard_stride;   // keys + s*shard_stride
+    u64* key_counts;               // [n_shards], appended
+    u64* counters;                 // {hits, sampled, valid, err}
+    u64* status; u32* ticket;      // chained scan workspace (zeroed per launch)
+    u32* digit_hist;               // optional fused per-digit histograms [passes][256] (n_shards==1)
+    u32 hist_passes;
+};
+
+constexpr int K1_THREADS = 512, K1_IPT = 8, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
+
+__device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
+    return (u32)((mix64((u64)cell) >> 32) % n_shards);
+}
+
+__global__ __launch_bounds__(K1_THREADS) void probe_filter_pack_kernel(const ProbeParams p) {
+    __shared__ u32 s_slot;
+    __shared__ u32 s_cnt[K1_IPT * K1_WAVES];       // hits per (item, wave), then exclusive
+    __shared__ u64 s_tile_base;
+    __shared__ u32 s_red[3][K1_WAVES];
+    __shared__ u32 s_shard_cnt[8];
+    __shared__ u64 s_shard_base[8];
+    __shared__ u32 s_err;
+    __shared__ u32 s_hist[8 * 256];
+
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u32 tile = take_ticket(p.ticket, &s_slot);
+    const u64 base = (u64)tile * K1_TILE;
+    if (base >= p.n) return;                     // uniform: ticket beyond the batch
+
+    if (tid < 8) s_shard_cnt[tid] = 0;
+    if (tid == 0) s_err = 0;
+    if (p.digit_hist) for (int i = tid; i < (int)p.hist_passes * 256; i += K1_THREADS) s_hist[i] = 0;
+
+    // ---- stage 1: loads + CB probe (E2/E3, bam2db_ds.c:366-380) ----
+    u64 gxk[K1_IPT]; u32 umi[K1_IPT], meta[K1_IPT], cell[K1_IPT], hrank[K1_IPT];
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        const u64 idx = base + (u64)j * K1_THREADS + tid;
+        const bool in = idx < p.n;
+        const u64 cbk = in ? p.cb[idx] : 0;
+        gxk[j]  = in ? p.gx[idx] : 0;
+        umi[j]  = in ? p.umi[idx] : 0;
+        meta[j] = in ? p.meta[idx] : 0;
+        cell[j] = table_probe(p.cells, cbk);
+        const u64 hm = __ballot(cell[j] != 0);
+        hrank[j] = rank_below(hm);
+        if (lane == 0) s_cnt[j * K1_WAVES + w] = (u32)__popcll(hm);
+    }
+    __syncthreads();
+
+    // ---- stage 2: hit ranks in record order → draw index (E4, :385) ----
+    if (w == 0) {
+        u32 c = (lane < K1_IPT * K1_WAVES) ? s_cnt[lane] : 0;     // 64 entries exactly
+        const u32 inc = wave_incl_scan32(c, lane);
+        if (lane < K1_IPT * K1_WAVES) s_cnt[lane] = inc - c;
+        const u32 total = __shfl(inc, WAVE - 1, WAVE);
+        bool timeout = false;
+        const u64 excl = chained_scan_wave(p.status, tile, total, lane, &timeout);
+        if (lane == 0) { s_tile_base = excl; if (timeout) s_err = 1; }
+    }
+    __syncthreads();
+    const u64 tile_base = s_tile_base;
+
+    // ---- stage 3: depth draw, xf, feature probe, UB, key (E5..E11, :387-434) ----
+    u32 n_hit = 0, n_samp = 0, n_valid = 0, errs = 0;
+    u64 key[K1_IPT]; u32 pos[K1_IPT]; u32 shard[K1_IPT]; bool emit[K1_IPT];
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        emit[j] = false; key[j] = 0; pos[j] = 0; shard[j] = 0;
+        bool alive = cell[j] != 0;
+        n_hit += alive;
+        if (alive) {
+            const u64 r = tile_base + s_cnt[j * K1_WAVES + w] + hrank[j];
+            if (r < p.n_draws) alive = (u64)p.draws[r] < p.threshold;
+            else { alive = false; errs |= (u32)ERR_DRAWS_SHORT; }
+        }
+        n_samp += alive;                                             // E6 :392
+        alive = alive && (meta[j] & META_XF_OK);                     // E7 :394-400
+        u32 feat = 0;
+        if (alive) feat = table_probe(p.feats, gxk[j]);              // E8 :403-410
+        alive = alive && feat != 0 && (meta[j] & META_HAS_UB);       // E9 :412-416
+        if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
+        if (alive) {
+            n_valid++;                                               // E12 :435
+            key[j] = make_key(p.L, cell[j], feat, umi[j], meta[j]);  // E10/E11
+            shard[j] = p.n_shards > 1 ? shard_of(cell[j], p.n_shards) : 0;
+        }
+        emit[j] = alive;
+        // reserve a slot in the tile-local shard list (order is irrelevant: keys are sorted next)
+        for (u32 s = 0; s < p.n_shards; ++s) {
+            const u64 m = __ballot(alive && shard[j] == s);
+            if (m) {
+                u32 b = 0;
+                if (lane == 0) b = atomicAdd(&s_shard_cnt[s], (u32)__popcll(m));
+                b = __shfl(b, 0, WAVE);
+                if (alive && shard[j] == s) pos[j] = b + rank_below(m);
+            }
+        }
+        if (p.digit_hist && alive) {
+            for (u32 q = 0; q < p.hist_passes; ++q) atomicAdd(&s_hist[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
+        }
+    }
+
+    // ---- stage 4: counters + global slot reservation ----
+    n_hit = wave_sum32(n_hit); n_samp = wave_sum32(n_samp); n_valid = wave_sum32(n_valid);
+    if (lane == 0) { s_red[0][w] = n_hit; s_red[1][w] = n_samp; s_red[2][w] = n_valid; }
+    if (errs) atomicOr(&s_err, errs);
+    __syncthreads();
+    if (tid < 3) {
+        u64 t = 0;
+        for (int i = 0; i < K1_WAVES; ++i) t += s_red[tid][i];
+        if (t) atomicAdd(&p.counters[tid], t);
+    }
+    if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
+    if (tid >= 64 && tid < 64 + (int)p.n_shards) {
+        const u32 s = tid - 64;
+        const u32 c = s_shard_cnt[s];
+        u64 b = c ? atomicAdd(&p.key_counts[s], (u64)c) : 0;
+        if (b + c > p.shard_stride) { atomicOr(&p.counters[3], ERR_KEYS_FULL); b = ~0ULL; }
+        s_shard_base[s] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        if (emit[j]) {
+            const u64 b = s_shard_base[shard[j]];
+            if (b != ~0ULL) p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];
+        }
+    }
+    if (p.digit_hist) {
+        for (int i = tid; i < (int)p.hist_passes * 256; i += K1_THREADS) {
+            const u32 v = s_hist[i];
+            if (v) atomicAdd(&p.digit_hist[i], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2: LSD radix sort, 8-bit digits.  Per pass: tile_count → row_scan → scatter.
+// ------------------------------------------------------------------------------------
+constexpr int RADIX = 256;
+constexpr int SORT_THREADS = 512, SORT_IPT = 16, SORT_TILE = SORT_THREADS * SORT_IPT, SORT_WAVES = SORT_THREADS / WAVE;
+
+__device__ __forceinline__ u32 num_tiles(u64 n) { return (u32)((n + SORT_TILE - 1) / SORT_TILE); }
+
+// global histograms of every digit: hist[pass][256]
+__global__ __launch_bounds__(256) void digit_hist_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
+                                                         u32 passes, u32* __restrict__ hist) {
+    __shared__ u32 s_h[8 * RADIX];
+    for (int i = threadIdx.x; i < (int)passes * RADIX; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const u64 n = *n_ptr;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const u64 k = keys[i];
+        for (u32 q = 0; q < passes; ++q) atomicAdd(&s_h[q * RADIX + ((k >> (8 * q)) & 255)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)passes * RADIX; i += 256) {
+        const u32 v = s_h[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+// bin_base[pass][d] = exclusive scan over d of hist[pass][d]; one block per pass
+__global__ __launch_bounds__(RADIX) void bin_base_kernel(const u32* __restrict__ hist, u32* __restrict__ bin_base) {
+    __shared__ u32 s_w[RADIX / WAVE];
+    const int d = threadIdx.x, lane = lane_id(), w = d >> 6;
+    const u32 v = hist[blockIdx.x * RADIX + d];
+    const u32 inc = wave_incl_scan32(v, lane);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    u32 off = 0;
+    for (int i = 0; i < w; ++i) off += s_w[i];
+    bin_base[blockIdx.x * RADIX + d] = off + inc - v;
+}
+
+// per-tile digit counts: cnt[d * T + tile]
+__global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
+                                                                  u32 shift, u32* __restrict__ cnt) {
+    __shared__ u32 s_h[RADIX];
+    const u64 n = *n_ptr;
+    const u32 T = num_tiles(n), tile = blockIdx.x;
+    if (tile >= T) return;
+    if (threadIdx.x < RADIX) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)tile * SORT_TILE;
+#pragma unroll
+    for (int j = 0; j < SORT_IPT; ++j) {
+        const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&s_h[(keys[idx] >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < RADIX) cnt[(u64)threadIdx.x * T + tile] = s_h[threadIdx.x];
+}
+
+// row d: exclusive scan of cnt[d][0..T) in place, plus bin_base[d]
+__global__ __launch_bounds__(1024) void row_scan_kernel(u32* __restrict__ cnt, const u64* __restrict__ n_ptr,
+                                                        const u32* __restrict__ bin_base) {
+    __shared__ u32 s_w[16];
+    __shared__ u32 s_carry;
+    const u32 T = num_tiles(*n_ptr);
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    u32* row = cnt + (u64)blockIdx.x * T;
+    if (threadIdx.x == 0) s_carry = bin_base[blockIdx.x];
+    __syncthreads();
+    for (u32 t0 = 0; t0 < T; t0 += 1024) {
+        const u32 t = t0 + threadIdx.x;
+        const u32 v = t < T ? row[t] : 0;
+        const u32 inc = wave_incl_scan32(v, lane);
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        u32 off = s_carry;
+        for (int i = 0; i < w; ++i) off += s_w[i];
+        if (t < T) row[t] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+}
+
+// match-any over the 8 digit bits: lanes holding the same digit (valid lanes only)
+__device__ __forceinline__ u64 match_digit(u32 d) {
+    u64 m = ~0ULL;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1;
+        const u64 bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+// scatter: stable within the tile (wave-major, item, lane == memory order)
+__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
+                                                               const u64* __restrict__ n_ptr, u32 shift,
+                                                               const u32* __restrict__ off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* s_keys = reinterpret_cast<u64*>(smem);                                    // SORT_TILE keys
+    u32* s_whist = reinterpret_cast<u32*>(smem + (size_t)SORT_TILE * 8);          // [WAVES][256]
+    u32* s_delta = s_whist + SORT_WAVES * RADIX;                                   // [256] global - local start
+    u32* s_start = s_delta + RADIX;                                                // [256] local bin start
+    u32* s_wtot  = s_start + RADIX;                                                // [4]
+
+    const u64 n = *n_ptr;
+    const u32 T = num_tiles(n), tile = blockIdx.x;
+    if (tile >= T) return;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u64 base = (u64)tile * SORT_TILE;
+    const u32 n_valid = (u32)((n - base) < (u64)SORT_TILE ? (n - base) : (u64)SORT_TILE);
+
+    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
+
+    // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
+    u64 key[SORT_IPT];
+    const u32 wbase = (u32)w * SORT_IPT * WAVE;
+#pragma unroll
+    for (int j = 0; j < SORT_IPT; ++j) {
+        const u32 li = wbase + j * WAVE + lane;
+        key[j] = li < n_valid ? in[base + li] : ~0ULL;
+    }
+    __syncthreads();
+
+    // rank inside the wave: per-wave histogram, no atomics (one leader per digit group)
+    u32 rnk[SORT_IPT];
+    u32* wh = s_whist + w * RADIX;
+#pragma unroll
+    for (int j = 0; j < SORT_IPT; ++j) {
+        const u32 li = wbase + j * WAVE + lane;
+        const u32 d = li < n_valid ? (u32)((key[j] >> shift) & 255) : 255u;
+        const u64 m = match_digit(d);
+        const u32 before = wh[d];
+        const u32 r = rank_below(m);
+        __builtin_amdgcn_wave_barrier();
+        if (r == 0) wh[d] = before + (u32)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        rnk[j] = before + r;
+    }
+    __syncthreads();
+
+    // per digit: exclusive offsets of the waves, tile totals → local bin starts
+    u32 run = 0, inc = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int i = 0; i < SORT_WAVES; ++i) { const u32 c = s_whist[i * RADIX + tid]; s_whist[i * RADIX + tid] = run; run += c; }
+        inc = wave_incl_scan32(run, lane);                 // over the 64 digits of this wave
+        if (lane == WAVE - 1) s_wtot[w] = inc;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        u32 o = 0;
+        for (int i = 0; i < w; ++i) o += s_wtot[i];
+        const u32 lstart = o + inc - run;                  // first tile-local slot of digit tid
+        s_start[tid] = lstart;
+        s_delta[tid] = off[(u64)tid * T + tile] - lstart;  // global slot = delta + local slot (mod 2^32)
+    }
+    __syncthreads();
+
+    // tile-local reorder through LDS
+#pragma unroll
+    for (int j = 0; j < SORT_IPT; ++j) {
+        const u32 li = wbase + j * WAVE + lane;
+        const u32 d = li < n_valid ? (u32)((key[j] >> shift) & 255) : 255u;
+        const u32 p = s_start[d] + wh[d] + rnk[j];
+        s_keys[p] = key[j];
+    }
+    __syncthreads();
+
+    // coalesced write-out: consecutive threads → consecutive slots of the same bin
+#pragma unroll
+    for (int j = 0; j < SORT_IPT; ++j) {
+        const u32 pidx = j * SORT_THREADS + tid;
+        if (pidx < n_valid) {
+            const u64 k = s_keys[pidx];
+            const u32 d = (u32)((k >> shift) & 255);
+            out[(u64)(u32)(s_delta[d] + pidx)] = k;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------
+// K3 / K3u: segmented unique + reduce over the sorted keys.
+//   UMI_ROWS = false: one row per (cell, feature); count = distinct non-NULL umi keys
+//   UMI_ROWS = true : one row per distinct key;    count = copies of that key
+// Row index = chained scan of the head flags; counts of groups that fit in one
+// wave-item are stored plainly, the pieces of groups that straddle a wave-item are
+// added atomically (count[] is zeroed before the launch).
+// ------------------------------------------------------------------------------------
+struct ReduceParams {
+    const u64* keys; const u64* n_ptr;
+    KeyLayout L; u32 feat_mask;
+    u32* feature; u32* cell; u32* count;   // UMI_ROWS: feature/cell unused
+    u64* ukeys;                            // UMI_ROWS only
+    u64* nrows;
+    u64* status; u32* ticket; u64* err;
+};
+
+constexpr int K3_THREADS = 512, K3_IPT = 8, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
+
+template <bool UMI_ROWS>
+__global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p) {
+    __shared__ u32 s_slot;
+    __shared__ u32 s_cnt[K3_IPT * K3_WAVES];
+    __shared__ u64 s_base;
+
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u32 tile = take_ticket(p.ticket, &s_slot);
+    const u64 n = *p.n_ptr;
+    const u32 T = (u32)((n + K3_TILE - 1) / K3_TILE);
+    if (tile >= T) return;
+    const u64 base = (u64)tile * K3_TILE;
+    const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
+    const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
+
+    u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT], vm[K3_IPT];
+#pragma unroll
+    for (int j = 0; j < K3_IPT; ++j) {
+        const u64 idx = base + (u64)j * K3_THREADS + tid;
+        const bool valid = idx < n;
+        const u64 k = valid ? p.keys[idx] : 0;
+        const u64 prev = (valid && idx > 0) ? p.keys[idx - 1] : ~k;
+        const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
+        const bool dist = UMI_ROWS ? valid
+                                   : (valid && ((k >> nn_shift) & 1) && (idx == 0 || k != prev));
+        key[j] = k;
+        hm[j] = __ballot(head); dm[j] = __ballot(dist); vm[j] = __ballot(valid);
+        if (lane == 0) s_cnt[j * K3_WAVES + w] = (u32)__popcll(hm[j]);
+    }
+    __syncthreads();
+    if (w == 0) {
+        const u32 c = s_cnt[lane];                       // exactly 64 entries
+        const u32 inc = wave_incl_scan32(c, lane);
+        s_cnt[lane] = inc - c;
+        const u32 total = __shfl(inc, WAVE - 1, WAVE);
+        bool timeout = false;
+        const u64 excl = chained_scan_wave(p.status, tile, total, lane, &timeout);
+        if (lane == 0) {
+            s_base = excl;
+            if (timeout) atomicOr(p.err, ERR_SPIN_TIMEOUT);
+            if (tile == T - 1) *p.nrows = excl + total;
+        }
+    }
+    __syncthreads();
+    const u64 row_base = s_base;
+    const u64 le = (lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1);
+#pragma unroll
+    for (int j = 0; j < K3_IPT; ++j) {
+        const bool valid = (vm[j] >> lane) & 1;
+        if (!valid) continue;
+        const u64 h_le = hm[j] & le;
+        const u64 row = row_base + s_cnt[j * K3_WAVES + w] + (u32)__popcll(h_le) - 1;
+        if ((hm[j] >> lane) & 1) {
+            if (UMI_ROWS) p.ukeys[row] = key[j];
+            else {
+                p.feature[row] = (u32)(key[j] >> p.L.feat_shift) & p.feat_mask;
+                p.cell[row] = (u32)(key[j] >> p.L.cell_shift);
+            }
+        }
+        // segment end: next lane starts a group, is past n, or is in the next wave-item
+        const bool next_head = lane < 63 && ((hm[j] >> (lane + 1)) & 1);
+        const bool next_invalid = lane < 63 && !((vm[j] >> (lane + 1)) & 1);
+        const bool seg_end = lane == 63 || next_head || next_invalid;
+        if (seg_end) {
+            const int start = h_le ? (63 - __builtin_clzll(h_le)) : 0;
+            const u64 range = le & ~((1ULL << start) - 1);
+            const u32 c = (u32)__popcll(dm[j] & range);
+            const bool whole = h_le != 0 && (next_head || next_invalid);
+            if (c) {
+                if (whole) p.count[row] = c;
+                else atomicAdd(&p.count[row], c);
+            }
+        }
+    }
+}
+
+}  // namespace fastf

@@ -1,0 +1,267 @@
+"""Host-side mirror of the engine C ABI (include/fastf_amd.h).
+
+Nothing here computes results: every call lands in libfastf_amd.so (HIP kernels on the
+device, C on the host).  If the library or a HIP device is missing the calls raise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Batch, Coo, EngineConfig, FastfError, ListsStruct, MT, UmiRows, check
+
+HAS_CB, HAS_XF, HAS_GX, HAS_UB = 1, 2, 4, 8
+
+
+def draw_threshold(rate_depth: float) -> int:
+    """Integer form of bam2db_ds.c:385-390: a record is kept iff draw < threshold."""
+    return int(_lib.lib().fastf_draw_threshold(C.c_float(rate_depth)))
+
+
+def mt_draws(seed: int, skip: int, n: int) -> np.ndarray:
+    """n MT19937 draws after init_genrand(seed) and `skip` discarded draws."""
+    L = _lib.lib()
+    mt = MT()
+    L.fastf_mt_seed(C.byref(mt), seed)
+    L.fastf_mt_skip(C.byref(mt), skip)
+    out = np.empty(n, dtype=np.uint32)
+    L.fastf_mt_fill(C.byref(mt), out.ctypes.data, n)
+    return out
+
+
+def sample_cells(n_cells: int, rate_cell: float, seed: int):
+    L = _lib.lib()
+    out = np.zeros(max(n_cells, 1), dtype=np.uint64)
+    ns, used = C.c_size_t(0), C.c_uint64(0)
+    rc = L.fastf_sample_cells(n_cells, C.c_float(rate_cell), seed, out.ctypes.data, C.byref(ns), C.byref(used))
+    if rc:
+        raise FastfError("sample size must lie in [0, n_cells]")
+    return out[:ns.value].copy(), int(used.value)
+
+
+class Lists:
+    """Barcode + feature lists as the reference builds them (bam2db_ds.c:229-337)."""
+
+    def __init__(self, barcodes: bytes, features: bytes, rate_cell=1.0, seed=926):
+        self._L = _lib.lib()
+        self._s = ListsStruct()
+        check(self._L.fastf_lists_load_mem(barcodes, len(barcodes), features, len(features),
+                                           C.c_float(rate_cell), seed, C.byref(self._s)))
+        s = self._s
+        self.n_lines_barcodes = s.n_lines_barcodes
+        self.n_sampled_target = s.n_sampled_target
+        self.n_cells = s.n_cells
+        self.n_features = s.n_features
+        self.mt_skip = int(s.mt_skip)
+        self.dup_barcodes, self.dup_features = s.dup_barcodes, s.dup_features
+        self.cell_keys = np.array([s.cell_key[i] for i in range(s.n_cells)], dtype=np.uint64)
+        self.feature_keys = np.array([s.feature_key[i] for i in range(s.n_features)], dtype=np.uint64)
+        self.barcodes = [s.barcode[i] for i in range(s.n_cells)]
+        self.features = [(s.feat_id[i], s.feat_name[i], s.feat_type[i]) for i in range(s.n_features)]
+
+    @property
+    def cell_dict(self):
+        return self._s.cell_dict
+
+    @property
+    def feat_dict(self):
+        return self._s.feat_dict
+
+    def barcodes_text(self) -> bytes:
+        return b"".join(b + b"\n" for b in self.barcodes)
+
+    def features_text(self) -> bytes:
+        return b"".join(b"\t".join(f) + b"\n" for f in self.features)
+
+    def close(self):
+        if self._s is not None:
+            self._L.fastf_lists_free(C.byref(self._s))
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_records(lists: Lists, flags, xf, cb, gx, ub):
+    """String-level records → packed SoA via the product's own packer (host_io.c)."""
+    L = _lib.lib()
+    L.fastf_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fastf_pack_records.restype = None
+    flags = np.ascontiguousarray(flags, dtype=np.uint8)
+    xf = np.ascontiguousarray(xf, dtype=np.int32)
+    cb, gx, ub = (np.ascontiguousarray(a) for a in (cb, gx, ub))
+    n = len(flags)
+    cb_key = np.empty(n, dtype=np.uint64)
+    gx_key = np.empty(n, dtype=np.uint64)
+    umi = np.empty(n, dtype=np.uint32)
+    meta = np.empty(n, dtype=np.uint32)
+    L.fastf_pack_records(lists.cell_dict, lists.feat_dict, n, flags.ctypes.data, xf.ctypes.data,
+                         cb.ctypes.data, cb.dtype.itemsize, gx.ctypes.data, gx.dtype.itemsize,
+                         ub.ctypes.data, ub.dtype.itemsize,
+                         cb_key.ctypes.data, gx_key.ctypes.data, umi.ctypes.data, meta.ctypes.data)
+    return cb_key, gx_key, umi, meta
+
+
+class Engine:
+    """fastf_engine_* (host buffers) and fastf_dev_* (device pointers) of include/fastf_amd.h."""
+
+    def __init__(self, cell_keys, feature_keys, rate_depth=1.0, seed=926, mt_skip=0,
+                 umi_max_bases=12, n_shards=1, shard_rank=0, device=0,
+                 batch_records=0, key_capacity=0, threshold=None):
+        self._L = _lib.lib()
+        self._cell_keys = np.ascontiguousarray(cell_keys, dtype=np.uint64)
+        self._feature_keys = np.ascontiguousarray(feature_keys, dtype=np.uint64)
+        cfg = EngineConfig()
+        cfg.cell_keys = self._cell_keys.ctypes.data
+        cfg.n_cells = len(self._cell_keys)
+        cfg.feature_keys = self._feature_keys.ctypes.data
+        cfg.n_features = len(self._feature_keys)
+        cfg.draw_threshold = draw_threshold(rate_depth) if threshold is None else threshold
+        cfg.umi_max_bases = umi_max_bases
+        cfg.mt_seed, cfg.mt_skip = seed, mt_skip
+        cfg.n_shards, cfg.shard_rank = n_shards, shard_rank
+        cfg.device = device
+        cfg.batch_records, cfg.key_capacity = batch_records, key_capacity
+        h = C.c_void_p()
+        check(self._L.fastf_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.n_shards = n_shards
+        cb, fb, ub, tb = (C.c_uint32() for _ in range(4))
+        check(self._L.fastf_engine_key_bits(h, C.byref(cb), C.byref(fb), C.byref(ub), C.byref(tb)))
+        self.cell_bits, self.feature_bits, self.umi_bits, self.key_bits = cb.value, fb.value, ub.value, tb.value
+
+    @classmethod
+    def from_lists(cls, lists: Lists, rate_depth=1.0, seed=926, **kw):
+        return cls(lists.cell_keys, lists.feature_keys, rate_depth=rate_depth, seed=seed,
+                   mt_skip=lists.mt_skip, **kw)
+
+    # ---- host-buffer streaming API ----
+    @staticmethod
+    def _batch(cb_key, gx_key, umi, meta):
+        arrs = (np.ascontiguousarray(cb_key, dtype=np.uint64), np.ascontiguousarray(gx_key, dtype=np.uint64),
+                np.ascontiguousarray(umi, dtype=np.uint32), np.ascontiguousarray(meta, dtype=np.uint32))
+        b = Batch(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, len(arrs[0]))
+        return b, arrs
+
+    def push(self, cb_key, gx_key, umi, meta, draws=None):
+        b, keep = self._batch(cb_key, gx_key, umi, meta)
+        if draws is None:
+            check(self._L.fastf_engine_push(self._h, C.byref(b)))
+        else:
+            d = np.ascontiguousarray(draws, dtype=np.uint32)
+            check(self._L.fastf_engine_push_draws(self._h, C.byref(b), d.ctypes.data, len(d)))
+        del keep
+
+    def finish(self):
+        coo = Coo()
+        cnt = (C.c_uint64 * 3)()
+        check(self._L.fastf_engine_finish(self._h, C.byref(coo), C.byref(cnt)))
+        n = coo.nnz
+
+        def arr(p):
+            return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)
+        return dict(feature=arr(coo.feature), cell=arr(coo.cell), count=arr(coo.count), nnz=n,
+                    total=int(cnt[0]), sampled=int(cnt[1]), valid=int(cnt[2]))
+
+    def umi_rows(self):
+        r = UmiRows()
+        check(self._L.fastf_engine_umi_rows(self._h, C.byref(r)))
+        n = r.n
+
+        def arr(p, dt=np.uint32):
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dtype=dt)
+        return dict(feature=arr(r.feature), cell=arr(r.cell), n_copy=arr(r.n_copy), umi=arr(r.umi),
+                    nonnull=arr(r.nonnull, np.uint8), n=n)
+
+    def format_matrix(self, res, bam_label: bytes, rate_cell, rate_depth, n_feature, n_barcode) -> bytes:
+        f = np.ascontiguousarray(res["feature"], dtype=np.uint32)
+        c = np.ascontiguousarray(res["cell"], dtype=np.uint32)
+        k = np.ascontiguousarray(res["count"], dtype=np.uint32)
+        coo = Coo(f.ctypes.data_as(C.POINTER(C.c_uint32)), c.ctypes.data_as(C.POINTER(C.c_uint32)),
+                  k.ctypes.data_as(C.POINTER(C.c_uint32)), len(f))
+        cnt = (C.c_uint64 * 3)(res["total"], res["sampled"], res["valid"])
+        out, n = C.c_void_p(), C.c_size_t()
+        check(self._L.fastf_format_matrix(bam_label, C.c_float(rate_cell), C.c_float(rate_depth), C.byref(cnt),
+                                          n_feature, n_barcode, C.byref(coo), C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            _libc_free(out)
+
+    def format_umi_rows(self, rows) -> bytes:
+        a = {k: np.ascontiguousarray(rows[k]) for k in ("feature", "cell", "n_copy", "umi", "nonnull")}
+        r = UmiRows(a["feature"].ctypes.data_as(C.POINTER(C.c_uint32)), a["cell"].ctypes.data_as(C.POINTER(C.c_uint32)),
+                    a["n_copy"].ctypes.data_as(C.POINTER(C.c_uint32)), a["umi"].ctypes.data_as(C.POINTER(C.c_uint32)),
+                    a["nonnull"].ctypes.data_as(C.POINTER(C.c_uint8)), rows["n"])
+        out, n = C.c_void_p(), C.c_size_t()
+        check(self._L.fastf_format_umi_rows(C.byref(r), C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            _libc_free(out)
+
+    def reset(self):
+        check(self._L.fastf_engine_reset(self._h))
+
+    def reseed(self, seed, skip=0):
+        check(self._L.fastf_engine_reseed(self._h, seed, skip))
+
+    # ---- timing of individual kernels (bench roofline leg) ----
+    def set_timing(self, on: bool):
+        check(self._L.fastf_engine_set_timing(self._h, 1 if on else 0))
+
+    def get_timing(self, which: int):
+        ms, n = C.c_double(), C.c_uint64()
+        check(self._L.fastf_engine_get_timing(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- device-level API: arguments are raw device pointers (ints) ----
+    def reserve(self, max_records, max_keys):
+        check(self._L.fastf_dev_reserve(self._h, max_records, max_keys))
+
+    def dev_count_hits(self, d_cb, n, d_out, stream=0):
+        check(self._L.fastf_dev_count_hits(self._h, d_cb, n, d_out, stream))
+
+    def dev_probe_pack(self, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_keys, shard_stride,
+                       d_key_counts, d_counters, stream=0):
+        check(self._L.fastf_dev_probe_pack(self._h, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws,
+                                           d_keys, shard_stride, d_key_counts, d_counters, stream))
+
+    def dev_sort(self, d_keys, d_tmp, d_n, max_n, key_bits=None, stream=0) -> bool:
+        in_tmp = C.c_int(0)
+        check(self._L.fastf_dev_sort(self._h, d_keys, d_tmp, d_n, max_n,
+                                     self.key_bits if key_bits is None else key_bits, C.byref(in_tmp), stream))
+        return bool(in_tmp.value)
+
+    def dev_reduce(self, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz, stream=0):
+        check(self._L.fastf_dev_reduce(self._h, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz, stream))
+
+    def dev_umi_rows(self, d_sorted, d_n, max_n, d_ukeys, d_ncopy, d_nrows, stream=0):
+        check(self._L.fastf_dev_umi_rows(self._h, d_sorted, d_n, max_n, d_ukeys, d_ncopy, d_nrows, stream))
+
+    def dev_error_bits(self) -> int:
+        b = C.c_uint64()
+        check(self._L.fastf_dev_error_bits(self._h, C.byref(b)))
+        return int(b.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fastf_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _libc_free(ptr):
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(ptr)

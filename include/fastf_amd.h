@@ -1,0 +1,209 @@
+/*
+ * fastf_amd.h — C ABI of the MI355X-native bam2db UMI-counting engine.
+ *
+ * Three layers, all plain C (pointers + sizes, no C++/torch types):
+ *
+ *   1. OUTER drop-in symbols — what the reference's own main.c binds
+ *        int bam2db(...)            replaces  src/bam2db_ds.c:106-573 (decl. bam2db_ds.h:62-70)
+ *        int _umi_copies_flag       replaces  src/bam2db_ds.c:3       (decl. bam2db_ds.h:23)
+ *        int cmd_bam2db(argc,argv)  replaces  src/main.c:288-362
+ *
+ *   2. INNER seam (host buffers in, COO out) — what replaces the reference's
+ *      per-record loop + SQLite aggregate (bam2db_ds.c:360-438, 480-483):
+ *        fastf_engine_create / _push / _finish / _umi_rows / _reset / _destroy
+ *      plus the host-side exact string→key packer that replaces
+ *      hash()+hash_table_lookup() key handling (bam2db_ds.c:96-104, hashtable.c:98-115).
+ *
+ *   3. DEVICE-level entry points (device pointers + a hipStream_t passed as void*)
+ *      for callers that already own HBM buffers (bench.py, the multi-GPU host in
+ *      fastf_amd/dist.py, kernel parity tests).
+ *
+ * Every function returns 0 on success and non-zero on failure unless stated;
+ * the message is available from fastf_last_error() (thread-local).
+ * The reference convention "0 ok / 1 fail + message on stderr" (bam2db_ds.h:60)
+ * is kept by the outer layer.
+ */
+#ifndef FASTF_AMD_H
+#define FASTF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================== */
+/* 1. outer drop-in symbols                                              */
+/* ===================================================================== */
+
+/* bam2db_ds.h:23 / bam2db_ds.c:3 — set by `-u/--umicopies` (main.c:309) */
+extern int _umi_copies_flag;
+
+/* bam2db_ds.h:62-70.  db_file is accepted and ignored (no SQLite). */
+int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file,
+           char *features_file, float rate_cell, float rate_depth, unsigned int seed);
+
+/* main.c:288-362; argv[0] == "bam2db". */
+int cmd_bam2db(int argc, const char **argv);
+
+const char *fastf_last_error(void);
+const char *fastf_version(void);
+
+/* ===================================================================== */
+/* 2a. host-side primitives of the path                                   */
+/* ===================================================================== */
+
+/* MT19937 stream — replaces the global-state generator of mt19937ar.c:56-140
+ * with an explicit state object; bit-identical output. */
+typedef struct fastf_mt { uint32_t s[624]; int idx; } fastf_mt_t;
+void     fastf_mt_seed(fastf_mt_t *mt, uint32_t seed);           /* mt19937ar.c:60-73   */
+uint32_t fastf_mt_next(fastf_mt_t *mt);                          /* mt19937ar.c:105-140 */
+void     fastf_mt_fill(fastf_mt_t *mt, uint32_t *out, size_t n); /* n consecutive draws */
+void     fastf_mt_skip(fastf_mt_t *mt, uint64_t n);
+
+/* Integer form of `genrand_real1() >= rate_depth → drop` (bam2db_ds.c:385-390):
+ * a record is kept iff draw < fastf_draw_threshold(rate). */
+uint64_t fastf_draw_threshold(float rate_depth);   /* 0 .. 2^32 */
+
+/* Cell sub-sampling — bam2db_ds.c:240-244 + utils.c:29-75.
+ * n_sampled = (size_t)(n_cells * rate_cell); writes the sorted 0-based line numbers.
+ * *draws_used = MT draws consumed (0 when n_sampled == n_cells). Returns non-zero if
+ * the reference would exit (n_sampled > n_cells) or the rate is negative/NaN. */
+int fastf_sample_cells(size_t n_cells, float rate_cell, unsigned int seed,
+                       uint64_t *lines_out, size_t *n_sampled, uint64_t *draws_used);
+
+/* 2-bit UMI codec — bam2db_ds.c:5-51 (+ size rule :419).  Packs up to 16 bases
+ * MSB-first into a left-aligned u32.  Returns meta bits (FASTF_META_*). */
+uint32_t fastf_pack_umi(const char *ub, size_t len, uint32_t *umi_out);
+
+#define FASTF_META_XF_OK      0x01u   /* xf present and in {25,17}   (bam2db_ds.c:397)  */
+#define FASTF_META_HAS_UB     0x02u   /* UB tag present              (bam2db_ds.c:412)  */
+#define FASTF_META_UMI_NONNULL 0x04u  /* every base in ACGT          (bam2db_ds.c:36-41)*/
+#define FASTF_META_UMI_TOOLONG 0x08u  /* > 16 bases: not representable, engine errors   */
+#define FASTF_META_LEN_SHIFT  4       /* bits 4..6: blob byte length (len+3)/4, 0..4     */
+#define FASTF_META_LEN_MASK   0x70u
+
+/* Exact string → 64-bit key packer.  Two strings get the same key iff they are
+ * equal (for every string registered with _add and every string later passed to
+ * _pack), which is what the reference's strcmp-verified table guarantees
+ * (hashtable.c:98-115).  Key 0 means "cannot match any registered string". */
+typedef struct fastf_keydict fastf_keydict_t;
+fastf_keydict_t *fastf_keydict_create(void);
+void     fastf_keydict_destroy(fastf_keydict_t *d);
+uint64_t fastf_keydict_add(fastf_keydict_t *d, const char *s, size_t len);
+uint64_t fastf_keydict_pack(const fastf_keydict_t *d, const char *s, size_t len);
+/* fixed-stride NUL-terminated strings; present may be NULL (all present) */
+void     fastf_keydict_pack_many(const fastf_keydict_t *d, const char *strs, size_t stride,
+                                 size_t n, const uint8_t *present, uint64_t *out);
+
+/* ===================================================================== */
+/* 2b. inner seam: the engine                                             */
+/* ===================================================================== */
+
+typedef struct fastf_engine fastf_engine_t;
+
+typedef struct fastf_engine_config {
+    const uint64_t *cell_keys;     /* key of cell_index i+1 (sampled barcodes, file order) */
+    uint32_t        n_cells;
+    const uint64_t *feature_keys;  /* key of feature_index i+1                             */
+    uint32_t        n_features;
+    uint64_t        draw_threshold;/* fastf_draw_threshold(rate_depth), 0..2^32            */
+    uint32_t        umi_max_bases; /* 1..16; widths of the packed sort key follow from it  */
+    uint32_t        mt_seed;       /* engine-owned draw stream: init_genrand(seed) …       */
+    uint64_t        mt_skip;       /* … advanced by the draws SampleInt consumed           */
+    uint32_t        n_shards;      /* cell-hash shards (1 = single GPU)                    */
+    uint32_t        shard_rank;    /* which shard this engine sorts/reduces                */
+    int32_t         device;        /* HIP device ordinal                                   */
+    uint64_t        batch_records; /* staging capacity (records per push), 0 = default     */
+    uint64_t        key_capacity;  /* initial key-store capacity, 0 = default; grows       */
+} fastf_engine_config_t;
+
+/* One SoA batch of packed records (host memory; pinned is faster, any works). */
+typedef struct fastf_batch {
+    const uint64_t *cb_key;   /* 0 = CB absent / cannot match                 */
+    const uint64_t *gx_key;   /* 0 = GX absent / cannot match                 */
+    const uint32_t *umi;      /* fastf_pack_umi()                             */
+    const uint32_t *meta;     /* FASTF_META_*                                 */
+    size_t          n;
+} fastf_batch_t;
+
+typedef struct fastf_coo {
+    const uint32_t *feature;  /* 1-based feature_index */
+    const uint32_t *cell;     /* 1-based cell_index    */
+    const uint32_t *count;    /* COUNT(DISTINCT non-NULL umi) — may be 0 */
+    size_t          nnz;      /* rows, ascending (cell, feature) */
+} fastf_coo_t;
+
+typedef struct fastf_umi_rows {     /* -u output, ascending (cell, feature, blob) */
+    const uint32_t *feature, *cell, *n_copy;
+    const uint32_t *umi;            /* left-aligned 2-bit bases; valid iff nonnull[i] */
+    const uint8_t  *nonnull;
+    size_t          n;
+} fastf_umi_rows_t;
+
+int  fastf_engine_create(const fastf_engine_config_t *cfg, fastf_engine_t **out);
+void fastf_engine_destroy(fastf_engine_t *e);
+/* H2D on the engine's copy stream, probe/filter/pack on its compute stream.  The
+ * batch may be reused by the caller as soon as the call returns. */
+int  fastf_engine_push(fastf_engine_t *e, const fastf_batch_t *batch);
+/* Same, with caller-supplied draws (draws[i] belongs to the i-th CB hit of this batch). */
+int  fastf_engine_push_draws(fastf_engine_t *e, const fastf_batch_t *batch,
+                             const uint32_t *draws, size_t n_draws);
+/* Sort + segmented unique/reduce over everything pushed; results stay valid until
+ * reset/destroy.  counters = {total, sampled, sampled_valid} (bam2db_ds.c:342-344). */
+int  fastf_engine_finish(fastf_engine_t *e, fastf_coo_t *coo, uint64_t counters[3]);
+int  fastf_engine_umi_rows(fastf_engine_t *e, fastf_umi_rows_t *rows);
+int  fastf_engine_reset(fastf_engine_t *e);
+/* key layout chosen at create time */
+int  fastf_engine_key_bits(const fastf_engine_t *e, uint32_t *cell_bits, uint32_t *feature_bits,
+                           uint32_t *umi_bits, uint32_t *total_bits);
+
+/* ===================================================================== */
+/* 3. device-level entry points (all pointers are device pointers)        */
+/* ===================================================================== */
+
+/* number of CB hits in a record range (multi-GPU: draw-rank base of each shard) */
+int fastf_dev_count_hits(fastf_engine_t *e, const uint64_t *d_cb_key, uint64_t n,
+                         uint64_t *d_hits_out, void *stream);
+
+/* K1: probe + filter + pack.  d_keys_out holds n_shards buffers of `shard_stride`
+ * keys each; d_key_counts[n_shards] (u64) are appended to (not reset);
+ * d_counters[4] = {hits, sampled, sampled_valid, error bits} are added to. */
+int fastf_dev_probe_pack(fastf_engine_t *e,
+                         const uint64_t *d_cb_key, const uint64_t *d_gx_key,
+                         const uint32_t *d_umi, const uint32_t *d_meta, uint64_t n,
+                         const uint32_t *d_draws, uint64_t n_draws,
+                         uint64_t *d_keys_out, uint64_t shard_stride,
+                         uint64_t *d_key_counts, uint64_t *d_counters, void *stream);
+
+/* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
+ * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
+ * *sorted_in_tmp tells where the result landed. */
+int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
+                   const uint64_t *d_n, uint64_t max_n, uint32_t key_bits,
+                   int *sorted_in_tmp, void *stream);
+
+/* K3: segmented unique/reduce of sorted keys → COO (SoA, capacity max_n rows);
+ * *d_nnz (u64) receives the row count. */
+int fastf_dev_reduce(fastf_engine_t *e, const uint64_t *d_sorted, const uint64_t *d_n,
+                     uint64_t max_n, uint32_t *d_feature, uint32_t *d_cell,
+                     uint32_t *d_count, uint64_t *d_nnz, void *stream);
+
+/* K3u: run-length rows for -u (capacity max_n rows). */
+int fastf_dev_umi_rows(fastf_engine_t *e, const uint64_t *d_sorted, const uint64_t *d_n,
+                       uint64_t max_n, uint64_t *d_ukeys, uint32_t *d_ncopy,
+                       uint64_t *d_nrows, void *stream);
+
+/* bytes of device workspace the engine holds for sorts of up to max_n keys
+ * (grown on demand by the calls above; call once up front to avoid growth in a
+ * timed region) */
+int fastf_dev_reserve(fastf_engine_t *e, uint64_t max_records, uint64_t max_keys);
+
+/* name of the dominant kernel symbols, for profile post-processing */
+const char *fastf_kernel_names(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTF_AMD_H */

@@ -1,0 +1,96 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import fastf_amd as F
+from helpers import Case, assert_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # BASELINE config 1: 100 k records, 1 k barcodes x 500 genes, keep-all, 64-UMI pool
+    "c1_100k": dict(n=100_000, n_bar=1000, n_gene=500, umi_pool=64),
+    "c1_half": dict(n=100_000, n_bar=1000, n_gene=500, umi_pool=64, rate_cell=0.5, rate_depth=0.5),
+    "mixed": dict(n=300_000, n_bar=3000, n_gene=2000, rate_cell=0.5, rate_depth=0.5, data_seed=7,
+                  cell_dist="lognormal", gene_dist="zipf", umi_len=12, dup_factor=4.0,
+                  p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.01, p_multi_gene=0.02, p_no_ub=0.01),
+    "tiny": dict(n=37, n_bar=5, n_gene=3, umi_pool=4, p_n_umi=0.2),
+    "one_tile_edge": dict(n=8192, n_bar=50, n_gene=20, umi_pool=16),
+    "tile_plus_one": dict(n=8193, n_bar=50, n_gene=20, umi_pool=16),
+    "skewed": dict(n=200_000, n_bar=2000, n_gene=300, gene_dist="zipf", umi_pool=4096, zipf_umi=1.5, data_seed=5),
+    "depth_tiny": dict(n=50_000, n_bar=100, n_gene=50, rate_depth=0.01, umi_pool=8),
+    "cells_none": dict(n=1000, n_bar=10, n_gene=5, rate_cell=0.05),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_engine_matches_oracle(name):
+    case = Case(**CASES[name])
+    ora = case.oracle()
+    lists = case.lists()
+    umi_max = 12
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=umi_max)
+    try:
+        eng.push(*case.packed(lists))
+        res = eng.finish()
+        rows = eng.umi_rows()
+        assert_matches_oracle(res, ora, eng, case, lists, rows)
+    finally:
+        eng.close()
+
+
+def test_multi_batch_push_equals_single():
+    case = Case(n=150_000, n_bar=800, n_gene=400, rate_depth=0.7, umi_pool=256, p_unlisted_cb=0.1, p_bad_xf=0.1)
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, batch_records=20_000)
+    try:
+        cbk, gxk, umi, meta = case.packed(lists)
+        cuts = [0, 1, 4097, 50_000, 50_001, 120_000, 150_000]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.push(cbk[a:b], gxk[a:b], umi[a:b], meta[a:b])
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+        # reset + caller-supplied draws give the same answer
+        eng.reset()
+        draws = F.mt_draws(case.seed, lists.mt_skip, case.n)
+        eng.push(cbk, gxk, umi, meta, draws=draws)
+        assert_matches_oracle(eng.finish(), ora)
+    finally:
+        eng.close()
+
+
+def test_empty_input():
+    case = Case(n=10, n_bar=4, n_gene=3)
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists)
+    try:
+        res = eng.finish()
+        assert res["nnz"] == 0 and res["total"] == 0
+        assert eng.umi_rows()["n"] == 0
+    finally:
+        eng.close()
+
+
+def test_survey_edge_case_fixture():
+    """the 9-record edge-case BAM of SURVEY.md §8c (reference output recorded there)"""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_8c.json")))["edge_case"]
+    bt, ft = fx["barcodes"].encode(), fx["features"].encode()
+    recs = fx["records"]
+    flags = np.full(len(recs), 15, np.uint8)
+    xf = np.full(len(recs), 25, np.int32)
+    cb = np.array([r[0].encode() for r in recs], dtype="S8")
+    gx = np.array([r[1].encode() for r in recs], dtype="S8")
+    ub = np.array([r[2].encode() for r in recs], dtype="S16")
+    lists = F.Lists(bt, ft, 1.0, 926)
+    eng = F.Engine.from_lists(lists, umi_max_bases=16)
+    try:
+        eng.push(*F.pack_records(lists, flags, xf, cb, gx, ub))
+        res = eng.finish()
+        assert [res["total"], res["sampled"], res["valid"]] == fx["counters"]
+        rows = ["%d %d %d" % t for t in zip(res["feature"], res["cell"], res["count"])]
+        assert rows == fx["matrix_rows"]
+        assert eng.format_umi_rows(eng.umi_rows()).decode().splitlines() == fx["umi_rows"]
+    finally:
+        eng.close()
