@@ -84,7 +84,7 @@ ABI_SYMBOLS = [
     "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
-    "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_kernel_names",
+    "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_hist_reset", "fastf_kernel_names",
 ]
 
 
@@ -133,8 +133,9 @@ def lib():
     L.fastf_engine_set_timing.argtypes = [vp, C.c_int]
     L.fastf_engine_get_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
     L.fastf_dev_count_hits.argtypes = [vp, vp, u64, vp, vp]
-    L.fastf_dev_probe_pack.argtypes = [vp, vp, vp, vp, vp, u64, vp, u64, vp, u64, vp, vp, vp]
-    L.fastf_dev_sort.argtypes = [vp, vp, vp, vp, u64, u32, C.POINTER(C.c_int), vp]
+    L.fastf_dev_probe_pack.argtypes = [vp, vp, vp, vp, vp, u64, vp, u64, vp, vp, u64, vp, vp, vp]
+    L.fastf_dev_sort.argtypes = [vp, vp, vp, vp, u64, u32, u32, C.POINTER(C.c_int), vp]
+    L.fastf_dev_hist_reset.argtypes = [vp, vp]
     L.fastf_dev_reduce.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp]
     L.fastf_dev_umi_rows.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.fastf_dev_reserve.argtypes = [vp, u64, u64]

@@ -93,13 +93,15 @@ struct fastf_engine {
     u64 c_sampled = 0, c_valid = 0;
     bool finished = false; int sorted_in_tmp = 0; u64 n_sorted = 0;
     // workspace
-    DevBuf d_status, d_ticket, d_hist, d_binbase, d_cnt;
+    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_hist, d_binbase, d_cnt;
+    const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
     bool fused_hist_valid = false;
     // timing
     bool timing = false;
     hipEvent_t t_ev[2] = {nullptr, nullptr};
     double t_scatter_ms = 0; u64 t_scatter_n = 0;
     double t_k1_ms = 0; u64 t_k1_n = 0;
+    double t_k1b_ms = 0; u64 t_k1b_n = 0;
     double t_k3_ms = 0; u64 t_k3_n = 0;
     double t_count_ms = 0; u64 t_count_n = 0;
 };
@@ -219,7 +221,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_status, &e->d_ticket, &e->d_hist, &e->d_binbase, &e->d_cnt};
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_hist, &e->d_binbase, &e->d_cnt};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -244,8 +246,12 @@ static u64 max_tiles_for(u64 n, u64 tile) { return (n + tile - 1) / tile + 1; }
 static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     const u64 t1 = max_tiles_for(max_records, K1_TILE), t3 = max_tiles_for(max_keys, K3_TILE);
     const u64 ts = max_tiles_for(max_keys, SORT_TILE);
-    if (e->d_status.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
-    if (e->d_ticket.ensure(64)) return 1;
+    if (max_records && e->d_cellidx.bytes < max_records * sizeof(u32)) {
+        e->cells_cached_for = nullptr;
+        if (e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
+    }
+    if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
+    if (e->d_tilebase.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
     if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(8 * RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure(ts * RADIX * sizeof(u32))) return 1;
@@ -271,16 +277,17 @@ static void t_end(fastf_engine* e, hipStream_t s, double* acc, u64* cnt) {
 extern "C" int fastf_engine_set_timing(fastf_engine_t* e, int on) {
     if (!e) return set_err("null engine");
     e->timing = on != 0;
-    e->t_scatter_ms = e->t_k1_ms = e->t_k3_ms = e->t_count_ms = 0;
-    e->t_scatter_n = e->t_k1_n = e->t_k3_n = e->t_count_n = 0;
+    e->t_scatter_ms = e->t_k1_ms = e->t_k1b_ms = e->t_k3_ms = e->t_count_ms = 0;
+    e->t_scatter_n = e->t_k1_n = e->t_k1b_n = e->t_k3_n = e->t_count_n = 0;
     return 0;
 }
-// which: 0 = K1 probe_filter_pack, 1 = K2 scatter, 2 = K3 reduce, 3 = K2 tile_count
+// which: 0 = K1a probe_cells, 1 = K2 scatter, 2 = K3 (head_count + scan + reduce), 3 = K2 tile_count,
+//        4 = K1b filter_pack
 extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* total_ms, uint64_t* launches) {
     if (!e) return set_err("null engine");
-    const double ms[4] = {e->t_k1_ms, e->t_scatter_ms, e->t_k3_ms, e->t_count_ms};
-    const u64 n[4] = {e->t_k1_n, e->t_scatter_n, e->t_k3_n, e->t_count_n};
-    if (which < 0 || which > 3) return set_err("bad timer index");
+    const double ms[5] = {e->t_k1_ms, e->t_scatter_ms, e->t_k3_ms, e->t_count_ms, e->t_k1b_ms};
+    const u64 n[5] = {e->t_k1_n, e->t_scatter_n, e->t_k3_n, e->t_count_n, e->t_k1b_n};
+    if (which < 0 || which > 4) return set_err("bad timer index");
     *total_ms = ms[which]; *launches = n[which];
     return 0;
 }
@@ -288,52 +295,75 @@ extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* tot
 // ------------------------------------------------------------------------------------
 // device-level entry points
 // ------------------------------------------------------------------------------------
+// K1a + scan: cell index per record, hit-rank base per tile, total hits
+static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s) {
+    if (reserve_workspace(e, n, 0)) return 1;
+    const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
+    t_begin(e, s);
+    hipLaunchKernelGGL(probe_cells_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
+                       (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
+    t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
+                       (u64*)e->d_tilebase.p, tiles, d_total_out);
+    HIP_OK(hipGetLastError());
+    e->cells_cached_for = cb; e->cells_cached_n = n;
+    return 0;
+}
+
 extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key, uint64_t n,
                                     uint64_t* d_hits_out, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s));
-    if (n == 0) return 0;
-    const u32 grid = (u32)std::min<u64>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(count_hits_kernel, dim3(grid), dim3(256), 0, s, (const u64*)d_cb_key, (u64)n, e->cells, (u64*)d_hits_out);
-    HIP_OK(hipGetLastError());
-    return 0;
+    if (n == 0) { HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s)); return 0; }
+    return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s);
 }
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
-                        const u32* draws, u64 n_draws, u64* keys, u64 stride, u64* key_counts, u64* counters,
-                        u32* fused_hist, hipStream_t s) {
+                        const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
+                        u64* counters, u32* fused_hist, hipStream_t s) {
     if (n == 0) return 0;
-    if (reserve_workspace(e, n, 0)) return 1;
-    const u64 tiles = (n + K1_TILE - 1) / K1_TILE;
-    HIP_OK(hipMemsetAsync(e->d_status.p, 0, tiles * sizeof(u64), s));
-    HIP_OK(hipMemsetAsync(e->d_ticket.p, 0, 16, s));
-    ProbeParams p{};
-    p.cb = cb; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
-    p.draws = draws; p.n_draws = n_draws;
-    p.cells = e->cells; p.feats = e->feats;
+    // K1a (skipped when fastf_dev_count_hits just ran on the very same records, same stream order)
+    if (!(e->cells_cached_for == cb && e->cells_cached_n == n))
+        if (launch_probe_cells(e, cb, n, nullptr, s)) return 1;
+    e->cells_cached_for = nullptr;
+    const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
+    PackParams p{};
+    p.cell = (const u32*)e->d_cellidx.p; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
+    p.tile_base = (const u64*)e->d_tilebase.p;
+    p.draws = draws; p.n_draws = n_draws; p.draw_base = draw_base;
+    p.feats = e->feats;
     p.threshold = e->threshold; p.L = e->L;
     p.n_shards = e->n_shards;
     p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
-    p.status = (u64*)e->d_status.p; p.ticket = (u32*)e->d_ticket.p;
     p.digit_hist = (e->n_shards == 1) ? fused_hist : nullptr;
     p.hist_passes = (e->L.total_bits + 7) / 8;
     t_begin(e, s);
-    hipLaunchKernelGGL(probe_filter_pack_kernel, dim3((u32)tiles), dim3(K1_THREADS), 0, s, p);
+    hipLaunchKernelGGL(filter_pack_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, p);
     HIP_OK(hipGetLastError());
-    t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
+    t_end(e, s, &e->t_k1b_ms, &e->t_k1b_n);
+    return 0;
+}
+
+extern "C" int fastf_dev_hist_reset(fastf_engine_t* e, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
+    HIP_OK(hipMemsetAsync(e->d_hist.p, 0, 8 * RADIX * sizeof(u32), (hipStream_t)stream));
     return 0;
 }
 
 extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key, const uint64_t* d_gx_key,
                                     const uint32_t* d_umi, const uint32_t* d_meta, uint64_t n,
-                                    const uint32_t* d_draws, uint64_t n_draws, uint64_t* d_keys_out,
-                                    uint64_t shard_stride, uint64_t* d_key_counts, uint64_t* d_counters, void* stream) {
+                                    const uint32_t* d_draws, uint64_t n_draws, const uint64_t* d_draw_base,
+                                    uint64_t* d_keys_out, uint64_t shard_stride, uint64_t* d_key_counts,
+                                    uint64_t* d_counters, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
+    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
-                        (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters, nullptr, (hipStream_t)stream);
+                        (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
+                        (u32*)e->d_hist.p, (hipStream_t)stream);
 }
 
 static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits,
@@ -369,32 +399,34 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
 }
 
 extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_tmp, const uint64_t* d_n,
-                              uint64_t max_n, uint32_t key_bits, int* sorted_in_tmp, void* stream) {
+                              uint64_t max_n, uint32_t key_bits, uint32_t flags, int* sorted_in_tmp, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     int dummy = 0;
-    return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits, false,
+    return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
+                       (flags & FASTF_SORT_HIST_READY) && e->n_shards == 1,
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream);
 }
 
 template <bool UMI_ROWS>
 static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u32* feature, u32* cell,
-                         u32* count, u64* ukeys, u64* nrows, u64* err, hipStream_t s) {
-    HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s));
-    if (max_n == 0) return 0;
+                         u32* count, u64* ukeys, u64* nrows, hipStream_t s) {
+    if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
     if (reserve_workspace(e, 0, max_n)) return 1;
-    const u64 tiles = (max_n + K3_TILE - 1) / K3_TILE;
-    HIP_OK(hipMemsetAsync(e->d_status.p, 0, tiles * sizeof(u64), s));
-    HIP_OK(hipMemsetAsync(e->d_ticket.p, 0, 16, s));
+    const u32 tiles = (u32)((max_n + K3_TILE - 1) / K3_TILE);
     HIP_OK(hipMemsetAsync(count, 0, max_n * sizeof(u32), s));
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
-    p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys; p.nrows = nrows;
-    p.status = (u64*)e->d_status.p; p.ticket = (u32*)e->d_ticket.p; p.err = err;
+    p.tile_heads = (u32*)e->d_tilecnt.p; p.row_base = (const u64*)e->d_tilebase.p;
+    p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
     t_begin(e, s);
-    hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3((u32)tiles), dim3(K3_THREADS), 0, s, p);
+    hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
+                       (u64*)e->d_tilebase.p, tiles, nrows);
+    hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
+    e->cells_cached_for = nullptr;          // d_tilecnt / d_tilebase were reused
     return 0;
 }
 
@@ -403,7 +435,7 @@ extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, con
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, d_feature, d_cell, d_count, nullptr,
-                                (u64*)d_nnz, (u64*)e->d_small.p + SM_COUNTERS + 3, (hipStream_t)stream);
+                                (u64*)d_nnz, (hipStream_t)stream);
 }
 
 extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
@@ -411,7 +443,7 @@ extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, c
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<true>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, nullptr, nullptr, d_ncopy,
-                               (u64*)d_ukeys, (u64*)d_nrows, (u64*)e->d_small.p + SM_COUNTERS + 3, (hipStream_t)stream);
+                               (u64*)d_ukeys, (u64*)d_nrows, (hipStream_t)stream);
 }
 
 extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
@@ -423,8 +455,8 @@ extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
 }
 
 extern "C" const char* fastf_kernel_names(void) {
-    return "probe_filter_pack_kernel,digit_hist_kernel,bin_base_kernel,tile_count_kernel,row_scan_kernel,"
-           "scatter_kernel,reduce_kernel,count_hits_kernel";
+    return "probe_cells_kernel,scan_tiles_kernel,filter_pack_kernel,digit_hist_kernel,bin_base_kernel,"
+           "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
 }
 
 // ------------------------------------------------------------------------------------
@@ -433,7 +465,7 @@ extern "C" const char* fastf_kernel_names(void) {
 static const char* err_bits_text(u64 bits) {
     static thread_local char buf[256];
     snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s", (unsigned long long)bits,
-             (bits & ERR_SPIN_TIMEOUT) ? " inter-workgroup wait timed out;" : "",
+             (bits & ERR_RESERVED) ? " (reserved bit 0);" : "",
              (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
              (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it; key must still fit 64 bits);" : "",
              (bits & ERR_KEYS_FULL) ? " key store full;" : "");
@@ -516,7 +548,7 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
         e->fused_hist_valid = true;
     }
     if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
-                     (const u32*)(ds + o_draw), nd, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
+                     (const u32*)(ds + o_draw), nd, nullptr, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
                      small + SM_COUNTERS, (u32*)e->d_hist.p, sk))
         return 1;
     HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
@@ -576,7 +608,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
                 return 1;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
             if (launch_reduce<false>(e, sorted, small + SM_KEYCOUNT, n, (u32*)e->d_feature.p, (u32*)e->d_cell.p,
-                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, small + SM_COUNTERS + 3, s))
+                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, s))
                 return 1;
         } else {
             HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
@@ -614,7 +646,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
         if (e->d_ukeys.ensure(n * 8) || e->d_ncopy.ensure(n * 4)) return 1;
         const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
         if (launch_reduce<true>(e, sorted, small + SM_KEYCOUNT, n, nullptr, nullptr, (u32*)e->d_ncopy.p,
-                                (u64*)e->d_ukeys.p, small + SM_NROWS_U, small + SM_COUNTERS + 3, s))
+                                (u64*)e->d_ukeys.p, small + SM_NROWS_U, s))
             return 1;
         HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));

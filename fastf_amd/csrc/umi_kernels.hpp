@@ -1,13 +1,13 @@
 // umi_kernels.hpp — hand-written HIP kernels of the bam2db hot path for gfx950 (CDNA4).
 //
-//   K0  count_hits_kernel         CB probe only (draw-rank base of a shard)
-//   K1  probe_filter_pack_kernel  §3.3 chain E3..E11 of the reference loop
-//                                 (bam2db_ds.c:374-434) on packed SoA records
+//   K1a probe_cells_kernel        CB probe, E2/E3 of the reference loop (bam2db_ds.c:366-380)
+//   K1b filter_pack_kernel        E4..E12 (:385-435): depth draw by hit rank, xf, GX probe,
+//                                 UB, packed 64-bit (cell, feature, umi) key
 //   K2  digit_hist / tile_count / row_scan / scatter: 64-bit LSD radix sort,
 //                                 8-bit digits — stands in for SQLite's sorter
 //                                 behind GROUP BY (bam2db_ds.c:480-483)
-//   K3  reduce_kernel             COUNT(DISTINCT umi) GROUP BY cell, feature
-//   K3u umi_rows_kernel           COUNT(*) GROUP BY cell, feature, umi (-u, :539-542)
+//   K3  head_count / reduce       COUNT(DISTINCT umi) GROUP BY cell, feature
+//   K3u (same, UMI_ROWS=true)     COUNT(*) GROUP BY cell, feature, umi (-u, :539-542)
 //
 // All of it is integer indexing: wave64 ballots/mbcnt for ranking, LDS for the
 // tile-local reorder, coalesced 8-byte streams to HBM.  No MFMA by design.
@@ -21,10 +21,9 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int WAVE = 64;
-constexpr u32 SPIN_LIMIT = 1u << 22;      // every inter-workgroup wait is bounded
 
 // error bits accumulated in counters[3]
-constexpr u64 ERR_SPIN_TIMEOUT = 1;
+constexpr u64 ERR_RESERVED = 1;            // (was: inter-workgroup wait timeout; no kernel waits on another now)
 constexpr u64 ERR_DRAWS_SHORT  = 2;
 constexpr u64 ERR_UMI_TOOLONG  = 4;
 constexpr u64 ERR_KEYS_FULL    = 8;
@@ -89,58 +88,6 @@ __device__ __forceinline__ u32 table_probe(const Table t, u64 key) {
 }
 
 // ------------------------------------------------------------------------------------
-// chained scan across tiles: 8-byte {flag:2, value:62} granules, one relaxed agent-scope
-// store / load each (the value IS the flag — no fence needed), wave-parallel look-back.
-// ------------------------------------------------------------------------------------
-constexpr u64 ST_AGG = 1ULL << 62, ST_INC = 2ULL << 62, ST_VAL = (1ULL << 62) - 1;
-
-__device__ __forceinline__ void st_store(u64* p, u64 v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 st_load(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Called by all 64 lanes of ONE wave.  Publishes `aggregate` for `tile`, returns the sum of
-// the aggregates of tiles [0, tile).  *timeout is set if a predecessor never shows up.
-__device__ __forceinline__ u64 chained_scan_wave(u64* status, u32 tile, u64 aggregate, int lane, bool* timeout) {
-    if (lane == 0) st_store(&status[tile], (tile == 0 ? ST_INC : ST_AGG) | aggregate);
-    if (tile == 0) return 0;
-    u64 excl = 0;
-    long long base = (long long)tile - 1;       // lane 0 looks at the nearest predecessor
-    u32 spins = 0;
-    for (;;) {
-        const long long idx = base - lane;
-        const u64 s = (idx >= 0) ? st_load(&status[idx]) : ST_INC;   // tile -1: inclusive 0
-        const u32 flag = (u32)(s >> 62);
-        const u64 m_inv = __ballot(flag == 0);
-        const u64 m_inc = __ballot(flag == 2);
-        const int first_inv = m_inv ? __builtin_ctzll(m_inv) : 64;
-        const int first_inc = m_inc ? __builtin_ctzll(m_inc) : 64;
-        if (first_inc < first_inv) {                                // resolved
-            excl += wave_sum64(lane <= first_inc ? (s & ST_VAL) : 0);
-            break;
-        }
-        if (first_inv > 0) {                                        // a run of aggregates
-            excl += wave_sum64(lane < first_inv ? (s & ST_VAL) : 0);
-            base -= first_inv;
-            if (first_inv == 64) continue;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > SPIN_LIMIT) { *timeout = true; break; }
-    }
-    if (lane == 0) st_store(&status[tile], ST_INC | (excl + aggregate));
-    return excl;
-}
-
-// ordered tile ticket: predecessors of a ticket are always running or done
-__device__ __forceinline__ u32 take_ticket(u32* counter, u32* s_slot) {
-    if (threadIdx.x == 0) *s_slot = atomicAdd(counter, 1u);
-    __syncthreads();
-    return *s_slot;
-}
-
-// ------------------------------------------------------------------------------------
 // packed sort key layout:  [cell][feature][nonnull:1][umi: 2*Lmax bits][len]
 // ------------------------------------------------------------------------------------
 struct KeyLayout {
@@ -171,48 +118,124 @@ __device__ __forceinline__ bool umi_overflows(const KeyLayout L, u32 umi, u32 me
 }
 
 // ------------------------------------------------------------------------------------
-// K0: count CB hits
+// batched probe: N independent first-slot loads in flight per lane (the tables live in L2,
+// so the cost is latency, not bytes); the rare collision continues in a scalar loop.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void count_hits_kernel(const u64* __restrict__ cb, u64 n, Table cells, u64* out) {
-    u32 local = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
-        local += table_probe(cells, cb[i]) != 0;
-    local = wave_sum32(local);
-    __shared__ u32 s[4];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    if (lane == 0) s[w] = local;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (u64)s[0] + s[1] + s[2] + s[3]);
+__device__ __forceinline__ u32 table_probe_from(const Table t, u64 key, u32 h) {
+    for (u32 i = 0; i <= t.mask; ++i) {
+        const uint4 s = t.slots[h];
+        const u64 k = ((u64)s.y << 32) | s.x;
+        if (k == key) return s.z;
+        if (k == 0) return 0;
+        h = (h + 1) & t.mask;
+    }
+    return 0;
+}
+
+template <int N>
+__device__ __forceinline__ void table_probe_batch(const Table t, const u64 (&key)[N], u32 (&val)[N]) {
+    u32 h[N]; uint4 s[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) h[j] = (u32)mix64(key[j]) & t.mask;
+#pragma unroll
+    for (int j = 0; j < N; ++j) s[j] = key[j] ? t.slots[h[j]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const u64 k = ((u64)s[j].y << 32) | s[j].x;
+        u32 v = 0;
+        if (key[j] != 0) {
+            if (k == key[j]) v = s[j].z;
+            else if (k != 0) v = table_probe_from(t, key[j], (h[j] + 1) & t.mask);
+        }
+        val[j] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------
-// K1: probe + filter + pack
+// exclusive scan of per-tile counts (one workgroup; T is a few thousand entries)
 // ------------------------------------------------------------------------------------
-struct ProbeParams {
-    const u64* cb; const u64* gx; const u32* umi; const u32* meta; u64 n;
-    const u32* draws; u64 n_draws;
-    Table cells, feats;
-    u64 threshold;                 // keep iff draw < threshold
-    KeyLayout L;
-    u32 n_shards;
-    u64* keys; u64 shard_stride;   // keys + s*shard_stride
-    u64* key_counts;               // [n_shards], appended
-    u64* counters;                 // {hits, sampled, valid, err}
-    u64* status; u32* ticket;      // chained scan workspace (zeroed per launch)
-    u32* digit_hist;               // optional fused per-digit histograms [passes][256] (n_shards==1)
-    u32 hist_passes;
-};
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(const u32* __restrict__ in, u64* __restrict__ out, u32 T,
+                                                          u64* __restrict__ total_out) {
+    __shared__ u32 s_w[16];
+    __shared__ u64 s_carry;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < T; t0 += 1024) {
+        const u32 t = t0 + threadIdx.x;
+        const u32 v = t < T ? in[t] : 0;
+        const u32 inc = wave_incl_scan32(v, lane);
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        u64 off = s_carry;
+        for (int i = 0; i < w; ++i) off += s_w[i];
+        if (t < T) out[t] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
 
+// ------------------------------------------------------------------------------------
+// K1a: CB probe (E2/E3, bam2db_ds.c:366-380) → cell index per record + hits per tile
+// K1b: depth draw by hit rank, xf, feature probe, UB, key pack (E4..E12, :385-435)
+// The hit rank of a record (= its position in the MT draw stream) is
+//   tile_base[tile] (scan of K1a's counts) + rank inside the tile (ballots, record order).
+// ------------------------------------------------------------------------------------
 constexpr int K1_THREADS = 512, K1_IPT = 8, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
 
 __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
 }
 
-__global__ __launch_bounds__(K1_THREADS) void probe_filter_pack_kernel(const ProbeParams p) {
-    __shared__ u32 s_slot;
+__global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __restrict__ cb, u64 n, Table cells,
+                                                                 u32* __restrict__ cell_out, u32* __restrict__ tile_hits) {
+    __shared__ u32 s_w[K1_WAVES];
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u64 base = (u64)blockIdx.x * K1_TILE;
+    u64 key[K1_IPT]; u32 cell[K1_IPT];
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        const u64 idx = base + (u64)j * K1_THREADS + tid;
+        key[j] = idx < n ? cb[idx] : 0;
+    }
+    table_probe_batch<K1_IPT>(cells, key, cell);
+    u32 hits = 0;
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        const u64 idx = base + (u64)j * K1_THREADS + tid;
+        if (idx < n) cell_out[idx] = cell[j];
+        hits += cell[j] != 0;
+    }
+    hits = wave_sum32(hits);
+    if (lane == 0) s_w[w] = hits;
+    __syncthreads();
+    if (tid == 0) {
+        u32 t = 0;
+        for (int i = 0; i < K1_WAVES; ++i) t += s_w[i];
+        tile_hits[blockIdx.x] = t;
+    }
+}
+
+struct PackParams {
+    const u32* cell; const u64* gx; const u32* umi; const u32* meta; u64 n;
+    const u64* tile_base;          // exclusive scan of tile_hits
+    const u32* draws; u64 n_draws;
+    const u64* draw_base;          // optional device-side offset into draws (sharded runs)
+    Table feats;
+    u64 threshold;                 // keep iff draw < threshold
+    KeyLayout L;
+    u32 n_shards;
+    u64* keys; u64 shard_stride;   // keys + s*shard_stride
+    u64* key_counts;               // [n_shards], appended
+    u64* counters;                 // {hits, sampled, valid, err}
+    u32* digit_hist;               // optional fused per-digit histograms [passes][256] (n_shards==1)
+    u32 hist_passes;
+};
+
+__global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParams p) {
     __shared__ u32 s_cnt[K1_IPT * K1_WAVES];       // hits per (item, wave), then exclusive
-    __shared__ u64 s_tile_base;
     __shared__ u32 s_red[3][K1_WAVES];
     __shared__ u32 s_shard_cnt[8];
     __shared__ u64 s_shard_base[8];
@@ -220,70 +243,77 @@ __global__ __launch_bounds__(K1_THREADS) void probe_filter_pack_kernel(const Pro
     __shared__ u32 s_hist[8 * 256];
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const u32 tile = take_ticket(p.ticket, &s_slot);
+    const u32 tile = blockIdx.x;
     const u64 base = (u64)tile * K1_TILE;
-    if (base >= p.n) return;                     // uniform: ticket beyond the batch
 
     if (tid < 8) s_shard_cnt[tid] = 0;
     if (tid == 0) s_err = 0;
     if (p.digit_hist) for (int i = tid; i < (int)p.hist_passes * 256; i += K1_THREADS) s_hist[i] = 0;
 
-    // ---- stage 1: loads + CB probe (E2/E3, bam2db_ds.c:366-380) ----
+    // ---- loads; hit ranks in record order (item-major, then wave, then lane) ----
     u64 gxk[K1_IPT]; u32 umi[K1_IPT], meta[K1_IPT], cell[K1_IPT], hrank[K1_IPT];
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
         const u64 idx = base + (u64)j * K1_THREADS + tid;
         const bool in = idx < p.n;
-        const u64 cbk = in ? p.cb[idx] : 0;
+        cell[j] = in ? p.cell[idx] : 0;
         gxk[j]  = in ? p.gx[idx] : 0;
         umi[j]  = in ? p.umi[idx] : 0;
         meta[j] = in ? p.meta[idx] : 0;
-        cell[j] = table_probe(p.cells, cbk);
+    }
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
         const u64 hm = __ballot(cell[j] != 0);
         hrank[j] = rank_below(hm);
         if (lane == 0) s_cnt[j * K1_WAVES + w] = (u32)__popcll(hm);
     }
     __syncthreads();
-
-    // ---- stage 2: hit ranks in record order → draw index (E4, :385) ----
     if (w == 0) {
-        u32 c = (lane < K1_IPT * K1_WAVES) ? s_cnt[lane] : 0;     // 64 entries exactly
+        const u32 c = s_cnt[lane];                                  // exactly 64 entries
         const u32 inc = wave_incl_scan32(c, lane);
-        if (lane < K1_IPT * K1_WAVES) s_cnt[lane] = inc - c;
-        const u32 total = __shfl(inc, WAVE - 1, WAVE);
-        bool timeout = false;
-        const u64 excl = chained_scan_wave(p.status, tile, total, lane, &timeout);
-        if (lane == 0) { s_tile_base = excl; if (timeout) s_err = 1; }
+        s_cnt[lane] = inc - c;
     }
     __syncthreads();
-    const u64 tile_base = s_tile_base;
+    const u64 tile_base = p.tile_base[tile] + (p.draw_base ? *p.draw_base : 0);
 
-    // ---- stage 3: depth draw, xf, feature probe, UB, key (E5..E11, :387-434) ----
+    // ---- depth draw (E4/E5 :385-390), xf (E7 :394-400) ----
     u32 n_hit = 0, n_samp = 0, n_valid = 0, errs = 0;
+    u32 draw[K1_IPT];
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        draw[j] = 0;
+        if (cell[j] != 0) {
+            const u64 r = tile_base + s_cnt[j * K1_WAVES + w] + hrank[j];
+            if (r < p.n_draws) draw[j] = p.draws[r];
+            else { cell[j] = 0; n_hit++; errs |= (u32)ERR_DRAWS_SHORT; }
+        }
+    }
+    u64 fkey[K1_IPT]; u32 feat[K1_IPT];
+#pragma unroll
+    for (int j = 0; j < K1_IPT; ++j) {
+        bool alive = cell[j] != 0;
+        n_hit += alive;
+        alive = alive && (u64)draw[j] < p.threshold;
+        n_samp += alive;                                             // E6 :392
+        alive = alive && (meta[j] & META_XF_OK);
+        fkey[j] = alive ? gxk[j] : 0;
+    }
+    table_probe_batch<K1_IPT>(p.feats, fkey, feat);                  // E8 :403-410
+
+    // ---- UB (E9 :412-416), key (E10/E11), slot in the tile-local shard list ----
     u64 key[K1_IPT]; u32 pos[K1_IPT]; u32 shard[K1_IPT]; bool emit[K1_IPT];
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
-        emit[j] = false; key[j] = 0; pos[j] = 0; shard[j] = 0;
-        bool alive = cell[j] != 0;
-        n_hit += alive;
-        if (alive) {
-            const u64 r = tile_base + s_cnt[j * K1_WAVES + w] + hrank[j];
-            if (r < p.n_draws) alive = (u64)p.draws[r] < p.threshold;
-            else { alive = false; errs |= (u32)ERR_DRAWS_SHORT; }
-        }
-        n_samp += alive;                                             // E6 :392
-        alive = alive && (meta[j] & META_XF_OK);                     // E7 :394-400
-        u32 feat = 0;
-        if (alive) feat = table_probe(p.feats, gxk[j]);              // E8 :403-410
-        alive = alive && feat != 0 && (meta[j] & META_HAS_UB);       // E9 :412-416
+        key[j] = 0; pos[j] = 0; shard[j] = 0;
+        const bool alive = feat[j] != 0 && (meta[j] & META_HAS_UB);
         if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
         if (alive) {
             n_valid++;                                               // E12 :435
-            key[j] = make_key(p.L, cell[j], feat, umi[j], meta[j]);  // E10/E11
+            key[j] = make_key(p.L, cell[j], feat[j], umi[j], meta[j]);
             shard[j] = p.n_shards > 1 ? shard_of(cell[j], p.n_shards) : 0;
         }
         emit[j] = alive;
-        // reserve a slot in the tile-local shard list (order is irrelevant: keys are sorted next)
+        // order inside a shard list is irrelevant: the keys are sorted next
         for (u32 s = 0; s < p.n_shards; ++s) {
             const u64 m = __ballot(alive && shard[j] == s);
             if (m) {
@@ -298,7 +328,7 @@ __global__ __launch_bounds__(K1_THREADS) void probe_filter_pack_kernel(const Pro
         }
     }
 
-    // ---- stage 4: counters + global slot reservation ----
+    // ---- counters + global slot reservation ----
     n_hit = wave_sum32(n_hit); n_samp = wave_sum32(n_samp); n_valid = wave_sum32(n_valid);
     if (lane == 0) { s_red[0][w] = n_hit; s_red[1][w] = n_samp; s_red[2][w] = n_valid; }
     if (errs) atomicOr(&s_err, errs);
@@ -519,33 +549,56 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
 // K3 / K3u: segmented unique + reduce over the sorted keys.
 //   UMI_ROWS = false: one row per (cell, feature); count = distinct non-NULL umi keys
 //   UMI_ROWS = true : one row per distinct key;    count = copies of that key
-// Row index = chained scan of the head flags; counts of groups that fit in one
-// wave-item are stored plainly, the pieces of groups that straddle a wave-item are
-// added atomically (count[] is zeroed before the launch).
+// K3a counts group heads per tile, scan_tiles_kernel turns that into row bases, K3b writes
+// the rows: counts of groups that fit in one wave-item are stored plainly, the pieces of
+// groups that straddle a wave-item are added atomically (count[] is zeroed before).
 // ------------------------------------------------------------------------------------
 struct ReduceParams {
     const u64* keys; const u64* n_ptr;
     KeyLayout L; u32 feat_mask;
+    u32* tile_heads;                       // K3a out
+    const u64* row_base;                   // K3b in (scan of tile_heads)
     u32* feature; u32* cell; u32* count;   // UMI_ROWS: feature/cell unused
     u64* ukeys;                            // UMI_ROWS only
-    u64* nrows;
-    u64* status; u32* ticket; u64* err;
 };
 
 constexpr int K3_THREADS = 512, K3_IPT = 8, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
 
 template <bool UMI_ROWS>
+__global__ __launch_bounds__(K3_THREADS) void head_count_kernel(const ReduceParams p) {
+    __shared__ u32 s_w[K3_WAVES];
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u64 n = *p.n_ptr;
+    const u64 base = (u64)blockIdx.x * K3_TILE;
+    const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
+    u32 heads = 0;
+#pragma unroll
+    for (int j = 0; j < K3_IPT; ++j) {
+        const u64 idx = base + (u64)j * K3_THREADS + tid;
+        if (idx < n) {
+            const u64 k = p.keys[idx];
+            heads += idx == 0 || (k >> gshift) != (p.keys[idx - 1] >> gshift);
+        }
+    }
+    heads = wave_sum32(heads);
+    if (lane == 0) s_w[w] = heads;
+    __syncthreads();
+    if (tid == 0) {
+        u32 t = 0;
+        for (int i = 0; i < K3_WAVES; ++i) t += s_w[i];
+        p.tile_heads[blockIdx.x] = t;
+    }
+}
+
+template <bool UMI_ROWS>
 __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p) {
-    __shared__ u32 s_slot;
     __shared__ u32 s_cnt[K3_IPT * K3_WAVES];
-    __shared__ u64 s_base;
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const u32 tile = take_ticket(p.ticket, &s_slot);
+    const u32 tile = blockIdx.x;
     const u64 n = *p.n_ptr;
-    const u32 T = (u32)((n + K3_TILE - 1) / K3_TILE);
-    if (tile >= T) return;
     const u64 base = (u64)tile * K3_TILE;
+    if (base >= n) return;
     const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
     const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
 
@@ -568,17 +621,9 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
         const u32 c = s_cnt[lane];                       // exactly 64 entries
         const u32 inc = wave_incl_scan32(c, lane);
         s_cnt[lane] = inc - c;
-        const u32 total = __shfl(inc, WAVE - 1, WAVE);
-        bool timeout = false;
-        const u64 excl = chained_scan_wave(p.status, tile, total, lane, &timeout);
-        if (lane == 0) {
-            s_base = excl;
-            if (timeout) atomicOr(p.err, ERR_SPIN_TIMEOUT);
-            if (tile == T - 1) *p.nrows = excl + total;
-        }
     }
     __syncthreads();
-    const u64 row_base = s_base;
+    const u64 row_base = p.row_base[tile];
     const u64 le = (lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1);
 #pragma unroll
     for (int j = 0; j < K3_IPT; ++j) {

@@ -1,0 +1,163 @@
+"""Sharded (multi-GPU) host path: one process per GPU, torch.distributed over RCCL.
+
+Partitioning: every rank owns a contiguous slice of the record stream and
+runs K1 on it; a key belongs to shard hash(cell_index) mod G, so all UMIs of a
+(cell, feature) group meet on one GPU.  Steps of one pass:
+
+  1. K0 hit count of the local slice → all_gather (one u64 per rank) → draw-rank base,
+     so that the keep/drop decision of record i uses the same MT draw as in a serial run
+     (bam2db_ds.c:385 is consumed only by CB hits, in record order);
+  2. K1 probe/filter/pack, keys written straight into one buffer per destination shard;
+  3. ONE exchange: all_to_all of the per-destination counts, then of the keys (xGMI);
+  4. local K2 sort + K3 reduce on the received keys;
+  5. counters all_reduce(sum); COO rows stay on their shard (gather_coo() merges them).
+
+The device stages are injected (``stages``): the default is the HIP engine; the CPU test
+suite drives the same orchestration over gloo with test doubles.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def owner_of_cell(cell_index: np.ndarray, n_shards: int) -> np.ndarray:
+    """host mirror of shard_of() in umi_kernels.hpp (murmur3 finaliser, top 32 bits, mod G)"""
+    x = cell_index.astype(np.uint64)
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xff51afd7ed558ccd)
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xc4ceb9fe1a85ec53)
+    x ^= x >> np.uint64(33)
+    return ((x >> np.uint64(32)) % np.uint64(n_shards)).astype(np.int64)
+
+
+class HipStages:
+    """device stages backed by libfastf_amd.so (fastf_dev_* entry points)"""
+
+    def __init__(self, engine, device):
+        self.eng, self.device = engine, device
+
+    def _s(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def count_hits(self, cb, n, out_hits):
+        self.eng.dev_count_hits(cb.data_ptr(), n, out_hits.data_ptr(), self._s())
+
+    def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters):
+        self.eng.dev_probe_pack(cb.data_ptr(), gx.data_ptr(), umi.data_ptr(), meta.data_ptr(), n,
+                                draws.data_ptr(), draws.numel(), keys_out.data_ptr(), stride,
+                                key_counts.data_ptr(), counters.data_ptr(), self._s(),
+                                d_draw_base=draw_base.data_ptr())
+
+    def hist_reset(self):
+        self.eng.dev_hist_reset(self._s())
+
+    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, hist_ready=False):
+        in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
+                                   hist_ready=hist_ready)
+        src = tmp if in_tmp else keys
+        self.eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, feature.data_ptr(), cell.data_ptr(),
+                            count.data_ptr(), nnz.data_ptr(), self._s())
+        return src
+
+
+class ShardedPass:
+    """Buffers + orchestration of one sharded pass; reusable across steps (bench loop)."""
+
+    def __init__(self, stages, n_local_max, device, group=None):
+        self.st, self.dev, self.group = stages, device, group
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        G, n = self.G, int(n_local_max)
+        i64, i32 = torch.int64, torch.int32
+        self.stride = n
+        self.keys_out = torch.empty((G, n), dtype=i64, device=device)
+        self.key_counts = torch.zeros(G, dtype=i64, device=device)
+        self.recv_counts = torch.zeros(G, dtype=i64, device=device)
+        self.counters = torch.zeros(4, dtype=i64, device=device)
+        self.hits = torch.zeros(1, dtype=i64, device=device)
+        self.all_hits = torch.zeros(G, dtype=i64, device=device)
+        self.draw_base = torch.zeros(1, dtype=i64, device=device)
+        self.recv_cap = G * n
+        self.recv = torch.empty(self.recv_cap, dtype=i64, device=device)
+        self.tmp = torch.empty(self.recv_cap, dtype=i64, device=device)
+        self.d_n = torch.zeros(1, dtype=i64, device=device)
+        self.feature = torch.empty(self.recv_cap, dtype=i32, device=device)
+        self.cell = torch.empty(self.recv_cap, dtype=i32, device=device)
+        self.count = torch.empty(self.recv_cap, dtype=i32, device=device)
+        self.nnz = torch.zeros(1, dtype=i64, device=device)
+        self.n_recv = 0
+        self.sorted = None
+
+    def run(self, cb, gx, umi, meta, n, draws):
+        """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident)."""
+        G, st = self.G, self.st
+        self.key_counts.zero_()
+        self.counters.zero_()
+        # 1. draw-rank base
+        if G > 1:
+            st.count_hits(cb, n, self.hits)
+            dist.all_gather_into_tensor(self.all_hits, self.hits, group=self.group)
+            self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
+        else:
+            self.draw_base.zero_()
+            st.hist_reset()                             # single shard: K1b accumulates the digit histograms
+        # 2. K1
+        st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
+                      self.key_counts, self.counters)
+        # 3. the exchange
+        if G > 1:
+            dist.all_to_all_single(self.recv_counts, self.key_counts, group=self.group)
+            send = self.key_counts.tolist()            # the one host sync of the pass
+            recv = self.recv_counts.tolist()
+            self.n_recv = int(sum(recv))
+            if dist.get_backend(self.group) == "nccl":
+                outs, o = [], 0
+                for c in recv:
+                    outs.append(self.recv[o:o + c]); o += c
+                ins = [self.keys_out[g, :send[g]] for g in range(G)]
+                dist.all_to_all(outs, ins, group=self.group)
+            else:                                       # gloo: contiguous send buffer
+                flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
+                dist.all_to_all_single(self.recv[:self.n_recv], flat, recv, send, group=self.group)
+            self.d_n.fill_(self.n_recv)
+            keys = self.recv
+            dist.all_reduce(self.counters[:3], group=self.group)
+        else:
+            self.d_n.copy_(self.key_counts[:1])
+            self.n_recv = n                             # upper bound; the device reads d_n
+            keys = self.keys_out.view(-1)
+        # 4. local sort + reduce
+        self.sorted = st.sort_reduce(keys, self.tmp, self.d_n, self.n_recv, self.feature, self.cell,
+                                     self.count, self.nnz, hist_ready=(G == 1))
+
+    def local_coo(self):
+        z = int(self.nnz.item())
+        return (self.feature[:z].cpu().numpy().astype(np.int64), self.cell[:z].cpu().numpy().astype(np.int64),
+                self.count[:z].cpu().numpy().astype(np.int64))
+
+    def gather_coo(self):
+        """All shards' rows on every rank, merged into the reference order (cell, feature)."""
+        f, c, k = self.local_coo()
+        if self.G == 1:
+            return f, c, k
+        z = torch.tensor([len(f)], dtype=torch.int64, device=self.dev)
+        zs = torch.zeros(self.G, dtype=torch.int64, device=self.dev)
+        dist.all_gather_into_tensor(zs, z, group=self.group)
+        zmax = int(zs.max().item())
+        pad = torch.zeros((3, zmax), dtype=torch.int64, device=self.dev)
+        pad[0, :len(f)] = torch.from_numpy(f).to(self.dev)
+        pad[1, :len(f)] = torch.from_numpy(c).to(self.dev)
+        pad[2, :len(f)] = torch.from_numpy(k).to(self.dev)
+        allp = torch.zeros((self.G, 3, zmax), dtype=torch.int64, device=self.dev)
+        dist.all_gather_into_tensor(allp.view(-1), pad.view(-1), group=self.group)
+        allp, zs = allp.cpu().numpy(), zs.cpu().numpy()
+        F = np.concatenate([allp[g, 0, :zs[g]] for g in range(self.G)])
+        Cc = np.concatenate([allp[g, 1, :zs[g]] for g in range(self.G)])
+        K = np.concatenate([allp[g, 2, :zs[g]] for g in range(self.G)])
+        order = np.lexsort((F, Cc))
+        return F[order], Cc[order], K[order]
+
+    def global_counters(self):
+        c = self.counters.cpu().numpy()
+        return int(c[0]), int(c[1]), int(c[2]), int(c[3])

@@ -228,14 +228,18 @@ class Engine:
         check(self._L.fastf_dev_count_hits(self._h, d_cb, n, d_out, stream))
 
     def dev_probe_pack(self, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_keys, shard_stride,
-                       d_key_counts, d_counters, stream=0):
-        check(self._L.fastf_dev_probe_pack(self._h, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws,
+                       d_key_counts, d_counters, stream=0, d_draw_base=None):
+        check(self._L.fastf_dev_probe_pack(self._h, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_draw_base,
                                            d_keys, shard_stride, d_key_counts, d_counters, stream))
 
-    def dev_sort(self, d_keys, d_tmp, d_n, max_n, key_bits=None, stream=0) -> bool:
+    def dev_hist_reset(self, stream=0):
+        check(self._L.fastf_dev_hist_reset(self._h, stream))
+
+    def dev_sort(self, d_keys, d_tmp, d_n, max_n, key_bits=None, stream=0, hist_ready=False) -> bool:
         in_tmp = C.c_int(0)
         check(self._L.fastf_dev_sort(self._h, d_keys, d_tmp, d_n, max_n,
-                                     self.key_bits if key_bits is None else key_bits, C.byref(in_tmp), stream))
+                                     self.key_bits if key_bits is None else key_bits,
+                                     1 if hist_ready else 0, C.byref(in_tmp), stream))
         return bool(in_tmp.value)
 
     def dev_reduce(self, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz, stream=0):

@@ -163,25 +163,31 @@ int  fastf_engine_key_bits(const fastf_engine_t *e, uint32_t *cell_bits, uint32_
 /* 3. device-level entry points (all pointers are device pointers)        */
 /* ===================================================================== */
 
-/* number of CB hits in a record range (multi-GPU: draw-rank base of each shard) */
+/* number of CB hits in a record range (multi-GPU: draw-rank base of each shard).  Runs K1a;
+ * a fastf_dev_probe_pack on the same d_cb_key/n right after reuses its result. */
 int fastf_dev_count_hits(fastf_engine_t *e, const uint64_t *d_cb_key, uint64_t n,
                          uint64_t *d_hits_out, void *stream);
 
 /* K1: probe + filter + pack.  d_keys_out holds n_shards buffers of `shard_stride`
  * keys each; d_key_counts[n_shards] (u64) are appended to (not reset);
- * d_counters[4] = {hits, sampled, sampled_valid, error bits} are added to. */
+ * d_counters[4] = {hits, sampled, sampled_valid, error bits} are added to.
+ * The i-th CB hit of this range uses d_draws[*d_draw_base + i] (d_draw_base may be NULL = 0):
+ * a sharded run keeps the whole draw stream resident and passes its hit-rank base here. */
 int fastf_dev_probe_pack(fastf_engine_t *e,
                          const uint64_t *d_cb_key, const uint64_t *d_gx_key,
                          const uint32_t *d_umi, const uint32_t *d_meta, uint64_t n,
-                         const uint32_t *d_draws, uint64_t n_draws,
+                         const uint32_t *d_draws, uint64_t n_draws, const uint64_t *d_draw_base,
                          uint64_t *d_keys_out, uint64_t shard_stride,
                          uint64_t *d_key_counts, uint64_t *d_counters, void *stream);
 
 /* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
  * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
  * *sorted_in_tmp tells where the result landed. */
+#define FASTF_SORT_HIST_READY 1u   /* digit histograms were accumulated by fastf_dev_probe_pack
+                                      (single shard) since the last fastf_dev_hist_reset       */
+int fastf_dev_hist_reset(fastf_engine_t *e, void *stream);
 int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
-                   const uint64_t *d_n, uint64_t max_n, uint32_t key_bits,
+                   const uint64_t *d_n, uint64_t max_n, uint32_t key_bits, uint32_t flags,
                    int *sorted_in_tmp, void *stream);
 
 /* K3: segmented unique/reduce of sorted keys → COO (SoA, capacity max_n rows);
