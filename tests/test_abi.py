@@ -1,0 +1,74 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/fastf_amd.h declares,
+and refuses to compute without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import fastf_amd as F
+from fastf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "fastf_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(fastf_[a-z0-9_]+|bam2db|cmd_bam2db|_umi_copies_flag)\s*\(", txt))
+    names.add("_umi_copies_flag")
+    names -= {"fastf_mt", "fastf_engine_config", "fastf_batch", "fastf_coo", "fastf_umi_rows"}
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.lib_path())
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), "missing export: " + name
+    for name in _lib.ABI_SYMBOLS:
+        assert name in declared or name == "_umi_copies_flag", name
+
+
+def test_no_reference_or_oracle_in_the_product_binary():
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle_" not in out
+    ldd = subprocess.run(["ldd", _lib.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "sqlite" not in ldd
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_engine_fails_loudly_without_gpu():
+    cells = np.array([1 << 62 | 5], dtype=np.uint64)
+    feats = np.array([2 << 62 | 7], dtype=np.uint64)
+    with pytest.raises(F.FastfError) as ei:
+        F.Engine(cells, feats)
+    assert "no CPU fallback" in str(ei.value)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    from fastf_amd import synth
+    bt, ft, bar, genes = synth.make_lists(5, 3)
+    fl, xf, cb, gx, ub = synth.make_records(20, bar, genes)
+    bam = tmp_path / "x.bam"
+    synth.write_bam(str(bam), fl, xf, cb, gx, ub)
+    (tmp_path / "b.tsv").write_bytes(bt)
+    (tmp_path / "f.tsv").write_bytes(ft)
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(tmp_path / "b.tsv"), "-f", str(tmp_path / "f.tsv"),
+                        "-o", str(tmp_path), "-c", "1", "-r", "1"], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "bam2db failed" in r.stderr and "no CPU fallback" in r.stderr
+    assert not (tmp_path / "matrix.mtx.gz").exists()
+
+
+def test_cli_argument_errors(tmp_path):
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(tmp_path / "missing.bam")], capture_output=True, text=True)
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    r = subprocess.run([_lib.cli_path(), "bam2db", "--bogus"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown option" in r.stderr
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--umicopies" in r.stdout

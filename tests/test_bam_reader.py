@@ -1,0 +1,107 @@
+"""BGZF/BAM front end of the product (host C, no GPU): records decoded from a BAM file give
+the same packed SoA as packing the generator's strings directly."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import fastf_amd as F
+from fastf_amd import synth, _lib
+from helpers import Case
+
+
+def read_all(path, lists, cap=1000):
+    L = _lib.lib()
+    h = L.fastf_bam_open(str(path).encode(), 0)
+    assert h, L.fastf_last_error()
+    outs = [[], [], [], []]
+    try:
+        while True:
+            cb = np.empty(cap, np.uint64); gx = np.empty(cap, np.uint64)
+            um = np.empty(cap, np.uint32); me = np.empty(cap, np.uint32)
+            n = L.fastf_bam_read_batch(h, lists.cell_dict, lists.feat_dict, cb.ctypes.data, gx.ctypes.data,
+                                       um.ctypes.data, me.ctypes.data, cap)
+            assert n >= 0, L.fastf_last_error()
+            if n == 0:
+                break
+            for o, a in zip(outs, (cb, gx, um, me)):
+                o.append(a[:n].copy())
+    finally:
+        L.fastf_bam_close(h)
+    return [np.concatenate(o) if o else np.zeros(0) for o in outs]
+
+
+@pytest.mark.parametrize("xf_type", [b"C", b"c", b"i", b"S"])
+def test_bam_roundtrip_equals_direct_packing(tmp_path, xf_type):
+    case = Case(n=30000, n_bar=300, n_gene=120, umi_pool=128, p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.2,
+                p_n_umi=0.02, p_multi_gene=0.05, p_no_ub=0.03)
+    lists = case.lists()
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, xf_type=xf_type)
+    got = read_all(bam, lists, cap=7001)
+    want = case.packed(lists)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_bam_other_aux_types_and_tag_order(tmp_path):
+    """tags of every aux type before/between the ones we need; first occurrence wins (bam_aux_get)"""
+    case = Case(n=500, n_bar=20, n_gene=10, umi_pool=8)
+    lists = case.lists()
+
+    def extra(i):
+        a = b"NHC" + bytes([i % 250]) + b"ASi" + struct.pack("<i", -i) + b"XYf" + struct.pack("<f", 1.5)
+        a += b"ZZZhello\0" + b"HHH1AE3\0" + b"BBBs" + struct.pack("<i", 3) + struct.pack("<hhh", 1, 2, 3)
+        a += b"BCBC" + struct.pack("<i", 2) + b"\1\2" + b"ddd" + struct.pack("<d", 2.5) + b"AAAx"
+        return a
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, extra_aux=extra)
+    got = read_all(bam, lists)
+    for g, w in zip(got, case.packed(lists)):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_bam_non_integer_xf_and_non_string_cb(tmp_path):
+    lists = F.Lists(b"AAAA-1\n", b"G1\tN\tT\n")
+    recs = [
+        synth.bam_record(b"a", synth.aux_Z(b"CB", b"AAAA-1") + b"xfA" + b"\x19" + synth.aux_Z(b"GX", b"G1") + synth.aux_Z(b"UB", b"ACGT")),
+        synth.bam_record(b"b", synth.aux_int(b"CB", 5) + synth.aux_int(b"xf", 25) + synth.aux_Z(b"GX", b"G1") + synth.aux_Z(b"UB", b"ACGT")),
+        synth.bam_record(b"c", synth.aux_Z(b"CB", b"AAAA-1") + synth.aux_int(b"xf", 17, b"s") + synth.aux_Z(b"GX", b"G1") + synth.aux_Z(b"UB", b"ACGT")),
+    ]
+    payload = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", 0) + b"".join(recs)
+    p = tmp_path / "t.bam"
+    p.write_bytes(synth._bgzf_block(payload) + synth._BGZF_EOF)
+    cb, gx, um, me = read_all(p, lists)
+    assert cb[0] != 0 and not (me[0] & 1)      # xf of type 'A' → bam_aux2i gives 0 → not 25/17
+    assert cb[1] == 0                          # CB not a string → lookup misses
+    assert cb[2] != 0 and (me[2] & 1)
+
+
+def test_bam_truncated_and_garbage(tmp_path):
+    L = _lib.lib()
+    p = tmp_path / "g.bam"
+    p.write_bytes(b"this is not a bam file at all")
+    assert not L.fastf_bam_open(str(p).encode(), 0)
+    assert not L.fastf_bam_open(str(tmp_path / "missing.bam").encode(), 0)
+    case = Case(n=2000, n_bar=20, n_gene=10)
+    lists = case.lists()
+    full = tmp_path / "full.bam"
+    synth.write_bam(str(full), case.flags, case.xf, case.cb, case.gx, case.ub)
+    data = full.read_bytes()
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(data[: len(data) // 2])
+    h = L.fastf_bam_open(str(cut).encode(), 0)
+    assert h
+    cb = np.empty(5000, np.uint64); gx = np.empty(5000, np.uint64); um = np.empty(5000, np.uint32); me = np.empty(5000, np.uint32)
+    n = L.fastf_bam_read_batch(h, lists.cell_dict, lists.feat_dict, cb.ctypes.data, gx.ctypes.data, um.ctypes.data, me.ctypes.data, 5000)
+    L.fastf_bam_close(h)
+    assert n < 2000      # stops at the damage instead of inventing records (error or short read)
+
+
+def test_empty_bam(tmp_path):
+    lists = F.Lists(b"AAAA-1\n", b"G1\tN\tT\n")
+    p = tmp_path / "e.bam"
+    synth.write_bam(str(p), np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(0, "S4"), np.zeros(0, "S4"), np.zeros(0, "S4"))
+    got = read_all(p, lists)
+    assert len(got[0]) == 0

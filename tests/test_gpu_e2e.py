@@ -1,0 +1,187 @@
+"""GPU end-to-end: the fastF CLI / bam2db() on real BAM files vs the oracle's bytes, and the
+sharded device path (n_shards > 1) simulated on one GPU."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fastf_amd as F
+from fastf_amd import synth, _lib
+from fastf_amd.dist import owner_of_cell
+from helpers import Case
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_inputs(tmp_path, case, gz_lists=False):
+    bam = tmp_path / "in.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub)
+    if gz_lists:
+        b, f = tmp_path / "barcodes.in.tsv.gz", tmp_path / "features.in.tsv.gz"
+        b.write_bytes(gzip.compress(case.bt)); f.write_bytes(gzip.compress(case.ft))
+    else:
+        b, f = tmp_path / "barcodes.in.tsv", tmp_path / "features.in.tsv"
+        b.write_bytes(case.bt); f.write_bytes(case.ft)
+    return bam, b, f
+
+
+def _read_gz(p):
+    return gzip.decompress(open(p, "rb").read())
+
+
+@pytest.mark.parametrize("name,kw,args,gz", [
+    ("keepall", dict(n=60_000, n_bar=500, n_gene=200, umi_pool=64, p_n_umi=0.01), ["-c", "1", "-r", "1"], False),
+    ("half", dict(n=120_000, n_bar=1000, n_gene=500, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=3.0,
+                  p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.005, p_multi_gene=0.02),
+     ["--cell=0.5", "--depth", "0.5", "-s926"], True),
+    ("seed", dict(n=20_000, n_bar=50, n_gene=40, rate_cell=0.3, rate_depth=0.25, seed=0x39e, umi_pool=16),
+     ["-c", "0.3", "-r0.25", "--seed=0x39e"], False),
+])
+def test_cli_outputs_equal_oracle_bytes(tmp_path, name, kw, args, gz):
+    case = Case(**kw)
+    bam, b, f = _write_inputs(tmp_path, case, gz)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    env = dict(os.environ, FASTF_BATCH_RECORDS="25000")          # several pushes
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out),
+                        "-d", str(tmp_path / "unused.db"), "-u"] + args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
+    assert _read_gz(out / "barcodes.tsv.gz") == ora["barcodes"]
+    assert _read_gz(out / "features.tsv.gz") == ora["features"]
+    assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
+    assert "total fastQ reads: %d" % ora["total"] in r.stdout
+    assert not (tmp_path / "unused.db").exists()
+
+
+def test_bam2db_symbol_in_process(tmp_path):
+    """the drop-in C symbol itself (what the reference's main.c would call)"""
+    import torch  # noqa: F401
+    case = Case(n=15_000, n_bar=100, n_gene=60, rate_depth=0.8, umi_pool=32)
+    bam, b, f = _write_inputs(tmp_path, case)
+    case.label = str(bam).encode()
+    case.umi_copies = False
+    ora = case.oracle()
+    L = _lib.lib()
+    rc = L.bam2db(str(bam).encode(), None, str(tmp_path).encode(), str(b).encode(), str(f).encode(),
+                  C.c_float(1.0), C.c_float(0.8), 926)
+    assert rc == 0
+    assert _read_gz(tmp_path / "matrix.mtx.gz") == ora["matrix"]
+    assert not (tmp_path / "umi.tsv.gz").exists()
+    # error convention: 1 + message, no crash
+    assert L.bam2db(b"/nonexistent.bam", None, str(tmp_path).encode(), str(b).encode(), str(f).encode(),
+                    C.c_float(1.0), C.c_float(1.0), 926) == 1
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_sharded_device_path_on_one_gpu(G):
+    """n_shards = G engines on one device: slices → K1a/K1b with a draw-rank base → per-shard buffers →
+    (in-process exchange) → sort + reduce per shard → merged rows == oracle"""
+    import torch
+    case = Case(n=200_000, n_bar=700, n_gene=300, rate_cell=0.8, rate_depth=0.6, umi_pool=512,
+                cell_dist="lognormal", p_unlisted_cb=0.1, p_bad_xf=0.1, p_n_umi=0.01)
+    ora = case.oracle()
+    lists = case.lists()
+    cbk, gxk, umi, meta = case.packed(lists)
+    n = case.n
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32)).to(dev)
+    draws = t(F.mt_draws(case.seed, lists.mt_skip, n))
+    engs = [F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, n_shards=G, shard_rank=r) for r in range(G)]
+    s = torch.cuda.current_stream().cuda_stream
+    cuts = [n * r // G for r in range(G + 1)]
+    stride = max(cuts[r + 1] - cuts[r] for r in range(G))
+    try:
+        hits = []
+        sl = []
+        for r in range(G):
+            a, b = cuts[r], cuts[r + 1]
+            sl.append([t(x[a:b].copy()) for x in (cbk, gxk, umi, meta)])
+            h = torch.zeros(1, dtype=torch.int64, device=dev)
+            engs[r].dev_count_hits(sl[r][0].data_ptr(), b - a, h.data_ptr(), s)
+            hits.append(h)
+        torch.cuda.synchronize()
+        base, acc = [], 0
+        for r in range(G):
+            base.append(acc); acc += int(hits[r].item())
+        keys_out = torch.zeros((G, G, stride), dtype=torch.int64, device=dev)
+        kc = torch.zeros((G, G), dtype=torch.int64, device=dev)
+        counters = torch.zeros((G, 4), dtype=torch.int64, device=dev)
+        for r in range(G):
+            a, b = cuts[r], cuts[r + 1]
+            db = torch.tensor([base[r]], dtype=torch.int64, device=dev)
+            engs[r].dev_probe_pack(sl[r][0].data_ptr(), sl[r][1].data_ptr(), sl[r][2].data_ptr(), sl[r][3].data_ptr(), b - a,
+                                   draws.data_ptr(), n, keys_out[r].data_ptr(), stride, kc[r].data_ptr(), counters[r].data_ptr(), s,
+                                   d_draw_base=db.data_ptr())
+        torch.cuda.synchronize()
+        kc_h = kc.cpu().numpy()
+        tot = counters.sum(0).cpu().numpy()
+        assert (int(tot[1]), int(tot[2]), int(tot[3])) == (ora["sampled"], ora["valid"], 0)
+        F_, C_, K_ = [], [], []
+        for sh in range(G):
+            recv = torch.cat([keys_out[r, sh, :kc_h[r, sh]] for r in range(G)])
+            m = recv.numel()
+            tmp = torch.empty_like(recv)
+            d_n = torch.tensor([m], dtype=torch.int64, device=dev)
+            in_tmp = engs[sh].dev_sort(recv.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), m, stream=s)
+            src = tmp if in_tmp else recv
+            f = torch.empty(max(m, 1), dtype=torch.int32, device=dev); c = torch.empty_like(f); k = torch.empty_like(f)
+            nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+            engs[sh].dev_reduce(src.data_ptr(), d_n.data_ptr(), m, f.data_ptr(), c.data_ptr(), k.data_ptr(), nnz.data_ptr(), s)
+            torch.cuda.synchronize()
+            z = int(nnz.item())
+            cc = c[:z].cpu().numpy().astype(np.int64)
+            assert (owner_of_cell(cc, G) == sh).all()           # host mirror of the device ownership hash
+            F_.append(f[:z].cpu().numpy().astype(np.int64)); C_.append(cc); K_.append(k[:z].cpu().numpy().astype(np.int64))
+        Fa, Ca, Ka = np.concatenate(F_), np.concatenate(C_), np.concatenate(K_)
+        order = np.lexsort((Fa, Ca))
+        np.testing.assert_array_equal(Fa[order], ora["feature"].astype(np.int64))
+        np.testing.assert_array_equal(Ca[order], ora["cell"].astype(np.int64))
+        np.testing.assert_array_equal(Ka[order], ora["count"].astype(np.int64))
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_full_size_properties_config2():
+    """BASELINE configs[1] at full size (10 M records): size-independent properties instead of the oracle:
+    sortedness of rows, row-count/sum invariants, idempotence, and equality with a 2-batch push."""
+    import torch  # noqa: F401
+    bt, ft, bar, genes = synth.make_lists(10_000, 30_000, seed=4242)
+    lists = F.Lists(bt, ft, 1.0, 926)
+    rng = np.random.default_rng(3)
+    n = 10_000_000
+    cbk = lists.cell_keys[rng.integers(0, lists.n_cells, n)]
+    gxk = lists.feature_keys[rng.integers(0, lists.n_features, n)]
+    pool = rng.integers(0, 1 << 20, size=1 << 16, dtype=np.uint32)
+    umi = (pool[rng.integers(0, len(pool), n)] << np.uint32(12)).astype(np.uint32)
+    meta = np.full(n, 1 | 2 | 4 | (3 << 4), dtype=np.uint32)
+    eng = F.Engine.from_lists(lists, rate_depth=0.5, seed=926, batch_records=6_000_000)
+    try:
+        eng.push(cbk, gxk, umi, meta)
+        r1 = eng.finish()
+        assert r1["total"] == n
+        T = F.draw_threshold(0.5)
+        assert r1["sampled"] == int((F.mt_draws(926, 0, n) < T).sum())      # every record hits: draws 0..n-1
+        assert r1["valid"] == r1["sampled"]
+        key = r1["cell"].astype(np.int64) * (1 << 20) + r1["feature"].astype(np.int64)
+        assert (np.diff(key) > 0).all()                                      # strictly ascending (cell, feature)
+        assert r1["count"].min() >= 1 and int(r1["count"].sum()) <= r1["valid"]
+        # distinct (cell, feature, umi) triples of the kept records, computed independently on the host
+        keep = F.mt_draws(926, 0, n) < T
+        trip = np.unique(np.stack([cbk[keep], gxk[keep], umi[keep].astype(np.uint64)]), axis=1).shape[1]
+        assert int(r1["count"].sum()) == trip
+        r1b = eng.finish()                                                   # idempotent
+        assert r1b["nnz"] == r1["nnz"] and np.array_equal(r1b["count"], r1["count"])
+        eng.reset(); eng.reseed(926, 0)
+        h = n // 3
+        eng.push(cbk[:h], gxk[:h], umi[:h], meta[:h]); eng.push(cbk[h:], gxk[h:], umi[h:], meta[h:])
+        r2 = eng.finish()
+        for k in ("cell", "feature", "count"):
+            assert np.array_equal(r1[k], r2[k])
+    finally:
+        eng.close()

@@ -1,0 +1,177 @@
+"""Host-side C of the product (libfastf_amd.so, no GPU needed) against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fastf_amd as F
+from fastf_amd import engine, synth, _lib
+from oracle import oracle as O
+from helpers import Case
+
+
+@pytest.mark.parametrize("seed,skip", [(926, 0), (926, 500), (1, 623), (1, 624), (77, 100000)])
+def test_mt_stream(seed, skip):
+    want = O.mt_stream(seed, skip + 5000)[skip:]
+    np.testing.assert_array_equal(F.mt_draws(seed, skip, 5000), want)
+
+
+@pytest.mark.parametrize("rate", [0.0, 1e-9, 0.01, 0.1, 0.25, 0.3, 0.5, 0.7, 0.999, 1.0, 1.5, -0.5, float("nan")])
+def test_draw_threshold_is_the_reference_compare(rate):
+    T = F.draw_threshold(rate)
+    L = O.lib()
+    probes = {0, 1, 0xFFFFFFFF, 0xFFFFFFFE, 0x7FFFFFFF, 0x80000000}
+    for d in (T - 2, T - 1, T, T + 1):
+        if 0 <= d <= 0xFFFFFFFF:
+            probes.add(d)
+    rng = np.random.default_rng(1)
+    probes.update(int(x) for x in rng.integers(0, 1 << 32, size=2000))
+    for d in probes:
+        assert (d < T) == bool(L.oracle_keep_draw(d, C.c_float(rate))), (rate, d, T)
+
+
+@pytest.mark.parametrize("n,rate,seed", [(6, 0.5, 926), (1000, 0.5, 926), (1000, 1.0, 3), (1000, 0.0, 3), (999, 0.333, 5), (50000, 0.25, 11), (3, 0.34, 1)])
+def test_sample_cells(n, rate, seed):
+    lines, used = engine.sample_cells(n, rate, seed)
+    k = O.lib().oracle_n_cells_sampled(n, C.c_float(rate))
+    np.testing.assert_array_equal(lines, O.sample_cells(n, k, seed))
+    assert used == (0 if k == n else k)
+
+
+def test_sample_cells_rejects_what_the_reference_exits_on():
+    with pytest.raises(F.FastfError):
+        engine.sample_cells(10, 1.5, 1)
+    with pytest.raises(F.FastfError):
+        engine.sample_cells(10, -0.1, 1)
+
+
+@pytest.mark.parametrize("umi", [b"", b"A", b"ACGT", b"ACGTA", b"ACGTACGTAC", b"TTTTTTTTTTTT", b"ACGTACGTACGTACGT", b"ACGTNACGTA", b"acgt", b"ACGTACGTACGTACGTA"])
+def test_pack_umi(umi):
+    out = C.c_uint32(0)
+    meta = _lib.lib().fastf_pack_umi(umi, len(umi), C.byref(out))
+    assert meta & 2
+    if len(umi) > 16:
+        assert meta & 8
+        return
+    blob = O.encode_dna(umi)
+    if blob is None:
+        assert not (meta & 4) and out.value == 0
+    else:
+        assert meta & 4
+        assert (meta >> 4) & 7 == len(blob)
+        assert out.value.to_bytes(4, "big")[:len(blob)] == blob
+        assert out.value.to_bytes(4, "big")[len(blob):] == b"\0" * (4 - len(blob))
+
+
+def _rand_strings(rng, n):
+    alph = [b"ACGT", b"ACGTN", b"0123456789", b"ENSGMUS_.-;abcxyz0123456789", bytes(range(33, 127))]
+    out = []
+    for _ in range(n):
+        a = alph[rng.integers(0, len(alph))]
+        ln = int(rng.integers(0, 30))
+        s = bytes(a[i] for i in rng.integers(0, len(a), size=ln))
+        if rng.random() < 0.3:
+            s += b"-" + str(int(rng.integers(0, 400))).encode()
+        if rng.random() < 0.3:
+            s = b"ENSG" + s + str(int(rng.integers(0, 10 ** int(rng.integers(1, 16))))).zfill(int(rng.integers(1, 16))).encode()
+        out.append(s)
+    return out
+
+
+def test_keydict_is_exact():
+    """pack(a) == pack(b)  <=>  a == b, for registered a and arbitrary b"""
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    reg = list(dict.fromkeys(_rand_strings(rng, 3000) + [b"", b"A", b"ACGT-1", b"ACGT-01", b"ACGT-255", b"ACGT-254",
+                                                             b"G1", b"G01", b"G1;G2", b"ENSG00000000003", b"ENSG00000000003.14",
+                                                             b"A" * 24, b"A" * 25, b"A" * 24 + b"-1", b"123", b"0123", b"9" * 13, b"9" * 14]))
+    d = L.fastf_keydict_create()
+    keys = {}
+    for s in reg:
+        k = L.fastf_keydict_add(d, s, len(s))
+        assert k != 0
+        keys[s] = k
+    assert len(set(keys.values())) == len(reg)                       # injective on the registered set
+    for s in reg:                                                    # stable
+        assert L.fastf_keydict_pack(d, s, len(s)) == keys[s]
+        assert L.fastf_keydict_add(d, s, len(s)) == keys[s]
+    regset = set(reg)
+    inv = {v: k for k, v in keys.items()}
+    probes = _rand_strings(rng, 6000) + [s + b"x" for s in reg[:500]] + [s[:-1] for s in reg[:500] if s]
+    for s in probes:
+        k = L.fastf_keydict_pack(d, s, len(s))
+        if s in regset:
+            assert k == keys[s]
+        else:
+            assert k == 0 or k not in inv, (s, inv.get(k))
+    L.fastf_keydict_destroy(d)
+
+
+def test_keydict_many_prefixes_fall_back_to_escape():
+    L = _lib.lib()
+    d = L.fastf_keydict_create()
+    reg = [b"P%dX_7" % i for i in range(20000)]                     # 20 000 distinct prefixes > 2^14
+    keys = [L.fastf_keydict_add(d, s, len(s)) for s in reg]
+    assert len(set(keys)) == len(reg) and 0 not in keys
+    for s, k in zip(reg, keys):
+        assert L.fastf_keydict_pack(d, s, len(s)) == k
+    assert L.fastf_keydict_pack(d, b"P99999X_7", 9) == 0
+    L.fastf_keydict_destroy(d)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=10, n_bar=1000, n_gene=500),
+    dict(n=10, n_bar=1000, n_gene=500, rate_cell=0.5),
+    dict(n=10, n_bar=7, n_gene=3, rate_cell=0.3, seed=5),
+])
+def test_lists_match_oracle(kw):
+    case = Case(**kw)
+    ora = case.oracle()
+    lists = case.lists()
+    assert lists.barcodes_text() == ora["barcodes"]
+    assert lists.features_text() == ora["features"]
+    assert (lists.n_features, lists.n_cells) == (ora["n_feature"], ora["n_barcode"])
+    assert lists.mt_skip == (0 if lists.n_sampled_target == lists.n_lines_barcodes else lists.n_sampled_target)
+
+
+def test_lists_quirks_match_oracle():
+    """duplicate barcode stalls insertion; duplicate/odd feature lines; CRLF; gz-style long lines"""
+    bar = b"AAAA-1\nCCCC-1\r\nAAAA-1\nGGGG-1\nTTTT-1\tx\n"
+    feat = b"G1\tN1\tGene Expression\nG2\tN2\tGene Expression\r\nG1\tdup\tGene Expression\n\tG9\tN9\tT9\nG3\t\tN3\tAntibody Capture\textra\n"
+    n = 4
+    flags = np.full(n, 15, np.uint8); xf = np.full(n, 25, np.int32)
+    cb = np.array([b"AAAA-1", b"CCCC-1", b"GGGG-1", b"TTTT-1"], dtype="S8")
+    gx = np.array([b"G1", b"G2", b"\tG9", b"G3"], dtype="S8")
+    ub = np.array([b"ACGTACGTAC"] * n, dtype="S16")
+    ora = O.run_bam2db(bar, feat, flags, xf, cb, gx, ub, 1.0, 1.0, 926)
+    lists = F.Lists(bar, feat, 1.0, 926)
+    assert lists.barcodes_text() == ora["barcodes"] == b"AAAA-1\nCCCC-1\n"
+    assert lists.features_text() == ora["features"]
+    assert lists.dup_barcodes == 1 and lists.dup_features == 1
+    # packed keys reproduce the oracle's hit pattern: rows for AAAA-1/G1 and CCCC-1/G2 only
+    k = F.pack_records(lists, flags, xf, cb, gx, ub)
+    cell_hit = np.isin(k[0], lists.cell_keys) & (k[0] != 0)
+    feat_hit = np.isin(k[1], lists.feature_keys) & (k[1] != 0)
+    assert cell_hit.tolist() == [True, True, False, False]
+    assert feat_hit.tolist() == [True, True, True, True]
+    assert ora["valid"] == 2
+
+
+def test_lists_bad_feature_line_is_an_error():
+    with pytest.raises(F.FastfError):
+        F.Lists(b"AAAA-1\n", b"G1\tonly two columns\n", 1.0, 926)
+
+
+def test_format_matrix_matches_oracle_text():
+    case = Case(n=5000, n_bar=40, n_gene=20, umi_pool=16, rate_depth=0.5)
+    ora = case.oracle()
+    lists = case.lists()
+    res = dict(feature=ora["feature"].astype(np.uint32), cell=ora["cell"].astype(np.uint32), count=ora["count"].astype(np.uint32),
+               total=ora["total"], sampled=ora["sampled"], valid=ora["valid"], nnz=ora["nnz"])
+    txt = engine.Engine.format_matrix(_FakeEngine(), res, case.label, case.rate_cell, case.rate_depth, lists.n_features, lists.n_cells)
+    assert txt == ora["matrix"]
+
+
+class _FakeEngine:
+    """format_matrix only needs the library handle (pure host formatting, no device)"""
+    _L = _lib.lib()
