@@ -300,7 +300,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     if (reserve_workspace(e, n, 0)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     t_begin(e, s);
-    hipLaunchKernelGGL(probe_cells_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
+    hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
                        (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
@@ -336,7 +336,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.threshold = e->threshold; p.L = e->L;
     p.n_shards = e->n_shards;
     p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
-    p.digit_hist = (e->n_shards == 1) ? fused_hist : nullptr;
+    p.digit_hist = (e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST")) ? fused_hist : nullptr;
     p.hist_passes = (e->L.total_bits + 7) / 8;
     t_begin(e, s);
     hipLaunchKernelGGL(filter_pack_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, p);
@@ -404,7 +404,7 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
     HIP_OK(hipSetDevice(e->device));
     int dummy = 0;
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
-                       (flags & FASTF_SORT_HIST_READY) && e->n_shards == 1,
+                       (flags & FASTF_SORT_HIST_READY) && e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST"),
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream);
 }
 

@@ -132,13 +132,20 @@ __device__ __forceinline__ u32 table_probe_from(const Table t, u64 key, u32 h) {
     return 0;
 }
 
-template <int N>
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4_t;
+
+template <int N, int AUX = 0>
 __device__ __forceinline__ void table_probe_batch(const Table t, const u64 (&key)[N], u32 (&val)[N]) {
     u32 h[N]; uint4 s[N];
+    // wave-uniform buffer descriptor over the table: 32-bit offsets, cache policy in AUX
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)t.slots, 0, (t.mask + 1u) * 16u, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < N; ++j) h[j] = (u32)mix64(key[j]) & t.mask;
+    for (int j = 0; j < N; ++j) h[j] = key[j] ? ((u32)mix64(key[j]) & t.mask) : 0u;   // dead lanes share slot 0
 #pragma unroll
-    for (int j = 0; j < N; ++j) s[j] = key[j] ? t.slots[h[j]] : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < N; ++j) {                              // unconditional: N loads back to back, one wait
+        const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(h[j] * 16u), 0, AUX);
+        s[j] = make_uint4((u32)v[0], (u32)v[1], (u32)v[2], (u32)v[3]);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const u64 k = ((u64)s[j].y << 32) | s[j].x;
@@ -189,6 +196,7 @@ __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
 }
 
+template <int AUX>
 __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __restrict__ cb, u64 n, Table cells,
                                                                  u32* __restrict__ cell_out, u32* __restrict__ tile_hits) {
     __shared__ u32 s_w[K1_WAVES];
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
         const u64 idx = base + (u64)j * K1_THREADS + tid;
         key[j] = idx < n ? cb[idx] : 0;
     }
-    table_probe_batch<K1_IPT>(cells, key, cell);
+    table_probe_batch<K1_IPT, AUX>(cells, key, cell);
     u32 hits = 0;
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
