@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-_LIB = os.path.join(HERE, "lib", "libfastf_amd.so")
+_LIB = os.environ.get("FASTF_LIB_OVERRIDE") or os.path.join(HERE, "lib", "libfastf_amd.so")   # override: A/B builds only
 _CLI = os.path.join(HERE, "bin", "fastF")
 
 

@@ -108,6 +108,8 @@ struct fastf_engine {
 
 enum { SM_KEYCOUNT = 0, SM_COUNTERS = 8, SM_NNZ = 12, SM_NROWS_U = 13, SM_N = 14, SM_WORDS = 16 };
 
+static int set_scatter_lds_limit();
+static u32 g_cu_count = 256;
 static size_t scatter_smem_bytes() {
     return (size_t)SORT_TILE * 8 + (size_t)SORT_WAVES * RADIX * 4 + RADIX * 4 * 2 + 64;
 }
@@ -159,6 +161,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 16) return set_err("umi_max_bases must be 1..16");
     if (cfg->n_shards < 1 || cfg->n_shards > 8 || cfg->shard_rank >= cfg->n_shards) return set_err("bad shard config");
     HIP_OK(hipSetDevice(cfg->device));
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) g_cu_count = (u32)pr.multiProcessorCount; }
 
     fastf_engine* e = new fastf_engine();
     e->device = cfg->device;
@@ -197,8 +200,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
             rc = set_err("hipHostMalloc failed"); break;
         }
         if (hipMemset(e->d_small.p, 0, SM_WORDS * sizeof(u64)) != hipSuccess) { rc = set_err("memset failed"); break; }
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) {
+        if (set_scatter_lds_limit()) {
             rc = set_err("cannot raise dynamic LDS limit to %zu bytes", scatter_smem_bytes()); break;
         }
         e->batch_cap = cfg->batch_records ? cfg->batch_records : (4ull << 20);
@@ -243,9 +245,21 @@ extern "C" int fastf_engine_key_bits(const fastf_engine_t* e, uint32_t* cell_bit
 // ------------------------------------------------------------------------------------
 static u64 max_tiles_for(u64 n, u64 tile) { return (n + tile - 1) / tile + 1; }
 
+// keys per thread of the sort tiles: the smallest that still needs the same number of rounds over the resident
+// workgroup slots (2 per CU) as the largest tile would, so every round is full
+static u32 choose_sort_ipt(u64 n) {
+    const char* f = getenv("FASTF_SORT_IPT");
+    if (f) { int v = atoi(f); if (v >= 1 && v <= SORT_IPT) return (u32)v; }
+    const u64 slots = 2ull * g_cu_count;
+    const u64 per_round_max = slots * SORT_TILE;
+    const u64 rounds = std::max<u64>(1, (n + per_round_max - 1) / per_round_max);
+    const u64 per_thread = (n + rounds * slots * SORT_THREADS - 1) / (rounds * slots * SORT_THREADS);
+    return (u32)std::min<u64>(SORT_IPT, std::max<u64>(1, per_thread));
+}
+
 static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     const u64 t1 = max_tiles_for(max_records, K1_TILE), t3 = max_tiles_for(max_keys, K3_TILE);
-    const u64 ts = max_tiles_for(max_keys, SORT_TILE);
+    const u64 ts = max_tiles_for(max_keys, (u64)choose_sort_ipt(max_keys) * SORT_THREADS);
     if (max_records && e->d_cellidx.bytes < max_records * sizeof(u32)) {
         e->cells_cached_for = nullptr;
         if (e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
@@ -295,6 +309,9 @@ extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* tot
 // ------------------------------------------------------------------------------------
 // device-level entry points
 // ------------------------------------------------------------------------------------
+static u64* g_k1_stamps = nullptr;   // diagnostic builds only
+extern "C" void fastf_debug_set_k1_stamps(void* p) { g_k1_stamps = (u64*)p; }
+
 // K1a + scan: cell index per record, hit-rank base per tile, total hits
 static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s) {
     if (reserve_workspace(e, n, 0)) return 1;
@@ -338,6 +355,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
     p.digit_hist = (e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST")) ? fused_hist : nullptr;
     p.hist_passes = (e->L.total_bits + 7) / 8;
+    p.stamps = g_k1_stamps;
     t_begin(e, s);
     hipLaunchKernelGGL(filter_pack_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, p);
     HIP_OK(hipGetLastError());
@@ -366,6 +384,26 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
                         (u32*)e->d_hist.p, (hipStream_t)stream);
 }
 
+static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
+extern "C" void fastf_debug_set_stamps(void* p) { g_stamps = (u64*)p; }
+static void launch_scatter(u32 pass, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt, u32 ipt) {
+#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(), s, src, dst, d_n, cnt, ipt, g_stamps)
+    switch (pass) {
+    case 0: SC(0); break;  case 1: SC(8); break;  case 2: SC(16); break; case 3: SC(24); break;
+    case 4: SC(32); break; case 5: SC(40); break; case 6: SC(48); break; default: SC(56); break;
+    }
+#undef SC
+}
+
+static int set_scatter_lds_limit() {
+    const void* fns[8] = {(const void*)scatter_kernel<0>, (const void*)scatter_kernel<8>, (const void*)scatter_kernel<16>,
+                          (const void*)scatter_kernel<24>, (const void*)scatter_kernel<32>, (const void*)scatter_kernel<40>,
+                          (const void*)scatter_kernel<48>, (const void*)scatter_kernel<56>};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) return 1;
+    return 0;
+}
+
 static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits,
                        bool hist_ready, int* sorted_in_tmp, hipStream_t s) {
     const u32 passes = (key_bits + 7) / 8;
@@ -374,7 +412,8 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
     if (passes > 8) return set_err("key_bits %u > 64", key_bits);
     if (max_n >= (1ull << 32)) return set_err("sort of %llu keys: limit is 2^32-1 per shard", (unsigned long long)max_n);
     if (reserve_workspace(e, 0, max_n)) return 1;
-    const u32 T = (u32)((max_n + SORT_TILE - 1) / SORT_TILE);
+    const u32 ipt = choose_sort_ipt(max_n);
+    const u32 T = (u32)((max_n + (u64)ipt * SORT_THREADS - 1) / ((u64)ipt * SORT_THREADS));
     u32* hist = (u32*)e->d_hist.p; u32* binbase = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
     if (!hist_ready) {
         HIP_OK(hipMemsetAsync(hist, 0, passes * RADIX * sizeof(u32), s));
@@ -386,12 +425,11 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         const u64* src = (q & 1) ? tmp : keys;
         u64* dst = (q & 1) ? keys : tmp;
         t_begin(e, s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
-        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, (const u32*)(binbase + q * RADIX));
+        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, (const u32*)(binbase + q * RADIX), ipt);
         t_begin(e, s);
-        hipLaunchKernelGGL(scatter_kernel, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(), s, src, dst, d_n, 8 * q,
-                           (const u32*)cnt);
+        launch_scatter(q, T, s, src, dst, d_n, (const u32*)cnt, ipt);
         t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
     }
     HIP_OK(hipGetLastError());

@@ -12,6 +12,9 @@
 // All of it is integer indexing: wave64 ballots/mbcnt for ranking, LDS for the
 // tile-local reorder, coalesced 8-byte streams to HBM.  No MFMA by design.
 #pragma once
+#ifndef FASTF_K1_THREADS
+#define FASTF_K1_THREADS 512
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const u32* __restrict_
 // The hit rank of a record (= its position in the MT draw stream) is
 //   tile_base[tile] (scan of K1a's counts) + rank inside the tile (ballots, record order).
 // ------------------------------------------------------------------------------------
-constexpr int K1_THREADS = 512, K1_IPT = 8, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
+constexpr int K1_THREADS = FASTF_K1_THREADS, K1_IPT = 8, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
 
 __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
@@ -240,9 +243,16 @@ struct PackParams {
     u64* counters;                 // {hits, sampled, valid, err}
     u32* digit_hist;               // optional fused per-digit histograms [passes][256] (n_shards==1)
     u32 hist_passes;
+    u64* stamps;                   // diagnostic builds only (-DFASTF_STAMPS)
 };
 
-__global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParams p) {
+#ifdef FASTF_STAMPS
+#define K1STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (p.stamps && threadIdx.x == 0) p.stamps[(u64)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define K1STAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(K1_THREADS, 6) void filter_pack_kernel(const PackParams p) {
     __shared__ u32 s_cnt[K1_IPT * K1_WAVES];       // hits per (item, wave), then exclusive
     __shared__ u32 s_red[3][K1_WAVES];
     __shared__ u32 s_shard_cnt[8];
@@ -258,6 +268,7 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
     if (tid == 0) s_err = 0;
     if (p.digit_hist) for (int i = tid; i < (int)p.hist_passes * 256; i += K1_THREADS) s_hist[i] = 0;
 
+    K1STAMP(0);
     // ---- loads; hit ranks in record order (item-major, then wave, then lane) ----
     u64 gxk[K1_IPT]; u32 umi[K1_IPT], meta[K1_IPT], cell[K1_IPT], hrank[K1_IPT];
 #pragma unroll
@@ -277,11 +288,13 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
     }
     __syncthreads();
     if (w == 0) {
-        const u32 c = s_cnt[lane];                                  // exactly 64 entries
+        static_assert(K1_IPT * K1_WAVES <= WAVE, "one wave scans the (item, wave) counts");
+        const u32 c = lane < K1_IPT * K1_WAVES ? s_cnt[lane] : 0;
         const u32 inc = wave_incl_scan32(c, lane);
-        s_cnt[lane] = inc - c;
+        if (lane < K1_IPT * K1_WAVES) s_cnt[lane] = inc - c;
     }
     __syncthreads();
+    K1STAMP(1);
     const u64 tile_base = p.tile_base[tile] + (p.draw_base ? *p.draw_base : 0);
 
     // ---- depth draw (E4/E5 :385-390), xf (E7 :394-400) ----
@@ -296,6 +309,7 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
             else { cell[j] = 0; n_hit++; errs |= (u32)ERR_DRAWS_SHORT; }
         }
     }
+    K1STAMP(2);
     u64 fkey[K1_IPT]; u32 feat[K1_IPT];
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
@@ -307,6 +321,7 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
         fkey[j] = alive ? gxk[j] : 0;
     }
     table_probe_batch<K1_IPT>(p.feats, fkey, feat);                  // E8 :403-410
+    K1STAMP(3);
 
     // ---- UB (E9 :412-416), key (E10/E11), slot in the tile-local shard list ----
     u64 key[K1_IPT]; u32 pos[K1_IPT]; u32 shard[K1_IPT]; bool emit[K1_IPT];
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
         }
     }
 
+    K1STAMP(4);
     // ---- counters + global slot reservation ----
     n_hit = wave_sum32(n_hit); n_samp = wave_sum32(n_samp); n_valid = wave_sum32(n_valid);
     if (lane == 0) { s_red[0][w] = n_hit; s_red[1][w] = n_samp; s_red[2][w] = n_valid; }
@@ -355,6 +371,7 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
         s_shard_base[s] = b;
     }
     __syncthreads();
+    K1STAMP(5);
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
         if (emit[j]) {
@@ -368,6 +385,7 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
             if (v) atomicAdd(&p.digit_hist[i], v);
         }
     }
+    K1STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------
@@ -376,7 +394,9 @@ __global__ __launch_bounds__(K1_THREADS) void filter_pack_kernel(const PackParam
 constexpr int RADIX = 256;
 constexpr int SORT_THREADS = 512, SORT_IPT = 16, SORT_TILE = SORT_THREADS * SORT_IPT, SORT_WAVES = SORT_THREADS / WAVE;
 
-__device__ __forceinline__ u32 num_tiles(u64 n) { return (u32)((n + SORT_TILE - 1) / SORT_TILE); }
+// tile size is chosen per sort (ipt = keys per thread, 1..SORT_IPT) so that the tiles fill whole rounds of the
+// resident workgroup slots: at 10 M keys a fixed 8192-key tile leaves the third round 38 % full
+__device__ __forceinline__ u32 num_tiles(u64 n, u32 ipt) { const u64 t = (u64)ipt * SORT_THREADS; return (u32)((n + t - 1) / t); }
 
 // global histograms of every digit: hist[pass][256]
 __global__ __launch_bounds__(256) void digit_hist_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
@@ -411,18 +431,24 @@ __global__ __launch_bounds__(RADIX) void bin_base_kernel(const u32* __restrict__
 
 // per-tile digit counts: cnt[d * T + tile]
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
-                                                                  u32 shift, u32* __restrict__ cnt) {
+                                                                  u32 shift, u32* __restrict__ cnt, u32 ipt) {
     __shared__ u32 s_h[RADIX];
     const u64 n = *n_ptr;
-    const u32 T = num_tiles(n), tile = blockIdx.x;
+    const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
     if (tile >= T) return;
     if (threadIdx.x < RADIX) s_h[threadIdx.x] = 0;
     __syncthreads();
-    const u64 base = (u64)tile * SORT_TILE;
+    const u64 base = (u64)tile * ipt * SORT_THREADS;
+    u64 k[SORT_IPT];
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
         const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&s_h[(keys[idx] >> shift) & 255], 1u);
+        k[j] = (j < (int)ipt && idx < n) ? keys[idx] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < SORT_IPT; ++j) {
+        const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
+        if (j < (int)ipt && idx < n) atomicAdd(&s_h[(k[j] >> shift) & 255], 1u);
     }
     __syncthreads();
     if (threadIdx.x < RADIX) cnt[(u64)threadIdx.x * T + tile] = s_h[threadIdx.x];
@@ -430,10 +456,10 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
 
 // row d: exclusive scan of cnt[d][0..T) in place, plus bin_base[d]
 __global__ __launch_bounds__(1024) void row_scan_kernel(u32* __restrict__ cnt, const u64* __restrict__ n_ptr,
-                                                        const u32* __restrict__ bin_base) {
+                                                        const u32* __restrict__ bin_base, u32 ipt) {
     __shared__ u32 s_w[16];
     __shared__ u32 s_carry;
-    const u32 T = num_tiles(*n_ptr);
+    const u32 T = num_tiles(*n_ptr, ipt);
     const int lane = lane_id(), w = threadIdx.x >> 6;
     u32* row = cnt + (u64)blockIdx.x * T;
     if (threadIdx.x == 0) s_carry = bin_base[blockIdx.x];
@@ -453,64 +479,76 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(u32* __restrict__ cnt, c
     }
 }
 
-// match-any over the 8 digit bits: lanes holding the same digit (valid lanes only)
-__device__ __forceinline__ u64 match_digit(u32 d) {
-    u64 m = ~0ULL;
+// match-any over the 8 digit bits: mask of the lanes holding the same digit.
+// Per bit: one sign-extending bit-field extract (0 / -1), one compare that yields the ballot,
+// and one v_bitop3 per mask half computing  m & ~(ballot ^ ext)  (truth table 0x90).
+__device__ __forceinline__ void match_digit(u32 d, u32& mlo, u32& mhi) {
+    mlo = ~0u; mhi = ~0u;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1;
-        const u64 bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        const int ext = __builtin_amdgcn_sbfe((int)d, b, 1);
+        const u64 bal = __builtin_amdgcn_ballot_w64(ext != 0);
+        mlo = __builtin_amdgcn_bitop3_b32(mlo, (u32)bal, (u32)ext, 0x90);
+        mhi = __builtin_amdgcn_bitop3_b32(mhi, (u32)(bal >> 32), (u32)ext, 0x90);
     }
-    return m;
 }
 
-// scatter: stable within the tile (wave-major, item, lane == memory order)
-__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
-                                                               const u64* __restrict__ n_ptr, u32 shift,
-                                                               const u32* __restrict__ off) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// scatter: stable within the tile (wave-major, item, lane == memory order).  SHIFT is a
+// template parameter so the digit is one v_bfe on the right key half; FULL tiles skip every
+// bounds check (only the last tile of a pass is partial).
+template <int SHIFT, bool FULL>
+__device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
+                                             u32 T, u32 tile, const u32* __restrict__ off, const int ipt, unsigned char* smem,
+                                             u64* stamps = nullptr) {
+#ifdef FASTF_STAMPS
+#define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    STAMP(0);
     u64* s_keys = reinterpret_cast<u64*>(smem);                                    // SORT_TILE keys
     u32* s_whist = reinterpret_cast<u32*>(smem + (size_t)SORT_TILE * 8);          // [WAVES][256]
     u32* s_delta = s_whist + SORT_WAVES * RADIX;                                   // [256] global - local start
     u32* s_start = s_delta + RADIX;                                                // [256] local bin start
     u32* s_wtot  = s_start + RADIX;                                                // [4]
-
-    const u64 n = *n_ptr;
-    const u32 T = num_tiles(n), tile = blockIdx.x;
-    if (tile >= T) return;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const u64 base = (u64)tile * SORT_TILE;
-    const u32 n_valid = (u32)((n - base) < (u64)SORT_TILE ? (n - base) : (u64)SORT_TILE);
 
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
 
     // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
     u64 key[SORT_IPT];
-    const u32 wbase = (u32)w * SORT_IPT * WAVE;
+    const u32 wbase = (u32)w * (u32)ipt * WAVE;
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
         const u32 li = wbase + j * WAVE + lane;
-        key[j] = li < n_valid ? in[base + li] : ~0ULL;
+        key[j] = (j < ipt && (FULL || li < n_valid)) ? in[base + li] : ~0ULL;
     }
     __syncthreads();
+#ifdef FASTF_STAMPS
+    asm volatile("" :: "v"(key[0]));
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    STAMP(1);
 
     // rank inside the wave: per-wave histogram, no atomics (one leader per digit group)
     u32 rnk[SORT_IPT];
     u32* wh = s_whist + w * RADIX;
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
+        if (j >= ipt) break;                               // wave-uniform
         const u32 li = wbase + j * WAVE + lane;
-        const u32 d = li < n_valid ? (u32)((key[j] >> shift) & 255) : 255u;
-        const u64 m = match_digit(d);
+        const u32 d = (FULL || li < n_valid) ? ((u32)(key[j] >> SHIFT) & 255u) : 255u;
+        u32 mlo, mhi;
+        match_digit(d, mlo, mhi);
         const u32 before = wh[d];
-        const u32 r = rank_below(m);
+        const u32 r = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
         __builtin_amdgcn_wave_barrier();
-        if (r == 0) wh[d] = before + (u32)__popcll(m);
+        if (r == 0) wh[d] = before + (u32)__popc(mlo) + (u32)__popc(mhi);
         __builtin_amdgcn_wave_barrier();
         rnk[j] = before + r;
     }
     __syncthreads();
+    STAMP(2);
 
     // per digit: exclusive offsets of the waves, tile totals → local bin starts
     u32 run = 0, inc = 0;
@@ -529,27 +567,52 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
         s_delta[tid] = off[(u64)tid * T + tile] - lstart;  // global slot = delta + local slot (mod 2^32)
     }
     __syncthreads();
+    STAMP(3);
 
     // tile-local reorder through LDS
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
+        if (j >= ipt) break;
         const u32 li = wbase + j * WAVE + lane;
-        const u32 d = li < n_valid ? (u32)((key[j] >> shift) & 255) : 255u;
+        const u32 d = (FULL || li < n_valid) ? ((u32)(key[j] >> SHIFT) & 255u) : 255u;
         const u32 p = s_start[d] + wh[d] + rnk[j];
         s_keys[p] = key[j];
     }
     __syncthreads();
+    STAMP(4);
 
     // coalesced write-out: consecutive threads → consecutive slots of the same bin
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
+        if (j >= ipt) break;
         const u32 pidx = j * SORT_THREADS + tid;
-        if (pidx < n_valid) {
+        if (FULL || pidx < n_valid) {
             const u64 k = s_keys[pidx];
-            const u32 d = (u32)((k >> shift) & 255);
+            const u32 d = (u32)(k >> SHIFT) & 255u;
             out[(u64)(u32)(s_delta[d] + pidx)] = k;
         }
     }
+    STAMP(5);
+#ifdef FASTF_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    STAMP(6);
+#endif
+#undef STAMP
+}
+
+template <int SHIFT>
+__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
+                                                               const u64* __restrict__ n_ptr,
+                                                               const u32* __restrict__ off, u32 ipt, u64* stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u64 n = *n_ptr;
+    const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
+    if (tile >= T) return;
+    const u32 tile_keys = ipt * SORT_THREADS;
+    const u64 base = (u64)tile * tile_keys;
+    const u32 n_valid = (u32)((n - base) < (u64)tile_keys ? (n - base) : (u64)tile_keys);
+    if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, (int)ipt, smem, stamps);
+    else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, (int)ipt, smem, stamps);
 }
 
 
