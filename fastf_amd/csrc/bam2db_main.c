@@ -14,9 +14,45 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <time.h>
 #include <unistd.h>
 
 int _umi_copies_flag = 0;
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+
+/* decoder thread: BAM → packed SoA batches, double-buffered, while the caller pushes the previous batch
+ * (and, for the first batch, while the HIP runtime and the engine come up) */
+typedef struct { uint64_t *cb, *gx; uint32_t *umi, *meta; long n; } dec_slot;
+typedef struct {
+    fastf_bam_t *bam; const fastf_lists_t *lists; size_t cap;
+    dec_slot slot[2]; int filled[2];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int stop; double t_decode;
+} dec_ctx;
+
+static void *decoder_main(void *vp)
+{
+    dec_ctx *d = (dec_ctx *)vp;
+    for (int k = 0;; k ^= 1) {
+        pthread_mutex_lock(&d->mu);
+        while (d->filled[k] && !d->stop) pthread_cond_wait(&d->cv, &d->mu);
+        int stop = d->stop;
+        pthread_mutex_unlock(&d->mu);
+        if (stop) break;
+        double t = now_s();
+        long n = fastf_bam_read_batch(d->bam, d->lists->cell_dict, d->lists->feat_dict, d->slot[k].cb, d->slot[k].gx,
+                                      d->slot[k].umi, d->slot[k].meta, d->cap);
+        d->t_decode += now_s() - t;
+        pthread_mutex_lock(&d->mu);
+        d->slot[k].n = n; d->filled[k] = 1;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+        if (n <= 0) break;
+    }
+    return NULL;
+}
 
 static uint32_t bits_for(uint64_t v) { uint32_t b = 0; while (b < 64 && (v >> b)) b++; return b ? b : 1; }
 
@@ -25,23 +61,43 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
 {
     (void)db_file;                      /* no SQLite in this engine */
     int rc = 1;
+    const int prof = getenv("FASTF_PROFILE") != NULL;
+    double t0 = now_s(), t_lists = 0, t_engine = 0, t_decode = 0, t_push = 0, t_finish = 0, t_write = 0, tt;
     fastf_lists_t lists; memset(&lists, 0, sizeof lists);
     fastf_bam_t *bam = NULL;
     fastf_engine_t *eng = NULL;
-    uint64_t *cb = NULL, *gx = NULL; uint32_t *umi = NULL, *meta = NULL;
+    dec_ctx dec; pthread_t dec_thread; int dec_started = 0; double t_wait = 0;
+    memset(&dec, 0, sizeof dec);
 
     bam = fastf_bam_open(bam_file, 0);
     if (!bam) { fprintf(stderr, "Fail to open BAM file %s (%s)\n", bam_file, fastf_last_error()); goto done; }
     fprintf(stderr, "Opened BAM file %s successfully\n", bam_file);
 
+    tt = now_s();
     if (fastf_lists_load(barcodes_file, features_file, rate_cell, seed, &lists)) {
         fprintf(stderr, "Fail to load barcode/feature lists: %s\n", fastf_last_error());
         goto done;
     }
+    t_lists = now_s() - tt;
     printf("Total number of cells: %zu\n", lists.n_lines_barcodes);
     printf("Actual number of sampled cell barcodes: %zu\n", lists.n_sampled_target);
     for (size_t i = 0; i < lists.dup_barcodes; i++) printf("Warning: Duplicate cell barcodes were found in %s!\n", barcodes_file);
     for (size_t i = 0; i < lists.dup_features; i++) printf("Warning: Duplicate feature names were found in %s!\n", features_file);
+
+    /* start decoding right away; the engine (HIP init, table upload) comes up meanwhile */
+    const char *bs = getenv("FASTF_BATCH_RECORDS");
+    const size_t cap = bs ? (size_t)strtoull(bs, NULL, 0) : ((size_t)4 << 20);
+    memset(&dec, 0, sizeof dec);
+    dec.bam = bam; dec.lists = &lists; dec.cap = cap;
+    pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
+    for (int k = 0; k < 2; k++) {
+        dec.slot[k].cb = (uint64_t *)malloc(cap * 8); dec.slot[k].gx = (uint64_t *)malloc(cap * 8);
+        dec.slot[k].umi = (uint32_t *)malloc(cap * 4); dec.slot[k].meta = (uint32_t *)malloc(cap * 4);
+        if (!dec.slot[k].cb || !dec.slot[k].gx || !dec.slot[k].umi || !dec.slot[k].meta) { fprintf(stderr, "out of memory\n"); goto done; }
+    }
+    printf("Start to convert bam file to UMI keys on the device...\n");
+    if (pthread_create(&dec_thread, NULL, decoder_main, &dec) != 0) { fprintf(stderr, "cannot start decoder thread\n"); goto done; }
+    dec_started = 1;
 
     fastf_engine_config_t cfg; memset(&cfg, 0, sizeof cfg);
     cfg.cell_keys = lists.cell_key; cfg.n_cells = (uint32_t)lists.n_cells;
@@ -55,25 +111,34 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     const char *ul = getenv("FASTF_UMI_MAX_BASES");
     if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);
     else cfg.umi_max_bases = (bits_for(cfg.n_cells) + bits_for(cfg.n_features) + 36 <= 64) ? 16 : 12;
-    const char *bs = getenv("FASTF_BATCH_RECORDS");
-    cfg.batch_records = bs ? strtoull(bs, NULL, 0) : (4ull << 20);
+    cfg.batch_records = cap;
+    tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    t_engine = now_s() - tt;
 
-    const size_t cap = (size_t)cfg.batch_records;
-    cb = (uint64_t *)malloc(cap * 8); gx = (uint64_t *)malloc(cap * 8);
-    umi = (uint32_t *)malloc(cap * 4); meta = (uint32_t *)malloc(cap * 4);
-    if (!cb || !gx || !umi || !meta) { fprintf(stderr, "out of memory\n"); goto done; }
-
-    printf("Start to convert bam file to UMI keys on the device...\n");
-    for (;;) {
-        long n = fastf_bam_read_batch(bam, lists.cell_dict, lists.feat_dict, cb, gx, umi, meta, cap);
+    for (int k = 0;; k ^= 1) {
+        tt = now_s();
+        pthread_mutex_lock(&dec.mu);
+        while (!dec.filled[k]) pthread_cond_wait(&dec.cv, &dec.mu);
+        pthread_mutex_unlock(&dec.mu);
+        t_wait += now_s() - tt;
+        const long n = dec.slot[k].n;
         if (n < 0) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
         if (n == 0) break;
-        fastf_batch_t batch = { cb, gx, umi, meta, (size_t)n };
+        fastf_batch_t batch = { dec.slot[k].cb, dec.slot[k].gx, dec.slot[k].umi, dec.slot[k].meta, (size_t)n };
+        tt = now_s();
         if (fastf_engine_push(eng, &batch)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+        t_push += now_s() - tt;
+        pthread_mutex_lock(&dec.mu);
+        dec.filled[k] = 0;
+        pthread_cond_broadcast(&dec.cv);
+        pthread_mutex_unlock(&dec.mu);
     }
+    t_decode = dec.t_decode;
     fastf_coo_t coo; uint64_t counters[3];
+    tt = now_s();
     if (fastf_engine_finish(eng, &coo, counters)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    t_finish = now_s() - tt;
     printf("In %s, total fastQ reads: %zu\n", bam_file, (size_t)counters[0]);
     printf("In %s, sampled fastQ reads: %zu\n", bam_file, (size_t)counters[1]);
     printf("In %s, sampled and valid fastQ reads: %zu\n", bam_file, (size_t)counters[2]);
@@ -85,14 +150,25 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
 
     fastf_umi_rows_t urows; memset(&urows, 0, sizeof urows);
     if (_umi_copies_flag && fastf_engine_umi_rows(eng, &urows)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    tt = now_s();
     if (fastf_write_outputs(path_out, bam_file, rate_cell, rate_depth, counters, &lists, &coo,
                             _umi_copies_flag ? &urows : NULL)) {
         fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error());
         goto done;
     }
+    t_write = now_s() - tt;
     rc = 0;
+    if (prof)
+        fprintf(stderr, "[bam2db] lists %.3f s, engine create %.3f s, BAM decode+pack %.3f s (decoder thread; main waited %.3f s), "
+                        "push (stage+H2D+K1 enqueue) %.3f s, finish (sort+reduce+D2H) %.3f s, write %.3f s, total so far %.3f s\n",
+                t_lists, t_engine, t_decode, t_wait, t_push, t_finish, t_write, now_s() - t0);
 done:
-    free(cb); free(gx); free(umi); free(meta);
+    if (dec_started) {
+        pthread_mutex_lock(&dec.mu); dec.stop = 1; dec.filled[0] = dec.filled[1] = 0;
+        pthread_cond_broadcast(&dec.cv); pthread_mutex_unlock(&dec.mu);
+        pthread_join(dec_thread, NULL);
+    }
+    for (int k = 0; k < 2; k++) { free(dec.slot[k].cb); free(dec.slot[k].gx); free(dec.slot[k].umi); free(dec.slot[k].meta); }
     if (eng) fastf_engine_destroy(eng);
     if (bam) fastf_bam_close(bam);
     fastf_lists_free(&lists);

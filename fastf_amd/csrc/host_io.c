@@ -194,81 +194,184 @@ void fastf_lists_free(fastf_lists_t *l)
 }
 
 /* ================================================================== */
-/* BAM reader                                                         */
+/* BAM reader — block-parallel BGZF inflate + parallel tag extraction  */
 /* ================================================================== */
+/*
+ * BGZF blocks are independent deflate streams, so a window of the file is handled as
+ *   1. read a chunk of compressed bytes, walk the block headers (BSIZE, ISIZE)        serial, cheap
+ *   2. inflate + CRC every block into its slot of one contiguous buffer               parallel
+ *   3. hop over the records (block_size fields) to find their offsets                 serial, cheap
+ *   4. scan aux tags, pack CB / GX / UB into the SoA slots of each record             parallel
+ * Record order is preserved: slot i of the output is the i-th record of the file.
+ */
+#include <pthread.h>
+#include <unistd.h>
+
+typedef struct { size_t coff; uint32_t clen, isize; size_t uoff; } bgzf_blk;
+
 struct fastf_bam {
     FILE *fp;
-    unsigned char *cbuf;        /* one compressed block (<= 64 KiB) */
-    unsigned char *ubuf;        /* inflated stream window */
-    size_t ulen, upos, ucap;
-    int eof;
+    int n_threads;
+    int file_eof;
+    unsigned char *cbuf; size_t ccap, clen;      /* compressed window (whole blocks + a partial tail) */
+    unsigned char *ubuf; size_t ucap, ulen, upos;/* inflated window; [upos, ulen) not yet consumed     */
+    bgzf_blk *blk; size_t nblk, blkcap;
+    size_t *rec; size_t reccap;                   /* offsets (into ubuf) of the records of one batch   */
     uint64_t n_records, n_no_xf, n_no_gx;
-    z_stream zs; int zs_init;
+    int failed;
+    double t_read, t_inflate, t_hop, t_pack;      /* FASTF_BAM_PROFILE=1 prints these at close */
 };
+
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 
 static inline uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 static inline uint32_t rd16(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
 
-/* inflate the next BGZF block and append it to the window; 0 ok, 1 EOF, -1 error */
-static int bgzf_next(fastf_bam_t *b)
+static int host_threads(int asked)
 {
-    unsigned char hdr[12];
-    size_t r = fread(hdr, 1, 12, b->fp);
-    if (r == 0) return 1;
-    if (r != 12 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) { io_err("not a BGZF block"); return -1; }
-    uint32_t xlen = rd16(hdr + 10);
-    unsigned char extra[65536];
-    if (fread(extra, 1, xlen, b->fp) != xlen) { io_err("truncated BGZF header"); return -1; }
-    int bsize = -1;
-    for (uint32_t i = 0; i + 4 <= xlen;) {
-        uint32_t slen = rd16(extra + i + 2);
-        if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) bsize = (int)rd16(extra + i + 4);
-        i += 4 + slen;
-    }
-    if (bsize < 0) { io_err("BGZF block without BC field"); return -1; }
-    long clen = (long)bsize + 1 - 12 - (long)xlen;            /* deflate data + crc32 + isize */
-    if (clen < 8) { io_err("bad BGZF block size"); return -1; }
-    if (fread(b->cbuf, 1, (size_t)clen, b->fp) != (size_t)clen) { io_err("truncated BGZF block"); return -1; }
-    uint32_t isize = rd32(b->cbuf + clen - 4);
-    /* compact the window, make room */
-    if (b->upos) { memmove(b->ubuf, b->ubuf + b->upos, b->ulen - b->upos); b->ulen -= b->upos; b->upos = 0; }
-    if (b->ulen + isize > b->ucap) { b->ucap = (b->ulen + isize) * 2; b->ubuf = (unsigned char *)realloc(b->ubuf, b->ucap); }
-    if (isize) {
-        z_stream *z = &b->zs;
-        if (!b->zs_init) { memset(z, 0, sizeof *z); if (inflateInit2(z, -15) != Z_OK) { io_err("inflateInit2"); return -1; } b->zs_init = 1; }
-        else inflateReset(z);
-        z->next_in = b->cbuf; z->avail_in = (uInt)(clen - 8);
-        z->next_out = b->ubuf + b->ulen; z->avail_out = isize;
-        int zr = inflate(z, Z_FINISH);
-        if (zr != Z_STREAM_END || z->avail_out != 0) { io_err("inflate failed (%d)", zr); return -1; }
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), b->ubuf + b->ulen, isize) != rd32(b->cbuf + clen - 8)) { io_err("BGZF CRC mismatch"); return -1; }
-        b->ulen += isize;
-    }
-    return 0;
+    if (asked > 0) return asked > 64 ? 64 : asked;
+    const char *e = getenv("FASTF_HOST_THREADS");
+    if (e && atoi(e) > 0) return atoi(e) > 64 ? 64 : atoi(e);
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    return n > 32 ? 32 : (int)n;
 }
 
-/* make at least `need` bytes available at upos; 0 ok, 1 clean EOF (no bytes), -1 error/truncated */
+/* ---- tiny fork/join helper: fn(arg, worker_index) on n_threads threads ---- */
+typedef struct { void (*fn)(void *, int); void *arg; int idx; } par_task;
+static void *par_tramp(void *p) { par_task *t = (par_task *)p; t->fn(t->arg, t->idx); return NULL; }
+static void par_run(int n_threads, void (*fn)(void *, int), void *arg)
+{
+    if (n_threads <= 1) { fn(arg, 0); return; }
+    pthread_t th[64]; par_task tk[64];
+    int started = 0;
+    for (int i = 1; i < n_threads; i++) {
+        tk[i].fn = fn; tk[i].arg = arg; tk[i].idx = i;
+        if (pthread_create(&th[i], NULL, par_tramp, &tk[i]) != 0) break;
+        started = i;
+    }
+    fn(arg, 0);
+    for (int i = 1; i <= started; i++) pthread_join(th[i], NULL);
+}
+
+/* ---- step 2: parallel inflate ---- */
+typedef struct { fastf_bam_t *b; size_t next; int err; pthread_mutex_t mu; } inflate_job;
+
+static void inflate_worker(void *vp, int widx)
+{
+    (void)widx;
+    inflate_job *j = (inflate_job *)vp;
+    fastf_bam_t *b = j->b;
+    z_stream z; memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) { j->err = 1; return; }
+    for (;;) {
+        size_t i = __atomic_fetch_add(&j->next, 8, __ATOMIC_RELAXED);      /* 8 blocks per grab */
+        if (i >= b->nblk || j->err) break;
+        size_t e = i + 8 < b->nblk ? i + 8 : b->nblk;
+        for (; i < e; i++) {
+            const bgzf_blk *k = &b->blk[i];
+            if (!k->isize) continue;
+            inflateReset(&z);
+            z.next_in = b->cbuf + k->coff; z.avail_in = k->clen;
+            z.next_out = b->ubuf + k->uoff; z.avail_out = k->isize;
+            int r = inflate(&z, Z_FINISH);
+            const unsigned char *tail = b->cbuf + k->coff + k->clen;       /* crc32, isize */
+            if (r != Z_STREAM_END || z.avail_out != 0 ||
+                (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->ubuf + k->uoff, k->isize) != rd32(tail)) { j->err = 1; break; }
+        }
+    }
+    inflateEnd(&z);
+}
+
+/* Refill the inflated window with the next chunk of the file.  0 ok (progress made), 1 EOF, -1 error */
+static int bam_fill(fastf_bam_t *b)
+{
+    if (b->failed) return -1;
+    /* keep the unconsumed tail at the front of the window */
+    if (b->upos) { memmove(b->ubuf, b->ubuf + b->upos, b->ulen - b->upos); b->ulen -= b->upos; b->upos = 0; }
+    for (;;) {
+        if (!b->file_eof) {
+            double t0 = now_s();
+            size_t want = b->ccap - b->clen;
+            size_t got = fread(b->cbuf + b->clen, 1, want, b->fp);
+            b->clen += got;
+            if (got < want) b->file_eof = 1;
+            b->t_read += now_s() - t0;
+        }
+        /* walk whole blocks */
+        b->nblk = 0;
+        size_t pos = 0, utotal = 0;
+        while (b->clen - pos >= 18) {
+            const unsigned char *h = b->cbuf + pos;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { b->failed = 1; return io_err("not a BGZF block") ? -1 : -1; }
+            uint32_t xlen = rd16(h + 10);
+            if (b->clen - pos < 12 + (size_t)xlen) break;
+            int bsize = -1;
+            for (uint32_t i = 0; i + 4 <= xlen;) {
+                uint32_t slen = rd16(h + 12 + i + 2);
+                if (h[12 + i] == 'B' && h[12 + i + 1] == 'C' && slen == 2) bsize = (int)rd16(h + 12 + i + 4);
+                i += 4 + slen;
+            }
+            if (bsize < 0) { b->failed = 1; io_err("BGZF block without BC field"); return -1; }
+            size_t total = (size_t)bsize + 1;
+            if (total < 12 + (size_t)xlen + 8) { b->failed = 1; io_err("bad BGZF block size"); return -1; }
+            if (b->clen - pos < total) break;
+            if (b->nblk == b->blkcap) { b->blkcap = b->blkcap ? b->blkcap * 2 : 4096; b->blk = (bgzf_blk *)realloc(b->blk, b->blkcap * sizeof *b->blk); }
+            bgzf_blk *k = &b->blk[b->nblk++];
+            k->coff = pos + 12 + xlen;
+            k->clen = (uint32_t)(total - 12 - xlen - 8);
+            k->isize = rd32(h + total - 4);
+            k->uoff = b->ulen + utotal;
+            utotal += k->isize;
+            pos += total;
+        }
+        if (b->nblk == 0) {
+            if (b->file_eof) {
+                if (b->clen - pos != 0) { b->failed = 1; io_err("truncated BGZF block at end of file"); return -1; }
+                return 1;
+            }
+            if (b->clen == b->ccap) { b->failed = 1; io_err("BGZF block larger than the read window"); return -1; }
+            continue;
+        }
+        if (b->ulen + utotal > b->ucap) { b->ucap = (b->ulen + utotal) * 3 / 2 + (1 << 20); b->ubuf = (unsigned char *)realloc(b->ubuf, b->ucap); }
+        inflate_job job; memset(&job, 0, sizeof job); job.b = b;
+        double t0 = now_s();
+        par_run(b->n_threads, inflate_worker, &job);
+        b->t_inflate += now_s() - t0;
+        if (job.err) { b->failed = 1; io_err("BGZF inflate/CRC failure"); return -1; }
+        b->ulen += utotal;
+        /* keep the partial block for the next round */
+        memmove(b->cbuf, b->cbuf + pos, b->clen - pos);
+        b->clen -= pos;
+        return 0;
+    }
+}
+
+/* make at least `need` bytes available at upos; 0 ok, 1 clean EOF (nothing left), -1 error/truncated */
 static int bam_need(fastf_bam_t *b, size_t need)
 {
     while (b->ulen - b->upos < need) {
-        if (b->eof) return (b->ulen == b->upos) ? 1 : -1;
-        int r = bgzf_next(b);
+        int r = bam_fill(b);
         if (r < 0) return -1;
-        if (r == 1) b->eof = 1;
+        if (r == 1) return (b->ulen == b->upos) ? 1 : -1;
     }
     return 0;
 }
 
 fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
 {
-    (void)n_threads;
     FILE *fp = fopen(path, "rb");
     if (!fp) { io_err("Fail to open BAM file %s", path); return NULL; }
     fastf_bam_t *b = (fastf_bam_t *)calloc(1, sizeof *b);
     b->fp = fp;
-    setvbuf(fp, NULL, _IOFBF, 1 << 22);
-    b->cbuf = (unsigned char *)malloc(1 << 16);
-    b->ucap = 1 << 20; b->ubuf = (unsigned char *)malloc(b->ucap);
+    b->n_threads = host_threads(n_threads);
+    setvbuf(fp, NULL, _IONBF, 0);
+    const char *w = getenv("FASTF_BAM_WINDOW");
+    b->ccap = w ? (size_t)strtoull(w, NULL, 0) : ((size_t)32 << 20);
+    if (b->ccap < (1 << 17)) b->ccap = 1 << 17;
+    b->cbuf = (unsigned char *)malloc(b->ccap);
+    b->ucap = b->ccap * 4; b->ubuf = (unsigned char *)malloc(b->ucap);
     /* header: magic, l_text, text, n_ref, {l_name, name, l_ref}* — what sam_hdr_read() consumes (bam2db_ds.c:340) */
     if (bam_need(b, 12) || memcmp(b->ubuf + b->upos, "BAM\1", 4) != 0) { io_err("%s is not a BAM file", path); fastf_bam_close(b); return NULL; }
     uint32_t l_text = rd32(b->ubuf + b->upos + 4);
@@ -287,9 +390,11 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
 void fastf_bam_close(fastf_bam_t *b)
 {
     if (!b) return;
-    if (b->zs_init) inflateEnd(&b->zs);
+    if (getenv("FASTF_BAM_PROFILE"))
+        fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s, record hop %.3f s, tag pack %.3f s\n",
+                (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack);
     if (b->fp) fclose(b->fp);
-    free(b->cbuf); free(b->ubuf); free(b);
+    free(b->cbuf); free(b->ubuf); free(b->blk); free(b->rec); free(b);
 }
 
 void fastf_bam_stats(const fastf_bam_t *b, uint64_t *n_records, uint64_t *n_no_xf, uint64_t *n_no_gx)
@@ -340,9 +445,10 @@ static int64_t aux_int(const unsigned char *p)
 }
 
 /* one record's aux block → packed fields; first occurrence of a tag wins (bam_aux_get) */
-static void pack_record(fastf_bam_t *b, const unsigned char *aux, const unsigned char *end,
+static void pack_record(const unsigned char *aux, const unsigned char *end,
                         const fastf_keydict_t *cells, const fastf_keydict_t *feats,
-                        uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta)
+                        uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta,
+                        uint64_t *n_no_xf, uint64_t *n_no_gx)
 {
     const unsigned char *cb = NULL, *xf = NULL, *gx = NULL, *ub = NULL;
     while (end - aux >= 3) {
@@ -363,11 +469,11 @@ static void pack_record(fastf_bam_t *b, const unsigned char *aux, const unsigned
         *cb_key = fastf_keydict_pack(cells, s, strlen(s));
     }
     if (xf) { int64_t q = aux_int(xf); if (q == 25 || q == 17) m |= FASTF_META_XF_OK; }
-    else if (*cb_key) b->n_no_xf++;               /* reference would dereference NULL if this record is kept */
+    else if (*cb_key) (*n_no_xf)++;               /* reference would dereference NULL if this record is kept */
     if (gx && *gx == 'Z') {
         const char *s = (const char *)gx + 1;
         *gx_key = fastf_keydict_pack(feats, s, strlen(s));
-    } else if (!gx && (m & FASTF_META_XF_OK) && *cb_key) b->n_no_gx++;
+    } else if (!gx && (m & FASTF_META_XF_OK) && *cb_key) (*n_no_gx)++;
     if (ub) {
         if (*ub == 'Z') { const char *s = (const char *)ub + 1; m |= fastf_pack_umi(s, strlen(s), umi); }
         /* a non-Z UB makes bam_aux2Z return NULL and encode_DNA(NULL) crash in the reference: treated as absent */
@@ -375,25 +481,74 @@ static void pack_record(fastf_bam_t *b, const unsigned char *aux, const unsigned
     *meta = m;
 }
 
+/* ---- step 4: parallel tag extraction + packing ---- */
+typedef struct {
+    fastf_bam_t *b; const fastf_keydict_t *cells, *feats;
+    uint64_t *cb_key, *gx_key; uint32_t *umi, *meta; size_t n; size_t next;
+    uint64_t no_xf[64], no_gx[64];
+} pack_job;
+
+static void pack_worker(void *vp, int widx)
+{
+    pack_job *j = (pack_job *)vp;
+    const unsigned char *u = j->b->ubuf;
+    uint64_t nxf = 0, ngx = 0;
+    for (;;) {
+        size_t i = __atomic_fetch_add(&j->next, 4096, __ATOMIC_RELAXED);
+        if (i >= j->n) break;
+        size_t e = i + 4096 < j->n ? i + 4096 : j->n;
+        for (; i < e; i++) {
+            const unsigned char *rec = u + j->b->rec[i] + 4;
+            uint32_t bs = rd32(rec - 4);
+            uint32_t l_read_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
+            uint64_t fixed = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+            if (fixed > bs) fixed = bs;            /* corrupt layout: no aux (validated again by the caller) */
+            pack_record(rec + fixed, rec + bs, j->cells, j->feats, j->cb_key + i, j->gx_key + i, j->umi + i, j->meta + i, &nxf, &ngx);
+        }
+    }
+    j->no_xf[widx] = nxf; j->no_gx[widx] = ngx;
+}
+
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                           uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap)
 {
+    if (b->reccap < cap) { b->reccap = cap; b->rec = (size_t *)realloc(b->rec, cap * sizeof *b->rec); }
     size_t n = 0;
+    double t_hop0 = now_s(), t_fill0 = b->t_read + b->t_inflate;
+    /* step 3: record offsets; the window is refilled only when it runs dry, so one batch never
+     * spans a refill (offsets stay valid) unless the window holds no complete record at all */
     while (n < cap) {
-        int r = bam_need(b, 4);
-        if (r == 1) break;                                     /* clean EOF */
-        if (r < 0) { fprintf(stderr, "Warning: truncated BAM stream after %llu records\n", (unsigned long long)b->n_records); break; }
+        if (b->ulen - b->upos < 4 || b->ulen - b->upos < 4 + (size_t)rd32(b->ubuf + b->upos)) {
+            if (n) break;                                       /* hand out what this window had */
+            size_t need = b->ulen - b->upos < 4 ? 4 : 4 + (size_t)rd32(b->ubuf + b->upos);
+            int r = bam_need(b, need);
+            if (r == 1) break;                                  /* clean EOF */
+            if (r < 0) {
+                if (b->failed) return -1;
+                fprintf(stderr, "Warning: truncated BAM stream after %llu records\n", (unsigned long long)b->n_records);
+                b->upos = b->ulen;
+                break;
+            }
+            continue;
+        }
         uint32_t bs = rd32(b->ubuf + b->upos);
-        if (bs < 32) { io_err("corrupt BAM record (block_size %u)", bs); return -1; }
-        if (bam_need(b, 4 + (size_t)bs)) { fprintf(stderr, "Warning: truncated BAM record after %llu records\n", (unsigned long long)b->n_records); break; }
+        if (bs < 32) { io_err("corrupt BAM record (block_size %u)", bs); b->failed = 1; return -1; }
         const unsigned char *rec = b->ubuf + b->upos + 4;
-        uint32_t l_read_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
-        uint64_t fixed = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
-        if (fixed > bs) { io_err("corrupt BAM record (fields exceed block_size)"); return -1; }
-        pack_record(b, rec + fixed, rec + bs, cells, feats, cb_key + n, gx_key + n, umi + n, meta + n);
+        uint64_t fixed = 32ull + rec[8] + 4ull * rd16(rec + 12) + ((uint64_t)rd32(rec + 16) + 1) / 2 + rd32(rec + 16);
+        if (fixed > bs) { io_err("corrupt BAM record (fields exceed block_size)"); b->failed = 1; return -1; }
+        b->rec[n++] = b->upos;
         b->upos += 4 + (size_t)bs;
-        b->n_records++;
-        n++;
+    }
+    b->t_hop += (now_s() - t_hop0) - (b->t_read + b->t_inflate - t_fill0);
+    if (n) {
+        double t0 = now_s();
+        pack_job job; memset(&job, 0, sizeof job);
+        job.b = b; job.cells = cells; job.feats = feats;
+        job.cb_key = cb_key; job.gx_key = gx_key; job.umi = umi; job.meta = meta; job.n = n;
+        par_run(n < 8192 ? 1 : b->n_threads, pack_worker, &job);
+        for (int i = 0; i < 64; i++) { b->n_no_xf += job.no_xf[i]; b->n_no_gx += job.no_gx[i]; }
+        b->n_records += n;
+        b->t_pack += now_s() - t0;
     }
     return (long)n;
 }
@@ -422,14 +577,12 @@ static void ob_u32(obuf *o, uint32_t v)
 }
 static void ob_ch(obuf *o, char c) { ob_room(o, 1); o->p[o->len++] = c; }
 
-int fastf_format_matrix(const char *bam_label, float rate_cell, float rate_depth, const uint64_t counters[3],
-                        size_t n_feature, size_t n_barcode, const fastf_coo_t *coo, char **out, size_t *out_len)
+/* bam2db_ds.c:498-513.  The reference's first line is written with the format
+ * "%%%MatrixMarket", which glibc renders as two percent signs followed by the word. */
+static int format_matrix_header(char *hdr, size_t cap, const char *bam_label, float rate_cell, float rate_depth,
+                                const uint64_t counters[3], size_t n_feature, size_t n_barcode, size_t nnz)
 {
-    obuf o = {0};
-    char hdr[2048];
-    /* bam2db_ds.c:498-513.  The reference's first line is written with the format
-     * "%%%MatrixMarket", which glibc renders as two percent signs followed by the word. */
-    int n = snprintf(hdr, sizeof hdr,
+    int n = snprintf(hdr, cap,
                      "%%%%MatrixMarket matrix coordinate integer general\n"
                      "%%metadata_json: \n"
                      "%%{\n"
@@ -444,14 +597,22 @@ int fastf_format_matrix(const char *bam_label, float rate_cell, float rate_depth
                      "%%}\n"
                      "%zu %zu %zu\n",
                      bam_label, rate_cell, rate_depth, (size_t)counters[0], (size_t)counters[1], (size_t)counters[2],
-                     n_feature, n_barcode, coo->nnz);
-    if (n < 0 || (size_t)n >= sizeof hdr) return io_err("matrix header too long");
+                     n_feature, n_barcode, nnz);
+    return (n < 0 || (size_t)n >= cap) ? -1 : n;
+}
+
+static void fmt_mtx_rows(void *ctx, size_t lo, size_t hi, obuf *o);
+static void fmt_umi_rows(void *ctx, size_t lo, size_t hi, obuf *o);
+
+int fastf_format_matrix(const char *bam_label, float rate_cell, float rate_depth, const uint64_t counters[3],
+                        size_t n_feature, size_t n_barcode, const fastf_coo_t *coo, char **out, size_t *out_len)
+{
+    obuf o = {0};
+    char hdr[4096];
+    if (format_matrix_header(hdr, sizeof hdr, bam_label, rate_cell, rate_depth, counters, n_feature, n_barcode, coo->nnz) < 0)
+        return io_err("matrix header too long");
     ob_str(&o, hdr);
-    for (size_t i = 0; i < coo->nnz; i++) {                 /* table2gz(db, "mtx", …, " ") :516 */
-        ob_u32(&o, coo->feature[i]); ob_ch(&o, ' ');
-        ob_u32(&o, coo->cell[i]);    ob_ch(&o, ' ');
-        ob_u32(&o, coo->count[i]);   ob_ch(&o, '\n');
-    }
+    fmt_mtx_rows((void *)coo, 0, coo->nnz, &o);
     ob_room(&o, 1); o.p[o.len] = '\0';
     *out = o.p; *out_len = o.len;
     return 0;
@@ -460,10 +621,102 @@ int fastf_format_matrix(const char *bam_label, float rate_cell, float rate_depth
 int fastf_format_umi_rows(const fastf_umi_rows_t *rows, char **out, size_t *out_len)
 {
     obuf o = {0};
-    for (size_t i = 0; i < rows->n; i++) {                  /* numi table, "\t" delimiter :552 */
-        ob_u32(&o, rows->feature[i]); ob_ch(&o, '\t');
-        ob_u32(&o, rows->cell[i]);    ob_ch(&o, '\t');
-        if (!rows->nonnull[i]) ob_str(&o, "NULL");          /* :634-636 */
+    fmt_umi_rows((void *)rows, 0, rows->n, &o);
+    ob_room(&o, 1); o.p[o.len] = '\0';
+    *out = o.p; *out_len = o.len;
+    return 0;
+}
+
+/* ---- chunk-parallel gzip writer (pigz style) ----------------------------------------
+ * The text is produced and deflated in independent chunks, each a complete gzip member;
+ * concatenated members are one valid gzip stream (RFC 1952 §2.2), so gzread()/gunzip give
+ * back exactly the concatenated text — parity is defined on the decompressed bytes. */
+typedef void (*chunk_fmt_fn)(void *ctx, size_t lo, size_t hi, obuf *o);
+
+typedef struct {
+    chunk_fmt_fn fmt; void *ctx; size_t n_items, per_chunk, n_chunks;
+    const char *prefix; size_t prefix_len;
+    unsigned char **out; size_t *out_len;
+    int level; size_t next; int err;
+} gz_job;
+
+static int gz_member(const char *text, size_t len, int level, unsigned char **out, size_t *out_len)
+{
+    z_stream z; memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 1;
+    size_t cap = deflateBound(&z, (uLong)len) + 64;
+    unsigned char *buf = (unsigned char *)malloc(cap);
+    z.next_in = (unsigned char *)text; z.avail_in = (uInt)len;
+    z.next_out = buf; z.avail_out = (uInt)cap;
+    int r = deflate(&z, Z_FINISH);
+    size_t n = z.total_out;
+    deflateEnd(&z);
+    if (r != Z_STREAM_END) { free(buf); return 1; }
+    *out = buf; *out_len = n;
+    return 0;
+}
+
+static void gz_worker(void *vp, int widx)
+{
+    (void)widx;
+    gz_job *j = (gz_job *)vp;
+    obuf o = {0};
+    for (;;) {
+        size_t c = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (c >= j->n_chunks || j->err) break;
+        o.len = 0;
+        if (c == 0 && j->prefix_len) { ob_room(&o, j->prefix_len); memcpy(o.p, j->prefix, j->prefix_len); o.len = j->prefix_len; }
+        size_t lo = c * j->per_chunk, hi = lo + j->per_chunk < j->n_items ? lo + j->per_chunk : j->n_items;
+        if (lo < hi) j->fmt(j->ctx, lo, hi, &o);
+        if (gz_member(o.p ? o.p : "", o.len, j->level, &j->out[c], &j->out_len[c])) j->err = 1;
+    }
+    free(o.p);
+}
+
+static int write_gz_chunks(const char *dir, const char *name, const char *prefix, size_t prefix_len,
+                           size_t n_items, size_t per_chunk, chunk_fmt_fn fmt, void *ctx)
+{
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s", dir, name);
+    FILE *f = fopen(path, "wb");
+    if (!f) { fprintf(stderr, "\x1b[31mError:\x1b[0m can not open file %s\n", path); return io_err("can not open file %s", path); }
+    gz_job j; memset(&j, 0, sizeof j);
+    j.fmt = fmt; j.ctx = ctx; j.n_items = n_items; j.per_chunk = per_chunk;
+    j.n_chunks = n_items ? (n_items + per_chunk - 1) / per_chunk : 1;
+    j.prefix = prefix; j.prefix_len = prefix_len;
+    j.out = (unsigned char **)calloc(j.n_chunks, sizeof *j.out);
+    j.out_len = (size_t *)calloc(j.n_chunks, sizeof *j.out_len);
+    const char *lv = getenv("FASTF_GZIP_LEVEL");
+    j.level = lv ? atoi(lv) : Z_DEFAULT_COMPRESSION;           /* gzopen(…, "wb") default, as the reference */
+    int nt = host_threads(0);
+    if ((size_t)nt > j.n_chunks) nt = (int)j.n_chunks;
+    par_run(nt, gz_worker, &j);
+    int rc = j.err ? io_err("gzip compression failed for %s", path) : 0;
+    for (size_t c = 0; c < j.n_chunks && !rc; c++)
+        if (fwrite(j.out[c], 1, j.out_len[c], f) != j.out_len[c]) rc = io_err("write error on %s", path);
+    for (size_t c = 0; c < j.n_chunks; c++) free(j.out[c]);
+    free(j.out); free(j.out_len);
+    if (fclose(f) != 0 && !rc) rc = io_err("close error on %s", path);
+    return rc;
+}
+
+static void fmt_mtx_rows(void *ctx, size_t lo, size_t hi, obuf *o)
+{
+    const fastf_coo_t *coo = (const fastf_coo_t *)ctx;
+    for (size_t i = lo; i < hi; i++) {                      /* table2gz(db, "mtx", …, " ") :516 */
+        ob_u32(o, coo->feature[i]); ob_ch(o, ' ');
+        ob_u32(o, coo->cell[i]);    ob_ch(o, ' ');
+        ob_u32(o, coo->count[i]);   ob_ch(o, '\n');
+    }
+}
+
+static void fmt_umi_rows(void *ctx, size_t lo, size_t hi, obuf *o)
+{
+    const fastf_umi_rows_t *rows = (const fastf_umi_rows_t *)ctx;
+    for (size_t i = lo; i < hi; i++) {                      /* numi table, "\t" delimiter :552 */
+        ob_u32(o, rows->feature[i]); ob_ch(o, '\t');
+        ob_u32(o, rows->cell[i]);    ob_ch(o, '\t');
+        if (!rows->nonnull[i]) ob_str(o, "NULL");           /* :634-636 */
         else {
             /* decode_DNA(blob, 10) (:629): always ten bases, whatever the blob length.  Blobs
              * shorter than 3 bytes are read out of bounds by the reference; here the missing
@@ -471,68 +724,45 @@ int fastf_format_umi_rows(const fastf_umi_rows_t *rows, char **out, size_t *out_
             char t[11];
             for (int k = 0; k < 10; k++) t[k] = "ACGT"[(rows->umi[i] >> (30 - 2 * k)) & 3];
             t[10] = '\0';
-            ob_str(&o, t);
+            ob_str(o, t);
         }
-        ob_ch(&o, '\t');
-        ob_u32(&o, rows->n_copy[i]); ob_ch(&o, '\n');
+        ob_ch(o, '\t');
+        ob_u32(o, rows->n_copy[i]); ob_ch(o, '\n');
     }
-    ob_room(&o, 1); o.p[o.len] = '\0';
-    *out = o.p; *out_len = o.len;
-    return 0;
 }
 
-static int write_gz(const char *dir, const char *name, const char *buf, size_t len)
+static void fmt_barcodes(void *ctx, size_t lo, size_t hi, obuf *o)
 {
-    char path[4096];
-    snprintf(path, sizeof path, "%s/%s", dir, name);
-    gzFile f = gzopen(path, "wb");
-    if (!f) { fprintf(stderr, "\x1b[31mError:\x1b[0m can not open file %s\n", path); return io_err("can not open file %s", path); }
-    gzbuffer(f, 1 << 20);
-    size_t off = 0;
-    while (off < len) {
-        unsigned chunk = (unsigned)(len - off > (1u << 30) ? (1u << 30) : len - off);
-        if (gzwrite(f, buf + off, chunk) != (int)chunk) { gzclose(f); return io_err("write error on %s", path); }
-        off += chunk;
+    const fastf_lists_t *l = (const fastf_lists_t *)ctx;
+    for (size_t i = lo; i < hi; i++) { ob_str(o, l->barcode[i]); ob_ch(o, '\n'); }      /* :520 */
+}
+
+static void fmt_features(void *ctx, size_t lo, size_t hi, obuf *o)
+{
+    const fastf_lists_t *l = (const fastf_lists_t *)ctx;
+    for (size_t i = lo; i < hi; i++) {                                                    /* :524 */
+        ob_str(o, l->feat_id[i]); ob_ch(o, '\t');
+        ob_str(o, l->feat_name[i]); ob_ch(o, '\t');
+        ob_str(o, l->feat_type[i]); ob_ch(o, '\n');
     }
-    if (gzclose(f) != Z_OK) return io_err("close error on %s", path);
-    return 0;
 }
 
 int fastf_write_outputs(const char *path_out, const char *bam_label, float rate_cell, float rate_depth,
                         const uint64_t counters[3], const fastf_lists_t *lists, const fastf_coo_t *coo,
                         const fastf_umi_rows_t *umi_rows)
 {
-    char *mtx = NULL; size_t mlen = 0;
-    if (fastf_format_matrix(bam_label, rate_cell, rate_depth, counters, lists->n_features, lists->n_cells, coo, &mtx, &mlen)) return 1;
-    int rc = write_gz(path_out, "matrix.mtx.gz", mtx, mlen);
-    free(mtx);
-    if (rc) return 1;
+    char hdr[4096];
+    int hl = format_matrix_header(hdr, sizeof hdr, bam_label, rate_cell, rate_depth, counters,
+                                  lists->n_features, lists->n_cells, coo->nnz);
+    if (hl < 0) return io_err("matrix header too long");
+    if (write_gz_chunks(path_out, "matrix.mtx.gz", hdr, (size_t)hl, coo->nnz, 1u << 18, fmt_mtx_rows, (void *)coo)) return 1;
     printf("matrix.mtx.gz is generated.\n");
-
-    obuf o = {0};
-    for (size_t i = 0; i < lists->n_cells; i++) { ob_str(&o, lists->barcode[i]); ob_ch(&o, '\n'); }   /* :520 */
-    rc = write_gz(path_out, "barcodes.tsv.gz", o.p ? o.p : "", o.len);
-    free(o.p);
-    if (rc) return 1;
+    if (write_gz_chunks(path_out, "barcodes.tsv.gz", NULL, 0, lists->n_cells, 1u << 18, fmt_barcodes, (void *)lists)) return 1;
     printf("barcodes.tsv.gz is generated.\n");
-
-    memset(&o, 0, sizeof o);
-    for (size_t i = 0; i < lists->n_features; i++) {                                                     /* :524 */
-        ob_str(&o, lists->feat_id[i]); ob_ch(&o, '\t');
-        ob_str(&o, lists->feat_name[i]); ob_ch(&o, '\t');
-        ob_str(&o, lists->feat_type[i]); ob_ch(&o, '\n');
-    }
-    rc = write_gz(path_out, "features.tsv.gz", o.p ? o.p : "", o.len);
-    free(o.p);
-    if (rc) return 1;
+    if (write_gz_chunks(path_out, "features.tsv.gz", NULL, 0, lists->n_features, 1u << 18, fmt_features, (void *)lists)) return 1;
     printf("features.tsv.gz is generated.\n");
-
     if (umi_rows) {                                                                                      /* :527-556 */
-        char *u = NULL; size_t ulen = 0;
-        if (fastf_format_umi_rows(umi_rows, &u, &ulen)) return 1;
-        rc = write_gz(path_out, "umi.tsv.gz", u ? u : "", ulen);
-        free(u);
-        if (rc) return 1;
+        if (write_gz_chunks(path_out, "umi.tsv.gz", NULL, 0, umi_rows->n, 1u << 18, fmt_umi_rows, (void *)umi_rows)) return 1;
         printf("umi.tsv.gz is generated.\n");
     }
     return 0;

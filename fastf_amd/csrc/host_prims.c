@@ -154,24 +154,31 @@ int fastf_sample_cells(size_t n_cells, float rate_cell, unsigned int seed,
 /* ------------------------------------------------------------------ */
 /* UMI codec                                                           */
 /* ------------------------------------------------------------------ */
+/* base → 2-bit code, 4 = not a base (encode_base, bam2db_ds.c:5-20: upper-case ACGT only) */
+static const uint8_t k_base_code[256] = {
+#define X4 4, 4, 4, 4
+#define X16 X4, X4, X4, X4
+    X16, X16, X16, X16,                                  /* 0x00-0x3f */
+    4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,      /* @ A B C D E F G H I J K L M N O */
+    4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,      /* P Q R S T ...                   */
+    X16, X16, X16, X16, X16, X16, X16, X16, X16, X16
+#undef X16
+#undef X4
+};
+
 uint32_t fastf_pack_umi(const char *ub, size_t len, uint32_t *umi_out)
 {
     uint32_t meta = FASTF_META_HAS_UB;
     *umi_out = 0;
     if (len > 16) return meta | FASTF_META_UMI_TOOLONG;
-    uint32_t packed = 0;
-    int ok = 1;
+    uint32_t packed = 0, bad = 0;
     for (size_t i = 0; i < len; i++) {
-        uint32_t code;
-        switch (ub[i]) {
-        case 'A': code = 0; break;
-        case 'C': code = 1; break;
-        case 'G': code = 2; break;
-        case 'T': code = 3; break;
-        default: code = 0; ok = 0; break;
-        }
-        packed |= code << (30 - 2 * i);
+        const uint32_t code = k_base_code[(unsigned char)ub[i]];
+        bad |= code;
+        packed = (packed << 2) | (code & 3);
     }
+    if (len) packed <<= 32 - 2 * len;
+    const int ok = !(bad & 4);
     if (ok) { meta |= FASTF_META_UMI_NONNULL; *umi_out = packed; }
     meta |= (uint32_t)((len + 3) / 4) << FASTF_META_LEN_SHIFT;
     return meta;
@@ -270,19 +277,15 @@ static uint64_t pack_dna(const char *s, size_t len)
 {
     uint64_t bases = 0;
     size_t n = 0;
-    while (n < len && n < 25) {
-        uint64_t c;
-        switch (s[n]) {
-        case 'A': c = 0; break; case 'C': c = 1; break;
-        case 'G': c = 2; break; case 'T': c = 3; break;
-        default: goto tail;
-        }
+    while (n < len) {
+        const uint64_t c = k_base_code[(unsigned char)s[n]];
+        if (c & 4) break;
         if (n == 24) return 0;                    /* 25th base: too long */
-        bases |= c << (46 - 2 * n);
+        bases = (bases << 2) | c;
         n++;
     }
-tail:
     if (n == 0) return 0;
+    bases <<= 48 - 2 * n;
     uint64_t suffix = 0;
     if (n < len) {
         if (s[n] != '-') return 0;

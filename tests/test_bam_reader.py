@@ -105,3 +105,36 @@ def test_empty_bam(tmp_path):
     synth.write_bam(str(p), np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(0, "S4"), np.zeros(0, "S4"), np.zeros(0, "S4"))
     got = read_all(p, lists)
     assert len(got[0]) == 0
+
+
+@pytest.mark.parametrize("window,threads", [(1 << 17, 1), (1 << 17, 3), (200_000, 8), (1 << 25, 5)])
+def test_reader_windows_and_threads_are_invisible(tmp_path, monkeypatch, window, threads):
+    """tiny read windows force records and BGZF blocks to straddle refills; any thread count gives
+    the same SoA in the same order"""
+    case = Case(n=60000, n_bar=300, n_gene=120, umi_pool=128, p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.2,
+                p_n_umi=0.02, p_multi_gene=0.05, p_no_ub=0.03)
+    lists = case.lists()
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, header_text=b"@HD\tVN:1.6\n" + b"@CO\tx\n" * 40000)
+    monkeypatch.setenv("FASTF_BAM_WINDOW", str(window))
+    monkeypatch.setenv("FASTF_HOST_THREADS", str(threads))
+    got = read_all(bam, lists, cap=9973)
+    for g, w in zip(got, case.packed(lists)):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_reader_rejects_corrupt_block(tmp_path):
+    case = Case(n=5000, n_bar=20, n_gene=10)
+    lists = case.lists()
+    p = tmp_path / "c.bam"
+    synth.write_bam(str(p), case.flags, case.xf, case.cb, case.gx, case.ub)
+    data = bytearray(p.read_bytes())
+    data[len(data) // 2] ^= 0xFF                      # flip a byte inside a deflate stream
+    p.write_bytes(bytes(data))
+    L = _lib.lib()
+    h = L.fastf_bam_open(str(p).encode(), 2)
+    if h:
+        cb = np.empty(9000, np.uint64); gx = np.empty(9000, np.uint64); um = np.empty(9000, np.uint32); me = np.empty(9000, np.uint32)
+        n = L.fastf_bam_read_batch(h, lists.cell_dict, lists.feat_dict, cb.ctypes.data, gx.ctypes.data, um.ctypes.data, me.ctypes.data, 9000)
+        L.fastf_bam_close(h)
+        assert n == -1 and b"BGZF" in L.fastf_last_error()

@@ -1,0 +1,71 @@
+/* gen_bam.c — fast synthetic BAM generator for end-to-end benchmarks (test tooling, not product).
+ *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len]
+ * Every record: unmapped, tags CB:Z (95 % from the list, 5 % random), xf:C (85 % 25/17), GX:Z, UB:Z.
+ * gcc -O2 -o gen_bam gen_bam.c -lz */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+static uint64_t s[2];
+static inline uint64_t rnd(void) { uint64_t a = s[0], b = s[1]; s[0] = b; a ^= a << 23; s[1] = a ^ b ^ (a >> 17) ^ (b >> 26); return s[1] + b; }
+
+static char **read_col1(const char *path, size_t *n)
+{
+    FILE *f = fopen(path, "r"); if (!f) { perror(path); exit(1); }
+    size_t cap = 1024; char **v = malloc(cap * sizeof *v); char line[2048]; *n = 0;
+    while (fgets(line, sizeof line, f)) { line[strcspn(line, "\t\r\n")] = 0; if (*n == cap) { cap *= 2; v = realloc(v, cap * sizeof *v); } v[(*n)++] = strdup(line); }
+    fclose(f); return v;
+}
+
+static FILE *out; static unsigned char blk[0xff00]; static size_t blen;
+static void flush_block(void)
+{
+    unsigned char comp[0x10000 + 64]; z_stream z; memset(&z, 0, sizeof z);
+    deflateInit2(&z, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    z.next_in = blk; z.avail_in = (uInt)blen; z.next_out = comp + 18; z.avail_out = sizeof comp - 26;
+    deflate(&z, Z_FINISH); size_t clen = z.total_out; deflateEnd(&z);
+    static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(comp, hdr, 16); uint16_t bsize = (uint16_t)(clen + 25); memcpy(comp + 16, &bsize, 2);
+    uint32_t crc = (uint32_t)crc32(crc32(0, NULL, 0), blk, (uInt)blen), isz = (uint32_t)blen;
+    memcpy(comp + 18 + clen, &crc, 4); memcpy(comp + 22 + clen, &isz, 4);
+    fwrite(comp, 1, clen + 26, out); blen = 0;
+}
+static void put(const void *p, size_t n)
+{
+    const unsigned char *q = p;
+    while (n) { size_t k = sizeof blk - blen; if (k > n) k = n; memcpy(blk + blen, q, k); blen += k; q += k; n -= k; if (blen == sizeof blk) flush_block(); }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len]\n"); return 1; }
+    size_t nb, ng; char **bar = read_col1(argv[2], &nb), **gen = read_col1(argv[3], &ng);
+    size_t n = strtoull(argv[4], NULL, 10); uint64_t seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 1; int ul = argc > 6 ? atoi(argv[6]) : 10;
+    s[0] = seed * 0x9E3779B97F4A7C15ull + 1; s[1] = seed ^ 0xD1B54A32D192ED03ull; for (int i = 0; i < 8; i++) rnd();
+    out = fopen(argv[1], "wb"); if (!out) { perror(argv[1]); return 1; }
+    static char obuf[1 << 22]; setvbuf(out, obuf, _IOFBF, sizeof obuf);
+    const char *text = "@HD\tVN:1.6\tSO:unsorted\n"; int32_t lt = (int32_t)strlen(text), nref = 0;
+    put("BAM\1", 4); put(&lt, 4); put(text, lt); put(&nref, 4);
+    unsigned char rec[512];
+    for (size_t i = 0; i < n; i++) {
+        unsigned char *p = rec + 4; int32_t m1 = -1, z = 0; char name[24]; int nl = snprintf(name, sizeof name, "r%zu", i) + 1;
+        memcpy(p, &m1, 4); memcpy(p + 4, &m1, 4); p[8] = (unsigned char)nl; p[9] = 0; uint16_t bin = 4680, nc = 0, fl = 4;
+        memcpy(p + 10, &bin, 2); memcpy(p + 12, &nc, 2); memcpy(p + 14, &fl, 2); memcpy(p + 16, &z, 4);
+        memcpy(p + 20, &m1, 4); memcpy(p + 24, &m1, 4); memcpy(p + 28, &z, 4); p += 32; memcpy(p, name, nl); p += nl;
+        uint64_t r = rnd();
+        *p++ = 'C'; *p++ = 'B'; *p++ = 'Z';
+        if ((r & 1023) < 51) { for (int k = 0; k < 16; k++) *p++ = "ACGT"[(rnd() >> 7) & 3]; memcpy(p, "-1", 3); p += 3; }
+        else { const char *b = bar[(r >> 10) % nb]; size_t l = strlen(b) + 1; memcpy(p, b, l); p += l; }
+        r = rnd(); unsigned xf = (r & 1023) < 870 ? ((r & 1024) ? 25 : 17) : (unsigned)((r >> 12) & 7);
+        *p++ = 'x'; *p++ = 'f'; *p++ = 'C'; *p++ = (unsigned char)xf;
+        { const char *g = gen[(r >> 16) % ng]; size_t l = strlen(g) + 1; *p++ = 'G'; *p++ = 'X'; *p++ = 'Z'; memcpy(p, g, l); p += l; }
+        r = rnd(); *p++ = 'U'; *p++ = 'B'; *p++ = 'Z'; for (int k = 0; k < ul; k++) { *p++ = "ACGT"[r & 3]; r >>= 2; } *p++ = 0;
+        int32_t bs = (int32_t)(p - rec - 4); memcpy(rec, &bs, 4); put(rec, (size_t)(p - rec));
+    }
+    if (blen) flush_block();
+    static const unsigned char eof[28] = {0x1f,0x8b,8,4,0,0,0,0,0,0xff,6,0,'B','C',2,0,0x1b,0,3,0,0,0,0,0,0,0,0,0};
+    fwrite(eof, 1, 28, out); fclose(out);
+    return 0;
+}
