@@ -507,7 +507,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
 #endif
     STAMP(0);
     u64* s_keys = reinterpret_cast<u64*>(smem);                                    // SORT_TILE keys
-    u32* s_whist = reinterpret_cast<u32*>(smem + (size_t)SORT_TILE * 8);          // [WAVES][256]
+    u32* s_whist = reinterpret_cast<u32*>(smem + (size_t)ipt * SORT_THREADS * 8);  // [WAVES][256]
     u32* s_delta = s_whist + SORT_WAVES * RADIX;                                   // [256] global - local start
     u32* s_start = s_delta + RADIX;                                                // [256] local bin start
     u32* s_wtot  = s_start + RADIX;                                                // [4]

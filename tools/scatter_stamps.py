@@ -2,8 +2,8 @@
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ["FASTF_LIB_OVERRIDE"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "stamps", "libfastf_amd.so")
 import fastf_amd._lib as _lib
-_lib._LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "stamps", "libfastf_amd.so")
 import fastf_amd as F
 N = 10_000_000
 cells = np.arange(1, 1001, dtype=np.uint64) | (np.uint64(1) << np.uint64(62))
@@ -14,7 +14,7 @@ keys = rng.integers(0, 1 << 56, size=N, dtype=np.uint64)
 dev = torch.device("cuda")
 d_keys = torch.from_numpy(keys.view(np.int64)).to(dev); d_tmp = torch.empty_like(d_keys)
 d_n = torch.tensor([N], dtype=torch.int64, device=dev)
-T = (N + 8191) // 8192
+IPT = int(os.environ.get("FASTF_SORT_IPT", "13")); T = (N + IPT * 512 - 1) // (IPT * 512)
 stamps = torch.zeros(T * 8, dtype=torch.int64, device=dev)
 L = _lib.lib(); L.fastf_debug_set_stamps.argtypes = [ctypes.c_void_p]
 s = torch.cuda.current_stream().cuda_stream
