@@ -93,7 +93,7 @@ struct fastf_engine {
     u64 c_sampled = 0, c_valid = 0;
     bool finished = false; int sorted_in_tmp = 0; u64 n_sorted = 0;
     // workspace
-    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_hist, d_binbase, d_cnt;
+    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_hist, d_binbase, d_cnt;
     const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
     bool fused_hist_valid = false;
     // timing
@@ -223,7 +223,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_hist, &e->d_binbase, &e->d_cnt};
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_hist, &e->d_binbase, &e->d_cnt};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -268,6 +268,7 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     }
     if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
     if (e->d_tilebase.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
+    if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(8 * RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure(ts * RADIX * sizeof(u32))) return 1;
@@ -454,16 +455,18 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
     if (reserve_workspace(e, 0, max_n)) return 1;
     const u32 tiles = (u32)((max_n + K3_TILE - 1) / K3_TILE);
-    HIP_OK(hipMemsetAsync(count, 0, max_n * sizeof(u32), s));
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
     p.tile_heads = (u32*)e->d_tilecnt.p; p.row_base = (const u64*)e->d_tilebase.p;
+    p.tile_carry = (u32*)e->d_tilecarry.p;
     p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
     t_begin(e, s);
     hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
                        (u64*)e->d_tilebase.p, tiles, nrows);
     hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
+    hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,
+                       (const u64*)e->d_tilebase.p, count, d_n);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
     e->cells_cached_for = nullptr;          // d_tilecnt / d_tilebase were reused

@@ -620,14 +620,17 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
 // K3 / K3u: segmented unique + reduce over the sorted keys.
 //   UMI_ROWS = false: one row per (cell, feature); count = distinct non-NULL umi keys
 //   UMI_ROWS = true : one row per distinct key;    count = copies of that key
-// K3a counts group heads per tile, scan_tiles_kernel turns that into row bases, K3b writes
-// the rows: counts of groups that fit in one wave-item are stored plainly, the pieces of
-// groups that straddle a wave-item are added atomically (count[] is zeroed before).
+// K3a counts group heads per tile, scan_tiles_kernel turns that into row bases, K3b stages the
+// tile's rows in LDS (identity + prefix count of distinct flags at each head: a row's count is the
+// difference of two neighbouring prefixes) and writes them with coalesced plain stores; the few
+// groups that straddle tiles are patched by carry_fix_kernel.  No atomics, no memset on the row
+// arrays (mixing plain stores and device-scope atomics on the same lines cost 60 us here).
 // ------------------------------------------------------------------------------------
 struct ReduceParams {
     const u64* keys; const u64* n_ptr;
     KeyLayout L; u32 feat_mask;
     u32* tile_heads;                       // K3a out
+    u32* tile_carry;                       // K3b out: distinct flags in front of the tile's first head
     const u64* row_base;                   // K3b in (scan of tile_heads)
     u32* feature; u32* cell; u32* count;   // UMI_ROWS: feature/cell unused
     u64* ukeys;                            // UMI_ROWS only
@@ -663,7 +666,12 @@ __global__ __launch_bounds__(K3_THREADS) void head_count_kernel(const ReducePara
 
 template <bool UMI_ROWS>
 __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p) {
-    __shared__ u32 s_cnt[K3_IPT * K3_WAVES];
+    // (item, wave) units in tile order: heads / distinct flags per unit, then their exclusive scans
+    __shared__ u32 s_h[K3_IPT * K3_WAVES], s_d[K3_IPT * K3_WAVES];
+    __shared__ u32 s_tot[2];
+    // rows of this tile, by local row: distinct-prefix at the head, and the row's identity
+    __shared__ u32 s_pd[K3_TILE + 1];
+    __shared__ u64 s_id[K3_TILE];          // UMI_ROWS: the key; else (cell << 32) | feature
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u32 tile = blockIdx.x;
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
     const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
     const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
 
-    u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT], vm[K3_IPT];
+    u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
 #pragma unroll
     for (int j = 0; j < K3_IPT; ++j) {
         const u64 idx = base + (u64)j * K3_THREADS + tid;
@@ -684,45 +692,49 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
         const bool dist = UMI_ROWS ? valid
                                    : (valid && ((k >> nn_shift) & 1) && (idx == 0 || k != prev));
         key[j] = k;
-        hm[j] = __ballot(head); dm[j] = __ballot(dist); vm[j] = __ballot(valid);
-        if (lane == 0) s_cnt[j * K3_WAVES + w] = (u32)__popcll(hm[j]);
+        hm[j] = __ballot(head); dm[j] = __ballot(dist);
+        if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }
     }
     __syncthreads();
     if (w == 0) {
-        const u32 c = s_cnt[lane];                       // exactly 64 entries
-        const u32 inc = wave_incl_scan32(c, lane);
-        s_cnt[lane] = inc - c;
+        static_assert(K3_IPT * K3_WAVES == WAVE, "one wave scans the (item, wave) units");
+        const u32 h = s_h[lane], d = s_d[lane];
+        const u32 hi = wave_incl_scan32(h, lane), di = wave_incl_scan32(d, lane);
+        s_h[lane] = hi - h; s_d[lane] = di - d;
+        if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = di; }   // sentinel: all distinct flags of the tile
     }
     __syncthreads();
-    const u64 row_base = p.row_base[tile];
-    const u64 le = (lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1);
+    const u32 n_rows = s_tot[0];
 #pragma unroll
     for (int j = 0; j < K3_IPT; ++j) {
-        const bool valid = (vm[j] >> lane) & 1;
-        if (!valid) continue;
-        const u64 h_le = hm[j] & le;
-        const u64 row = row_base + s_cnt[j * K3_WAVES + w] + (u32)__popcll(h_le) - 1;
         if ((hm[j] >> lane) & 1) {
-            if (UMI_ROWS) p.ukeys[row] = key[j];
-            else {
-                p.feature[row] = (u32)(key[j] >> p.L.feat_shift) & p.feat_mask;
-                p.cell[row] = (u32)(key[j] >> p.L.cell_shift);
-            }
+            const u32 r = s_h[j * K3_WAVES + w] + rank_below(hm[j]);
+            s_pd[r] = s_d[j * K3_WAVES + w] + rank_below(dm[j]);
+            s_id[r] = UMI_ROWS ? key[j]
+                               : (((u64)(u32)(key[j] >> p.L.cell_shift)) << 32) | ((u32)(key[j] >> p.L.feat_shift) & p.feat_mask);
         }
-        // segment end: next lane starts a group, is past n, or is in the next wave-item
-        const bool next_head = lane < 63 && ((hm[j] >> (lane + 1)) & 1);
-        const bool next_invalid = lane < 63 && !((vm[j] >> (lane + 1)) & 1);
-        const bool seg_end = lane == 63 || next_head || next_invalid;
-        if (seg_end) {
-            const int start = h_le ? (63 - __builtin_clzll(h_le)) : 0;
-            const u64 range = le & ~((1ULL << start) - 1);
-            const u32 c = (u32)__popcll(dm[j] & range);
-            const bool whole = h_le != 0 && (next_head || next_invalid);
-            if (c) {
-                if (whole) p.count[row] = c;
-                else atomicAdd(&p.count[row], c);
-            }
-        }
+    }
+    __syncthreads();
+    // distinct flags in front of the first head belong to a group that started in an earlier tile
+    if (tid == 0) p.tile_carry[tile] = n_rows ? s_pd[0] : s_tot[1];
+    const u64 row_base = p.row_base[tile];
+    for (u32 r = tid; r < n_rows; r += K3_THREADS) {
+        const u32 c = s_pd[r + 1] - s_pd[r];
+        const u64 id = s_id[r];
+        p.count[row_base + r] = c;
+        if (UMI_ROWS) p.ukeys[row_base + r] = id;
+        else { p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32); }
+    }
+}
+
+// groups that straddle tiles: add the carried distinct counts to the row whose head is in an earlier tile
+__global__ __launch_bounds__(256) void carry_fix_kernel(const u32* __restrict__ tile_carry, const u64* __restrict__ row_base,
+                                                        u32* __restrict__ count, const u64* __restrict__ n_ptr) {
+    const u64 n = *n_ptr;
+    const u32 T = (u32)((n + K3_TILE - 1) / K3_TILE);
+    for (u32 t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+        const u32 c = tile_carry[t];
+        if (c && t > 0) atomicAdd(&count[row_base[t] - 1], c);
     }
 }
 
