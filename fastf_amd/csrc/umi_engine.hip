@@ -271,7 +271,7 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(8 * RADIX * sizeof(u32))) return 1;
-    if (e->d_cnt.ensure(ts * RADIX * sizeof(u32))) return 1;
+    if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
     return 0;
 }
 

@@ -397,6 +397,8 @@ constexpr int SORT_THREADS = 512, SORT_IPT = 16, SORT_TILE = SORT_THREADS * SORT
 // tile size is chosen per sort (ipt = keys per thread, 1..SORT_IPT) so that the tiles fill whole rounds of the
 // resident workgroup slots: at 10 M keys a fixed 8192-key tile leaves the third round 38 % full
 __device__ __forceinline__ u32 num_tiles(u64 n, u32 ipt) { const u64 t = (u64)ipt * SORT_THREADS; return (u32)((n + t - 1) / t); }
+// rows of cnt[d][tile] are padded to a multiple of 4 tiles so a row scan can use 16-byte accesses
+__device__ __forceinline__ u32 row_stride(u32 T) { return (T + 3u) & ~3u; }
 
 // global histograms of every digit: hist[pass][256]
 __global__ __launch_bounds__(256) void digit_hist_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
@@ -429,16 +431,18 @@ __global__ __launch_bounds__(RADIX) void bin_base_kernel(const u32* __restrict__
     bin_base[blockIdx.x * RADIX + d] = off + inc - v;
 }
 
-// per-tile digit counts: cnt[d * T + tile]
+// per-tile digit counts: cnt[d * T + tile].  Four LDS copies of the histogram (lane & 3) keep the
+// same-address atomic conflicts of skewed digits (e.g. the constant length bits) four times shorter.
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
                                                                   u32 shift, u32* __restrict__ cnt, u32 ipt) {
-    __shared__ u32 s_h[RADIX];
+    __shared__ u32 s_h[4 * RADIX];
     const u64 n = *n_ptr;
     const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
     if (tile >= T) return;
-    if (threadIdx.x < RADIX) s_h[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) s_h[i] = 0;
     __syncthreads();
     const u64 base = (u64)tile * ipt * SORT_THREADS;
+    u32* my = s_h + (threadIdx.x & 3) * RADIX;
     u64 k[SORT_IPT];
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
@@ -448,31 +452,41 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
 #pragma unroll
     for (int j = 0; j < SORT_IPT; ++j) {
         const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-        if (j < (int)ipt && idx < n) atomicAdd(&s_h[(k[j] >> shift) & 255], 1u);
+        if (j < (int)ipt && idx < n) atomicAdd(&my[(k[j] >> shift) & 255], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < RADIX) cnt[(u64)threadIdx.x * T + tile] = s_h[threadIdx.x];
+    if (threadIdx.x < RADIX) {
+        const int d = threadIdx.x;
+        cnt[(u64)d * row_stride(T) + tile] = s_h[d] + s_h[RADIX + d] + s_h[2 * RADIX + d] + s_h[3 * RADIX + d];
+    }
 }
 
-// row d: exclusive scan of cnt[d][0..T) in place, plus bin_base[d]
+// row d: exclusive scan of cnt[d][0..T) in place, plus bin_base[d]; 4 tiles per thread (one uint4)
 __global__ __launch_bounds__(1024) void row_scan_kernel(u32* __restrict__ cnt, const u64* __restrict__ n_ptr,
                                                         const u32* __restrict__ bin_base, u32 ipt) {
     __shared__ u32 s_w[16];
     __shared__ u32 s_carry;
-    const u32 T = num_tiles(*n_ptr, ipt);
+    const u32 T = num_tiles(*n_ptr, ipt), S = row_stride(T);
     const int lane = lane_id(), w = threadIdx.x >> 6;
-    u32* row = cnt + (u64)blockIdx.x * T;
+    uint4* row = reinterpret_cast<uint4*>(cnt + (u64)blockIdx.x * S);
     if (threadIdx.x == 0) s_carry = bin_base[blockIdx.x];
     __syncthreads();
-    for (u32 t0 = 0; t0 < T; t0 += 1024) {
-        const u32 t = t0 + threadIdx.x;
-        const u32 v = t < T ? row[t] : 0;
-        const u32 inc = wave_incl_scan32(v, lane);
+    for (u32 q0 = 0; q0 * 4 < T; q0 += 1024) {
+        const u32 q = q0 + threadIdx.x;                        // quad index; tiles 4q .. 4q+3
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q * 4 < T) v = row[q];                             // padding tiles are never written: mask them
+        if (q * 4 + 1 >= T) v.y = 0;
+        if (q * 4 + 2 >= T) v.z = 0;
+        if (q * 4 + 3 >= T) v.w = 0;
+        if (q * 4 >= T) v.x = 0;
+        const u32 sum = v.x + v.y + v.z + v.w;
+        const u32 inc = wave_incl_scan32(sum, lane);
         if (lane == WAVE - 1) s_w[w] = inc;
         __syncthreads();
         u32 off = s_carry;
         for (int i = 0; i < w; ++i) off += s_w[i];
-        if (t < T) row[t] = off + inc - v;
+        const u32 e0 = off + inc - sum;
+        if (q * 4 < T) row[q] = make_uint4(e0, e0 + v.x, e0 + v.x + v.y, e0 + v.x + v.y + v.z);
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();
@@ -564,7 +578,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         for (int i = 0; i < w; ++i) o += s_wtot[i];
         const u32 lstart = o + inc - run;                  // first tile-local slot of digit tid
         s_start[tid] = lstart;
-        s_delta[tid] = off[(u64)tid * T + tile] - lstart;  // global slot = delta + local slot (mod 2^32)
+        s_delta[tid] = off[(u64)tid * row_stride(T) + tile] - lstart;  // global slot = delta + local slot (mod 2^32)
     }
     __syncthreads();
     STAMP(3);

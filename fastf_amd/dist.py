@@ -72,12 +72,14 @@ class ShardedPass:
         i64, i32 = torch.int64, torch.int32
         self.stride = n
         self.keys_out = torch.empty((G, n), dtype=i64, device=device)
-        self.key_counts = torch.zeros(G, dtype=i64, device=device)
+        # per-step scalars live in one buffer so a step clears them with a single fill
+        self._small = torch.zeros(G + 4 + 1, dtype=i64, device=device)
+        self.key_counts = self._small[:G]
+        self.counters = self._small[G:G + 4]
+        self.draw_base = self._small[G + 4:G + 5]
         self.recv_counts = torch.zeros(G, dtype=i64, device=device)
-        self.counters = torch.zeros(4, dtype=i64, device=device)
         self.hits = torch.zeros(1, dtype=i64, device=device)
         self.all_hits = torch.zeros(G, dtype=i64, device=device)
-        self.draw_base = torch.zeros(1, dtype=i64, device=device)
         self.recv_cap = G * n
         self.recv = torch.empty(self.recv_cap, dtype=i64, device=device)
         self.tmp = torch.empty(self.recv_cap, dtype=i64, device=device)
@@ -92,15 +94,13 @@ class ShardedPass:
     def run(self, cb, gx, umi, meta, n, draws):
         """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident)."""
         G, st = self.G, self.st
-        self.key_counts.zero_()
-        self.counters.zero_()
+        self._small.zero_()
         # 1. draw-rank base
         if G > 1:
             st.count_hits(cb, n, self.hits)
             dist.all_gather_into_tensor(self.all_hits, self.hits, group=self.group)
             self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
         else:
-            self.draw_base.zero_()
             st.hist_reset()                             # single shard: K1b accumulates the digit histograms
         # 2. K1
         st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
@@ -108,8 +108,8 @@ class ShardedPass:
         # 3. the exchange
         if G > 1:
             dist.all_to_all_single(self.recv_counts, self.key_counts, group=self.group)
-            send = self.key_counts.tolist()            # the one host sync of the pass
-            recv = self.recv_counts.tolist()
+            both = torch.cat([self.key_counts, self.recv_counts]).tolist()   # the one host sync of the pass
+            send, recv = both[:G], both[G:]
             self.n_recv = int(sum(recv))
             if dist.get_backend(self.group) == "nccl":
                 outs, o = [], 0

@@ -14,7 +14,8 @@ from collections import defaultdict
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("fastf::", "")
+    n = name.split("(")[0].replace("void ", "").replace("fastf::", "")
+    return "scatter_kernel" if n.startswith("scatter_kernel<") else n      # one kernel, 8 digit-shift instantiations
 
 
 def counters(d, cname):
@@ -40,7 +41,10 @@ def main():
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.0f" % float(r["AverageNs"]),
                         r["Percentage"], r["MinNs"], r["MaxNs"]])
     fetch, write = counters(fdir, "FETCH_SIZE"), counters(wdir, "WRITE_SIZE")
-    avg = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+    tot, calls = defaultdict(float), defaultdict(int)
+    for r in rows:
+        tot[short(r["Name"])] += float(r["TotalDurationNs"]); calls[short(r["Name"])] += int(r["Calls"])
+    avg = {k: tot[k] / calls[k] for k in tot}
     tc = fetch.get("tile_count_kernel", [])
     cal = (8.0 * n_keys) / (sum(tc) / len(tc) * 1024) if tc else None
     summ = {"_note": "per-launch averages; FETCH/WRITE in KiB as reported by rocprofv3 --pmc (separate passes); "
