@@ -106,7 +106,8 @@ struct fastf_engine {
     double t_count_ms = 0; u64 t_count_n = 0;
 };
 
-enum { SM_KEYCOUNT = 0, SM_COUNTERS = 8, SM_NNZ = 12, SM_NROWS_U = 13, SM_N = 14, SM_WORDS = 16 };
+// key_counts (one returning atomic per tile) and counters (three atomics per tile) sit on different 256-B segments
+enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 66, SM_WORDS = 80 };
 
 static int set_scatter_lds_limit();
 static u32 g_cu_count = 256;

@@ -12,6 +12,9 @@
 // All of it is integer indexing: wave64 ballots/mbcnt for ranking, LDS for the
 // tile-local reorder, coalesced 8-byte streams to HBM.  No MFMA by design.
 #pragma once
+#ifndef FASTF_K1_IPT
+#define FASTF_K1_IPT 8
+#endif
 #ifndef FASTF_K1_THREADS
 #define FASTF_K1_THREADS 512
 #endif
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const u32* __restrict_
 // The hit rank of a record (= its position in the MT draw stream) is
 //   tile_base[tile] (scan of K1a's counts) + rank inside the tile (ballots, record order).
 // ------------------------------------------------------------------------------------
-constexpr int K1_THREADS = FASTF_K1_THREADS, K1_IPT = 8, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
+constexpr int K1_THREADS = FASTF_K1_THREADS, K1_IPT = FASTF_K1_IPT, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
 
 __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);

@@ -72,11 +72,12 @@ class ShardedPass:
         i64, i32 = torch.int64, torch.int32
         self.stride = n
         self.keys_out = torch.empty((G, n), dtype=i64, device=device)
-        # per-step scalars live in one buffer so a step clears them with a single fill
-        self._small = torch.zeros(G + 4 + 1, dtype=i64, device=device)
+        # per-step scalars live in one buffer so a step clears them with a single fill, but 512 B apart:
+        # atomics (key_counts, counters) and the plain loads of draw_base must not share a cache line
+        self._small = torch.zeros(192, dtype=i64, device=device)
         self.key_counts = self._small[:G]
-        self.counters = self._small[G:G + 4]
-        self.draw_base = self._small[G + 4:G + 5]
+        self.counters = self._small[64:68]
+        self.draw_base = self._small[128:129]
         self.recv_counts = torch.zeros(G, dtype=i64, device=device)
         self.hits = torch.zeros(1, dtype=i64, device=device)
         self.all_hits = torch.zeros(G, dtype=i64, device=device)
