@@ -216,6 +216,12 @@ struct fastf_bam {
     unsigned char *cbuf; size_t ccap, clen;      /* compressed window (whole blocks + a partial tail) */
     unsigned char *ubuf; size_t ucap, ulen, upos;/* inflated window; [upos, ulen) not yet consumed     */
     bgzf_blk *blk; size_t nblk, blkcap;
+    /* prefetch: a filler thread reads + inflates the NEXT window into nbuf[NX_RESERVE ...) while the caller
+     * hops/packs the current one; the unconsumed tail of the current window is copied in front of it */
+    unsigned char *nbuf; size_t ncap, nlen;
+    pthread_t filler; int filler_started;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int want_fill, fill_done, fill_result, quit, drained;
     size_t *rec; size_t reccap;                   /* offsets (into ubuf) of the records of one batch   */
     uint64_t n_records, n_no_xf, n_no_gx;
     int failed;
@@ -227,6 +233,8 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 static inline uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 static inline uint32_t rd16(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+
+#define NX_RESERVE ((size_t)1 << 20)
 
 static int host_threads(int asked)
 {
@@ -274,22 +282,20 @@ static void inflate_worker(void *vp, int widx)
             if (!k->isize) continue;
             inflateReset(&z);
             z.next_in = b->cbuf + k->coff; z.avail_in = k->clen;
-            z.next_out = b->ubuf + k->uoff; z.avail_out = k->isize;
+            z.next_out = b->nbuf + k->uoff; z.avail_out = k->isize;
             int r = inflate(&z, Z_FINISH);
             const unsigned char *tail = b->cbuf + k->coff + k->clen;       /* crc32, isize */
             if (r != Z_STREAM_END || z.avail_out != 0 ||
-                (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->ubuf + k->uoff, k->isize) != rd32(tail)) { j->err = 1; break; }
+                (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->nbuf + k->uoff, k->isize) != rd32(tail)) { j->err = 1; break; }
         }
     }
     inflateEnd(&z);
 }
 
-/* Refill the inflated window with the next chunk of the file.  0 ok (progress made), 1 EOF, -1 error */
-static int bam_fill(fastf_bam_t *b)
+/* Filler side: read the next chunk of the file and inflate it into nbuf[NX_RESERVE, nlen).
+ * 0 ok (nlen set), 1 EOF, -1 error */
+static int fill_next(fastf_bam_t *b)
 {
-    if (b->failed) return -1;
-    /* keep the unconsumed tail at the front of the window */
-    if (b->upos) { memmove(b->ubuf, b->ubuf + b->upos, b->ulen - b->upos); b->ulen -= b->upos; b->upos = 0; }
     for (;;) {
         if (!b->file_eof) {
             double t0 = now_s();
@@ -304,7 +310,7 @@ static int bam_fill(fastf_bam_t *b)
         size_t pos = 0, utotal = 0;
         while (b->clen - pos >= 18) {
             const unsigned char *h = b->cbuf + pos;
-            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { b->failed = 1; return io_err("not a BGZF block") ? -1 : -1; }
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { io_err("not a BGZF block"); return -1; }
             uint32_t xlen = rd16(h + 10);
             if (b->clen - pos < 12 + (size_t)xlen) break;
             int bsize = -1;
@@ -313,39 +319,97 @@ static int bam_fill(fastf_bam_t *b)
                 if (h[12 + i] == 'B' && h[12 + i + 1] == 'C' && slen == 2) bsize = (int)rd16(h + 12 + i + 4);
                 i += 4 + slen;
             }
-            if (bsize < 0) { b->failed = 1; io_err("BGZF block without BC field"); return -1; }
+            if (bsize < 0) { io_err("BGZF block without BC field"); return -1; }
             size_t total = (size_t)bsize + 1;
-            if (total < 12 + (size_t)xlen + 8) { b->failed = 1; io_err("bad BGZF block size"); return -1; }
+            if (total < 12 + (size_t)xlen + 8) { io_err("bad BGZF block size"); return -1; }
             if (b->clen - pos < total) break;
             if (b->nblk == b->blkcap) { b->blkcap = b->blkcap ? b->blkcap * 2 : 4096; b->blk = (bgzf_blk *)realloc(b->blk, b->blkcap * sizeof *b->blk); }
             bgzf_blk *k = &b->blk[b->nblk++];
             k->coff = pos + 12 + xlen;
             k->clen = (uint32_t)(total - 12 - xlen - 8);
             k->isize = rd32(h + total - 4);
-            k->uoff = b->ulen + utotal;
+            k->uoff = NX_RESERVE + utotal;
             utotal += k->isize;
             pos += total;
         }
         if (b->nblk == 0) {
             if (b->file_eof) {
-                if (b->clen - pos != 0) { b->failed = 1; io_err("truncated BGZF block at end of file"); return -1; }
+                if (b->clen - pos != 0) { io_err("truncated BGZF block at end of file"); return -1; }
                 return 1;
             }
-            if (b->clen == b->ccap) { b->failed = 1; io_err("BGZF block larger than the read window"); return -1; }
+            if (b->clen == b->ccap) { io_err("BGZF block larger than the read window"); return -1; }
             continue;
         }
-        if (b->ulen + utotal > b->ucap) { b->ucap = (b->ulen + utotal) * 3 / 2 + (1 << 20); b->ubuf = (unsigned char *)realloc(b->ubuf, b->ucap); }
+        if (NX_RESERVE + utotal > b->ncap) { b->ncap = (NX_RESERVE + utotal) * 5 / 4 + (1 << 20); free(b->nbuf); b->nbuf = (unsigned char *)malloc(b->ncap); }
         inflate_job job; memset(&job, 0, sizeof job); job.b = b;
         double t0 = now_s();
         par_run(b->n_threads, inflate_worker, &job);
         b->t_inflate += now_s() - t0;
-        if (job.err) { b->failed = 1; io_err("BGZF inflate/CRC failure"); return -1; }
-        b->ulen += utotal;
-        /* keep the partial block for the next round */
-        memmove(b->cbuf, b->cbuf + pos, b->clen - pos);
+        if (job.err) { io_err("BGZF inflate/CRC failure"); return -1; }
+        b->nlen = NX_RESERVE + utotal;
+        memmove(b->cbuf, b->cbuf + pos, b->clen - pos);       /* keep the partial block for the next round */
         b->clen -= pos;
         return 0;
     }
+}
+
+static void *filler_main(void *vp)
+{
+    fastf_bam_t *b = (fastf_bam_t *)vp;
+    for (;;) {
+        pthread_mutex_lock(&b->mu);
+        while (!b->want_fill && !b->quit) pthread_cond_wait(&b->cv, &b->mu);
+        if (b->quit) { pthread_mutex_unlock(&b->mu); break; }
+        b->want_fill = 0;
+        pthread_mutex_unlock(&b->mu);
+        int r = fill_next(b);
+        pthread_mutex_lock(&b->mu);
+        b->fill_result = r; b->fill_done = 1;
+        pthread_cond_broadcast(&b->cv);
+        pthread_mutex_unlock(&b->mu);
+        if (r != 0) break;                                    /* EOF or error: nothing more to prefetch */
+    }
+    return NULL;
+}
+
+static void request_fill(fastf_bam_t *b)
+{
+    pthread_mutex_lock(&b->mu);
+    b->fill_done = 0; b->want_fill = 1;
+    pthread_cond_broadcast(&b->cv);
+    pthread_mutex_unlock(&b->mu);
+}
+
+/* Consumer side: make the prefetched window current, carrying the unconsumed tail over.
+ * 0 ok (progress made), 1 EOF, -1 error */
+static int bam_fill(fastf_bam_t *b)
+{
+    if (b->failed) return -1;
+    if (b->drained) return 1;
+    pthread_mutex_lock(&b->mu);
+    while (!b->fill_done) pthread_cond_wait(&b->cv, &b->mu);
+    const int r = b->fill_result;
+    pthread_mutex_unlock(&b->mu);
+    if (r < 0) { b->failed = 1; return -1; }
+    if (r == 1) { b->drained = 1; return 1; }
+    const size_t tail = b->ulen - b->upos;
+    size_t start;
+    if (tail <= NX_RESERVE) {
+        start = NX_RESERVE - tail;
+        memcpy(b->nbuf + start, b->ubuf + b->upos, tail);
+    } else {                                                  /* a record longer than the reserve: make room */
+        const size_t data = b->nlen - NX_RESERVE;
+        unsigned char *nb = (unsigned char *)malloc(tail + data + (1 << 20));
+        memcpy(nb, b->ubuf + b->upos, tail);
+        memcpy(nb + tail, b->nbuf + NX_RESERVE, data);
+        free(b->nbuf); b->nbuf = nb; b->ncap = tail + data + (1 << 20); b->nlen = tail + data;
+        start = 0;
+    }
+    unsigned char *tb = b->ubuf; size_t tc = b->ucap;
+    b->ubuf = b->nbuf; b->ucap = b->ncap; b->ulen = b->nlen; b->upos = start;
+    b->nbuf = tb; b->ncap = tc; b->nlen = 0;
+    request_fill(b);                                          /* overlap the next window with this one's parsing */
+    return 0;
 }
 
 /* make at least `need` bytes available at upos; 0 ok, 1 clean EOF (nothing left), -1 error/truncated */
@@ -371,7 +435,12 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     b->ccap = w ? (size_t)strtoull(w, NULL, 0) : ((size_t)32 << 20);
     if (b->ccap < (1 << 17)) b->ccap = 1 << 17;
     b->cbuf = (unsigned char *)malloc(b->ccap);
-    b->ucap = b->ccap * 4; b->ubuf = (unsigned char *)malloc(b->ucap);
+    b->ucap = 1 << 16; b->ubuf = (unsigned char *)malloc(b->ucap);
+    b->ncap = NX_RESERVE + b->ccap * 4; b->nbuf = (unsigned char *)malloc(b->ncap);
+    pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv, NULL);
+    if (pthread_create(&b->filler, NULL, filler_main, b) != 0) { io_err("cannot start the BAM prefetch thread"); fastf_bam_close(b); return NULL; }
+    b->filler_started = 1;
+    request_fill(b);
     /* header: magic, l_text, text, n_ref, {l_name, name, l_ref}* — what sam_hdr_read() consumes (bam2db_ds.c:340) */
     if (bam_need(b, 12) || memcmp(b->ubuf + b->upos, "BAM\1", 4) != 0) { io_err("%s is not a BAM file", path); fastf_bam_close(b); return NULL; }
     uint32_t l_text = rd32(b->ubuf + b->upos + 4);
@@ -393,8 +462,13 @@ void fastf_bam_close(fastf_bam_t *b)
     if (getenv("FASTF_BAM_PROFILE"))
         fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s, record hop %.3f s, tag pack %.3f s\n",
                 (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack);
+    if (b->filler_started) {
+        pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv); pthread_mutex_unlock(&b->mu);
+        pthread_join(b->filler, NULL);
+        pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv);
+    }
     if (b->fp) fclose(b->fp);
-    free(b->cbuf); free(b->ubuf); free(b->blk); free(b->rec); free(b);
+    free(b->cbuf); free(b->ubuf); free(b->nbuf); free(b->blk); free(b->rec); free(b);
 }
 
 void fastf_bam_stats(const fastf_bam_t *b, uint64_t *n_records, uint64_t *n_no_xf, uint64_t *n_no_gx)
