@@ -20,6 +20,14 @@ CASES = {
     "skewed": dict(n=200_000, n_bar=2000, n_gene=300, gene_dist="zipf", umi_pool=4096, zipf_umi=1.5, data_seed=5),
     "depth_tiny": dict(n=50_000, n_bar=100, n_gene=50, rate_depth=0.01, umi_pool=8),
     "cells_none": dict(n=1000, n_bar=10, n_gene=5, rate_cell=0.05),
+    # groups far larger than a reduce tile (4096 keys): the carry fix-up path, counts in the tens of thousands
+    "huge_groups": dict(n=400_000, n_bar=3, n_gene=2, umi_len=12, data_seed=11),
+    "one_group_all_dups": dict(n=100_000, n_bar=1, n_gene=1, umi_pool=1),
+    "one_group_null_umis": dict(n=30_000, n_bar=1, n_gene=1, umi_pool=3, p_n_umi=0.9),
+    # BASELINE config 5 shape, scaled: 100 k barcodes, Zipf-skewed UMI reuse from a 4096-pool per gene
+    "c5_like": dict(n=1_500_000, n_bar=100_000, n_gene=400, umi_len=12, umi_pool=4096, zipf_umi=1.5, data_seed=9),
+    "every_record_misses": dict(n=20_000, n_bar=50, n_gene=20, p_unlisted_cb=1.0),
+    "no_cb_at_all": dict(n=20_000, n_bar=50, n_gene=20, p_no_cb=1.0),
 }
 
 
@@ -35,6 +43,47 @@ def test_engine_matches_oracle(name):
         res = eng.finish()
         rows = eng.umi_rows()
         assert_matches_oracle(res, ora, eng, case, lists, rows)
+    finally:
+        eng.close()
+
+
+def test_mixed_umi_lengths_0_to_16():
+    """UMI lengths 0..16 in one run (blob byte lengths 0..4): the length field and zero padding decide equality"""
+    from fastf_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    n = 60_000
+    bt, ft, bar, genes = synth.make_lists(40, 30, seed=5)
+    flags, xf, cb, gx, _ = synth.make_records(n, bar, genes, seed=6)
+    lens = rng.integers(0, 17, size=n)
+    pool = [b"", b"A", b"AC", b"ACG", b"ACGT", b"ACGTA", b"ACGTAAAA", b"ACGTAAAAA", b"ACGTAAAAAAAA", b"ACGTAAAAAAAAA",
+            b"ACGTACGTACGTACGT", b"ACGTACGTACGTACGA", b"TTTTTTTTTTTTTTTT", b"ACGTN", b"NNNN", b"TTTT", b"TTTTA", b"TTTTAAAA"]
+    ub = np.array([pool[i % len(pool)] if rng.random() < 0.7 else bytes(rng.choice(list(b"ACGT"), size=lens[i]).tolist())
+                   for i in range(n)], dtype="S17")
+    cb, gx = synth.as_cstr(cb), synth.as_cstr(gx)
+    ora = O.run_bam2db(bt, ft, flags, xf, cb, gx, ub, 1.0, 0.8, 926, b"synthetic.bam", True)
+    lists = F.Lists(bt, ft, 1.0, 926)
+    eng = F.Engine.from_lists(lists, rate_depth=0.8, seed=926, umi_max_bases=16)
+    try:
+        eng.push(*F.pack_records(lists, flags, xf, cb, gx, ub))
+        res = eng.finish()
+        case = Case(n=1, n_bar=2, n_gene=2); case.rate_cell, case.rate_depth, case.label = 1.0, 0.8, b"synthetic.bam"
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
+def test_umi_longer_than_engine_limit_is_an_error_not_a_wrong_answer():
+    from fastf_amd import synth
+    bt, ft, bar, genes = synth.make_lists(10, 5, seed=5)
+    flags, xf, cb, gx, ub = synth.make_records(5000, bar, genes, seed=6, umi_len=14)
+    lists = F.Lists(bt, ft, 1.0, 926)
+    eng = F.Engine.from_lists(lists, umi_max_bases=12)
+    try:
+        eng.push(*F.pack_records(lists, flags, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)))
+        with pytest.raises(F.FastfError) as ei:
+            eng.finish()
+        assert "umi_max_bases" in str(ei.value)
     finally:
         eng.close()
 
