@@ -34,12 +34,17 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     stats = glob.glob(os.path.join(sdir, "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(stats)))
+    agg = {}
+    for r in rows:                      # the 8 digit-shift instantiations of scatter_kernel are one kernel
+        k = short(r["Name"])
+        a = agg.setdefault(k, [0, 0.0, 0.0, 1e30, 0.0])
+        a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"]); a[2] += float(r["Percentage"])
+        a[3] = min(a[3], float(r["MinNs"])); a[4] = max(a[4], float(r["MaxNs"]))
     with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
-        for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.0f" % float(r["AverageNs"]),
-                        r["Percentage"], r["MinNs"], r["MaxNs"]])
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, a[0], "%.0f" % a[1], "%.0f" % (a[1] / a[0]), "%.2f" % a[2], "%.0f" % a[3], "%.0f" % a[4]])
     fetch, write = counters(fdir, "FETCH_SIZE"), counters(wdir, "WRITE_SIZE")
     tot, calls = defaultdict(float), defaultdict(int)
     for r in rows:
