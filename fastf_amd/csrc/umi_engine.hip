@@ -92,6 +92,9 @@ struct fastf_engine {
     u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;
     u64 c_sampled = 0, c_valid = 0;
     bool finished = false; int sorted_in_tmp = 0; u64 n_sorted = 0;
+    u32 dev_hist_first = 0;
+    u32 skip_bits = 0;           // low key bits the matrix path leaves unsorted (dedup needs adjacency of equal keys only)
+    bool fully_sorted = false;
     // workspace
     DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_hist, d_binbase, d_cnt;
     const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
@@ -181,6 +184,12 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         delete e; return 1;
     }
     e->threshold = cfg->draw_threshold;
+    {   // keep >= 10 bits of the UMI field in the sorted part; everything below a multiple of 8 is skipped
+        const char* sk = getenv("FASTF_SORT_SKIP_BITS");
+        const u32 fs = e->L.feat_shift;
+        e->skip_bits = sk ? (u32)atoi(sk) : (fs > 10 ? 8 * ((fs - 10) / 8) : 0);
+        if (e->skip_bits % 8 || e->skip_bits >= fs) e->skip_bits = 0;
+    }
     e->n_shards = cfg->n_shards; e->shard_rank = cfg->shard_rank;
     fastf_mt_seed(&e->mt, cfg->mt_seed);
     fastf_mt_skip(&e->mt, cfg->mt_skip);
@@ -229,6 +238,12 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     delete e;
+}
+
+extern "C" int fastf_engine_skip_bits(const fastf_engine_t* e, uint32_t* bits) {
+    if (!e || !bits) return set_err("null argument");
+    *bits = e->skip_bits;
+    return 0;
 }
 
 extern "C" int fastf_engine_key_bits(const fastf_engine_t* e, uint32_t* cell_bits, uint32_t* feature_bits,
@@ -342,7 +357,7 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
-                        u64* counters, u32* fused_hist, hipStream_t s) {
+                        u64* counters, u32* fused_hist, u32 hist_first, hipStream_t s) {
     if (n == 0) return 0;
     // K1a (skipped when fastf_dev_count_hits just ran on the very same records, same stream order)
     if (!(e->cells_cached_for == cb && e->cells_cached_n == n))
@@ -359,6 +374,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
     p.digit_hist = (e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST")) ? fused_hist : nullptr;
     p.hist_passes = (e->L.total_bits + 7) / 8;
+    p.hist_first = hist_first;
     p.stamps = g_k1_stamps;
     t_begin(e, s);
     hipLaunchKernelGGL(filter_pack_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, p);
@@ -367,9 +383,10 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     return 0;
 }
 
-extern "C" int fastf_dev_hist_reset(fastf_engine_t* e, void* stream) {
+extern "C" int fastf_dev_hist_reset(fastf_engine_t* e, uint32_t flags, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
+    e->dev_hist_first = (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits / 8 : 0;   // digits the coming sort will not use
     if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     HIP_OK(hipMemsetAsync(e->d_hist.p, 0, 8 * RADIX * sizeof(u32), (hipStream_t)stream));
     return 0;
@@ -385,7 +402,7 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
     if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
-                        (u32*)e->d_hist.p, (hipStream_t)stream);
+                        (u32*)e->d_hist.p, e->dev_hist_first, (hipStream_t)stream);
 }
 
 static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
@@ -408,10 +425,11 @@ static int set_scatter_lds_limit() {
     return 0;
 }
 
-static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits,
+static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits, u32 low_bit,
                        bool hist_ready, int* sorted_in_tmp, hipStream_t s) {
     const u32 passes = (key_bits + 7) / 8;
-    *sorted_in_tmp = (int)(passes & 1);
+    const u32 first = std::min(low_bit / 8, passes);           // digit passes below low_bit are skipped
+    *sorted_in_tmp = (int)((passes - first) & 1);
     if (max_n == 0) return 0;
     if (passes > 8) return set_err("key_bits %u > 64", key_bits);
     if (max_n >= (1ull << 32)) return set_err("sort of %llu keys: limit is 2^32-1 per shard", (unsigned long long)max_n);
@@ -425,9 +443,9 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         hipLaunchKernelGGL(digit_hist_kernel, dim3(grid), dim3(256), 0, s, (const u64*)keys, d_n, passes, hist);
     }
     hipLaunchKernelGGL(bin_base_kernel, dim3(passes), dim3(RADIX), 0, s, (const u32*)hist, binbase);
-    for (u32 q = 0; q < passes; ++q) {
-        const u64* src = (q & 1) ? tmp : keys;
-        u64* dst = (q & 1) ? keys : tmp;
+    for (u32 q = first; q < passes; ++q) {
+        const u64* src = ((q - first) & 1) ? tmp : keys;
+        u64* dst = ((q - first) & 1) ? keys : tmp;
         t_begin(e, s);
         hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
@@ -446,18 +464,20 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
     HIP_OK(hipSetDevice(e->device));
     int dummy = 0;
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
+                       (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0,
                        (flags & FASTF_SORT_HIST_READY) && e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST"),
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream);
 }
 
 template <bool UMI_ROWS>
 static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u32* feature, u32* cell,
-                         u32* count, u64* ukeys, u64* nrows, hipStream_t s) {
+                         u32* count, u64* ukeys, u64* nrows, u32 low_skip, hipStream_t s) {
     if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
     if (reserve_workspace(e, 0, max_n)) return 1;
     const u32 tiles = (u32)((max_n + K3_TILE - 1) / K3_TILE);
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
+    p.low_skip = UMI_ROWS ? 0 : low_skip;
     p.tile_heads = (u32*)e->d_tilecnt.p; p.row_base = (const u64*)e->d_tilebase.p;
     p.tile_carry = (u32*)e->d_tilecarry.p;
     p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
@@ -475,11 +495,12 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
 }
 
 extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
-                                uint32_t* d_feature, uint32_t* d_cell, uint32_t* d_count, uint64_t* d_nnz, void* stream) {
+                                uint32_t* d_feature, uint32_t* d_cell, uint32_t* d_count, uint64_t* d_nnz, uint32_t flags,
+                                void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, d_feature, d_cell, d_count, nullptr,
-                                (u64*)d_nnz, (hipStream_t)stream);
+                                (u64*)d_nnz, (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0, (hipStream_t)stream);
 }
 
 extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
@@ -487,7 +508,7 @@ extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, c
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<true>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, nullptr, nullptr, d_ncopy,
-                               (u64*)d_ukeys, (u64*)d_nrows, (hipStream_t)stream);
+                               (u64*)d_ukeys, (u64*)d_nrows, 0, (hipStream_t)stream);
 }
 
 extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
@@ -593,7 +614,7 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     }
     if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
                      (const u32*)(ds + o_draw), nd, nullptr, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
-                     small + SM_COUNTERS, (u32*)e->d_hist.p, sk))
+                     small + SM_COUNTERS, (u32*)e->d_hist.p, e->skip_bits / 8, sk))
         return 1;
     HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
     e->batch_in_flight = true;
@@ -647,12 +668,15 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         if (n) {
             if (e->d_tmp.ensure(e->key_cap * sizeof(u64))) return 1;
             if (e->d_feature.ensure(n * 4) || e->d_cell.ensure(n * 4) || e->d_count.ensure(n * 4)) return 1;
-            if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits,
+            // the matrix only needs equal keys to be neighbours inside a (cell, feature) group: the lowest digit
+            // passes are skipped and K3 resolves the short unsorted runs (fastf_engine_umi_rows sorts fully)
+            if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
                             e->fused_hist_valid, &e->sorted_in_tmp, s))
                 return 1;
+            e->fully_sorted = e->skip_bits == 0;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
             if (launch_reduce<false>(e, sorted, small + SM_KEYCOUNT, n, (u32*)e->d_feature.p, (u32*)e->d_cell.p,
-                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, s))
+                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, e->skip_bits, s))
                 return 1;
         } else {
             HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
@@ -688,9 +712,17 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
     std::vector<u64> ukeys;
     if (n) {
         if (e->d_ukeys.ensure(n * 8) || e->d_ncopy.ensure(n * 4)) return 1;
+        if (!e->fully_sorted) {            // -u rows are ordered by blob: finish the sort (every key is still there, permuted)
+            u64* from = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
+            u64* other = e->sorted_in_tmp ? (u64*)e->d_keys.p : (u64*)e->d_tmp.p;
+            int in_other = 0;
+            if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, false, &in_other, s)) return 1;
+            if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
+            e->fully_sorted = true;
+        }
         const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
         if (launch_reduce<true>(e, sorted, small + SM_KEYCOUNT, n, nullptr, nullptr, (u32*)e->d_ncopy.p,
-                                (u64*)e->d_ukeys.p, small + SM_NROWS_U, s))
+                                (u64*)e->d_ukeys.p, small + SM_NROWS_U, 0, s))
             return 1;
         HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));

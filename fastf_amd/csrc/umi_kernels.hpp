@@ -246,6 +246,7 @@ struct PackParams {
     u64* counters;                 // {hits, sampled, valid, err}
     u32* digit_hist;               // optional fused per-digit histograms [passes][256] (n_shards==1)
     u32 hist_passes;
+    u32 hist_first;                // digit passes below this one are skipped by the sort: no histogram needed
     u64* stamps;                   // diagnostic builds only (-DFASTF_STAMPS)
 };
 
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
 struct ReduceParams {
     const u64* keys; const u64* n_ptr;
     KeyLayout L; u32 feat_mask;
+    u32 low_skip;                          // the keys are sorted on bits >= low_skip only (0 = fully sorted)
     u32* tile_heads;                       // K3a out
     u32* tile_carry;                       // K3b out: distinct flags in front of the tile's first head
     const u64* row_base;                   // K3b in (scan of tile_heads)
@@ -706,8 +708,27 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
         const u64 k = valid ? p.keys[idx] : 0;
         const u64 prev = (valid && idx > 0) ? p.keys[idx - 1] : ~k;
         const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
-        const bool dist = UMI_ROWS ? valid
-                                   : (valid && ((k >> nn_shift) & 1) && (idx == 0 || k != prev));
+        bool dist;
+        if (UMI_ROWS) dist = valid;
+        else {
+            dist = valid && ((k >> nn_shift) & 1);
+            if (dist && idx > 0) {
+                if (p.low_skip == 0) dist = k != prev;
+                else {
+                    // keys that agree on the sorted bits are neighbours but in arbitrary order: this key is a new UMI
+                    // iff no earlier key of that little run equals it.  The run is (cell, feature, top UMI bits), i.e.
+                    // 1/2^(sorted UMI bits) of a group plus its exact duplicates — a step or two in practice.
+                    const u64 run = k >> p.low_skip;
+                    u64 q = prev, at = idx - 1;
+                    for (;;) {
+                        if ((q >> p.low_skip) != run) break;
+                        if (q == k) { dist = false; break; }
+                        if (at == 0) break;
+                        q = p.keys[--at];
+                    }
+                }
+            }
+        }
         key[j] = k;
         hm[j] = __ballot(head); dm[j] = __ballot(dist);
         if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }

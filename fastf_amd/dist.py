@@ -50,14 +50,15 @@ class HipStages:
                                 d_draw_base=draw_base.data_ptr())
 
     def hist_reset(self):
-        self.eng.dev_hist_reset(self._s())
+        self.eng.dev_hist_reset(self._s(), skip_low=True)
 
     def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, hist_ready=False):
+        # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs
         in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
-                                   hist_ready=hist_ready)
+                                   hist_ready=hist_ready, skip_low=True)
         src = tmp if in_tmp else keys
         self.eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, feature.data_ptr(), cell.data_ptr(),
-                            count.data_ptr(), nnz.data_ptr(), self._s())
+                            count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=True)
         return src
 
 

@@ -185,7 +185,11 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
  * *sorted_in_tmp tells where the result landed. */
 #define FASTF_SORT_HIST_READY 1u   /* digit histograms were accumulated by fastf_dev_probe_pack
                                       (single shard) since the last fastf_dev_hist_reset       */
-int fastf_dev_hist_reset(fastf_engine_t *e, void *stream);
+#define FASTF_SORT_SKIP_LOW   2u   /* leave the low fastf_engine_skip_bits() bits unsorted: enough for the matrix
+                                      (equal keys stay neighbours of their (cell, feature, top-UMI-bits) run);
+                                      pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
+int fastf_engine_skip_bits(const fastf_engine_t *e, uint32_t *bits);
+int fastf_dev_hist_reset(fastf_engine_t *e, uint32_t flags, void *stream);   /* flags: FASTF_SORT_SKIP_LOW if the sort will skip */
 int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
                    const uint64_t *d_n, uint64_t max_n, uint32_t key_bits, uint32_t flags,
                    int *sorted_in_tmp, void *stream);
@@ -194,7 +198,7 @@ int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
  * *d_nnz (u64) receives the row count. */
 int fastf_dev_reduce(fastf_engine_t *e, const uint64_t *d_sorted, const uint64_t *d_n,
                      uint64_t max_n, uint32_t *d_feature, uint32_t *d_cell,
-                     uint32_t *d_count, uint64_t *d_nnz, void *stream);
+                     uint32_t *d_count, uint64_t *d_nnz, uint32_t flags, void *stream);
 
 /* K3u: run-length rows for -u (capacity max_n rows). */
 int fastf_dev_umi_rows(fastf_engine_t *e, const uint64_t *d_sorted, const uint64_t *d_n,

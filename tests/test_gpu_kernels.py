@@ -88,3 +88,46 @@ def test_dev_reduce_matches_numpy(env, n, n_groups, seed):
     np.testing.assert_array_equal(d_f.cpu().numpy()[:nnz].astype(np.int64), (ug & np.uint64((1 << 9) - 1)).astype(np.int64))
     np.testing.assert_array_equal(d_k.cpu().numpy()[:nnz].astype(np.int64), want)
     assert eng.dev_error_bits() == 0
+
+
+@pytest.mark.parametrize("n,n_groups,low_values,seed", [(200_000, 50_000, 1 << 16, 1), (120_000, 3, 1 << 16, 2),
+                                                        (60_000, 1, 5000, 3), (300_000, 200_000, 4, 4)])
+def test_group_only_sort_plus_run_aware_reduce(env, n, n_groups, low_values, seed):
+    """FASTF_SORT_SKIP_LOW: only the high digits are sorted; equal keys are neighbours of their run but unordered.
+    The reduce kernel must still count distinct non-NULL keys per (cell, feature) exactly — including long runs
+    (one group, thousands of distinct low parts sharing the sorted prefix) and heavy duplication."""
+    torch, F, eng = env
+    skip = eng.skip_bits
+    assert skip == 16                       # this engine: feat_shift 27 → two low digit passes skipped
+    rng = np.random.default_rng(seed)
+    fs, cs = 27, 36
+    cell = rng.integers(1, 1001, size=n_groups, dtype=np.uint64)
+    feat = rng.integers(1, 501, size=n_groups, dtype=np.uint64)
+    g = rng.integers(0, n_groups, size=n)
+    nonnull = (rng.random(n) > 0.05).astype(np.uint64)
+    hi = rng.integers(0, 4, size=n, dtype=np.uint64) << np.uint64(22)          # few distinct sorted UMI bits → long runs
+    lo = rng.integers(0, low_values, size=n, dtype=np.uint64) << np.uint64(2)  # part of it lies below bit 16
+    umi = (hi | lo) & np.uint64((1 << 26) - 1)
+    keys = (cell[g] << np.uint64(cs)) | (feat[g] << np.uint64(fs)) | ((nonnull << np.uint64(26)) | (umi * nonnull) | (np.uint64(3) * nonnull))
+    d_keys = _t(torch, keys)
+    d_tmp = torch.empty_like(d_keys)
+    d_n = torch.tensor([n], dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), n, stream=s, skip_low=True)
+    src = d_tmp if in_tmp else d_keys
+    got_keys = src.cpu().numpy().view(np.uint64)
+    assert (np.diff((got_keys >> np.uint64(skip)).astype(np.int64)) >= 0).all()           # sorted on the high bits
+    np.testing.assert_array_equal(np.sort(got_keys), np.sort(keys))                       # a permutation
+    d_f = torch.empty(n, dtype=torch.int32, device="cuda"); d_c = torch.empty_like(d_f); d_k = torch.empty_like(d_f)
+    d_nnz = torch.zeros(1, dtype=torch.int64, device="cuda")
+    eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(),
+                   stream=s, skip_low=True)
+    torch.cuda.synchronize()
+    nnz = int(d_nnz.item())
+    ug = np.unique(keys >> np.uint64(fs))
+    assert nnz == len(ug)
+    uk = np.unique(keys[(keys >> np.uint64(26)) & np.uint64(1) == 1])
+    want = np.zeros(len(ug), dtype=np.int64)
+    np.add.at(want, np.searchsorted(ug, uk >> np.uint64(fs)), 1)
+    np.testing.assert_array_equal(d_k.cpu().numpy()[:nnz].astype(np.int64), want)
+    np.testing.assert_array_equal(d_c.cpu().numpy()[:nnz].astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64))
