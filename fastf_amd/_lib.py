@@ -85,7 +85,8 @@ ABI_SYMBOLS = [
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits",
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
-    "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_hist_reset", "fastf_kernel_names",
+    "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_hist_reset", "fastf_dev_error_bits",
+    "fastf_dev_clear_error_bits", "fastf_kernel_names",
 ]
 
 
@@ -142,6 +143,7 @@ def lib():
     L.fastf_dev_umi_rows.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.fastf_dev_reserve.argtypes = [vp, u64, u64]
     L.fastf_dev_error_bits.argtypes = [vp, C.POINTER(u64)]
+    L.fastf_dev_clear_error_bits.argtypes = [vp, u64, vp]
     L.fastf_lists_load_mem.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_float, C.c_uint, C.POINTER(ListsStruct)]
     L.fastf_lists_load.argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_uint, C.POINTER(ListsStruct)]
     L.fastf_lists_free.argtypes = [C.POINTER(ListsStruct)]

@@ -480,6 +480,7 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     p.low_skip = UMI_ROWS ? 0 : low_skip;
     p.tile_heads = (u32*)e->d_tilecnt.p; p.row_base = (const u64*)e->d_tilebase.p;
     p.tile_carry = (u32*)e->d_tilecarry.p;
+    p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
     p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
     t_begin(e, s);
     hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
@@ -519,6 +520,17 @@ extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
     return 0;
 }
 
+extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void* stream) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    u64 cur = 0;
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    HIP_OK(hipMemcpy(&cur, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64), hipMemcpyDeviceToHost));
+    cur &= ~mask;
+    HIP_OK(hipMemcpy((u64*)e->d_small.p + SM_COUNTERS + 3, &cur, sizeof(u64), hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" const char* fastf_kernel_names(void) {
     return "probe_cells_kernel,scan_tiles_kernel,filter_pack_kernel,digit_hist_kernel,bin_base_kernel,"
            "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
@@ -529,11 +541,12 @@ extern "C" const char* fastf_kernel_names(void) {
 // ------------------------------------------------------------------------------------
 static const char* err_bits_text(u64 bits) {
     static thread_local char buf[256];
-    snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s", (unsigned long long)bits,
+    snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s%s", (unsigned long long)bits,
              (bits & ERR_RESERVED) ? " (reserved bit 0);" : "",
              (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
              (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it; key must still fit 64 bits);" : "",
-             (bits & ERR_KEYS_FULL) ? " key store full;" : "");
+             (bits & ERR_KEYS_FULL) ? " key store full;" : "",
+             (bits & ERR_RUN_TOO_LONG) ? " unsorted run longer than the group-only path handles: sort fully (drop FASTF_SORT_SKIP_LOW);" : "");
     return buf;
 }
 
@@ -683,6 +696,24 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         }
         HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        if (n && (e->h_small[SM_COUNTERS + 3] & ERR_RUN_TOO_LONG)) {
+            // runs of keys that agree on the sorted bits are long in this data (very deep (cell, feature) groups):
+            // finish the sort and reduce exactly; every key is still in the store, permuted
+            u64* from = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
+            u64* other = e->sorted_in_tmp ? (u64*)e->d_keys.p : (u64*)e->d_tmp.p;
+            int in_other = 0;
+            const u64 keep = e->h_small[SM_COUNTERS + 3] & ~ERR_RUN_TOO_LONG;
+            HIP_OK(hipMemcpyAsync(small + SM_COUNTERS + 3, &keep, sizeof(u64), hipMemcpyHostToDevice, s));
+            if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, false, &in_other, s)) return 1;
+            if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
+            e->fully_sorted = true;
+            const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
+            if (launch_reduce<false>(e, sorted, small + SM_KEYCOUNT, n, (u32*)e->d_feature.p, (u32*)e->d_cell.p,
+                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, 0, s))
+                return 1;
+            HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+        }
         if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
         const u64 nnz = e->h_small[SM_NNZ];
         e->h_feature.resize(nnz); e->h_cell.resize(nnz); e->h_count.resize(nnz);

@@ -33,6 +33,8 @@ constexpr u64 ERR_RESERVED = 1;            // (was: inter-workgroup wait timeout
 constexpr u64 ERR_DRAWS_SHORT  = 2;
 constexpr u64 ERR_UMI_TOOLONG  = 4;
 constexpr u64 ERR_KEYS_FULL    = 8;
+constexpr u64 ERR_RUN_TOO_LONG = 16;       // group-only sort: an unsorted run exceeded RUN_CAP steps → caller must sort fully
+constexpr u32 RUN_CAP = 128;
 
 // meta bits (mirror of fastf_amd.h)
 constexpr u32 META_XF_OK = 1, META_HAS_UB = 2, META_UMI_NONNULL = 4, META_UMI_TOOLONG = 8;
@@ -650,6 +652,7 @@ struct ReduceParams {
     u32 low_skip;                          // the keys are sorted on bits >= low_skip only (0 = fully sorted)
     u32* tile_heads;                       // K3a out
     u32* tile_carry;                       // K3b out: distinct flags in front of the tile's first head
+    u64* err;                              // error bits (ERR_RUN_TOO_LONG)
     const u64* row_base;                   // K3b in (scan of tile_heads)
     u32* feature; u32* cell; u32* count;   // UMI_ROWS: feature/cell unused
     u64* ukeys;                            // UMI_ROWS only
@@ -701,6 +704,7 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
     const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
 
     u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
+    bool too_long = false;
 #pragma unroll
     for (int j = 0; j < K3_IPT; ++j) {
         const u64 idx = base + (u64)j * K3_THREADS + tid;
@@ -720,10 +724,11 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
                     // 1/2^(sorted UMI bits) of a group plus its exact duplicates — a step or two in practice.
                     const u64 run = k >> p.low_skip;
                     u64 q = prev, at = idx - 1;
-                    for (;;) {
+                    for (u32 steps = 0;; ++steps) {
                         if ((q >> p.low_skip) != run) break;
                         if (q == k) { dist = false; break; }
                         if (at == 0) break;
+                        if (steps == RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
                         q = p.keys[--at];
                     }
                 }
@@ -733,6 +738,7 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
         hm[j] = __ballot(head); dm[j] = __ballot(dist);
         if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }
     }
+    if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
     __syncthreads();
     if (w == 0) {
         static_assert(K3_IPT * K3_WAVES == WAVE, "one wave scans the (item, wave) units");

@@ -31,11 +31,24 @@ def owner_of_cell(cell_index: np.ndarray, n_shards: int) -> np.ndarray:
     return ((x >> np.uint64(32)) % np.uint64(n_shards)).astype(np.int64)
 
 
+RUN_TOO_LONG = 16      # FASTF_ERR_RUN_TOO_LONG
+
+
 class HipStages:
     """device stages backed by libfastf_amd.so (fastf_dev_* entry points)"""
 
     def __init__(self, engine, device):
         self.eng, self.device = engine, device
+        self.skip_low = True       # matrix-only sort: low digit passes skipped (switched off if the data has long runs)
+
+    def run_too_long(self):
+        """True if the last group-only reduce met an unsorted run beyond its cap; clears the flag (synchronises)"""
+        if not self.skip_low:
+            return False
+        if self.eng.dev_error_bits() & RUN_TOO_LONG:
+            self.eng.dev_clear_error_bits(RUN_TOO_LONG, self._s())
+            return True
+        return False
 
     def _s(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -50,15 +63,15 @@ class HipStages:
                                 d_draw_base=draw_base.data_ptr())
 
     def hist_reset(self):
-        self.eng.dev_hist_reset(self._s(), skip_low=True)
+        self.eng.dev_hist_reset(self._s(), skip_low=self.skip_low)
 
     def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, hist_ready=False):
         # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs
         in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
-                                   hist_ready=hist_ready, skip_low=True)
+                                   hist_ready=hist_ready and self.skip_low, skip_low=self.skip_low)
         src = tmp if in_tmp else keys
         self.eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, feature.data_ptr(), cell.data_ptr(),
-                            count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=True)
+                            count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=self.skip_low)
         return src
 
 
@@ -92,6 +105,7 @@ class ShardedPass:
         self.nnz = torch.zeros(1, dtype=i64, device=device)
         self.n_recv = 0
         self.sorted = None
+        self._verified = False     # the group-only sort was checked against its run cap for the current result
 
     def run(self, cb, gx, umi, meta, n, draws):
         """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident)."""
@@ -132,8 +146,25 @@ class ShardedPass:
         # 4. local sort + reduce
         self.sorted = st.sort_reduce(keys, self.tmp, self.d_n, self.n_recv, self.feature, self.cell,
                                      self.count, self.nnz, hist_ready=(G == 1))
+        self._keys_buf = keys
+        self._verified = False
+
+    def ensure_exact(self):
+        """If the group-only sort met runs beyond its cap, finish the sort and reduce again (every key is still in
+        the buffers, permuted).  Costs one synchronisation; called before results are read."""
+        if self._verified:
+            return
+        self._verified = True
+        st = self.st
+        if getattr(st, "run_too_long", None) and st.run_too_long():
+            st.skip_low = False                         # this data has deep groups: later passes sort fully right away
+            src = self.sorted
+            other = self.tmp if src.data_ptr() != self.tmp.data_ptr() else self._keys_buf
+            self.sorted = st.sort_reduce(src, other, self.d_n, self.n_recv, self.feature, self.cell,
+                                         self.count, self.nnz, hist_ready=False)
 
     def local_coo(self):
+        self.ensure_exact()
         z = int(self.nnz.item())
         return (self.feature[:z].cpu().numpy().astype(np.int64), self.cell[:z].cpu().numpy().astype(np.int64),
                 self.count[:z].cpu().numpy().astype(np.int64))
@@ -161,5 +192,6 @@ class ShardedPass:
         return F[order], Cc[order], K[order]
 
     def global_counters(self):
+        self.ensure_exact()
         c = self.counters.cpu().numpy()
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])

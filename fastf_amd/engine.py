@@ -260,6 +260,9 @@ class Engine:
         check(self._L.fastf_dev_error_bits(self._h, C.byref(b)))
         return int(b.value)
 
+    def dev_clear_error_bits(self, mask, stream=0):
+        check(self._L.fastf_dev_clear_error_bits(self._h, mask, stream))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.fastf_engine_destroy(self._h)

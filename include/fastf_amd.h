@@ -210,6 +210,13 @@ int fastf_dev_umi_rows(fastf_engine_t *e, const uint64_t *d_sorted, const uint64
  * timed region) */
 int fastf_dev_reserve(fastf_engine_t *e, uint64_t max_records, uint64_t max_keys);
 
+/* Error bits raised by device kernels since the last clear (synchronises).  Bit 16 (FASTF_ERR_RUN_TOO_LONG) after
+ * a FASTF_SORT_SKIP_LOW reduce means the result of that reduce is not valid: sort fully and reduce again
+ * (fastf_engine_finish does this by itself). */
+#define FASTF_ERR_RUN_TOO_LONG 16u
+int fastf_dev_error_bits(fastf_engine_t *e, uint64_t *bits);
+int fastf_dev_clear_error_bits(fastf_engine_t *e, uint64_t mask, void *stream);
+
 /* name of the dominant kernel symbols, for profile post-processing */
 const char *fastf_kernel_names(void);
 

@@ -123,6 +123,17 @@ def test_group_only_sort_plus_run_aware_reduce(env, n, n_groups, low_values, see
     eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(),
                    stream=s, skip_low=True)
     torch.cuda.synchronize()
+    long_runs = low_values >= 1000 and n_groups <= 3          # thousands of distinct low parts per run
+    flagged = bool(eng.dev_error_bits() & 16)
+    assert flagged == long_runs
+    if flagged:                                               # the documented contract: sort fully, reduce again
+        eng.dev_clear_error_bits(16, s)
+        other = d_keys if in_tmp else d_tmp
+        in_other = eng.dev_sort(src.data_ptr(), other.data_ptr(), d_n.data_ptr(), n, stream=s)
+        src = other if in_other else src
+        eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert eng.dev_error_bits() == 0
     nnz = int(d_nnz.item())
     ug = np.unique(keys >> np.uint64(fs))
     assert nnz == len(ug)

@@ -73,6 +73,32 @@ def test_mixed_umi_lengths_0_to_16():
         eng.close()
 
 
+def test_long_unsorted_runs_fall_back_to_the_full_sort():
+    """two (cell, feature) groups whose 12-bp UMIs all start with the same 5 bases: the run of keys that agree on the
+    sorted bits holds ~16 k distinct UMIs, far beyond the group-only path's cap — the engine must finish the sort itself"""
+    from fastf_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    n = 120_000
+    bt, ft, bar, genes = synth.make_lists(2, 1, seed=5)
+    flags, xf, cb, gx, _ = synth.make_records(n, bar, genes, seed=6)
+    tail = synth._kmers(rng.integers(0, 1 << 14, size=n, dtype=np.uint64), 7)
+    ub = synth._as_S(np.concatenate([np.tile(np.frombuffer(b"ACGTA", dtype=np.uint8), (n, 1)), tail], axis=1), 13)
+    cb, gx = synth.as_cstr(cb), synth.as_cstr(gx)
+    ora = O.run_bam2db(bt, ft, flags, xf, cb, gx, ub, 1.0, 1.0, 926, b"synthetic.bam", True)
+    assert ora["count"].max() > 10_000
+    lists = F.Lists(bt, ft, 1.0, 926)
+    eng = F.Engine.from_lists(lists, umi_max_bases=12)
+    try:
+        assert eng.skip_bits == 16
+        eng.push(*F.pack_records(lists, flags, xf, cb, gx, ub))
+        res = eng.finish()
+        case = Case(n=1, n_bar=2, n_gene=2); case.rate_cell, case.rate_depth, case.label = 1.0, 1.0, b"synthetic.bam"
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
 def test_umi_longer_than_engine_limit_is_an_error_not_a_wrong_answer():
     from fastf_amd import synth
     bt, ft, bar, genes = synth.make_lists(10, 5, seed=5)
