@@ -534,6 +534,8 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
 
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
+    // this tile's global bin offsets: issued now, needed only after the ranking
+    const u32 g_off = tid < RADIX ? off[(u64)tid * row_stride(T) + tile] : 0u;
 
     // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
     u64 key[SORT_IPT];
@@ -584,7 +586,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         for (int i = 0; i < w; ++i) o += s_wtot[i];
         const u32 lstart = o + inc - run;                  // first tile-local slot of digit tid
         s_start[tid] = lstart;
-        s_delta[tid] = off[(u64)tid * row_stride(T) + tile] - lstart;  // global slot = delta + local slot (mod 2^32)
+        s_delta[tid] = g_off - lstart;                     // global slot = delta + local slot (mod 2^32)
     }
     __syncthreads();
     STAMP(3);
