@@ -121,11 +121,9 @@ static size_t scatter_smem_bytes(u32 ipt = SORT_IPT) {        // LDS follows the
 // ------------------------------------------------------------------------------------
 // table build (host) + upload
 // ------------------------------------------------------------------------------------
-static u64 h_mix64(u64 x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
-    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
-    x ^= x >> 33;
-    return x;
+static u32 h_slot_hash(u64 key) {          // host mirror of slot_hash() in umi_kernels.hpp
+    const u32 h = (u32)key * 0x9E3779B1u + (u32)(key >> 32) * 0x85EBCA77u;
+    return h ^ (h >> 15);
 }
 
 static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char* what) {
@@ -135,7 +133,7 @@ static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char
     for (u32 i = 0; i < n; ++i) {
         const u64 k = keys[i];
         if (k == 0) return set_err("%s key %u is 0 (unpackable string?)", what, i);
-        u32 h = (u32)h_mix64(k) & (cap - 1);
+        u32 h = h_slot_hash(k) & (cap - 1);
         for (;;) {
             uint4& s = slots[h];
             const u64 sk = ((u64)s.y << 32) | s.x;

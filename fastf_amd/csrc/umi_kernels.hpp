@@ -82,9 +82,16 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 // ------------------------------------------------------------------------------------
 struct Table { const uint4* slots; u32 mask; };
 
+// slot hash: two 32-bit multiplies (integer multiplies are quarter-rate; the murmur finaliser costs eight) —
+// the key halves carry the entropy (bases / gene number) in different bits, the sum of the two products mixes them
+__device__ __forceinline__ u32 slot_hash(u64 key) {
+    const u32 h = (u32)key * 0x9E3779B1u + (u32)(key >> 32) * 0x85EBCA77u;
+    return h ^ (h >> 15);
+}
+
 __device__ __forceinline__ u32 table_probe(const Table t, u64 key) {
     if (key == 0) return 0;
-    u32 h = (u32)mix64(key) & t.mask;
+    u32 h = slot_hash(key) & t.mask;
     for (u32 i = 0; i <= t.mask; ++i) {
         const uint4 s = t.slots[h];
         const u64 k = ((u64)s.y << 32) | s.x;
@@ -148,7 +155,7 @@ __device__ __forceinline__ void table_probe_batch(const Table t, const u64 (&key
     // wave-uniform buffer descriptor over the table: 32-bit offsets, cache policy in AUX
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)t.slots, 0, (t.mask + 1u) * 16u, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < N; ++j) h[j] = key[j] ? ((u32)mix64(key[j]) & t.mask) : 0u;   // dead lanes share slot 0
+    for (int j = 0; j < N; ++j) h[j] = key[j] ? (slot_hash(key[j]) & t.mask) : 0u;   // dead lanes share slot 0
 #pragma unroll
     for (int j = 0; j < N; ++j) {                              // unconditional: N loads back to back, one wait
         const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(h[j] * 16u), 0, AUX);
