@@ -71,6 +71,9 @@ struct fastf_engine {
     u32 n_shards = 1, shard_rank = 0;
     DevBuf tab_cells, tab_feats;
     Table cells{}, feats{};
+    DevBuf img_cells, img_genes;         // LDS table images (fast path, when the lists allow it)
+    CellLds lds_cells{}; GeneLds lds_genes{};
+    bool use_lds_cells = false, use_lds_genes = false; u32 genes_blocks_per_cu = 1;
     // draw stream
     fastf_mt_t mt{};
     std::vector<u32> pending_draws;      // generated, not yet consumed
@@ -149,6 +152,76 @@ static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char
     return 0;
 }
 
+// LDS images (see umi_kernels.hpp "LDS-resident tables"); both return 0 and leave use_* false when not eligible
+static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
+    if (n == 0 || n > 11000) return 0;
+    const u64 fam = keys[0] >> 49;
+    for (u32 i = 0; i < n; ++i) {
+        const u64 k = keys[i];
+        if ((k >> 62) != 1 || (k >> 49) != fam || (k & 0xFFFFu) != 0 || ((k >> 57) & 31) > 16) return 0;
+    }
+    u32 slots = 256;
+    while (slots * 7 < (u64)n * 10) slots <<= 1;                      // load <= 0.7
+    std::vector<u32> img((size_t)slots * 6 / 4 + 4, 0u);
+    u32* code = img.data();
+    unsigned short* idx = reinterpret_cast<unsigned short*>(img.data() + slots);
+    for (u32 i = 0; i < n; ++i) {
+        const u32 c = (u32)(keys[i] >> 16);
+        u32 h = c * 0x9E3779B1u; h ^= h >> 15;
+        u32 sl = h & (slots - 1);
+        while (idx[sl]) sl = (sl + 1) & (slots - 1);
+        code[sl] = c; idx[sl] = (unsigned short)(i + 1);
+    }
+    const size_t bytes = ((size_t)slots * 6 + 15) & ~(size_t)15;
+    if (e->img_cells.ensure(bytes)) return 1;
+    HIP_OK(hipMemcpy(e->img_cells.p, img.data(), bytes, hipMemcpyHostToDevice));
+    e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.slots = slots; e->lds_cells.family = (u32)fam;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) return 0;
+    e->use_lds_cells = true;
+    return 0;
+}
+
+static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
+    if (n == 0 || n > 65535) return 0;
+    // most common ID-form family
+    std::vector<u64> fams;
+    for (u32 i = 0; i < n; ++i) if ((keys[i] >> 62) == 2) fams.push_back(keys[i] >> 44);
+    if (fams.size() * 2 < n) return 0;
+    std::sort(fams.begin(), fams.end());
+    u64 best = fams[0]; size_t best_n = 0;
+    for (size_t i = 0; i < fams.size();) { size_t j = i; while (j < fams.size() && fams[j] == fams[i]) ++j; if (j - i > best_n) { best_n = j - i; best = fams[i]; } i = j; }
+    if (best_n * 2 < n) return 0;
+    const u64 VM = 0xFFFFFFFFFFFull;
+    u64 vmin = ~0ull, vmax = 0;
+    for (u32 i = 0; i < n; ++i) if ((keys[i] >> 44) == best) { const u64 v = keys[i] & VM; vmin = std::min(vmin, v); vmax = std::max(vmax, v); }
+    const u64 range = vmax - vmin + 1;
+    if (range > (1ull << 22)) return 0;
+    const u32 words = (u32)((range + 31) / 32), rank_pad = (words + 1u) & ~1u;
+    const size_t bytes = (((size_t)words * 4 + (size_t)rank_pad * 2 + best_n * 2) + 15) & ~(size_t)15;
+    if (bytes > 120 * 1024) return 0;
+    std::vector<u32> img(bytes / 4 + 4, 0u);
+    u32* bitmap = img.data();
+    unsigned short* rank = reinterpret_cast<unsigned short*>(img.data() + words);
+    unsigned short* perm = rank + rank_pad;
+    std::vector<std::pair<u64, u32>> vals; vals.reserve(best_n);
+    for (u32 i = 0; i < n; ++i) if ((keys[i] >> 44) == best) vals.push_back({(keys[i] & VM) - vmin, i + 1});
+    std::sort(vals.begin(), vals.end());
+    for (size_t r = 0; r < vals.size(); ++r) { bitmap[vals[r].first >> 5] |= 1u << (vals[r].first & 31); perm[r] = (unsigned short)vals[r].second; }
+    u32 acc = 0;
+    for (u32 w = 0; w < words; ++w) { rank[w] = (unsigned short)acc; acc += (u32)__builtin_popcount(bitmap[w]); }
+    if (e->img_genes.ensure(bytes)) return 1;
+    HIP_OK(hipMemcpy(e->img_genes.p, img.data(), bytes, hipMemcpyHostToDevice));
+    e->lds_genes.image = (const u32*)e->img_genes.p; e->lds_genes.words = words; e->lds_genes.n_perm = (u32)best_n;
+    e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) return 0;
+    const size_t per_block = bytes + 10 * 1024;                      // + the kernel's static LDS
+    e->genes_blocks_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / per_block));
+    e->use_lds_genes = true;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // create / destroy
 // ------------------------------------------------------------------------------------
@@ -203,6 +276,16 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         }
         if ((rc = build_table((const u64*)cfg->cell_keys, cfg->n_cells, e->tab_cells, e->cells, "cell"))) break;
         if ((rc = build_table((const u64*)cfg->feature_keys, cfg->n_features, e->tab_feats, e->feats, "feature"))) break;
+        {
+            const char* lt = getenv("FASTF_LDS_TABLES");             // "0" keeps both lookups on the L2 tables
+            if (!(lt && lt[0] == '0')) {
+                // the LDS cell table needs ~100 KB, i.e. one 16-wave workgroup per CU: measured slower (117 us) than the
+                // 32-wave L2 gather (88 us) at 10 k cells, so it stays opt-in until the table is made smaller
+                const char* lc = getenv("FASTF_LDS_CELLS");
+                if (lc && lc[0] == '1' && (rc = build_cell_lds(e, (const u64*)cfg->cell_keys, cfg->n_cells))) break;
+                if ((rc = build_gene_lds(e, (const u64*)cfg->feature_keys, cfg->n_features))) break;
+            }
+        }
         if ((rc = e->d_small.ensure(SM_WORDS * sizeof(u64)))) break;
         if (hipHostMalloc((void**)&e->h_small, SM_WORDS * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
             rc = set_err("hipHostMalloc failed"); break;
@@ -230,7 +313,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
         if (e->t_ev[i]) (void)hipEventDestroy(e->t_ev[i]);
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
-    DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
+    DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_hist, &e->d_binbase, &e->d_cnt};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -334,8 +417,16 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     if (reserve_workspace(e, n, 0)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     t_begin(e, s);
-    hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
-                       (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
+    if (e->use_lds_cells) {
+        HIP_OK(hipMemsetAsync(e->d_tilecnt.p, 0, (size_t)tiles * sizeof(u32), s));
+        const u32 grid = std::min<u32>(g_cu_count, (tiles + 1) / 2);
+        const size_t smem = ((size_t)e->lds_cells.slots * 6 + 15) & ~(size_t)15;
+        hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), smem, s, cb, n, e->lds_cells,
+                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
+    } else {
+        hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
+                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
+    }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
                        (u64*)e->d_tilebase.p, tiles, d_total_out);
@@ -374,8 +465,15 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.hist_passes = (e->L.total_bits + 7) / 8;
     p.hist_first = hist_first;
     p.stamps = g_k1_stamps;
+    p.n_tiles = tiles;
+    p.genes = e->lds_genes;
     t_begin(e, s);
-    hipLaunchKernelGGL(filter_pack_kernel, dim3(tiles), dim3(K1_THREADS), 0, s, p);
+    if (e->use_lds_genes) {
+        const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
+        hipLaunchKernelGGL(filter_pack_kernel<true>, dim3(grid), dim3(K1_THREADS), e->lds_genes.bytes, s, p);
+    } else {
+        hipLaunchKernelGGL(filter_pack_kernel<false>, dim3(tiles), dim3(K1_THREADS), 0, s, p);
+    }
     HIP_OK(hipGetLastError());
     t_end(e, s, &e->t_k1b_ms, &e->t_k1b_n);
     return 0;
@@ -530,7 +628,7 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 }
 
 extern "C" const char* fastf_kernel_names(void) {
-    return "probe_cells_kernel,scan_tiles_kernel,filter_pack_kernel,digit_hist_kernel,bin_base_kernel,"
+    return "probe_cells_kernel,probe_cells_lds_kernel,scan_tiles_kernel,filter_pack_kernel,digit_hist_kernel,bin_base_kernel,"
            "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
 }
 

@@ -241,12 +241,91 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
     }
 }
 
+// ------------------------------------------------------------------------------------
+// LDS-resident tables (the fast path when the lists allow it; the L2 tables above stay the
+// general path).  Exactness rests on the key packing, not on hashing:
+//   cells: every registered barcode is of the DNA form with the same length (<= 16 bases) and the
+//          same "-N" suffix, so key bits 63:49 are one constant ("family") and bits 47:16 hold the
+//          bases: a 32-bit code identifies the barcode.  An open-addressed set of (code, index)
+//          pairs for <= ~11 k cells is < 100 KB.  A tag key outside the family cannot be a
+//          registered barcode.
+//   genes: registered feature ids of one ID-form family (<prefix><n digits>, key bits 63:44) map
+//          through a bitmap over [vmin, vmax] + per-word rank + permutation to the feature index:
+//          exact hit or exact miss with three LDS reads; keys of other families use the L2 table.
+// ------------------------------------------------------------------------------------
+struct CellLds { const u32* image; u32 slots; u32 family; };          // image: u32 code[slots] | u16 index[slots]
+struct GeneLds { const u32* image; u32 words; u32 n_perm; u32 family; u64 vmin; u64 range; u32 bytes; };
+                                                                      // image: u32 bitmap[words] | u16 rank[words] (padded) | u16 perm[n_perm]
+
+__device__ __forceinline__ u32 cell_code_hash(u32 code) { const u32 h = code * 0x9E3779B1u; return h ^ (h >> 15); }
+
+
+// K1a, LDS mode: persistent 1024-thread workgroups (one per CU: the table takes ~100 KB of LDS); each
+// 512-thread half walks its own tiles, hit counts go to tile_hits[] (zeroed before) with one atomic per wave.
+__global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
+                                                               u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                               u32 n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32* s_code = reinterpret_cast<u32*>(smem);
+    unsigned short* s_idx = reinterpret_cast<unsigned short*>(smem + (size_t)c.slots * 4);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(c.image);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const u32 n16 = (c.slots * 6u + 15u) / 16u;
+        for (u32 i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = lane_id();
+    const u32 half = threadIdx.x >> 9, htid = threadIdx.x & 511;
+    const u32 mask = c.slots - 1;
+    for (u32 tile = blockIdx.x * 2 + half; tile < n_tiles; tile += gridDim.x * 2) {
+        const u64 base = (u64)tile * K1_TILE;
+        u64 key[K1_IPT]; u32 slot[K1_IPT], code[K1_IPT], cell[K1_IPT];
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            const u64 idx = base + (u64)j * 512 + htid;
+            key[j] = idx < n ? cb[idx] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            code[j] = (u32)(key[j] >> 16);
+            slot[j] = cell_code_hash(code[j]) & mask;
+        }
+        u32 hits = 0;
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            const bool fam = (u32)(key[j] >> 49) == c.family && (key[j] & 0xFFFFu) == 0;
+            u32 v = 0;
+            if (fam) {
+                u32 sl = slot[j];
+                for (u32 t = 0; t <= mask; ++t) {
+                    const u32 i = s_idx[sl];
+                    if (i == 0) break;
+                    if (s_code[sl] == code[j]) { v = i; break; }
+                    sl = (sl + 1) & mask;
+                }
+            }
+            cell[j] = v;
+            hits += v != 0;
+        }
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            const u64 idx = base + (u64)j * 512 + htid;
+            if (idx < n) cell_out[idx] = cell[j];
+        }
+        hits = wave_sum32(hits);
+        if (lane == 0 && hits) atomicAdd(&tile_hits[tile], hits);
+    }
+}
+
 struct PackParams {
     const u32* cell; const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
     const u32* draws; u64 n_draws;
     const u64* draw_base;          // optional device-side offset into draws (sharded runs)
     Table feats;
+    GeneLds genes;                 // LDS fast path of the feature lookup (LDS_GENES instantiation)
+    u32 n_tiles;
     u64 threshold;                 // keep iff draw < threshold
     KeyLayout L;
     u32 n_shards;
@@ -265,16 +344,28 @@ struct PackParams {
 #define K1STAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(K1_THREADS, 6) void filter_pack_kernel(const PackParams p) {
+template <bool LDS_GENES>
+__global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_kernel(const PackParams p) {
     __shared__ u32 s_cnt[K1_IPT * K1_WAVES];       // hits per (item, wave), then exclusive
     __shared__ u32 s_red[3][K1_WAVES];
     __shared__ u32 s_shard_cnt[8];
     __shared__ u64 s_shard_base[8];
     __shared__ u32 s_err;
     __shared__ u32 s_hist[8 * 256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // LDS_GENES: the gene image
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const u32 tile = blockIdx.x;
+    const u32* s_bitmap = reinterpret_cast<const u32*>(smem);
+    const unsigned short* s_rank = reinterpret_cast<const unsigned short*>(smem + (size_t)p.genes.words * 4);
+    const unsigned short* s_perm = s_rank + ((p.genes.words + 1u) & ~1u);
+    if (LDS_GENES) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.genes.image);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += K1_THREADS) dst[i] = src[i];
+    }
+
+    // LDS_GENES: persistent workgroups walk the tiles; otherwise one tile per workgroup (grid = n_tiles)
+    auto do_tile = [&](const u32 tile) {
     const u64 base = (u64)tile * K1_TILE;
 
     if (tid < 8) s_shard_cnt[tid] = 0;
@@ -333,7 +424,25 @@ __global__ __launch_bounds__(K1_THREADS, 6) void filter_pack_kernel(const PackPa
         alive = alive && (meta[j] & META_XF_OK);
         fkey[j] = alive ? gxk[j] : 0;
     }
-    table_probe_batch<K1_IPT>(p.feats, fkey, feat);                  // E8 :403-410
+    if (LDS_GENES) {                                                 // E8 :403-410, bitmap + rank + permutation in LDS
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            u32 f = 0;
+            const u64 k = fkey[j];
+            if (k != 0) {
+                if ((u32)(k >> 44) == p.genes.family) {
+                    const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;       // wraps to huge when below vmin
+                    if (v < p.genes.range) {
+                        const u32 wd = s_bitmap[(u32)v >> 5], bit = (u32)v & 31u;
+                        if ((wd >> bit) & 1u) f = s_perm[s_rank[(u32)v >> 5] + __popc(wd & ((1u << bit) - 1u))];
+                    }
+                } else f = table_probe(p.feats, k);                  // other id families / escaped strings
+            }
+            feat[j] = f;
+        }
+    } else {
+        table_probe_batch<K1_IPT>(p.feats, fkey, feat);              // E8 :403-410
+    }
     K1STAMP(3);
 
     // ---- UB (E9 :412-416), key (E10/E11), slot in the tile-local shard list ----
@@ -360,7 +469,7 @@ __global__ __launch_bounds__(K1_THREADS, 6) void filter_pack_kernel(const PackPa
             }
         }
         if (p.digit_hist && alive) {
-            for (u32 q = 0; q < p.hist_passes; ++q) atomicAdd(&s_hist[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
+            for (u32 q = p.hist_first; q < p.hist_passes; ++q) atomicAdd(&s_hist[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
         }
     }
 
@@ -393,12 +502,22 @@ __global__ __launch_bounds__(K1_THREADS, 6) void filter_pack_kernel(const PackPa
         }
     }
     if (p.digit_hist) {
-        for (int i = tid; i < (int)p.hist_passes * 256; i += K1_THREADS) {
+        for (int i = tid + (int)p.hist_first * 256; i < (int)p.hist_passes * 256; i += K1_THREADS) {
             const u32 v = s_hist[i];
             if (v) atomicAdd(&p.digit_hist[i], v);
         }
     }
     K1STAMP(6);
+    };  // do_tile
+    if constexpr (LDS_GENES) {
+        __syncthreads();                           // gene image is in LDS
+        for (u32 tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+            do_tile(tile);
+            __syncthreads();                       // the next tile re-initialises the shared scalars
+        }
+    } else {
+        do_tile(blockIdx.x);
+    }
 }
 
 // ------------------------------------------------------------------------------------
