@@ -153,33 +153,66 @@ static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char
 }
 
 // LDS images (see umi_kernels.hpp "LDS-resident tables"); both return 0 and leave use_* false when not eligible
+static u32 h_fmix32(u32 h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+
+// compress-hash-displace perfect hash of the 32-bit barcode codes (host mirror of chd_bucket / chd_slot)
 static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
-    if (n == 0 || n > 11000) return 0;
+    if (n == 0 || n > 12000) return 0;
     const u64 fam = keys[0] >> 49;
+    std::vector<u32> code(n);
     for (u32 i = 0; i < n; ++i) {
         const u64 k = keys[i];
         if ((k >> 62) != 1 || (k >> 49) != fam || (k & 0xFFFFu) != 0 || ((k >> 57) & 31) > 16) return 0;
+        code[i] = (u32)(k >> 16);
     }
-    u32 slots = 256;
-    while (slots * 7 < (u64)n * 10) slots <<= 1;                      // load <= 0.7
-    std::vector<u32> img((size_t)slots * 6 / 4 + 4, 0u);
-    u32* code = img.data();
-    unsigned short* idx = reinterpret_cast<unsigned short*>(img.data() + slots);
-    for (u32 i = 0; i < n; ++i) {
-        const u32 c = (u32)(keys[i] >> 16);
-        u32 h = c * 0x9E3779B1u; h ^= h >> 15;
-        u32 sl = h & (slots - 1);
-        while (idx[sl]) sl = (sl + 1) & (slots - 1);
-        code[sl] = c; idx[sl] = (unsigned short)(i + 1);
+    const u32 B = std::max<u32>(1, (n + 3) / 4);
+    for (u32 attempt = 0; attempt < 8; ++attempt) {
+        const u32 m = n + n / 50 * attempt + (attempt ? 8 : 0);         // minimal first, +2 % slots per retry
+        const u32 m_even = (m + 1u) & ~1u;
+        std::vector<std::vector<u32>> bucket(B);
+        for (u32 i = 0; i < n; ++i) bucket[(u32)(((u64)h_fmix32(code[i]) * B) >> 32)].push_back(i);
+        std::vector<u32> order(B);
+        for (u32 i = 0; i < B; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return bucket[a].size() > bucket[b].size(); });
+        std::vector<u32> slot_code(m, 0); std::vector<unsigned short> slot_idx(m_even, 0), disp(B, 0);
+        bool ok = true;
+        std::vector<u32> trial;
+        for (u32 bi : order) {
+            const auto& items = bucket[bi];
+            if (items.empty()) continue;
+            bool placed = false;
+            for (u32 d = 0; d < 65536 && !placed; ++d) {
+                trial.clear();
+                bool fits = true;
+                for (u32 it : items) {
+                    const u32 sl = (u32)(((u64)h_fmix32(code[it] ^ (d * 0x9E3779B1u + 0x7F4A7C15u)) * m) >> 32);
+                    if (slot_idx[sl] || std::find(trial.begin(), trial.end(), sl) != trial.end()) { fits = false; break; }
+                    trial.push_back(sl);
+                }
+                if (!fits) continue;
+                for (size_t t = 0; t < items.size(); ++t) { slot_code[trial[t]] = code[items[t]]; slot_idx[trial[t]] = (unsigned short)(items[t] + 1); }
+                disp[bi] = (unsigned short)d;
+                placed = true;
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (!ok) continue;
+        const size_t bytes = (((size_t)m * 4 + (size_t)m_even * 2 + (size_t)B * 2) + 15) & ~(size_t)15;
+        if (bytes > 78 * 1024) return 0;
+        std::vector<unsigned char> img(bytes + 16, 0);
+        memcpy(img.data(), slot_code.data(), (size_t)m * 4);
+        memcpy(img.data() + (size_t)m * 4, slot_idx.data(), (size_t)m_even * 2);
+        memcpy(img.data() + (size_t)m * 4 + (size_t)m_even * 2, disp.data(), (size_t)B * 2);
+        if (e->img_cells.ensure(bytes)) return 1;
+        HIP_OK(hipMemcpy(e->img_cells.p, img.data(), bytes, hipMemcpyHostToDevice));
+        e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.m = m; e->lds_cells.buckets = B;
+        e->lds_cells.family = (u32)fam; e->lds_cells.bytes = (u32)bytes;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) != hipSuccess) return 0;
+        e->use_lds_cells = true;
+        return 0;
     }
-    const size_t bytes = ((size_t)slots * 6 + 15) & ~(size_t)15;
-    if (e->img_cells.ensure(bytes)) return 1;
-    HIP_OK(hipMemcpy(e->img_cells.p, img.data(), bytes, hipMemcpyHostToDevice));
-    e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.slots = slots; e->lds_cells.family = (u32)fam;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess) return 0;
-    e->use_lds_cells = true;
-    return 0;
+    return 0;                                                            // no displacement set found: stay on the L2 table
 }
 
 static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
@@ -279,10 +312,8 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         {
             const char* lt = getenv("FASTF_LDS_TABLES");             // "0" keeps both lookups on the L2 tables
             if (!(lt && lt[0] == '0')) {
-                // the LDS cell table needs ~100 KB, i.e. one 16-wave workgroup per CU: measured slower (117 us) than the
-                // 32-wave L2 gather (88 us) at 10 k cells, so it stays opt-in until the table is made smaller
                 const char* lc = getenv("FASTF_LDS_CELLS");
-                if (lc && lc[0] == '1' && (rc = build_cell_lds(e, (const u64*)cfg->cell_keys, cfg->n_cells))) break;
+                if (!(lc && lc[0] == '0') && (rc = build_cell_lds(e, (const u64*)cfg->cell_keys, cfg->n_cells))) break;
                 if ((rc = build_gene_lds(e, (const u64*)cfg->feature_keys, cfg->n_features))) break;
             }
         }
@@ -419,9 +450,8 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     t_begin(e, s);
     if (e->use_lds_cells) {
         HIP_OK(hipMemsetAsync(e->d_tilecnt.p, 0, (size_t)tiles * sizeof(u32), s));
-        const u32 grid = std::min<u32>(g_cu_count, (tiles + 1) / 2);
-        const size_t smem = ((size_t)e->lds_cells.slots * 6 + 15) & ~(size_t)15;
-        hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), smem, s, cb, n, e->lds_cells,
+        const u32 grid = std::min<u32>(2 * g_cu_count, (tiles + 1) / 2);
+        hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
                            (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
     } else {
         hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,

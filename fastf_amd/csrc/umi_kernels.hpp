@@ -246,65 +246,57 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
 // general path).  Exactness rests on the key packing, not on hashing:
 //   cells: every registered barcode is of the DNA form with the same length (<= 16 bases) and the
 //          same "-N" suffix, so key bits 63:49 are one constant ("family") and bits 47:16 hold the
-//          bases: a 32-bit code identifies the barcode.  An open-addressed set of (code, index)
-//          pairs for <= ~11 k cells is < 100 KB.  A tag key outside the family cannot be a
-//          registered barcode.
+//          bases: a 32-bit code identifies the barcode.  A perfect hash (compress-hash-displace:
+//          bucket → 16-bit displacement → slot, no empty probing) keeps (code, index) for 12 k
+//          cells in 78 KB, so two 1024-thread workgroups share a CU.  A tag key outside the family
+//          cannot be a registered barcode.
 //   genes: registered feature ids of one ID-form family (<prefix><n digits>, key bits 63:44) map
 //          through a bitmap over [vmin, vmax] + per-word rank + permutation to the feature index:
 //          exact hit or exact miss with three LDS reads; keys of other families use the L2 table.
 // ------------------------------------------------------------------------------------
-struct CellLds { const u32* image; u32 slots; u32 family; };          // image: u32 code[slots] | u16 index[slots]
+struct CellLds { const u32* image; u32 m; u32 buckets; u32 family; u32 bytes; };
+                                                                      // image: u32 code[m] | u16 index[m'] | u16 disp[buckets]  (m' = m rounded up to even)
 struct GeneLds { const u32* image; u32 words; u32 n_perm; u32 family; u64 vmin; u64 range; u32 bytes; };
                                                                       // image: u32 bitmap[words] | u16 rank[words] (padded) | u16 perm[n_perm]
 
-__device__ __forceinline__ u32 cell_code_hash(u32 code) { const u32 h = code * 0x9E3779B1u; return h ^ (h >> 15); }
+__device__ __forceinline__ u32 fmix32(u32 h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+__device__ __forceinline__ u32 chd_bucket(u32 code, u32 buckets) { return (u32)(((u64)fmix32(code) * buckets) >> 32); }
+__device__ __forceinline__ u32 chd_slot(u32 code, u32 disp, u32 m) { return (u32)(((u64)fmix32(code ^ (disp * 0x9E3779B1u + 0x7F4A7C15u)) * m) >> 32); }
 
 
-// K1a, LDS mode: persistent 1024-thread workgroups (one per CU: the table takes ~100 KB of LDS); each
-// 512-thread half walks its own tiles, hit counts go to tile_hits[] (zeroed before) with one atomic per wave.
-__global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
-                                                               u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                               u32 n_tiles) {
+// K1a, LDS mode: persistent 1024-thread workgroups (two per CU); each 512-thread half walks its own tiles,
+// hit counts go to tile_hits[] (zeroed before) with one atomic per wave.
+__global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
+                                                                  u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                                  u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32* s_code = reinterpret_cast<u32*>(smem);
-    unsigned short* s_idx = reinterpret_cast<unsigned short*>(smem + (size_t)c.slots * 4);
+    const u32 m_even = (c.m + 1u) & ~1u;
+    const u32* s_code = reinterpret_cast<const u32*>(smem);
+    const unsigned short* s_idx = reinterpret_cast<const unsigned short*>(smem + (size_t)c.m * 4);
+    const unsigned short* s_disp = s_idx + m_even;
     {
         const uint4* src = reinterpret_cast<const uint4*>(c.image);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        const u32 n16 = (c.slots * 6u + 15u) / 16u;
-        for (u32 i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+        for (u32 i = threadIdx.x; i < (c.bytes + 15u) / 16u; i += 1024) dst[i] = src[i];
     }
     __syncthreads();
     const int lane = lane_id();
     const u32 half = threadIdx.x >> 9, htid = threadIdx.x & 511;
-    const u32 mask = c.slots - 1;
     for (u32 tile = blockIdx.x * 2 + half; tile < n_tiles; tile += gridDim.x * 2) {
         const u64 base = (u64)tile * K1_TILE;
-        u64 key[K1_IPT]; u32 slot[K1_IPT], code[K1_IPT], cell[K1_IPT];
+        u64 key[K1_IPT]; u32 cell[K1_IPT];
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const u64 idx = base + (u64)j * 512 + htid;
             key[j] = idx < n ? cb[idx] : 0;
         }
-#pragma unroll
-        for (int j = 0; j < K1_IPT; ++j) {
-            code[j] = (u32)(key[j] >> 16);
-            slot[j] = cell_code_hash(code[j]) & mask;
-        }
         u32 hits = 0;
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
+            const u32 code = (u32)(key[j] >> 16);
             const bool fam = (u32)(key[j] >> 49) == c.family && (key[j] & 0xFFFFu) == 0;
-            u32 v = 0;
-            if (fam) {
-                u32 sl = slot[j];
-                for (u32 t = 0; t <= mask; ++t) {
-                    const u32 i = s_idx[sl];
-                    if (i == 0) break;
-                    if (s_code[sl] == code[j]) { v = i; break; }
-                    sl = (sl + 1) & mask;
-                }
-            }
+            const u32 sl = chd_slot(code, s_disp[chd_bucket(code, c.buckets)], c.m);
+            const u32 v = (fam && s_code[sl] == code) ? s_idx[sl] : 0u;       // empty slots carry index 0
             cell[j] = v;
             hits += v != 0;
         }
