@@ -145,7 +145,8 @@ def main():
                                    % (N, G, args.barcodes, args.genes),
                        "records_per_gpu": N, "key_bits": eng.key_bits, "radix_passes": passes,
                        "radix_passes_executed": passes - (eng.skip_bits // 8 if sp.st.skip_low else 0),
-                       "sharding": "cell-hash, one all-to-all" if G > 1 else "single GPU"},
+                       "sharding": "cell-hash, one all-to-all" if G > 1 else "single GPU",
+                       "lookup_tables": eng.table_modes},
             "roofline": {"bound": "hbm", "kernel": "scatter_kernel (one 8-bit LSD radix pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

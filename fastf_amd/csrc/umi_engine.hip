@@ -352,6 +352,13 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     delete e;
 }
 
+extern "C" int fastf_engine_table_modes(const fastf_engine_t* e, int* cells_in_lds, int* genes_in_lds) {
+    if (!e) return set_err("null engine");
+    if (cells_in_lds) *cells_in_lds = e->use_lds_cells;
+    if (genes_in_lds) *genes_in_lds = e->use_lds_genes;
+    return 0;
+}
+
 extern "C" int fastf_engine_skip_bits(const fastf_engine_t* e, uint32_t* bits) {
     if (!e || !bits) return set_err("null argument");
     *bits = e->skip_bits;

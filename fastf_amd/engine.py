@@ -247,6 +247,13 @@ class Engine:
                                        2 if skip_low else 0, stream))
 
     @property
+    def table_modes(self) -> str:
+        c, g = C.c_int(), C.c_int()
+        check(self._L.fastf_engine_table_modes(self._h, C.byref(c), C.byref(g)))
+        return "cells:%s genes:%s" % ("LDS perfect hash" if c.value else "L2 open addressing",
+                                      "LDS bitmap+rank" if g.value else "L2 open addressing")
+
+    @property
     def skip_bits(self) -> int:
         b = C.c_uint32()
         check(self._L.fastf_engine_skip_bits(self._h, C.byref(b)))

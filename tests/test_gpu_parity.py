@@ -114,6 +114,58 @@ def test_umi_longer_than_engine_limit_is_an_error_not_a_wrong_answer():
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["c1_half", "mixed", "skewed", "tile_plus_one"])
+@pytest.mark.parametrize("env", [{"FASTF_LDS_TABLES": "0"}, {"FASTF_LDS_CELLS": "0"}, {"FASTF_SORT_SKIP_BITS": "0"}])
+def test_general_paths_match_oracle(name, env, monkeypatch):
+    """the same cases with the LDS tables off (L2 open-addressed probes) and with the full 7-pass sort"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = Case(**CASES[name])
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12)
+    try:
+        eng.push(*case.packed(lists))
+        assert_matches_oracle(eng.finish(), ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
+def test_mixed_name_forms_use_both_lookup_paths():
+    """barcodes and gene ids of several forms: 16-mers with and without suffix, free text, two Ensembl families, plain
+    names, versioned ids — the barcode list is not LDS-eligible (L2 probes), the gene list has one LDS family and the
+    rest resolved through the L2 table inside the same kernel"""
+    from fastf_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(23)
+    def mer(k): return bytes(rng.choice(list(b"ACGT"), k).tolist())
+    bars = [mer(16) + b"-1" for _ in range(300)] + [mer(16) for _ in range(50)] + [mer(14) + b"-2" for _ in range(50)] + \
+           [b"cell_%d" % i for i in range(40)] + [mer(26) + b"-1" for _ in range(10)]
+    genes = [b"ENSG%011d" % (1000 + 7 * i) for i in range(400)] + [b"ENSMUSG%011d" % (5 + 3 * i) for i in range(150)] + \
+            [b"GFP", b"mCherry", b"ENSG00000000003.14", b"LINC01409", b"7SK", b"AC114498.1"]
+    bt = b"".join(b + b"\n" for b in bars)
+    ft = b"".join(g + b"\tname\tGene Expression\n" for g in genes)
+    n = 120_000
+    unl_b = [mer(16) + b"-1" for _ in range(50)] + [b"cell_x", b"", b"ACGT"]
+    unl_g = [b"ENSG%011d" % 999, b"ENSG%011d" % (1000 + 7 * 400), b"ENSG%011d" % 1001, b"ENSMUSG%011d" % 6, b"GFP2", b"gfp",
+             b"ENSG00000000003", b"ENSG00000000003.15", b"ENSG0000001007"]
+    cb = np.array([(bars + unl_b)[i] for i in rng.integers(0, len(bars) + len(unl_b), n)], dtype="S32")
+    gx = np.array([(genes + unl_g)[i] for i in rng.integers(0, len(genes) + len(unl_g), n)], dtype="S32")
+    ub = synth._as_S(synth._kmers(rng.integers(0, 1 << 20, size=n, dtype=np.uint64) % np.uint64(3000), 10), 11)
+    flags = np.full(n, 15, np.uint8); xf = np.where(rng.random(n) < 0.9, 25, 3).astype(np.int32)
+    ora = O.run_bam2db(bt, ft, flags, xf, cb, gx, ub, 0.8, 0.7, 926, b"synthetic.bam", True)
+    assert ora["nnz"] > 10_000
+    lists = F.Lists(bt, ft, 0.8, 926)
+    eng = F.Engine.from_lists(lists, rate_depth=0.7, seed=926, umi_max_bases=12)
+    try:
+        eng.push(*F.pack_records(lists, flags, xf, cb, gx, ub))
+        res = eng.finish()
+        case = Case(n=1, n_bar=2, n_gene=2); case.rate_cell, case.rate_depth, case.label = 0.8, 0.7, b"synthetic.bam"
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
 def test_multi_batch_push_equals_single():
     case = Case(n=150_000, n_bar=800, n_gene=400, rate_depth=0.7, umi_pool=256, p_unlisted_cb=0.1, p_bad_xf=0.1)
     ora = case.oracle()
