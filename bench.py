@@ -54,7 +54,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FASTF_BENCH_BACKEND", "nccl")     # "gloo" only for the one-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     N, G = args.records, world
     seed, rate_cell, rate_depth = 926, 1.0, 1.0

@@ -82,6 +82,10 @@ class ShardedPass:
         self.st, self.dev, self.group = stages, device, group
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # gloo has no all_to_all on device tensors: with that backend and HBM buffers every collective is staged
+        # through host memory (rehearsal of the N>1 path on a box whose ranks share one GPU; RCCL refuses that)
+        self.host_staged = (dist.is_initialized() and dist.get_backend(group) != "nccl"
+                            and torch.device(device).type == "cuda")
         G, n = self.G, int(n_local_max)
         i64, i32 = torch.int64, torch.int32
         self.stride = n
@@ -114,7 +118,7 @@ class ShardedPass:
         # 1. draw-rank base
         if G > 1:
             st.count_hits(cb, n, self.hits)
-            dist.all_gather_into_tensor(self.all_hits, self.hits, group=self.group)
+            self._all_gather(self.all_hits, self.hits)
             self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
         else:
             st.hist_reset()                             # single shard: K1b accumulates the digit histograms
@@ -123,7 +127,7 @@ class ShardedPass:
                       self.key_counts, self.counters)
         # 3. the exchange
         if G > 1:
-            dist.all_to_all_single(self.recv_counts, self.key_counts, group=self.group)
+            self._all_to_all_single(self.recv_counts, self.key_counts)
             both = torch.cat([self.key_counts, self.recv_counts]).tolist()   # the one host sync of the pass
             send, recv = both[:G], both[G:]
             self.n_recv = int(sum(recv))
@@ -135,10 +139,10 @@ class ShardedPass:
                 dist.all_to_all(outs, ins, group=self.group)
             else:                                       # gloo: contiguous send buffer
                 flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
-                dist.all_to_all_single(self.recv[:self.n_recv], flat, recv, send, group=self.group)
+                self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
             self.d_n.fill_(self.n_recv)
             keys = self.recv
-            dist.all_reduce(self.counters[:3], group=self.group)
+            self._all_reduce(self.counters[:3])
         else:
             self.d_n.copy_(self.key_counts[:1])
             self.n_recv = n                             # upper bound; the device reads d_n
@@ -148,6 +152,31 @@ class ShardedPass:
                                      self.count, self.nnz, hist_ready=(G == 1))
         self._keys_buf = keys
         self._verified = False
+
+    # ---- collectives: direct on RCCL (and on CPU tensors over gloo), staged through the host otherwise ----
+    def _all_gather(self, out, inp):
+        if self.host_staged:
+            o = out.cpu()
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def _all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        if self.host_staged:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def _all_reduce(self, t):
+        if self.host_staged:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
 
     def ensure_exact(self):
         """If the group-only sort met runs beyond its cap, finish the sort and reduce again (every key is still in
@@ -176,14 +205,14 @@ class ShardedPass:
             return f, c, k
         z = torch.tensor([len(f)], dtype=torch.int64, device=self.dev)
         zs = torch.zeros(self.G, dtype=torch.int64, device=self.dev)
-        dist.all_gather_into_tensor(zs, z, group=self.group)
+        self._all_gather(zs, z)
         zmax = int(zs.max().item())
         pad = torch.zeros((3, zmax), dtype=torch.int64, device=self.dev)
         pad[0, :len(f)] = torch.from_numpy(f).to(self.dev)
         pad[1, :len(f)] = torch.from_numpy(c).to(self.dev)
         pad[2, :len(f)] = torch.from_numpy(k).to(self.dev)
         allp = torch.zeros((self.G, 3, zmax), dtype=torch.int64, device=self.dev)
-        dist.all_gather_into_tensor(allp.view(-1), pad.view(-1), group=self.group)
+        self._all_gather(allp.view(-1), pad.view(-1))
         allp, zs = allp.cpu().numpy(), zs.cpu().numpy()
         F = np.concatenate([allp[g, 0, :zs[g]] for g in range(self.G)])
         Cc = np.concatenate([allp[g, 1, :zs[g]] for g in range(self.G)])
