@@ -99,6 +99,17 @@ void     oracle_decode_dna(const uint8_t *blob, size_t n_bases, char *out); /* :
 /* the depth test of bam2db_ds.c:385-390 on one raw draw: 1 = record kept */
 int      oracle_keep_draw(uint32_t draw, float rate_depth);
 
+/* --- crb / extract, fastf_oracle_tags.c ------------------- */
+/* extract_bam (extract.c:135-216): tag histogram as an insertion-order BST printed in pre-order,
+ * "value,count\n".  type 0 = string tag, type 1 = sprintf("%d", bam_aux2i()).  *total_printed is the
+ * doubled record count the reference prints (extract.c:163,165). */
+int oracle_extract(size_t n, const uint8_t *present, const char *vals, size_t stride, const int64_t *ivals, int type,
+                   char **csv_out, size_t *csv_len, uint64_t *total_printed, uint64_t *valid);
+/* read_bam + print_CB_node (extract.c:64-133, 47-62): "CB;CR,count;CR,count;...\n" rows, both trees pre-order. */
+int oracle_crb(size_t n, const uint8_t *has_cb, const uint8_t *has_cr, const char *cb, size_t cb_stride,
+               const char *cr, size_t cr_stride, char **txt_out, size_t *txt_len, uint64_t *read_count, uint64_t *undefined);
+void oracle_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfastf_oracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libfastf_ref.so")
+REF_TREE_PATH = os.path.join(HERE, "_ref", "libfastf_ref_tree.so")
 
 HAS_CB, HAS_XF, HAS_GX, HAS_UB = 1, 2, 4, 8
 MAX_BLOB = 16
@@ -47,10 +48,10 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
-    if force or not os.path.exists(LIB_PATH) or \
-            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "fastf_oracle.c")):
+    srcs = [os.path.join(HERE, f) for f in ("fastf_oracle.c", "fastf_oracle_tags.c", "fastf_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "liboracle"])
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_PATH)):
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(REF_PATH) or not os.path.exists(REF_TREE_PATH)):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
 
 
@@ -80,8 +81,61 @@ def lib():
         L.oracle_decode_dna.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
         L.oracle_keep_draw.argtypes = [C.c_uint32, C.c_float]
         L.oracle_keep_draw.restype = C.c_int
+        L.oracle_extract.restype = C.c_int
+        L.oracle_extract.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.oracle_crb.restype = C.c_int
+        L.oracle_crb.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.oracle_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+def run_extract(present, vals=None, ivals=None):
+    """extract_bam restated: vals = numpy 'S<k>' array (type 0) or ivals = int64 array (type 1).
+    Returns (csv bytes, total_printed, valid)."""
+    L = lib()
+    present = np.ascontiguousarray(present, dtype=np.uint8)
+    n = len(present)
+    out, ln, tot, val = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint64()
+    if ivals is None:
+        v, st = _fixed(vals)
+        L.oracle_extract(n, present.ctypes.data, v.ctypes.data, st, None, 0, C.byref(out), C.byref(ln), C.byref(tot), C.byref(val))
+    else:
+        iv = np.ascontiguousarray(ivals, dtype=np.int64)
+        L.oracle_extract(n, present.ctypes.data, None, 0, iv.ctypes.data, 1, C.byref(out), C.byref(ln), C.byref(tot), C.byref(val))
+    txt = C.string_at(out.value, ln.value)
+    L.oracle_free(out)
+    return txt, int(tot.value), int(val.value)
+
+
+def run_crb(has_cb, has_cr, cb, cr):
+    """read_bam + print_CB_node restated.  Returns (text bytes, read_count, undefined)."""
+    L = lib()
+    has_cb = np.ascontiguousarray(has_cb, dtype=np.uint8)
+    has_cr = np.ascontiguousarray(has_cr, dtype=np.uint8)
+    cb, cbs = _fixed(cb)
+    cr, crs = _fixed(cr)
+    out, ln, rc_, ud = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint64()
+    L.oracle_crb(len(has_cb), has_cb.ctypes.data, has_cr.ctypes.data, cb.ctypes.data, cbs, cr.ctypes.data, crs,
+                 C.byref(out), C.byref(ln), C.byref(rc_), C.byref(ud))
+    txt = C.string_at(out.value, ln.value)
+    L.oracle_free(out)
+    return txt, int(rc_.value), int(ud.value)
+
+
+def ref_tree_lib():
+    """The reference's own filter.c (insert_tree / print_tree / print_tree_same_row), None if not built."""
+    if not os.path.exists(REF_TREE_PATH):
+        return None
+    R = C.CDLL(REF_TREE_PATH)
+    R.insert_tree.argtypes = [C.c_void_p, C.c_char_p]
+    R.insert_tree.restype = C.c_void_p
+    R.print_tree.argtypes = [C.c_void_p, C.c_void_p]
+    R.print_tree_same_row.argtypes = [C.c_void_p, C.c_void_p]
+    R.free_tree_node.argtypes = [C.c_void_p]
+    return R
 
 
 def ref_lib():
