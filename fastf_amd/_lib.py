@@ -68,6 +68,14 @@ class ListsStruct(C.Structure):
     ]
 
 
+class TagHistResult(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_valid", C.c_uint64), ("n_key1_present", C.c_uint64),
+                ("key1", C.POINTER(C.c_uint64)), ("count1", C.POINTER(C.c_uint64)), ("first1", C.POINTER(C.c_uint64)),
+                ("n1", C.c_size_t),
+                ("pair_k1", C.POINTER(C.c_uint32)), ("pair_key2", C.POINTER(C.c_uint64)),
+                ("pair_count", C.POINTER(C.c_uint64)), ("pair_first", C.POINTER(C.c_uint64)), ("n_pairs", C.c_size_t)]
+
+
 class MT(C.Structure):
     _fields_ = [("s", C.c_uint32 * 624), ("idx", C.c_int)]
 
@@ -87,6 +95,10 @@ ABI_SYMBOLS = [
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_hist_reset", "fastf_dev_error_bits",
     "fastf_dev_clear_error_bits", "fastf_kernel_names",
+    # crb / extract
+    "extract_bam", "read_bam", "free_CB_node", "print_CB_node", "cmd_crb", "cmd_extract",
+    "fastf_crb_text", "fastf_extract_text", "fastf_keydict_intern", "fastf_keydict_decode",
+    "fastf_taghist_create", "fastf_taghist_destroy", "fastf_taghist_push", "fastf_taghist_finish",
 ]
 
 
@@ -158,6 +170,27 @@ def lib():
     L.fastf_format_matrix.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(u64 * 3), sz, sz,
                                       C.POINTER(Coo), C.POINTER(vp), C.POINTER(sz)]
     L.fastf_format_umi_rows.argtypes = [C.POINTER(UmiRows), C.POINTER(vp), C.POINTER(sz)]
+    L.fastf_keydict_intern.argtypes = [vp, C.c_char_p, sz]
+    L.fastf_keydict_intern.restype = u64
+    L.fastf_keydict_decode.argtypes = [vp, u64, C.c_char_p, sz]
+    L.fastf_keydict_decode.restype = C.c_long
+    L.fastf_taghist_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.fastf_taghist_destroy.argtypes = [vp]
+    L.fastf_taghist_destroy.restype = None
+    L.fastf_taghist_push.argtypes = [vp, vp, vp, sz]
+    L.fastf_taghist_finish.argtypes = [vp, C.POINTER(TagHistResult)]
+    L.fastf_crb_text.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
+    L.fastf_extract_text.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64), C.POINTER(u64)]
+    L.fastf_bam_read_tags.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.c_int, vp, vp, sz, C.POINTER(u64)]
+    L.fastf_bam_read_tags.restype = C.c_long
+    L.read_bam.argtypes = [C.c_char_p]
+    L.read_bam.restype = vp
+    L.print_CB_node.argtypes = [vp, vp]
+    L.print_CB_node.restype = None
+    L.free_CB_node.argtypes = [vp]
+    L.free_CB_node.restype = None
+    L.extract_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.extract_bam.restype = None
     L.bam2db.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, C.c_uint]
     _lib = L
     return L

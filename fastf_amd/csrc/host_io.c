@@ -590,14 +590,14 @@ static void pack_worker(void *vp, int widx)
     j->no_xf[widx] = nxf; j->no_gx[widx] = ngx;
 }
 
-long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
-                          uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap)
+/* step 3: offsets of up to cap records into b->rec; the window is refilled only when it runs dry, so one batch
+ * never spans a refill (offsets stay valid) unless the window holds no complete record at all.
+ * Returns the count, 0 at EOF, -1 on error. */
+static long bam_hop_records(fastf_bam_t *b, size_t cap)
 {
     if (b->reccap < cap) { b->reccap = cap; b->rec = (size_t *)realloc(b->rec, cap * sizeof *b->rec); }
     size_t n = 0;
     double t_hop0 = now_s(), t_fill0 = b->t_read + b->t_inflate;
-    /* step 3: record offsets; the window is refilled only when it runs dry, so one batch never
-     * spans a refill (offsets stay valid) unless the window holds no complete record at all */
     while (n < cap) {
         if (b->ulen - b->upos < 4 || b->ulen - b->upos < 4 + (size_t)rd32(b->ubuf + b->upos)) {
             if (n) break;                                       /* hand out what this window had */
@@ -621,6 +621,15 @@ long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fa
         b->upos += 4 + (size_t)bs;
     }
     b->t_hop += (now_s() - t_hop0) - (b->t_read + b->t_inflate - t_fill0);
+    return (long)n;
+}
+
+long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
+                          uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap)
+{
+    long hopped = bam_hop_records(b, cap);
+    if (hopped < 0) return -1;
+    size_t n = (size_t)hopped;
     if (n) {
         double t0 = now_s();
         pack_job job; memset(&job, 0, sizeof job);
@@ -632,6 +641,77 @@ long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fa
         b->t_pack += now_s() - t0;
     }
     return (long)n;
+}
+
+/* ---- generic tag reader for the histogram paths (crb: CB + CR, extract: any tag) ----
+ * Same windowed record hop as fastf_bam_read_batch; per record the first occurrence of each wanted tag
+ * (bam_aux_get) becomes a 64-bit key:
+ *   type 0 (string, bam_aux2Z): fastf_keydict_intern of the Z value; a tag of another type makes bam_aux2Z return
+ *          NULL, which the reference passes to strcmp/strcpy (extract.c:102-103,189) — undefined there, counted
+ *          in `undefined` and treated as absent here;
+ *   type 1 (integer, bam_aux2i → "%d", extract.c:192): key = 2^32 | (uint32)(int)value, 0 for non-integer types
+ *          as bam_aux2i does.
+ * key 0 = tag absent. */
+typedef struct {
+    fastf_bam_t *b; fastf_keydict_t *dict; const char *t1, *t2; int type;
+    uint64_t *k1, *k2; size_t n; size_t next;
+    uint64_t undef[64];
+} tag_job;
+
+static uint64_t tag_key(const unsigned char *val, fastf_keydict_t *dict, int type, uint64_t *undef)
+{
+    if (type == 1) return (1ull << 32) | (uint32_t)(int32_t)aux_int(val);
+    if (*val != 'Z') { (*undef)++; return 0; }
+    const char *s = (const char *)val + 1;
+    return fastf_keydict_intern(dict, s, strlen(s));
+}
+
+static void tag_worker(void *vp, int widx)
+{
+    tag_job *j = (tag_job *)vp;
+    const unsigned char *u = j->b->ubuf;
+    uint64_t undef = 0;
+    for (;;) {
+        size_t i = __atomic_fetch_add(&j->next, 4096, __ATOMIC_RELAXED);
+        if (i >= j->n) break;
+        size_t e = i + 4096 < j->n ? i + 4096 : j->n;
+        for (; i < e; i++) {
+            const unsigned char *rec = u + j->b->rec[i] + 4;
+            uint32_t bs = rd32(rec - 4);
+            uint32_t l_read_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
+            uint64_t fixed = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+            if (fixed > bs) fixed = bs;
+            const unsigned char *aux = rec + fixed, *end = rec + bs, *v1 = NULL, *v2 = NULL;
+            while (end - aux >= 3) {
+                const unsigned char *val = aux + 2;
+                long sz = aux_skip(val, end);
+                if (sz < 0) break;
+                if (aux[0] == (unsigned char)j->t1[0] && aux[1] == (unsigned char)j->t1[1]) { if (!v1) v1 = val; }
+                else if (j->t2 && aux[0] == (unsigned char)j->t2[0] && aux[1] == (unsigned char)j->t2[1]) { if (!v2) v2 = val; }
+                aux = val + sz;
+            }
+            j->k1[i] = v1 ? tag_key(v1, j->dict, j->type, &undef) : 0;
+            if (j->k2) j->k2[i] = v2 ? tag_key(v2, j->dict, j->type, &undef) : 0;
+        }
+    }
+    j->undef[widx] = undef;
+}
+
+long fastf_bam_read_tags(fastf_bam_t *b, fastf_keydict_t *dict, const char *tag1, const char *tag2, int type,
+                         uint64_t *key1, uint64_t *key2, size_t cap, uint64_t *n_undefined)
+{
+    if (!tag1 || strlen(tag1) != 2 || (tag2 && strlen(tag2) != 2)) { io_err("a BAM tag name has exactly two characters"); return -1; }
+    long n = bam_hop_records(b, cap);
+    if (n <= 0) return n;
+    tag_job job; memset(&job, 0, sizeof job);
+    job.b = b; job.dict = dict; job.t1 = tag1; job.t2 = tag2; job.type = type;
+    job.k1 = key1; job.k2 = tag2 ? key2 : NULL; job.n = (size_t)n;
+    double t0 = now_s();
+    par_run(n < 8192 ? 1 : b->n_threads, tag_worker, &job);
+    b->t_pack += now_s() - t0;
+    b->n_records += (uint64_t)n;
+    if (n_undefined) for (int i = 0; i < 64; i++) *n_undefined += job.undef[i];
+    return n;
 }
 
 /* ================================================================== */
@@ -754,11 +834,33 @@ static void gz_worker(void *vp, int widx)
     free(o.p);
 }
 
+static int write_gz_chunks_path(const char *path, const char *prefix, size_t prefix_len,
+                                size_t n_items, size_t per_chunk, chunk_fmt_fn fmt, void *ctx);
 static int write_gz_chunks(const char *dir, const char *name, const char *prefix, size_t prefix_len,
                            size_t n_items, size_t per_chunk, chunk_fmt_fn fmt, void *ctx)
 {
     char path[4096];
     snprintf(path, sizeof path, "%s/%s", dir, name);
+    return write_gz_chunks_path(path, prefix, prefix_len, n_items, per_chunk, fmt, ctx);
+}
+
+/* a finished text as one gzip file (crb output, main.c:262 gzopen(path, "w")): 4 MiB slices, one member each */
+typedef struct { const char *text; } text_ctx;
+static void fmt_text_slice(void *ctx, size_t lo, size_t hi, obuf *o)
+{
+    ob_room(o, hi - lo);
+    memcpy(o->p + o->len, ((text_ctx *)ctx)->text + lo, hi - lo);
+    o->len += hi - lo;
+}
+int fastf_write_gz_text(const char *path, const char *text, size_t len)
+{
+    text_ctx c = { text };
+    return write_gz_chunks_path(path, NULL, 0, len, (size_t)4 << 20, fmt_text_slice, &c);
+}
+
+static int write_gz_chunks_path(const char *path, const char *prefix, size_t prefix_len,
+                                size_t n_items, size_t per_chunk, chunk_fmt_fn fmt, void *ctx)
+{
     FILE *f = fopen(path, "wb");
     if (!f) { fprintf(stderr, "\x1b[31mError:\x1b[0m can not open file %s\n", path); return io_err("can not open file %s", path); }
     gz_job j; memset(&j, 0, sizeof j);

@@ -41,6 +41,11 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                           uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap);
+/* Tag reader of the histogram paths (crb / extract): per record the key of tag1 (and tag2, or NULL) — type 0 string
+ * (interned in dict), type 1 integer; 0 = absent.  Returns the count, 0 at EOF, -1 on error; *n_undefined is
+ * incremented for string-mode tags that are not of type Z (NULL dereference in the reference, extract.c:102-103,189). */
+long fastf_bam_read_tags(fastf_bam_t *b, fastf_keydict_t *dict, const char *tag1, const char *tag2, int type,
+                         uint64_t *key1, uint64_t *key2, size_t cap, uint64_t *n_undefined);
 /* counts of records whose reference behaviour is undefined (xf / GX missing where the
  * reference dereferences NULL, bam2db_ds.c:394-395,403-404); they are skipped here */
 void fastf_bam_stats(const fastf_bam_t *b, uint64_t *n_records, uint64_t *n_no_xf, uint64_t *n_no_gx);
@@ -54,6 +59,16 @@ int fastf_write_outputs(const char *path_out, const char *bam_label, float rate_
 int fastf_format_matrix(const char *bam_label, float rate_cell, float rate_depth, const uint64_t counters[3],
                         size_t n_feature, size_t n_barcode, const fastf_coo_t *coo, char **out, size_t *out_len);
 int fastf_format_umi_rows(const fastf_umi_rows_t *rows, char **out, size_t *out_len);
+
+/* extract.c:47-62 (declared here because of zlib's gzFile) */
+#include <zlib.h>
+void print_CB_node(CB_node *root, gzFile fp);
+
+/* pre-order of the insertion-order BST of m distinct strings with first-occurrence positions first[] (tag_cmds.c) */
+void fastf_tag_tree_preorder(const char *const *strs, const uint64_t *first, uint32_t m, uint32_t *order);
+
+/* text → gzip file (chunk-parallel members) */
+int fastf_write_gz_text(const char *path, const char *text, size_t len);
 
 /* string-level records → packed SoA (flags: 1 CB, 2 xf, 4 GX, 8 UB present) */
 void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *feats, size_t n,

@@ -11,6 +11,8 @@
  */
 #include "fastf_amd.h"
 
+#include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -193,7 +195,9 @@ uint32_t fastf_pack_umi(const char *ub, size_t len, uint32_t *umi_out)
  *                  [61:57] length  [56:49] suffix+1 (0 = none)  [47:0] bases, first base on top
  *   2  ID form     <prefix><1..13 digits>; prefix = everything before the trailing digit run
  *                  [61:48] prefix id  [47:44] digit count  [43:0] value
- *   3  escape      [61:0] ordinal of the registered string (anything else that was registered)
+ *   3  bit 61 = 0: escape   [60:0] ordinal of the registered string (anything else that was registered)
+ *      bit 61 = 1: DNA+N    [ACGTN]{1,16} with at least one N ( '-' canonical-decimal 0..254 )?   (raw CR/UR tags)
+ *                  [60:56] length  [55:48] suffix+1  [47:0] 3 bits per base, first base on top (N = 4)
  *   0  (whole key 0) cannot equal any registered string
  * Classification depends on the string alone (plus the append-only prefix table), so a
  * registered string and an equal tag string always take the same route.
@@ -204,12 +208,17 @@ typedef struct { kd_ent *e; size_t cap, n; } kd_map;
 struct fastf_keydict {
     kd_map prefixes;      /* prefix string → id        */
     kd_map escapes;       /* whole string  → ordinal   */
+    const char **prefix_by_id; size_t prefix_cap;     /* reverse tables for fastf_keydict_decode */
+    const char **escape_by_ord; size_t escape_cap;
+    pthread_mutex_t mu;   /* fastf_keydict_intern: writers and map readers */
+    uint64_t generation;  /* distinguishes dictionaries that reuse an address (thread-local caches) */
 };
+static uint64_t g_kd_generation;
 
 /* one-entry per-thread cache: real inputs use a handful of prefixes.  Prefix strings are
  * individually malloc'ed and never freed before the dict, so the pointer stays valid
  * across rehashes; the dict pointer guards against reuse across dictionaries. */
-static __thread struct { const fastf_keydict_t *d; const char *p; uint32_t len; uint64_t id; } tl_prefix;
+static __thread struct { const fastf_keydict_t *d; uint64_t gen; const char *p; uint32_t len; uint64_t id; } tl_prefix;
 
 #define KD_MAX_PREFIX (1u << 14)
 
@@ -231,7 +240,7 @@ static const kd_ent *map_find(const kd_map *m, const char *s, size_t len)
     }
 }
 
-static void map_put(kd_map *m, const char *s, size_t len, uint64_t val)
+static const char *map_put(kd_map *m, const char *s, size_t len, uint64_t val)
 {
     if ((m->n + 1) * 2 > m->cap) {
         size_t ncap = m->cap ? m->cap * 2 : 64;
@@ -251,6 +260,18 @@ static void map_put(kd_map *m, const char *s, size_t len, uint64_t val)
     memcpy(m->e[j].s, s, len); m->e[j].s[len] = '\0';
     m->e[j].len = (uint32_t)len; m->e[j].val = val;
     m->n++;
+    return m->e[j].s;
+}
+
+static void rev_put(const char ***tab, size_t *cap, uint64_t id, const char *s)
+{
+    if (id >= *cap) {
+        size_t ncap = *cap ? *cap * 2 : 64;
+        while (id >= ncap) ncap *= 2;
+        *tab = (const char **)realloc((void *)*tab, ncap * sizeof **tab);
+        *cap = ncap;
+    }
+    (*tab)[id] = s;
 }
 
 static void map_free(kd_map *m)
@@ -261,7 +282,11 @@ static void map_free(kd_map *m)
 
 fastf_keydict_t *fastf_keydict_create(void)
 {
-    return (fastf_keydict_t *)calloc(1, sizeof(fastf_keydict_t));
+    fastf_keydict_t *d = (fastf_keydict_t *)calloc(1, sizeof(fastf_keydict_t));
+    if (!d) return NULL;
+    pthread_mutex_init(&d->mu, NULL);
+    d->generation = __atomic_add_fetch(&g_kd_generation, 1, __ATOMIC_RELAXED);
+    return d;
 }
 
 void fastf_keydict_destroy(fastf_keydict_t *d)
@@ -269,6 +294,8 @@ void fastf_keydict_destroy(fastf_keydict_t *d)
     if (!d) return;
     if (tl_prefix.d == d) tl_prefix.d = NULL;
     map_free(&d->prefixes); map_free(&d->escapes);
+    free((void *)d->prefix_by_id); free((void *)d->escape_by_ord);
+    pthread_mutex_destroy(&d->mu);
     free(d);
 }
 
@@ -303,6 +330,42 @@ static uint64_t pack_dna(const char *s, size_t len)
     return (1ull << 62) | ((uint64_t)n << 57) | (suffix << 49) | bases;
 }
 
+/* DNA+N form (raw barcodes / UMIs with uncalled bases); 0 when the string is not of that form.  Pure ACGT strings
+ * never get here as keys of this form: pack_dna() is tried first and this form requires at least one N. */
+static uint64_t pack_dna_n(const char *s, size_t len)
+{
+    uint64_t bases = 0;
+    size_t n = 0;
+    int has_n = 0;
+    while (n < len) {
+        uint64_t c = k_base_code[(unsigned char)s[n]];
+        if (c & 4) {
+            if (s[n] != 'N') break;
+            c = 4; has_n = 1;
+        }
+        if (n == 16) return 0;
+        bases = (bases << 3) | c;
+        n++;
+    }
+    if (n == 0 || !has_n) return 0;
+    bases <<= 48 - 3 * n;
+    uint64_t suffix = 0;
+    if (n < len) {
+        if (s[n] != '-') return 0;
+        size_t d = n + 1, nd = len - d;
+        if (nd == 0 || nd > 3) return 0;
+        if (s[d] == '0' && nd > 1) return 0;
+        uint32_t v = 0;
+        for (size_t i = d; i < len; i++) {
+            if (s[i] < '0' || s[i] > '9') return 0;
+            v = v * 10 + (uint32_t)(s[i] - '0');
+        }
+        if (v > 254) return 0;
+        suffix = v + 1;
+    }
+    return (3ull << 62) | (1ull << 61) | ((uint64_t)n << 56) | (suffix << 48) | bases;
+}
+
 /* splits <prefix><digits>; returns digit count (0 = not of the ID form) */
 static size_t split_id(const char *s, size_t len, uint64_t *value)
 {
@@ -324,13 +387,15 @@ uint64_t fastf_keydict_add(fastf_keydict_t *d, const char *s, size_t len)
 {
     uint64_t k = pack_dna(s, len);
     if (k) return k;
+    if ((k = pack_dna_n(s, len))) return k;
     uint64_t value;
     size_t nd = split_id(s, len, &value);
     if (nd) {
         size_t plen = len - nd;
         const kd_ent *p = map_find(&d->prefixes, s, plen);
         if (!p && d->prefixes.n < KD_MAX_PREFIX) {
-            map_put(&d->prefixes, s, plen, d->prefixes.n);
+            const uint64_t id = d->prefixes.n;
+            rev_put(&d->prefix_by_id, &d->prefix_cap, id, map_put(&d->prefixes, s, plen, id));
             p = map_find(&d->prefixes, s, plen);
         }
         if (p) return make_id(p->val, nd, value);
@@ -338,7 +403,7 @@ uint64_t fastf_keydict_add(fastf_keydict_t *d, const char *s, size_t len)
     const kd_ent *e = map_find(&d->escapes, s, len);
     if (e) return (3ull << 62) | e->val;
     uint64_t ord = d->escapes.n;
-    map_put(&d->escapes, s, len, ord);
+    rev_put(&d->escape_by_ord, &d->escape_cap, ord, map_put(&d->escapes, s, len, ord));
     return (3ull << 62) | ord;
 }
 
@@ -346,20 +411,113 @@ uint64_t fastf_keydict_pack(const fastf_keydict_t *d, const char *s, size_t len)
 {
     uint64_t k = pack_dna(s, len);
     if (k) return k;
+    if ((k = pack_dna_n(s, len))) return k;
     uint64_t value;
     size_t nd = split_id(s, len, &value);
     if (nd) {
         size_t plen = len - nd;
-        if (tl_prefix.d == d && tl_prefix.len == plen && memcmp(tl_prefix.p, s, plen) == 0)
+        if (tl_prefix.d == d && tl_prefix.gen == d->generation && tl_prefix.len == plen && memcmp(tl_prefix.p, s, plen) == 0)
             return make_id(tl_prefix.id, nd, value);
         const kd_ent *p = map_find(&d->prefixes, s, plen);
         if (p) {
-            tl_prefix.d = d; tl_prefix.p = p->s; tl_prefix.len = p->len; tl_prefix.id = p->val;
+            tl_prefix.d = d; tl_prefix.gen = d->generation; tl_prefix.p = p->s; tl_prefix.len = p->len; tl_prefix.id = p->val;
             return make_id(p->val, nd, value);
         }
     }
     const kd_ent *e = map_find(&d->escapes, s, len);
     return e ? ((3ull << 62) | e->val) : 0;
+}
+
+/* Thread-safe "pack, registering the string if it is new" — the tag-histogram paths (crb / extract) have no list of
+ * strings up front.  DNA forms need no dictionary; prefixes and escapes are looked up in small per-thread caches
+ * first (entries point at strings the dictionary never frees or moves before its destruction) and under the
+ * dictionary mutex otherwise.  Must not run concurrently with fastf_keydict_add / _pack on the same dictionary. */
+#define TL_ESC_SLOTS 2048
+static __thread struct { uint64_t gen; const char *p; uint32_t len; uint64_t key; } tl_esc[TL_ESC_SLOTS];
+
+uint64_t fastf_keydict_intern(fastf_keydict_t *d, const char *s, size_t len)
+{
+    uint64_t k = pack_dna(s, len);
+    if (k) return k;
+    if ((k = pack_dna_n(s, len))) return k;
+    uint64_t value;
+    size_t nd = split_id(s, len, &value);
+    if (nd) {
+        size_t plen = len - nd;
+        if (tl_prefix.d == d && tl_prefix.gen == d->generation && tl_prefix.len == plen && memcmp(tl_prefix.p, s, plen) == 0)
+            return make_id(tl_prefix.id, nd, value);
+        pthread_mutex_lock(&d->mu);
+        const kd_ent *p = map_find(&d->prefixes, s, plen);
+        if (!p && d->prefixes.n < KD_MAX_PREFIX) {
+            const uint64_t id = d->prefixes.n;
+            rev_put(&d->prefix_by_id, &d->prefix_cap, id, map_put(&d->prefixes, s, plen, id));
+            p = map_find(&d->prefixes, s, plen);
+        }
+        if (p) {
+            tl_prefix.d = d; tl_prefix.gen = d->generation; tl_prefix.p = p->s; tl_prefix.len = p->len; tl_prefix.id = p->val;
+            k = make_id(p->val, nd, value);
+        }
+        pthread_mutex_unlock(&d->mu);
+        if (k) return k;
+    }
+    const uint64_t h = fnv1a(s, len);
+    const size_t slot = (size_t)(h ^ (h >> 32)) & (TL_ESC_SLOTS - 1);
+    if (tl_esc[slot].gen == d->generation && tl_esc[slot].len == len && memcmp(tl_esc[slot].p, s, len) == 0)
+        return tl_esc[slot].key;
+    pthread_mutex_lock(&d->mu);
+    const kd_ent *e = map_find(&d->escapes, s, len);
+    if (!e) {
+        const uint64_t ord = d->escapes.n;
+        rev_put(&d->escape_by_ord, &d->escape_cap, ord, map_put(&d->escapes, s, len, ord));
+        e = map_find(&d->escapes, s, len);
+    }
+    k = (3ull << 62) | e->val;
+    tl_esc[slot].gen = d->generation; tl_esc[slot].p = e->s; tl_esc[slot].len = e->len; tl_esc[slot].key = k;
+    pthread_mutex_unlock(&d->mu);
+    return k;
+}
+
+/* key → string (inverse of add / pack / intern on this dictionary).  Returns the length, or -1 for a key this
+ * dictionary did not produce or a buffer that is too small (cap includes the terminating NUL). */
+long fastf_keydict_decode(const fastf_keydict_t *d, uint64_t key, char *buf, size_t cap)
+{
+    static const char B[5] = {'A', 'C', 'G', 'T', 'N'};
+    const unsigned form = (unsigned)(key >> 62);
+    size_t n = 0;
+    if (form == 1 || (form == 3 && (key >> 61 & 1))) {
+        const int wide = form == 3;
+        const size_t nb = wide ? (size_t)(key >> 56 & 31) : (size_t)(key >> 57 & 31);
+        const unsigned suffix = wide ? (unsigned)(key >> 48 & 255) : (unsigned)(key >> 49 & 255);
+        if (nb == 0 || nb > (wide ? 16u : 24u) || nb + 5 > cap) return -1;
+        for (size_t i = 0; i < nb; i++) {
+            const unsigned c = wide ? (unsigned)(key >> (45 - 3 * i) & 7) : (unsigned)(key >> (46 - 2 * i) & 3);
+            if (c > 4) return -1;
+            buf[n++] = B[c];
+        }
+        if (suffix) n += (size_t)snprintf(buf + n, cap - n, "-%u", suffix - 1);
+        buf[n] = '\0';
+        return (long)n;
+    }
+    if (form == 2) {
+        const uint64_t pid = key >> 48 & 0x3fff, nd = key >> 44 & 15, value = key & 0xfffffffffffull;
+        if (pid >= d->prefixes.n || nd == 0 || nd > 13) return -1;
+        const char *p = d->prefix_by_id[pid];
+        const size_t pl = strlen(p);
+        if (pl + nd + 1 > cap) return -1;
+        memcpy(buf, p, pl);
+        snprintf(buf + pl, cap - pl, "%0*llu", (int)nd, (unsigned long long)value);
+        return (long)(pl + nd);
+    }
+    if (form == 3) {
+        const uint64_t ord = key & ((1ull << 61) - 1);
+        if (ord >= d->escapes.n) return -1;
+        const char *p = d->escape_by_ord[ord];
+        const size_t pl = strlen(p);
+        if (pl + 1 > cap) return -1;
+        memcpy(buf, p, pl + 1);
+        return (long)pl;
+    }
+    return -1;
 }
 
 void fastf_keydict_pack_many(const fastf_keydict_t *d, const char *strs, size_t stride,

@@ -1,0 +1,534 @@
+/*
+ * tag_cmds.c — `crb` and `extract` on the tag-histogram engine.
+ *
+ * Drop-in symbols (same names, signatures and output bytes as the reference):
+ *   void     extract_bam(char *bam_file, const char *tag, int type)   extract.c:135-216 (decl. extract.h:26)
+ *   CB_node *read_bam(char *bam_file)                                 extract.c:64-133  (decl. extract.h:24)
+ *   void     print_CB_node(CB_node *root, gzFile fp)                  extract.c:47-62
+ *   void     free_CB_node(CB_node *root)                              extract.c:33-45
+ *   int      cmd_crb(int argc, const char **argv)                     main.c:231-286
+ *   int      cmd_extract(int argc, const char **argv)                 main.c:364-402
+ *
+ * The reference inserts every record's tag string into an unbalanced binary search tree (filter.c:105-124,
+ * extract.c:3-31) and prints the tree in pre-order.  A tree built by inserting distinct keys in sequence is the
+ * Cartesian tree of the keys in strcmp order with "position of first occurrence" as heap priority, so the output
+ * is a function of (distinct values, their counts, their first-occurrence positions) — which the device computes
+ * with a radix sort + run-length + first-index pass (tag_hist.hpp).  The host side here reads the BAM, packs tag
+ * strings into exact 64-bit keys, and turns the device result into the tree order and the output text.
+ * No CPU fallback: without a HIP device fastf_taghist_create fails and the commands return an error.
+ */
+#define _GNU_SOURCE
+#include "host_io.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+/* ------------------------------------------------------------------ */
+/* insertion-order BST of distinct strings, without inserting          */
+/* ------------------------------------------------------------------ */
+typedef struct { const char *s; uint64_t first, count; } tag_ent;
+
+static int cmp_ent_idx(const void *a, const void *b, void *ctx)
+{
+    const tag_ent *ent = (const tag_ent *)ctx;
+    return strcmp(ent[*(const uint32_t *)a].s, ent[*(const uint32_t *)b].s);
+}
+
+/* Shape of the tree the reference would have built: left/right child (index into ent, -1 = none) and the root.
+ * sorted[] receives the strcmp order.  All arrays have m entries. */
+static int32_t bst_shape(const tag_ent *ent, uint32_t m, uint32_t *sorted, int32_t *left, int32_t *right)
+{
+    for (uint32_t i = 0; i < m; i++) { sorted[i] = i; left[i] = right[i] = -1; }
+    qsort_r(sorted, m, sizeof *sorted, cmp_ent_idx, (void *)ent);
+    /* Cartesian tree (min `first` on top) over the sorted sequence, with the usual right-spine stack */
+    uint32_t *stack = (uint32_t *)malloc((m ? m : 1) * sizeof *stack);
+    uint32_t top = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        const uint32_t x = sorted[j];
+        int32_t last = -1;
+        while (top && ent[stack[top - 1]].first > ent[x].first) last = (int32_t)stack[--top];
+        left[x] = last;
+        if (top) right[stack[top - 1]] = (int32_t)x;
+        stack[top++] = x;
+    }
+    int32_t root = m ? (int32_t)stack[0] : -1;
+    free(stack);
+    return root;
+}
+
+/* pre-order (node, left, right — filter.c:139-148) of that tree into order[] */
+static void bst_preorder(int32_t root, const int32_t *left, const int32_t *right, uint32_t m, uint32_t *order)
+{
+    int32_t *stack = (int32_t *)malloc((m ? m : 1) * sizeof *stack);
+    uint32_t top = 0, k = 0;
+    if (root >= 0) stack[top++] = root;
+    while (top) {
+        const int32_t x = stack[--top];
+        order[k++] = (uint32_t)x;
+        if (right[x] >= 0) stack[top++] = right[x];
+        if (left[x] >= 0) stack[top++] = left[x];
+    }
+    free(stack);
+}
+
+/* host-side tree order on its own (exported for the CPU test suite): order[] = pre-order of the insertion-order BST
+ * of the m distinct strings whose first occurrences are first[] */
+void fastf_tag_tree_preorder(const char *const *strs, const uint64_t *first, uint32_t m, uint32_t *order)
+{
+    tag_ent *ent = (tag_ent *)malloc((m ? m : 1) * sizeof *ent);
+    uint32_t *sorted = (uint32_t *)malloc((m ? m : 1) * sizeof *sorted);
+    int32_t *left = (int32_t *)malloc((m ? m : 1) * sizeof *left), *right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
+    for (uint32_t i = 0; i < m; i++) { ent[i].s = strs[i]; ent[i].first = first[i]; ent[i].count = 1; }
+    bst_preorder(bst_shape(ent, m, sorted, left, right), left, right, m, order);
+    free(ent); free(sorted); free(left); free(right);
+}
+
+typedef struct { char *p; size_t len, cap; } tbuf;
+static void tb_put(tbuf *b, const char *s, size_t n)
+{
+    if (b->len + n + 1 > b->cap) {
+        while (b->len + n + 1 > b->cap) b->cap = b->cap ? b->cap * 2 : (1u << 16);
+        b->p = (char *)realloc(b->p, b->cap);
+    }
+    memcpy(b->p + b->len, s, n);
+    b->len += n;
+}
+static void tb_count(tbuf *b, uint64_t v, char after)     /* ",<count><after>" — "%s,%ld" filter.c:145,166 */
+{
+    char t[32];
+    int n = snprintf(t, sizeof t, ",%llu%c", (unsigned long long)v, after);
+    tb_put(b, t, (size_t)n);
+}
+
+/* ------------------------------------------------------------------ */
+/* BAM → device histogram                                              */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    fastf_keydict_t *dict;
+    fastf_taghist_t *hist;
+    fastf_taghist_result_t res;
+    uint64_t n_records, n_undefined;
+} tag_run;
+
+static void tag_run_free(tag_run *r)
+{
+    if (r->hist) fastf_taghist_destroy(r->hist);
+    if (r->dict) fastf_keydict_destroy(r->dict);
+    memset(r, 0, sizeof *r);
+}
+
+static int tag_run_bam(const char *bam_file, const char *tag1, const char *tag2, int type, tag_run *r)
+{
+    memset(r, 0, sizeof *r);
+    fastf_bam_t *bam = fastf_bam_open(bam_file, 0);
+    if (!bam) return 1;
+    const size_t cap = (size_t)4 << 20;
+    uint64_t *k1 = (uint64_t *)malloc(cap * sizeof *k1), *k2 = tag2 ? (uint64_t *)malloc(cap * sizeof *k2) : NULL;
+    int rc = 1;
+    r->dict = fastf_keydict_create();
+    if (!k1 || (tag2 && !k2) || !r->dict) { fastf_set_error_("out of memory"); goto done; }
+    if (fastf_taghist_create(0, &r->hist)) goto done;
+    for (;;) {
+        long n = fastf_bam_read_tags(bam, r->dict, tag1, tag2, type, k1, k2, cap, &r->n_undefined);
+        if (n < 0) goto done;
+        if (n == 0) break;
+        if (fastf_taghist_push(r->hist, k1, k2, (size_t)n)) goto done;
+        r->n_records += (uint64_t)n;
+    }
+    if (fastf_taghist_finish(r->hist, &r->res)) goto done;
+    rc = 0;
+done:
+    free(k1); free(k2);
+    fastf_bam_close(bam);
+    if (rc) { char keep[512]; snprintf(keep, sizeof keep, "%s", fastf_last_error()); tag_run_free(r); fastf_set_error_(keep); }
+    return rc;
+}
+
+/* decoded strings of n keys in one pool; type 1 keys print as "%d" (extract.c:192) */
+static char *decode_keys(const fastf_keydict_t *d, const uint64_t *keys, size_t n, int type, const char ***strs_out)
+{
+    size_t cap = n * 24 + 64, len = 0;
+    char *pool = (char *)malloc(cap);
+    size_t *off = (size_t *)malloc((n ? n : 1) * sizeof *off);
+    for (size_t i = 0; i < n; i++) {
+        if (cap - len < 4200) { cap = cap * 2 + 8192; pool = (char *)realloc(pool, cap); }
+        long l;
+        if (type == 1) l = snprintf(pool + len, cap - len, "%d", (int)(int32_t)(uint32_t)keys[i]);
+        else l = fastf_keydict_decode(d, keys[i], pool + len, cap - len > 4096 ? 4096 : cap - len);
+        if (l < 0) {                       /* a tag value longer than 4 KiB: give it all the room it needs */
+            cap = cap * 2 + (1u << 20); pool = (char *)realloc(pool, cap);
+            l = fastf_keydict_decode(d, keys[i], pool + len, cap - len);
+            if (l < 0) { free(pool); free(off); fastf_set_error_("undecodable tag key"); return NULL; }
+        }
+        off[i] = len;
+        len += (size_t)l + 1;
+    }
+    const char **strs = (const char **)malloc((n ? n : 1) * sizeof *strs);
+    for (size_t i = 0; i < n; i++) strs[i] = pool + off[i];
+    free(off);
+    *strs_out = strs;
+    return pool;
+}
+
+/* ------------------------------------------------------------------ */
+/* extract                                                             */
+/* ------------------------------------------------------------------ */
+/* tag histogram of a BAM as the bytes of tag_summary.csv; *valid = records that carry the tag (extract.c:185) */
+int fastf_extract_text(const char *bam_file, const char *tag, int type, char **csv, size_t *csv_len,
+                       uint64_t *n_records, uint64_t *n_valid)
+{
+    tag_run r;
+    if (tag_run_bam(bam_file, tag, NULL, type ? 1 : 0, &r)) return 1;
+    /* `switch (type)` has cases 0 and 1 only (extract.c:186-196): any other type counts valid reads and inserts nothing */
+    const size_t m = (type == 0 || type == 1) ? r.res.n1 : 0;
+    const char **strs = NULL;
+    char *pool = decode_keys(r.dict, r.res.key1, m, type ? 1 : 0, &strs);
+    if (!pool) { tag_run_free(&r); return 1; }
+    tag_ent *ent = (tag_ent *)malloc((m ? m : 1) * sizeof *ent);
+    uint32_t *sorted = (uint32_t *)malloc((m ? m : 1) * sizeof *sorted), *order = (uint32_t *)malloc((m ? m : 1) * sizeof *order);
+    int32_t *left = (int32_t *)malloc((m ? m : 1) * sizeof *left), *right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
+    for (size_t i = 0; i < m; i++) { ent[i].s = strs[i]; ent[i].first = r.res.first1[i]; ent[i].count = r.res.count1[i]; }
+    int32_t root = bst_shape(ent, (uint32_t)m, sorted, left, right);
+    bst_preorder(root, left, right, (uint32_t)m, order);
+    tbuf out = {0};
+    tb_put(&out, "", 0);
+    for (size_t k = 0; k < m; k++) {                                /* print_tree, filter.c:139-148 */
+        const tag_ent *e = &ent[order[k]];
+        tb_put(&out, e->s, strlen(e->s));
+        tb_count(&out, e->count, '\n');
+    }
+    if (!out.p) out.p = (char *)calloc(1, 1);
+    *csv = out.p; *csv_len = out.len;
+    if (n_records) *n_records = r.n_records;
+    if (n_valid) *n_valid = r.res.n_valid + r.n_undefined;
+    if (r.n_undefined)
+        fprintf(stderr, "Warning: %llu records carry tag %s with a non-string type; the reference passes NULL to strcmp there "
+                "(extract.c:189) — skipped\n", (unsigned long long)r.n_undefined, tag);
+    free(ent); free(sorted); free(order); free(left); free(right); free(strs); free(pool);
+    tag_run_free(&r);
+    return 0;
+}
+
+void extract_bam(char *bam_file, const char *tag, int type)
+{
+    char *csv = NULL; size_t len = 0; uint64_t n = 0, valid = 0;
+    if (fastf_extract_text(bam_file, tag, type, &csv, &len, &n, &valid)) {
+        fprintf(stderr, "ERROR: Cannot open bam file %s (%s)\n", bam_file, fastf_last_error());      /* extract.c:142 */
+        exit(1);
+    }
+    FILE *fp = fopen("tag_summary.csv", "w");                       /* extract.c:200-202 */
+    if (!fp || fwrite(csv, 1, len, fp) != len) { fprintf(stderr, "ERROR: Cannot write tag_summary.csv\n"); exit(1); }
+    fclose(fp);
+    free(csv);
+    printf("Processed all %lu reads\n", (unsigned long)(2 * n));    /* total_count is incremented twice per record, :163,165 */
+    printf("Valid reads: %lu\n", (unsigned long)valid);             /* :207 */
+}
+
+/* ------------------------------------------------------------------ */
+/* crb                                                                 */
+/* ------------------------------------------------------------------ */
+/* reference tree types node / CB_node (filter.h:28-34, extract.h:8-13): fastf_amd.h */
+
+typedef struct {
+    tag_run r;
+    size_t n_cb;                 /* CBs that occur in at least one valid (CB, CR) record */
+    tag_ent *cb;                 /* [n_cb] */
+    size_t *cr_lo;               /* [n_cb + 1] slice of cr[] per CB */
+    tag_ent *cr;                 /* [n_pairs] */
+    char *pool1, *pool2; const char **s1, **s2;
+} crb_data;
+
+static void crb_free(crb_data *c)
+{
+    free(c->cb); free(c->cr_lo); free(c->cr); free(c->pool1); free(c->pool2); free(c->s1); free(c->s2);
+    tag_run_free(&c->r);
+    memset(c, 0, sizeof *c);
+}
+
+static int crb_load(const char *bam_file, crb_data *c)
+{
+    memset(c, 0, sizeof *c);
+    if (tag_run_bam(bam_file, "CB", "CR", 0, &c->r)) return 1;
+    const fastf_taghist_result_t *res = &c->r.res;
+    c->pool1 = decode_keys(c->r.dict, res->key1, res->n1, 0, &c->s1);
+    c->pool2 = c->pool1 ? decode_keys(c->r.dict, res->pair_key2, res->n_pairs, 0, &c->s2) : NULL;
+    if (!c->pool1 || !c->pool2) { crb_free(c); return 1; }
+    c->cb = (tag_ent *)malloc((res->n1 ? res->n1 : 1) * sizeof *c->cb);
+    c->cr_lo = (size_t *)malloc((res->n1 + 1) * sizeof *c->cr_lo);
+    c->cr = (tag_ent *)malloc((res->n_pairs ? res->n_pairs : 1) * sizeof *c->cr);
+    size_t p = 0;
+    for (size_t i = 0; i < res->n1; i++) {                  /* pairs are ordered by key1 rank, so each CB owns a slice */
+        if (res->count1[i] == 0) continue;                  /* CB seen only on records without CR */
+        c->cb[c->n_cb].s = c->s1[i]; c->cb[c->n_cb].first = res->first1[i]; c->cb[c->n_cb].count = res->count1[i];
+        c->cr_lo[c->n_cb] = p;
+        while (p < res->n_pairs && res->pair_k1[p] == i) {
+            c->cr[p].s = c->s2[p]; c->cr[p].first = res->pair_first[p]; c->cr[p].count = res->pair_count[p];
+            p++;
+        }
+        c->n_cb++;
+    }
+    c->cr_lo[c->n_cb] = p;
+    if (p != res->n_pairs) { fastf_set_error_("crb: pair table is not grouped by CB"); crb_free(c); return 1; }
+    /* a record with CB but no (string) CR is a NULL dereference in the reference (extract.c:102-103) */
+    const uint64_t n_cb_only = res->n_key1_present - res->n_valid;
+    if (n_cb_only || c->r.n_undefined)
+        fprintf(stderr, "Warning: %llu records carry CB without a string CR (%llu CB/CR tags of a non-string type); the reference "
+                "dereferences NULL there (extract.c:102-103) — skipped\n",
+                (unsigned long long)n_cb_only, (unsigned long long)c->r.n_undefined);
+    return 0;
+}
+
+/* the bytes print_CB_node would write for the whole tree */
+int fastf_crb_text(const char *bam_file, char **txt, size_t *txt_len, uint64_t *n_records)
+{
+    crb_data c;
+    if (crb_load(bam_file, &c)) return 1;
+    const uint32_t m = (uint32_t)c.n_cb;
+    size_t max_cr = 1;
+    for (size_t i = 0; i < c.n_cb; i++) if (c.cr_lo[i + 1] - c.cr_lo[i] > max_cr) max_cr = c.cr_lo[i + 1] - c.cr_lo[i];
+    const size_t w = m > max_cr ? m : max_cr;
+    uint32_t *sorted = (uint32_t *)malloc((w ? w : 1) * sizeof *sorted), *order = (uint32_t *)malloc((m ? m : 1) * sizeof *order);
+    uint32_t *order2 = (uint32_t *)malloc(max_cr * sizeof *order2);
+    int32_t *left = (int32_t *)malloc((w ? w : 1) * sizeof *left), *right = (int32_t *)malloc((w ? w : 1) * sizeof *right);
+    int32_t root = bst_shape(c.cb, m, sorted, left, right);
+    bst_preorder(root, left, right, m, order);
+    tbuf out = {0};
+    tb_put(&out, "", 0);
+    for (uint32_t k = 0; k < m; k++) {                      /* print_CB_node, extract.c:47-62 */
+        const uint32_t i = order[k];
+        tb_put(&out, c.cb[i].s, strlen(c.cb[i].s)); tb_put(&out, ";", 1);
+        const tag_ent *cr = c.cr + c.cr_lo[i];
+        const uint32_t mc = (uint32_t)(c.cr_lo[i + 1] - c.cr_lo[i]);
+        int32_t r2 = bst_shape(cr, mc, sorted, left, right);
+        bst_preorder(r2, left, right, mc, order2);
+        for (uint32_t q = 0; q < mc; q++) {                 /* print_tree_same_row, filter.c:160-169 */
+            tb_put(&out, cr[order2[q]].s, strlen(cr[order2[q]].s));
+            tb_count(&out, cr[order2[q]].count, ';');
+        }
+        tb_put(&out, "\n", 1);
+    }
+    if (!out.p) out.p = (char *)calloc(1, 1);
+    *txt = out.p; *txt_len = out.len;
+    if (n_records) *n_records = c.r.n_records;
+    free(sorted); free(order); free(order2); free(left); free(right);
+    crb_free(&c);
+    return 0;
+}
+
+static node *build_nodes(const tag_ent *ent, uint32_t m, uint32_t *sorted, int32_t *left, int32_t *right)
+{
+    int32_t root = bst_shape(ent, m, sorted, left, right);
+    if (root < 0) return NULL;
+    node **nd = (node **)malloc(m * sizeof *nd);
+    for (uint32_t i = 0; i < m; i++) {
+        nd[i] = (node *)malloc(sizeof(node));
+        nd[i]->data = strdup(ent[i].s); nd[i]->count = (long)ent[i].count;
+    }
+    for (uint32_t i = 0; i < m; i++) {
+        nd[i]->left = left[i] >= 0 ? nd[left[i]] : NULL;
+        nd[i]->right = right[i] >= 0 ? nd[right[i]] : NULL;
+    }
+    node *r = nd[root];
+    free(nd);
+    return r;
+}
+
+/* extract.c:64-133: the tree the reference's read_bam returns, node for node (every node and string is
+ * malloc'ed, so the reference's free_CB_node / free_tree_node can release it) */
+CB_node *read_bam(char *bam_file)
+{
+    crb_data c;
+    if (crb_load(bam_file, &c)) {
+        fprintf(stderr, "ERROR: Cannot open bam file %s (%s)\n", bam_file, fastf_last_error());      /* extract.c:71 */
+        exit(1);
+    }
+    const uint32_t m = (uint32_t)c.n_cb;
+    size_t max_cr = 1;
+    for (size_t i = 0; i < c.n_cb; i++) if (c.cr_lo[i + 1] - c.cr_lo[i] > max_cr) max_cr = c.cr_lo[i + 1] - c.cr_lo[i];
+    const size_t w = m > max_cr ? m : max_cr;
+    uint32_t *sorted = (uint32_t *)malloc((w ? w : 1) * sizeof *sorted);
+    int32_t *left = (int32_t *)malloc((w ? w : 1) * sizeof *left), *right = (int32_t *)malloc((w ? w : 1) * sizeof *right);
+    CB_node **nd = (CB_node **)malloc((m ? m : 1) * sizeof *nd);
+    for (uint32_t i = 0; i < m; i++) {
+        nd[i] = (CB_node *)malloc(sizeof(CB_node));
+        nd[i]->CB = strdup(c.cb[i].s);
+        nd[i]->CR = build_nodes(c.cr + c.cr_lo[i], (uint32_t)(c.cr_lo[i + 1] - c.cr_lo[i]), sorted, left, right);
+    }
+    int32_t root = bst_shape(c.cb, m, sorted, left, right);
+    for (uint32_t i = 0; i < m; i++) {
+        nd[i]->left = left[i] >= 0 ? nd[left[i]] : NULL;
+        nd[i]->right = right[i] >= 0 ? nd[right[i]] : NULL;
+    }
+    CB_node *r = root >= 0 ? nd[root] : NULL;
+    printf("Processed all %lu reads\n", (unsigned long)c.r.n_records);                               /* extract.c:125 */
+    free(nd); free(sorted); free(left); free(right);
+    crb_free(&c);
+    return r;
+}
+
+void print_CB_node(CB_node *root, gzFile fp)                 /* extract.c:47-62, iterative */
+{
+    size_t cap = 64, top = 0, cap2 = 64;
+    CB_node **st = (CB_node **)malloc(cap * sizeof *st);
+    node **st2 = (node **)malloc(cap2 * sizeof *st2);
+    if (root) st[top++] = root;
+    while (top) {
+        CB_node *c = st[--top];
+        gzprintf(fp, "%s;", c->CB);
+        size_t t2 = 0;
+        if (c->CR) st2[t2++] = c->CR;
+        while (t2) {                                         /* print_tree_same_row, filter.c:160-169 */
+            node *n = st2[--t2];
+            gzprintf(fp, "%s,%ld;", n->data, n->count);
+            if (t2 + 2 > cap2) { cap2 *= 2; st2 = (node **)realloc(st2, cap2 * sizeof *st2); }
+            if (n->right) st2[t2++] = n->right;
+            if (n->left) st2[t2++] = n->left;
+        }
+        gzprintf(fp, "\n");
+        if (top + 2 > cap) { cap *= 2; st = (CB_node **)realloc(st, cap * sizeof *st); }
+        if (c->right) st[top++] = c->right;
+        if (c->left) st[top++] = c->left;
+    }
+    free(st); free(st2);
+}
+
+static void free_nodes(node *root)
+{
+    size_t cap = 64, top = 0;
+    node **st = (node **)malloc(cap * sizeof *st);
+    if (root) st[top++] = root;
+    while (top) {
+        node *n = st[--top];
+        if (top + 2 > cap) { cap *= 2; st = (node **)realloc(st, cap * sizeof *st); }
+        if (n->left) st[top++] = n->left;
+        if (n->right) st[top++] = n->right;
+        free(n->data); free(n);
+    }
+    free(st);
+}
+
+void free_CB_node(CB_node *root)                             /* extract.c:33-45, iterative */
+{
+    size_t cap = 64, top = 0;
+    CB_node **st = (CB_node **)malloc(cap * sizeof *st);
+    if (root) st[top++] = root;
+    while (top) {
+        CB_node *c = st[--top];
+        if (top + 2 > cap) { cap *= 2; st = (CB_node **)realloc(st, cap * sizeof *st); }
+        if (c->left) st[top++] = c->left;
+        if (c->right) st[top++] = c->right;
+        free(c->CB); free_nodes(c->CR); free(c);
+    }
+    free(st);
+}
+
+/* ------------------------------------------------------------------ */
+/* CLI (option syntax of argparse.c:149-197: -x v, -xv, --long v, --long=v) */
+/* ------------------------------------------------------------------ */
+struct topt { char s; const char *l; int has_arg; };
+
+/* returns the option matched for argv[*i] (value in *val), NULL at the first non-option; exits on errors */
+static const struct topt *next_opt(const struct topt *opts, int argc, const char **argv, int *i, const char **val)
+{
+    const char *a = argv[*i];
+    const struct topt *o = NULL;
+    *val = NULL;
+    if (a[0] != '-' || !a[1]) return NULL;
+    if (a[1] == '-') {
+        if (!a[2]) return NULL;
+        const char *eq = strchr(a + 2, '=');
+        size_t nl = eq ? (size_t)(eq - a - 2) : strlen(a + 2);
+        for (const struct topt *k = opts; k->l; k++)
+            if (strlen(k->l) == nl && strncmp(k->l, a + 2, nl) == 0) { o = k; break; }
+        if (o && eq) *val = eq + 1;
+    } else {
+        for (const struct topt *k = opts; k->l; k++) if (k->s == a[1]) { o = k; break; }
+        if (o && o->has_arg && a[2]) *val = a + 2;
+    }
+    if (!o) { fprintf(stderr, "error: unknown option `%s`\n", a); exit(129); }
+    if (o->has_arg && !*val) {
+        if (*i + 1 >= argc) { fprintf(stderr, "error: option `%s` requires a value\n", a); exit(129); }
+        *val = argv[++*i];
+    }
+    return o;
+}
+
+int cmd_crb(int argc, const char **argv)                     /* main.c:231-286 */
+{
+    static const struct topt opts[] = {{'h', "help", 0}, {'b', "bam", 1}, {'o', "out", 1}, {0, NULL, 0}};
+    const char *bam = NULL, *out = ".";
+    for (int i = 1; i < argc; i++) {
+        const char *val;
+        const struct topt *o = next_opt(opts, argc, argv, &i, &val);
+        if (!o) break;
+        switch (o->s) {
+        case 'h':
+            printf("Usage: fastF crb [options]\n\nExtract CR and CB tags from bam file and summarize them with frequencies to a tsv file.\n\n"
+                   "    -h, --help        show this help message and exit\n"
+                   "    -b, --bam=<str>   path to bam file\n"
+                   "    -o, --out=<str>   path to output file\n");
+            exit(0);
+        case 'b': bam = val; break;
+        case 'o': out = val; break;
+        }
+    }
+    if (bam == NULL) {
+        fprintf(stderr, "\x1b[31mError:\x1b[0m path to bam file can not been NULL while extracting .\n");          /* main.c:253 */
+        exit(1);
+    }
+    {   /* main.c:261-267: the output must be creatable before the BAM is read */
+        FILE *probe = fopen(out, "wb");
+        if (!probe) { fprintf(stderr, "\x1b[31mError:\x1b[0m can not open file %s\n", out); exit(1); }
+        fclose(probe);
+    }
+    char *txt = NULL; size_t len = 0; uint64_t n = 0;
+    if (fastf_crb_text(bam, &txt, &len, &n)) {
+        fprintf(stderr, "ERROR: Cannot open bam file %s (%s)\n", bam, fastf_last_error());
+        exit(1);
+    }
+    printf("Processed all %lu reads\n", (unsigned long)n);     /* extract.c:125 */
+    printf("Writing to file...\n");                            /* main.c:272 */
+    int rc = fastf_write_gz_text(out, txt, len);
+    free(txt);
+    if (rc) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); return 1; }
+    printf("Done.\n");                                         /* main.c:284 */
+    return 0;
+}
+
+int cmd_extract(int argc, const char **argv)                  /* main.c:364-402 */
+{
+    static const struct topt opts[] = {{'h', "help", 0}, {'b', "bam", 1}, {'t', "tag", 1}, {'T', "type", 1}, {0, NULL, 0}};
+    const char *bam = NULL, *tag = NULL;
+    int type = 0;
+    for (int i = 1; i < argc; i++) {
+        const char *val;
+        const struct topt *o = next_opt(opts, argc, argv, &i, &val);
+        if (!o) break;
+        char *end = NULL;
+        switch (o->s) {
+        case 'h':
+            printf("Usage: fastF extract [options]\n\nExtract the tag of bam file.\n\n"
+                   "    -h, --help        show this help message and exit\n"
+                   "    -b, --bam=<str>   path to bam file\n"
+                   "    -t, --tag=<str>   tag of bam file\n"
+                   "    -T, --type=<int>  type of tag, 0: string, 1: integer\n");
+            exit(0);
+        case 'b': bam = val; break;
+        case 't': tag = val; break;
+        case 'T':
+            type = (int)strtol(val, &end, 0);                  /* argparse.c:88-92 */
+            if (!*val || *end) { fprintf(stderr, "error: option `%s` expects an integer value\n", argv[i]); exit(129); }
+            break;
+        }
+    }
+    if (!bam || access(bam, F_OK) == -1) {
+        fprintf(stderr, "\x1b[31mError:\x1b[0m bam file: %s does not exist.\n", bam ? bam : "(null)");              /* main.c:386 */
+        exit(1);
+    }
+    if (tag == NULL) { fprintf(stderr, "\x1b[31mError:\x1b[0m --tag is required.\n"); exit(1); }                     /* main.c:392 */
+    extract_bam((char *)bam, tag, type);
+    return 0;
+}

@@ -938,3 +938,8 @@ extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t sk
     e->pending_draws.clear();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// tag histogram (crb / extract): same translation unit, reuses K2 and K3u
+// ------------------------------------------------------------------------------------
+#include "tag_hist.hpp"

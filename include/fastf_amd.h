@@ -7,6 +7,9 @@
  *        int bam2db(...)            replaces  src/bam2db_ds.c:106-573 (decl. bam2db_ds.h:62-70)
  *        int _umi_copies_flag       replaces  src/bam2db_ds.c:3       (decl. bam2db_ds.h:23)
  *        int cmd_bam2db(argc,argv)  replaces  src/main.c:288-362
+ *      and, for the tag-histogram commands,
+ *        extract_bam / read_bam / print_CB_node / free_CB_node   replace  src/extract.c (decl. extract.h:15-26)
+ *        cmd_crb / cmd_extract                                   replace  src/main.c:231-286, 364-402
  *
  *   2. INNER seam (host buffers in, COO out) — what replaces the reference's
  *      per-record loop + SQLite aggregate (bam2db_ds.c:360-438, 480-483):
@@ -46,6 +49,30 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file,
 
 /* main.c:288-362; argv[0] == "bam2db". */
 int cmd_bam2db(int argc, const char **argv);
+
+/* --- crb / extract: src/extract.c.  The tree types are the reference's (filter.h:28-34, extract.h:8-13); they are
+ * declared here under guards so that this header can be included next to the reference's own. --- */
+#ifndef FASTF_NO_TREE_TYPES
+#if !defined(FASTQ_FILTER_H)
+typedef struct node { char *data; long int count; struct node *left; struct node *right; } node;
+#endif
+#if !defined(EXTRACT_H)
+typedef struct CB_node { node *CR; char *CB; struct CB_node *left; struct CB_node *right; } CB_node;
+#endif
+/* extract.c:135-216 — histogram of one tag (type 0: string, 1: integer) → ./tag_summary.csv, counters on stdout */
+void extract_bam(char *bam_file, const char *tag, int type);
+/* extract.c:64-133 — the CB → CR tree of the reference, node for node (malloc'ed; release with free_CB_node) */
+CB_node *read_bam(char *bam_file);
+/* extract.c:33-45.  print_CB_node(CB_node *, gzFile) (extract.c:47-62) is exported too; it is declared in
+ * host_io.h / the reference's extract.h because its second parameter is zlib's gzFile. */
+void free_CB_node(CB_node *root);
+#endif
+int cmd_crb(int argc, const char **argv);       /* main.c:231-286; argv[0] == "crb"     */
+int cmd_extract(int argc, const char **argv);   /* main.c:364-402; argv[0] == "extract" */
+/* the same results as bytes: the decompressed content of `crb`'s output file / of tag_summary.csv (malloc'ed) */
+int fastf_crb_text(const char *bam_file, char **txt, size_t *txt_len, uint64_t *n_records);
+int fastf_extract_text(const char *bam_file, const char *tag, int type, char **csv, size_t *csv_len,
+                       uint64_t *n_records, uint64_t *n_valid);
 
 const char *fastf_last_error(void);
 const char *fastf_version(void);
@@ -93,6 +120,10 @@ fastf_keydict_t *fastf_keydict_create(void);
 void     fastf_keydict_destroy(fastf_keydict_t *d);
 uint64_t fastf_keydict_add(fastf_keydict_t *d, const char *s, size_t len);
 uint64_t fastf_keydict_pack(const fastf_keydict_t *d, const char *s, size_t len);
+/* pack, registering the string when it is new (thread-safe; the tag-histogram paths have no list up front) */
+uint64_t fastf_keydict_intern(fastf_keydict_t *d, const char *s, size_t len);
+/* key → string; returns the length or -1 (unknown key / buffer too small; cap counts the NUL) */
+long     fastf_keydict_decode(const fastf_keydict_t *d, uint64_t key, char *buf, size_t cap);
 /* fixed-stride NUL-terminated strings; present may be NULL (all present) */
 void     fastf_keydict_pack_many(const fastf_keydict_t *d, const char *strs, size_t stride,
                                  size_t n, const uint8_t *present, uint64_t *out);
@@ -158,6 +189,31 @@ int  fastf_engine_reset(fastf_engine_t *e);
 /* key layout chosen at create time */
 int  fastf_engine_key_bits(const fastf_engine_t *e, uint32_t *cell_bits, uint32_t *feature_bits,
                            uint32_t *umi_bits, uint32_t *total_bits);
+
+/* ===================================================================== */
+/* 2c. inner seam of crb / extract: the tag histogram                     */
+/* ===================================================================== */
+/* Replaces the per-record insert_tree / insert_CB_node loops (extract.c:88-108, 161-197; filter.c:105-124):
+ * host buffers of exact 64-bit tag keys in (0 = tag absent), per distinct value its count and the index of the
+ * record it first occurred on out — the three things the shape of the reference's insertion-order tree depends on. */
+typedef struct fastf_taghist fastf_taghist_t;
+typedef struct fastf_taghist_result {
+    uint64_t n_records;              /* records pushed                                                     */
+    uint64_t n_valid;                /* records with key1 != 0 (pair mode: and key2 != 0)                   */
+    uint64_t n_key1_present;         /* records with key1 != 0                                              */
+    /* level 1: distinct key1, ascending key value.  Pair mode: count1/first1 cover valid records only, and an
+     * entry whose key1 never met a key2 has count1 == 0. */
+    const uint64_t *key1, *count1, *first1; size_t n1;
+    /* pair mode: distinct (key1, key2) of valid records, grouped by key1 in level-1 order */
+    const uint32_t *pair_k1;         /* index into key1[]                                                   */
+    const uint64_t *pair_key2, *pair_count, *pair_first; size_t n_pairs;
+} fastf_taghist_result_t;
+int  fastf_taghist_create(int device, fastf_taghist_t **out);
+void fastf_taghist_destroy(fastf_taghist_t *h);
+/* key2 == NULL: single-tag histogram; otherwise the two-level (key1 → key2) histogram.  One mode per object. */
+int  fastf_taghist_push(fastf_taghist_t *h, const uint64_t *key1, const uint64_t *key2, size_t n);
+/* result arrays are owned by the object and stay valid until the next finish / destroy */
+int  fastf_taghist_finish(fastf_taghist_t *h, fastf_taghist_result_t *result);
 
 /* ===================================================================== */
 /* 3. device-level entry points (all pointers are device pointers)        */

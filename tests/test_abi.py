@@ -17,9 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "fastf_amd.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = set(re.findall(r"\b(fastf_[a-z0-9_]+|bam2db|cmd_bam2db|_umi_copies_flag)\s*\(", txt))
+    names = set(re.findall(r"\b(fastf_[a-z0-9_]+|bam2db|cmd_bam2db|cmd_crb|cmd_extract|extract_bam|read_bam|free_CB_node|"
+                           r"_umi_copies_flag)\s*\(", txt))
     names.add("_umi_copies_flag")
-    names -= {"fastf_mt", "fastf_engine_config", "fastf_batch", "fastf_coo", "fastf_umi_rows"}
+    names.add("print_CB_node")          # declared in host_io.h / the reference's extract.h (zlib's gzFile in its signature)
+    names -= {"fastf_mt", "fastf_engine_config", "fastf_batch", "fastf_coo", "fastf_umi_rows", "fastf_taghist_result"}
     return sorted(names)
 
 
@@ -63,6 +65,25 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
     assert r.returncode == 1
     assert "bam2db failed" in r.stderr and "no CPU fallback" in r.stderr
     assert not (tmp_path / "matrix.mtx.gz").exists()
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_tag_commands_fail_loudly_without_gpu(tmp_path):
+    from fastf_amd.tags import TagHist, crb_text
+    with pytest.raises(F.FastfError) as ei:
+        TagHist()
+    assert "no CPU fallback" in str(ei.value)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tag_helpers import TagCase
+    c = TagCase(n=50, n_cb=3)
+    c.write(str(tmp_path / "t.bam"))
+    with pytest.raises(F.FastfError):
+        crb_text(str(tmp_path / "t.bam"))
+    r = subprocess.run([_lib.cli_path(), "crb", "-b", str(tmp_path / "t.bam"), "-o", str(tmp_path / "o.gz")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    r = subprocess.run([_lib.cli_path(), "extract", "-b", str(tmp_path / "t.bam"), "-t", "CB"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and not (tmp_path / "tag_summary.csv").exists()
 
 
 def test_cli_argument_errors(tmp_path):
