@@ -177,19 +177,15 @@ static int th_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 n, 
     if (reserve_workspace(e, 0, n)) return 1;
     const u32 ipt = choose_sort_ipt(n);
     const u32 T = (u32)((n + (u64)ipt * SORT_THREADS - 1) / ((u64)ipt * SORT_THREADS));
-    u32* hist = (u32*)e->d_hist.p; u32* binbase = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
-    HIP_OK(hipMemsetAsync(hist, 0, 8 * RADIX * sizeof(u32), s));
-    const u32 grid = (u32)std::min<u64>((n + 4095) / 4096, 1024);
-    hipLaunchKernelGGL(digit_hist_kernel, dim3(grid), dim3(256), 0, s, (const u64*)keys, d_n, 8u, hist);
-    hipLaunchKernelGGL(bin_base_kernel, dim3(8), dim3(RADIX), 0, s, (const u32*)hist, binbase);
+    u32* bintot = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
     int flip = 0;
     for (u32 q = 0; q < 8; ++q) {
         if (!((pass_mask >> q) & 1)) continue;
         const u64* src = flip ? tmp : keys;
         u64* dst = flip ? keys : tmp;
         hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt);
-        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, (const u32*)(binbase + q * RADIX), ipt);
-        launch_scatter(q, T, s, src, dst, d_n, (const u32*)cnt, ipt);
+        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
+        launch_scatter(q, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt);
         flip ^= 1;
     }
     HIP_OK(hipGetLastError());

@@ -95,13 +95,11 @@ struct fastf_engine {
     u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;
     u64 c_sampled = 0, c_valid = 0;
     bool finished = false; int sorted_in_tmp = 0; u64 n_sorted = 0;
-    u32 dev_hist_first = 0;
     u32 skip_bits = 0;           // low key bits the matrix path leaves unsorted (dedup needs adjacency of equal keys only)
     bool fully_sorted = false;
     // workspace
-    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_hist, d_binbase, d_cnt;
+    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
     const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
-    bool fused_hist_valid = false;
     // timing
     bool timing = false;
     hipEvent_t t_ev[2] = {nullptr, nullptr};
@@ -118,7 +116,7 @@ enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 6
 static int set_scatter_lds_limit();
 static u32 g_cu_count = 256;
 static size_t scatter_smem_bytes(u32 ipt = SORT_IPT) {        // LDS follows the tile size: smaller tiles → more workgroups per CU
-    return (size_t)ipt * SORT_THREADS * 8 + (size_t)SORT_WAVES * RADIX * 4 + RADIX * 4 * 2 + 64;
+    return (size_t)ipt * SORT_THREADS * 8 + (size_t)SORT_WAVES * RADIX * 4 + RADIX * 4 * 2 + 64;     // 64: s_wtot[8] + slack
 }
 
 // ------------------------------------------------------------------------------------
@@ -345,7 +343,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_hist, &e->d_binbase, &e->d_cnt};
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -404,8 +402,7 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
     if (e->d_tilebase.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
-    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
-    if (e->d_binbase.ensure(8 * RADIX * sizeof(u32))) return 1;
+    if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
     return 0;
 }
@@ -483,7 +480,7 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
-                        u64* counters, u32* fused_hist, u32 hist_first, hipStream_t s) {
+                        u64* counters, hipStream_t s) {
     if (n == 0) return 0;
     // K1a (skipped when fastf_dev_count_hits just ran on the very same records, same stream order)
     if (!(e->cells_cached_for == cb && e->cells_cached_n == n))
@@ -498,9 +495,6 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.threshold = e->threshold; p.L = e->L;
     p.n_shards = e->n_shards;
     p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
-    p.digit_hist = (e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST")) ? fused_hist : nullptr;
-    p.hist_passes = (e->L.total_bits + 7) / 8;
-    p.hist_first = hist_first;
     p.stamps = g_k1_stamps;
     p.n_tiles = tiles;
     p.genes = e->lds_genes;
@@ -519,9 +513,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
 extern "C" int fastf_dev_hist_reset(fastf_engine_t* e, uint32_t flags, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
-    e->dev_hist_first = (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits / 8 : 0;   // digits the coming sort will not use
-    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
-    HIP_OK(hipMemsetAsync(e->d_hist.p, 0, 8 * RADIX * sizeof(u32), (hipStream_t)stream));
+    (void)flags; (void)stream;      // kept for ABI compatibility: the sort derives its bin bases from the per-tile counts now
     return 0;
 }
 
@@ -532,16 +524,16 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
                                     uint64_t* d_counters, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
-    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
     return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
-                        (u32*)e->d_hist.p, e->dev_hist_first, (hipStream_t)stream);
+                        (hipStream_t)stream);
 }
 
 static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
 extern "C" void fastf_debug_set_stamps(void* p) { g_stamps = (u64*)p; }
-static void launch_scatter(u32 pass, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt, u32 ipt) {
-#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, ipt, g_stamps)
+static void launch_scatter(u32 pass, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt,
+                           const u32* bin_tot, u32 ipt) {
+#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, g_stamps)
     switch (pass) {
     case 0: SC(0); break;  case 1: SC(8); break;  case 2: SC(16); break; case 3: SC(24); break;
     case 4: SC(32); break; case 5: SC(40); break; case 6: SC(48); break; default: SC(56); break;
@@ -559,7 +551,7 @@ static int set_scatter_lds_limit() {
 }
 
 static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits, u32 low_bit,
-                       bool hist_ready, int* sorted_in_tmp, hipStream_t s) {
+                       int* sorted_in_tmp, hipStream_t s) {
     const u32 passes = (key_bits + 7) / 8;
     const u32 first = std::min(low_bit / 8, passes);           // digit passes below low_bit are skipped
     *sorted_in_tmp = (int)((passes - first) & 1);
@@ -569,22 +561,16 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
     if (reserve_workspace(e, 0, max_n)) return 1;
     const u32 ipt = choose_sort_ipt(max_n);
     const u32 T = (u32)((max_n + (u64)ipt * SORT_THREADS - 1) / ((u64)ipt * SORT_THREADS));
-    u32* hist = (u32*)e->d_hist.p; u32* binbase = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
-    if (!hist_ready) {
-        HIP_OK(hipMemsetAsync(hist, 0, passes * RADIX * sizeof(u32), s));
-        const u32 grid = (u32)std::min<u64>((max_n + 4095) / 4096, 1024);
-        hipLaunchKernelGGL(digit_hist_kernel, dim3(grid), dim3(256), 0, s, (const u64*)keys, d_n, passes, hist);
-    }
-    hipLaunchKernelGGL(bin_base_kernel, dim3(passes), dim3(RADIX), 0, s, (const u32*)hist, binbase);
+    u32* bintot = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
     for (u32 q = first; q < passes; ++q) {
         const u64* src = ((q - first) & 1) ? tmp : keys;
         u64* dst = ((q - first) & 1) ? keys : tmp;
         t_begin(e, s);
         hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
-        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, (const u32*)(binbase + q * RADIX), ipt);
+        hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         t_begin(e, s);
-        launch_scatter(q, T, s, src, dst, d_n, (const u32*)cnt, ipt);
+        launch_scatter(q, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt);
         t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
     }
     HIP_OK(hipGetLastError());
@@ -598,7 +584,6 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
     int dummy = 0;
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
                        (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0,
-                       (flags & FASTF_SORT_HIST_READY) && e->n_shards == 1 && !getenv("FASTF_NO_FUSED_HIST"),
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream);
 }
 
@@ -665,7 +650,7 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 }
 
 extern "C" const char* fastf_kernel_names(void) {
-    return "probe_cells_kernel,probe_cells_lds_kernel,scan_tiles_kernel,filter_pack_kernel,digit_hist_kernel,bin_base_kernel,"
+    return "probe_cells_kernel,probe_cells_lds_kernel,scan_tiles_kernel,filter_pack_kernel,"
            "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
 }
 
@@ -753,14 +738,9 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     HIP_OK(hipEventRecord(e->ev_copy[cur], sc));
     HIP_OK(hipStreamWaitEvent(sk, e->ev_copy[cur], 0));
     u64* small = (u64*)e->d_small.p;
-    if (e->d_hist.ensure(8 * RADIX * sizeof(u32))) return 1;
-    if (e->total_records == 0) {
-        HIP_OK(hipMemsetAsync(e->d_hist.p, 0, 8 * RADIX * sizeof(u32), sk));
-        e->fused_hist_valid = true;
-    }
     if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
                      (const u32*)(ds + o_draw), nd, nullptr, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
-                     small + SM_COUNTERS, (u32*)e->d_hist.p, e->skip_bits / 8, sk))
+                     small + SM_COUNTERS, sk))
         return 1;
     HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
     e->batch_in_flight = true;
@@ -817,7 +797,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             // the matrix only needs equal keys to be neighbours inside a (cell, feature) group: the lowest digit
             // passes are skipped and K3 resolves the short unsorted runs (fastf_engine_umi_rows sorts fully)
             if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
-                            e->fused_hist_valid, &e->sorted_in_tmp, s))
+                            &e->sorted_in_tmp, s))
                 return 1;
             e->fully_sorted = e->skip_bits == 0;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
@@ -837,7 +817,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             int in_other = 0;
             const u64 keep = e->h_small[SM_COUNTERS + 3] & ~ERR_RUN_TOO_LONG;
             HIP_OK(hipMemcpyAsync(small + SM_COUNTERS + 3, &keep, sizeof(u64), hipMemcpyHostToDevice, s));
-            if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, false, &in_other, s)) return 1;
+            if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, &in_other, s)) return 1;
             if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
             e->fully_sorted = true;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
@@ -857,7 +837,6 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         }
         e->n_sorted = n;
         e->finished = true;
-        e->fused_hist_valid = false;       // histograms describe the unsorted store only once
     }
     coo->feature = e->h_feature.data(); coo->cell = e->h_cell.data(); coo->count = e->h_count.data();
     coo->nnz = e->h_feature.size();
@@ -880,7 +859,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
             u64* from = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
             u64* other = e->sorted_in_tmp ? (u64*)e->d_keys.p : (u64*)e->d_tmp.p;
             int in_other = 0;
-            if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, false, &in_other, s)) return 1;
+            if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, &in_other, s)) return 1;
             if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
             e->fully_sorted = true;
         }
@@ -925,7 +904,7 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) {
     memset(e->h_small, 0, SM_WORDS * sizeof(u64));
     e->batch_in_flight = false;
     e->total_records = e->hits_so_far = e->keys_so_far = e->c_sampled = e->c_valid = 0;
-    e->finished = false; e->fused_hist_valid = false;
+    e->finished = false;
     e->pending_draws.clear();
     return 0;
 }

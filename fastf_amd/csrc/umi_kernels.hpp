@@ -324,9 +324,6 @@ struct PackParams {
     u64* keys; u64 shard_stride;   // keys + s*shard_stride
     u64* key_counts;               // [n_shards], appended
     u64* counters;                 // {hits, sampled, valid, err}
-    u32* digit_hist;               // optional fused per-digit histograms [passes][256] (n_shards==1)
-    u32 hist_passes;
-    u32 hist_first;                // digit passes below this one are skipped by the sort: no histogram needed
     u64* stamps;                   // diagnostic builds only (-DFASTF_STAMPS)
 };
 
@@ -343,7 +340,6 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
     __shared__ u32 s_shard_cnt[8];
     __shared__ u64 s_shard_base[8];
     __shared__ u32 s_err;
-    __shared__ u32 s_hist[8 * 256];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // LDS_GENES: the gene image
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
@@ -362,7 +358,6 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
 
     if (tid < 8) s_shard_cnt[tid] = 0;
     if (tid == 0) s_err = 0;
-    if (p.digit_hist) for (int i = tid; i < (int)p.hist_passes * 256; i += K1_THREADS) s_hist[i] = 0;
 
     K1STAMP(0);
     // ---- loads; hit ranks in record order (item-major, then wave, then lane) ----
@@ -460,9 +455,6 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
                 if (alive && shard[j] == s) pos[j] = b + rank_below(m);
             }
         }
-        if (p.digit_hist && alive) {
-            for (u32 q = p.hist_first; q < p.hist_passes; ++q) atomicAdd(&s_hist[q * 256 + ((key[j] >> (8 * q)) & 255)], 1u);
-        }
     }
 
     K1STAMP(4);
@@ -493,12 +485,6 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
             if (b != ~0ULL) p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];
         }
     }
-    if (p.digit_hist) {
-        for (int i = tid + (int)p.hist_first * 256; i < (int)p.hist_passes * 256; i += K1_THREADS) {
-            const u32 v = s_hist[i];
-            if (v) atomicAdd(&p.digit_hist[i], v);
-        }
-    }
     K1STAMP(6);
     };  // do_tile
     if constexpr (LDS_GENES) {
@@ -523,37 +509,6 @@ constexpr int SORT_THREADS = 512, SORT_IPT = 16, SORT_TILE = SORT_THREADS * SORT
 __device__ __forceinline__ u32 num_tiles(u64 n, u32 ipt) { const u64 t = (u64)ipt * SORT_THREADS; return (u32)((n + t - 1) / t); }
 // rows of cnt[d][tile] are padded to a multiple of 4 tiles so a row scan can use 16-byte accesses
 __device__ __forceinline__ u32 row_stride(u32 T) { return (T + 3u) & ~3u; }
-
-// global histograms of every digit: hist[pass][256]
-__global__ __launch_bounds__(256) void digit_hist_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
-                                                         u32 passes, u32* __restrict__ hist) {
-    __shared__ u32 s_h[8 * RADIX];
-    for (int i = threadIdx.x; i < (int)passes * RADIX; i += 256) s_h[i] = 0;
-    __syncthreads();
-    const u64 n = *n_ptr;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        const u64 k = keys[i];
-        for (u32 q = 0; q < passes; ++q) atomicAdd(&s_h[q * RADIX + ((k >> (8 * q)) & 255)], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (int)passes * RADIX; i += 256) {
-        const u32 v = s_h[i];
-        if (v) atomicAdd(&hist[i], v);
-    }
-}
-
-// bin_base[pass][d] = exclusive scan over d of hist[pass][d]; one block per pass
-__global__ __launch_bounds__(RADIX) void bin_base_kernel(const u32* __restrict__ hist, u32* __restrict__ bin_base) {
-    __shared__ u32 s_w[RADIX / WAVE];
-    const int d = threadIdx.x, lane = lane_id(), w = d >> 6;
-    const u32 v = hist[blockIdx.x * RADIX + d];
-    const u32 inc = wave_incl_scan32(v, lane);
-    if (lane == WAVE - 1) s_w[w] = inc;
-    __syncthreads();
-    u32 off = 0;
-    for (int i = 0; i < w; ++i) off += s_w[i];
-    bin_base[blockIdx.x * RADIX + d] = off + inc - v;
-}
 
 // per-tile digit counts: cnt[d * T + tile].  Four LDS copies of the histogram (lane & 3) keep the
 // same-address atomic conflicts of skewed digits (e.g. the constant length bits) four times shorter.
@@ -585,15 +540,16 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
     }
 }
 
-// row d: exclusive scan of cnt[d][0..T) in place, plus bin_base[d]; 4 tiles per thread (one uint4)
+// row d: exclusive scan of cnt[d][0..T) in place, and the row total (= keys with digit d) into bin_tot[d];
+// 4 tiles per thread (one uint4).  The scatter turns bin_tot into bin bases itself (a 256-wide scan per tile).
 __global__ __launch_bounds__(1024) void row_scan_kernel(u32* __restrict__ cnt, const u64* __restrict__ n_ptr,
-                                                        const u32* __restrict__ bin_base, u32 ipt) {
+                                                        u32* __restrict__ bin_tot, u32 ipt) {
     __shared__ u32 s_w[16];
     __shared__ u32 s_carry;
     const u32 T = num_tiles(*n_ptr, ipt), S = row_stride(T);
     const int lane = lane_id(), w = threadIdx.x >> 6;
     uint4* row = reinterpret_cast<uint4*>(cnt + (u64)blockIdx.x * S);
-    if (threadIdx.x == 0) s_carry = bin_base[blockIdx.x];
+    if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (u32 q0 = 0; q0 * 4 < T; q0 += 1024) {
         const u32 q = q0 + threadIdx.x;                        // quad index; tiles 4q .. 4q+3
@@ -615,6 +571,7 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(u32* __restrict__ cnt, c
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();
     }
+    if (threadIdx.x == 0) bin_tot[blockIdx.x] = s_carry;
 }
 
 // match-any over the 8 digit bits: mask of the lanes holding the same digit.
@@ -636,8 +593,8 @@ __device__ __forceinline__ void match_digit(u32 d, u32& mlo, u32& mhi) {
 // bounds check (only the last tile of a pass is partial).
 template <int SHIFT, bool FULL>
 __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
-                                             u32 T, u32 tile, const u32* __restrict__ off, const int ipt, unsigned char* smem,
-                                             u64* stamps = nullptr) {
+                                             u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
+                                             const int ipt, unsigned char* smem, u64* stamps = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -648,12 +605,13 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     u32* s_whist = reinterpret_cast<u32*>(smem + (size_t)ipt * SORT_THREADS * 8);  // [WAVES][256]
     u32* s_delta = s_whist + SORT_WAVES * RADIX;                                   // [256] global - local start
     u32* s_start = s_delta + RADIX;                                                // [256] local bin start
-    u32* s_wtot  = s_start + RADIX;                                                // [4]
+    u32* s_wtot  = s_start + RADIX;                                                // [4] tile-local, [4] global
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
 
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
     // this tile's global bin offsets: issued now, needed only after the ranking
     const u32 g_off = tid < RADIX ? off[(u64)tid * row_stride(T) + tile] : 0u;
+    const u32 g_tot = tid < RADIX ? bin_tot[tid] : 0u;     // keys of the whole pass with digit tid → bin base by a scan below
 
     // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
     u64 key[SORT_IPT];
@@ -691,20 +649,21 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     STAMP(2);
 
     // per digit: exclusive offsets of the waves, tile totals → local bin starts
-    u32 run = 0, inc = 0;
+    u32 run = 0, inc = 0, ginc = 0;
     if (tid < RADIX) {
 #pragma unroll
         for (int i = 0; i < SORT_WAVES; ++i) { const u32 c = s_whist[i * RADIX + tid]; s_whist[i * RADIX + tid] = run; run += c; }
         inc = wave_incl_scan32(run, lane);                 // over the 64 digits of this wave
-        if (lane == WAVE - 1) s_wtot[w] = inc;
+        ginc = wave_incl_scan32(g_tot, lane);
+        if (lane == WAVE - 1) { s_wtot[w] = inc; s_wtot[4 + w] = ginc; }
     }
     __syncthreads();
     if (tid < RADIX) {
-        u32 o = 0;
-        for (int i = 0; i < w; ++i) o += s_wtot[i];
+        u32 o = 0, go = 0;
+        for (int i = 0; i < w; ++i) { o += s_wtot[i]; go += s_wtot[4 + i]; }
         const u32 lstart = o + inc - run;                  // first tile-local slot of digit tid
         s_start[tid] = lstart;
-        s_delta[tid] = g_off - lstart;                     // global slot = delta + local slot (mod 2^32)
+        s_delta[tid] = (go + ginc - g_tot) + g_off - lstart;   // global slot = bin base + offset in the bin + local slot - local start
     }
     __syncthreads();
     STAMP(3);
@@ -743,7 +702,8 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
 template <int SHIFT>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
                                                                const u64* __restrict__ n_ptr,
-                                                               const u32* __restrict__ off, u32 ipt, u64* stamps) {
+                                                               const u32* __restrict__ off, const u32* __restrict__ bin_tot,
+                                                               u32 ipt, u64* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u64 n = *n_ptr;
     const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
@@ -751,8 +711,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
     const u32 tile_keys = ipt * SORT_THREADS;
     const u64 base = (u64)tile * tile_keys;
     const u32 n_valid = (u32)((n - base) < (u64)tile_keys ? (n - base) : (u64)tile_keys);
-    if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, (int)ipt, smem, stamps);
-    else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, (int)ipt, smem, stamps);
+    if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, stamps);
+    else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, stamps);
 }
 
 

@@ -239,8 +239,8 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
 /* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
  * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
  * *sorted_in_tmp tells where the result landed. */
-#define FASTF_SORT_HIST_READY 1u   /* digit histograms were accumulated by fastf_dev_probe_pack
-                                      (single shard) since the last fastf_dev_hist_reset       */
+#define FASTF_SORT_HIST_READY 1u   /* accepted and ignored (earlier builds pre-computed digit histograms in K1b; the
+                                      sort now takes its bin bases from the per-tile counts of each pass)        */
 #define FASTF_SORT_SKIP_LOW   2u   /* leave the low fastf_engine_skip_bits() bits unsorted: enough for the matrix
                                       (equal keys stay neighbours of their (cell, feature, top-UMI-bits) run);
                                       pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
@@ -248,7 +248,7 @@ int fastf_engine_skip_bits(const fastf_engine_t *e, uint32_t *bits);
 /* which lookup structure the lists qualified for: 1 = LDS-resident (barcodes: perfect hash of 32-bit codes; genes:
  * bitmap + rank + permutation over one id family), 0 = open-addressed table in L2 */
 int fastf_engine_table_modes(const fastf_engine_t *e, int *cells_in_lds, int *genes_in_lds);
-int fastf_dev_hist_reset(fastf_engine_t *e, uint32_t flags, void *stream);   /* flags: FASTF_SORT_SKIP_LOW if the sort will skip */
+int fastf_dev_hist_reset(fastf_engine_t *e, uint32_t flags, void *stream);   /* no-op, kept for ABI compatibility */
 int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
                    const uint64_t *d_n, uint64_t max_n, uint32_t key_bits, uint32_t flags,
                    int *sorted_in_tmp, void *stream);
