@@ -229,22 +229,32 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     const u64 range = vmax - vmin + 1;
     if (range > (1ull << 22)) return 0;
     const u32 words = (u32)((range + 31) / 32), rank_pad = (words + 1u) & ~1u;
-    const size_t bytes = (((size_t)words * 4 + (size_t)rank_pad * 2 + best_n * 2) + 15) & ~(size_t)15;
+    size_t bytes = (((size_t)words * 4 + (size_t)rank_pad * 2 + best_n * 2) + 15) & ~(size_t)15;
+    // a dense id range is cheaper as a direct table (one LDS read per lookup instead of bitmap + rank + permutation)
+    const size_t direct_bytes = ((size_t)range * 2 + 15) & ~(size_t)15;
+    const bool direct = direct_bytes <= bytes + bytes / 8 && !getenv("FASTF_GENES_NO_DIRECT");
+    if (direct) bytes = direct_bytes;
     if (bytes > 120 * 1024) return 0;
     std::vector<u32> img(bytes / 4 + 4, 0u);
+    if (direct) {
+        unsigned short* tab = reinterpret_cast<unsigned short*>(img.data());
+        for (u32 i = 0; i < n; ++i) if ((keys[i] >> 44) == best) tab[(keys[i] & VM) - vmin] = (unsigned short)(i + 1);
+    }
     u32* bitmap = img.data();
     unsigned short* rank = reinterpret_cast<unsigned short*>(img.data() + words);
     unsigned short* perm = rank + rank_pad;
-    std::vector<std::pair<u64, u32>> vals; vals.reserve(best_n);
-    for (u32 i = 0; i < n; ++i) if ((keys[i] >> 44) == best) vals.push_back({(keys[i] & VM) - vmin, i + 1});
-    std::sort(vals.begin(), vals.end());
-    for (size_t r = 0; r < vals.size(); ++r) { bitmap[vals[r].first >> 5] |= 1u << (vals[r].first & 31); perm[r] = (unsigned short)vals[r].second; }
-    u32 acc = 0;
-    for (u32 w = 0; w < words; ++w) { rank[w] = (unsigned short)acc; acc += (u32)__builtin_popcount(bitmap[w]); }
+    if (!direct) {
+        std::vector<std::pair<u64, u32>> vals; vals.reserve(best_n);
+        for (u32 i = 0; i < n; ++i) if ((keys[i] >> 44) == best) vals.push_back({(keys[i] & VM) - vmin, i + 1});
+        std::sort(vals.begin(), vals.end());
+        for (size_t r = 0; r < vals.size(); ++r) { bitmap[vals[r].first >> 5] |= 1u << (vals[r].first & 31); perm[r] = (unsigned short)vals[r].second; }
+        u32 acc = 0;
+        for (u32 w = 0; w < words; ++w) { rank[w] = (unsigned short)acc; acc += (u32)__builtin_popcount(bitmap[w]); }
+    }
     if (e->img_genes.ensure(bytes)) return 1;
     HIP_OK(hipMemcpy(e->img_genes.p, img.data(), bytes, hipMemcpyHostToDevice));
     e->lds_genes.image = (const u32*)e->img_genes.p; e->lds_genes.words = words; e->lds_genes.n_perm = (u32)best_n;
-    e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes;
+    e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes; e->lds_genes.direct = direct ? 1u : 0u;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess) return 0;
     const size_t per_block = bytes + 10 * 1024;                      // + the kernel's static LDS
@@ -353,7 +363,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
 extern "C" int fastf_engine_table_modes(const fastf_engine_t* e, int* cells_in_lds, int* genes_in_lds) {
     if (!e) return set_err("null engine");
     if (cells_in_lds) *cells_in_lds = e->use_lds_cells;
-    if (genes_in_lds) *genes_in_lds = e->use_lds_genes;
+    if (genes_in_lds) *genes_in_lds = e->use_lds_genes ? (e->lds_genes.direct ? 2 : 1) : 0;
     return 0;
 }
 
@@ -501,9 +511,9 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     t_begin(e, s);
     if (e->use_lds_genes) {
         const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
-        hipLaunchKernelGGL(filter_pack_kernel<true>, dim3(grid), dim3(K1_THREADS), e->lds_genes.bytes, s, p);
+        hipLaunchKernelGGL(filter_pack_kernel<true>, dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);
     } else {
-        hipLaunchKernelGGL(filter_pack_kernel<false>, dim3(tiles), dim3(K1_THREADS), 0, s, p);
+        hipLaunchKernelGGL(filter_pack_kernel<false>, dim3(tiles), dim3(K1B_THREADS), 0, s, p);
     }
     HIP_OK(hipGetLastError());
     t_end(e, s, &e->t_k1b_ms, &e->t_k1b_n);

@@ -256,8 +256,9 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
 // ------------------------------------------------------------------------------------
 struct CellLds { const u32* image; u32 m; u32 buckets; u32 family; u32 bytes; };
                                                                       // image: u32 code[m] | u16 index[m'] | u16 disp[buckets]  (m' = m rounded up to even)
-struct GeneLds { const u32* image; u32 words; u32 n_perm; u32 family; u64 vmin; u64 range; u32 bytes; };
+struct GeneLds { const u32* image; u32 words; u32 n_perm; u32 family; u64 vmin; u64 range; u32 bytes; u32 direct; };
                                                                       // image: u32 bitmap[words] | u16 rank[words] (padded) | u16 perm[n_perm]
+                                                                      // direct (dense id range): u16 index[range], 0 = not a listed id
 
 __device__ __forceinline__ u32 fmix32(u32 h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
 __device__ __forceinline__ u32 chd_bucket(u32 code, u32 buckets) { return (u32)(((u64)fmix32(code) * buckets) >> 32); }
@@ -310,6 +311,20 @@ __global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __r
     }
 }
 
+// K1b geometry: the same 4096-record tiles as K1a, as THREADS x IPT
+// 1024 threads x 4 records at 8 waves per SIMD (64 VGPRs): measured 87 us vs 99 us for 512 x 8 at 4 waves per SIMD
+#ifndef FASTF_K1B_THREADS
+#define FASTF_K1B_THREADS 1024
+#endif
+#ifndef FASTF_K1B_MINWAVES
+#define FASTF_K1B_MINWAVES 8
+#endif
+#ifndef FASTF_K1B_MINWAVES_L2
+#define FASTF_K1B_MINWAVES_L2 8
+#endif
+constexpr int K1B_THREADS = FASTF_K1B_THREADS, K1B_IPT = K1_TILE / K1B_THREADS, K1B_WAVES = K1B_THREADS / WAVE;
+static_assert(K1B_THREADS * K1B_IPT == K1_TILE, "K1b walks K1a's tiles");
+
 struct PackParams {
     const u32* cell; const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
@@ -334,9 +349,9 @@ struct PackParams {
 #endif
 
 template <bool LDS_GENES>
-__global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_kernel(const PackParams p) {
-    __shared__ u32 s_cnt[K1_IPT * K1_WAVES];       // hits per (item, wave), then exclusive
-    __shared__ u32 s_red[3][K1_WAVES];
+__global__ __launch_bounds__(K1B_THREADS, LDS_GENES ? FASTF_K1B_MINWAVES : FASTF_K1B_MINWAVES_L2) void filter_pack_kernel(const PackParams p) {
+    __shared__ u32 s_cnt[K1B_IPT * K1B_WAVES];       // hits per (item, wave), then exclusive
+    __shared__ u32 s_red[3][K1B_WAVES];
     __shared__ u32 s_shard_cnt[8];
     __shared__ u64 s_shard_base[8];
     __shared__ u32 s_err;
@@ -346,10 +361,11 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
     const u32* s_bitmap = reinterpret_cast<const u32*>(smem);
     const unsigned short* s_rank = reinterpret_cast<const unsigned short*>(smem + (size_t)p.genes.words * 4);
     const unsigned short* s_perm = s_rank + ((p.genes.words + 1u) & ~1u);
+    const unsigned short* s_direct = reinterpret_cast<const unsigned short*>(smem);      // direct mode: u16 index[range]
     if (LDS_GENES) {
         const uint4* src = reinterpret_cast<const uint4*>(p.genes.image);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += K1_THREADS) dst[i] = src[i];
+        for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += K1B_THREADS) dst[i] = src[i];
     }
 
     // LDS_GENES: persistent workgroups walk the tiles; otherwise one tile per workgroup (grid = n_tiles)
@@ -361,10 +377,10 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
 
     K1STAMP(0);
     // ---- loads; hit ranks in record order (item-major, then wave, then lane) ----
-    u64 gxk[K1_IPT]; u32 umi[K1_IPT], meta[K1_IPT], cell[K1_IPT], hrank[K1_IPT];
+    u64 gxk[K1B_IPT]; u32 umi[K1B_IPT], meta[K1B_IPT], cell[K1B_IPT], hrank[K1B_IPT];
 #pragma unroll
-    for (int j = 0; j < K1_IPT; ++j) {
-        const u64 idx = base + (u64)j * K1_THREADS + tid;
+    for (int j = 0; j < K1B_IPT; ++j) {
+        const u64 idx = base + (u64)j * K1B_THREADS + tid;
         const bool in = idx < p.n;
         cell[j] = in ? p.cell[idx] : 0;
         gxk[j]  = in ? p.gx[idx] : 0;
@@ -372,70 +388,97 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
         meta[j] = in ? p.meta[idx] : 0;
     }
 #pragma unroll
-    for (int j = 0; j < K1_IPT; ++j) {
+    for (int j = 0; j < K1B_IPT; ++j) {
         const u64 hm = __ballot(cell[j] != 0);
         hrank[j] = rank_below(hm);
-        if (lane == 0) s_cnt[j * K1_WAVES + w] = (u32)__popcll(hm);
+        if (lane == 0) s_cnt[j * K1B_WAVES + w] = (u32)__popcll(hm);
     }
     __syncthreads();
     if (w == 0) {
-        static_assert(K1_IPT * K1_WAVES <= WAVE, "one wave scans the (item, wave) counts");
-        const u32 c = lane < K1_IPT * K1_WAVES ? s_cnt[lane] : 0;
+        static_assert(K1B_IPT * K1B_WAVES <= WAVE, "one wave scans the (item, wave) counts");
+        const u32 c = lane < K1B_IPT * K1B_WAVES ? s_cnt[lane] : 0;
         const u32 inc = wave_incl_scan32(c, lane);
-        if (lane < K1_IPT * K1_WAVES) s_cnt[lane] = inc - c;
+        if (lane < K1B_IPT * K1B_WAVES) s_cnt[lane] = inc - c;
     }
     __syncthreads();
     K1STAMP(1);
     const u64 tile_base = p.tile_base[tile] + (p.draw_base ? *p.draw_base : 0);
 
-    // ---- depth draw (E4/E5 :385-390), xf (E7 :394-400) ----
+    // ---- depth draw (E4/E5 :385-390): the loads are issued here and consumed after the feature lookup ----
     u32 n_hit = 0, n_samp = 0, n_valid = 0, errs = 0;
-    u32 draw[K1_IPT];
+    u32 draw[K1B_IPT];
 #pragma unroll
-    for (int j = 0; j < K1_IPT; ++j) {
+    for (int j = 0; j < K1B_IPT; ++j) {
         draw[j] = 0;
         if (cell[j] != 0) {
-            const u64 r = tile_base + s_cnt[j * K1_WAVES + w] + hrank[j];
+            const u64 r = tile_base + s_cnt[j * K1B_WAVES + w] + hrank[j];
             if (r < p.n_draws) draw[j] = p.draws[r];
             else { cell[j] = 0; n_hit++; errs |= (u32)ERR_DRAWS_SHORT; }
         }
     }
     K1STAMP(2);
-    u64 fkey[K1_IPT]; u32 feat[K1_IPT];
+    u64 fkey[K1B_IPT]; u32 feat[K1B_IPT];
+    if (LDS_GENES) {
+        // E8 :403-410 ahead of E5/E7: the LDS lookup does not depend on the draw, so it runs while the draw loads are
+        // in flight (for every CB hit with a good xf; a record the draw drops just wastes one lookup)
 #pragma unroll
-    for (int j = 0; j < K1_IPT; ++j) {
-        bool alive = cell[j] != 0;
-        n_hit += alive;
-        alive = alive && (u64)draw[j] < p.threshold;
-        n_samp += alive;                                             // E6 :392
-        alive = alive && (meta[j] & META_XF_OK);
-        fkey[j] = alive ? gxk[j] : 0;
-    }
-    if (LDS_GENES) {                                                 // E8 :403-410, bitmap + rank + permutation in LDS
+        for (int j = 0; j < K1B_IPT; ++j) fkey[j] = (cell[j] != 0 && (meta[j] & META_XF_OK)) ? gxk[j] : 0;
+        if (p.genes.direct) {                                        // dense id range: one table read
 #pragma unroll
-        for (int j = 0; j < K1_IPT; ++j) {
-            u32 f = 0;
-            const u64 k = fkey[j];
-            if (k != 0) {
-                if ((u32)(k >> 44) == p.genes.family) {
-                    const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;       // wraps to huge when below vmin
-                    if (v < p.genes.range) {
-                        const u32 wd = s_bitmap[(u32)v >> 5], bit = (u32)v & 31u;
-                        if ((wd >> bit) & 1u) f = s_perm[s_rank[(u32)v >> 5] + __popc(wd & ((1u << bit) - 1u))];
-                    }
-                } else f = table_probe(p.feats, k);                  // other id families / escaped strings
+            for (int j = 0; j < K1B_IPT; ++j) {
+                u32 f = 0;
+                const u64 k = fkey[j];
+                if (k != 0) {
+                    if ((u32)(k >> 44) == p.genes.family) {
+                        const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;   // wraps to huge when below vmin
+                        if (v < p.genes.range) f = s_direct[(u32)v];
+                    } else f = table_probe(p.feats, k);              // other id families / escaped strings
+                }
+                feat[j] = f;
             }
-            feat[j] = f;
+        } else {                                                     // sparse range: bitmap word + rank (one wait), then the permutation
+#pragma unroll
+            for (int j = 0; j < K1B_IPT; ++j) {
+                u32 f = 0;
+                const u64 k = fkey[j];
+                if (k != 0) {
+                    if ((u32)(k >> 44) == p.genes.family) {
+                        const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;
+                        if (v < p.genes.range) {
+                            const u32 wd = s_bitmap[(u32)v >> 5], rk = s_rank[(u32)v >> 5], bit = (u32)v & 31u;
+                            if ((wd >> bit) & 1u) f = s_perm[rk + __popc(wd & ((1u << bit) - 1u))];
+                        }
+                    } else f = table_probe(p.feats, k);
+                }
+                feat[j] = f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K1B_IPT; ++j) {
+            bool alive = cell[j] != 0;
+            n_hit += alive;
+            alive = alive && (u64)draw[j] < p.threshold;
+            n_samp += alive;                                         // E6 :392
+            if (!alive) feat[j] = 0;
         }
     } else {
-        table_probe_batch<K1_IPT>(p.feats, fkey, feat);              // E8 :403-410
+#pragma unroll
+        for (int j = 0; j < K1B_IPT; ++j) {
+            bool alive = cell[j] != 0;
+            n_hit += alive;
+            alive = alive && (u64)draw[j] < p.threshold;
+            n_samp += alive;                                         // E6 :392
+            alive = alive && (meta[j] & META_XF_OK);                 // E7 :394-400
+            fkey[j] = alive ? gxk[j] : 0;
+        }
+        table_probe_batch<K1B_IPT>(p.feats, fkey, feat);              // E8 :403-410
     }
     K1STAMP(3);
 
     // ---- UB (E9 :412-416), key (E10/E11), slot in the tile-local shard list ----
-    u64 key[K1_IPT]; u32 pos[K1_IPT]; u32 shard[K1_IPT]; bool emit[K1_IPT];
+    u64 key[K1B_IPT]; u32 pos[K1B_IPT]; u32 shard[K1B_IPT]; bool emit[K1B_IPT];
 #pragma unroll
-    for (int j = 0; j < K1_IPT; ++j) {
+    for (int j = 0; j < K1B_IPT; ++j) {
         key[j] = 0; pos[j] = 0; shard[j] = 0;
         const bool alive = feat[j] != 0 && (meta[j] & META_HAS_UB);
         if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
@@ -465,7 +508,7 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
     __syncthreads();
     if (tid < 3) {
         u64 t = 0;
-        for (int i = 0; i < K1_WAVES; ++i) t += s_red[tid][i];
+        for (int i = 0; i < K1B_WAVES; ++i) t += s_red[tid][i];
         if (t) atomicAdd(&p.counters[tid], t);
     }
     if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
@@ -479,7 +522,7 @@ __global__ __launch_bounds__(K1_THREADS, LDS_GENES ? 4 : 6) void filter_pack_ker
     __syncthreads();
     K1STAMP(5);
 #pragma unroll
-    for (int j = 0; j < K1_IPT; ++j) {
+    for (int j = 0; j < K1B_IPT; ++j) {
         if (emit[j]) {
             const u64 b = s_shard_base[shard[j]];
             if (b != ~0ULL) p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];

@@ -251,7 +251,7 @@ class Engine:
         c, g = C.c_int(), C.c_int()
         check(self._L.fastf_engine_table_modes(self._h, C.byref(c), C.byref(g)))
         return "cells:%s genes:%s" % ("LDS perfect hash" if c.value else "L2 open addressing",
-                                      "LDS bitmap+rank" if g.value else "L2 open addressing")
+                                      {0: "L2 open addressing", 1: "LDS bitmap+rank", 2: "LDS direct table"}[g.value])
 
     @property
     def skip_bits(self) -> int:

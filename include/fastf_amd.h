@@ -246,7 +246,8 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
                                       pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
 int fastf_engine_skip_bits(const fastf_engine_t *e, uint32_t *bits);
 /* which lookup structure the lists qualified for: 1 = LDS-resident (barcodes: perfect hash of 32-bit codes; genes:
- * bitmap + rank + permutation over one id family), 0 = open-addressed table in L2 */
+ * bitmap + rank + permutation over one id family; genes: 2 = direct index table over a dense id range),
+ * 0 = open-addressed table in L2 */
 int fastf_engine_table_modes(const fastf_engine_t *e, int *cells_in_lds, int *genes_in_lds);
 int fastf_dev_hist_reset(fastf_engine_t *e, uint32_t flags, void *stream);   /* no-op, kept for ABI compatibility */
 int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
