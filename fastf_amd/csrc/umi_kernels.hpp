@@ -545,7 +545,13 @@ __global__ __launch_bounds__(K1B_THREADS, LDS_GENES ? FASTF_K1B_MINWAVES : FASTF
 // K2: LSD radix sort, 8-bit digits.  Per pass: tile_count → row_scan → scatter.
 // ------------------------------------------------------------------------------------
 constexpr int RADIX = 256;
-constexpr int SORT_THREADS = 512, SORT_IPT = 16, SORT_TILE = SORT_THREADS * SORT_IPT, SORT_WAVES = SORT_THREADS / WAVE;
+#ifndef FASTF_SORT_IPT_MAX
+#define FASTF_SORT_IPT_MAX 16
+#endif
+#ifndef FASTF_SORT_THREADS
+#define FASTF_SORT_THREADS 512
+#endif
+constexpr int SORT_THREADS = FASTF_SORT_THREADS, SORT_IPT = FASTF_SORT_IPT_MAX, SORT_TILE = SORT_THREADS * SORT_IPT, SORT_WAVES = SORT_THREADS / WAVE;
 
 // tile size is chosen per sort (ipt = keys per thread, 1..SORT_IPT) so that the tiles fill whole rounds of the
 // resident workgroup slots: at 10 M keys a fixed 8192-key tile leaves the third round 38 % full
