@@ -185,3 +185,108 @@ def test_full_size_properties_config2():
             assert np.array_equal(r1[k], r2[k])
     finally:
         eng.close()
+
+
+def _molecule_stream(rng, n, n_cells_all, n_genes, cell_w, gene_w, umi_bits, dup):
+    """n reads drawn from n/dup molecules (cell, gene, umi): 10x-like duplication"""
+    n_mol = max(1, int(n / dup))
+    mol_cell = rng.choice(n_cells_all, size=n_mol, p=cell_w).astype(np.int32)
+    mol_gene = rng.choice(n_genes, size=n_mol, p=gene_w).astype(np.int32)
+    mol_umi = rng.integers(0, 1 << umi_bits, size=n_mol, dtype=np.uint32)
+    return mol_cell, mol_gene, mol_umi
+
+
+def test_full_size_properties_config3():
+    """BASELINE configs[2] at full size on one GPU: 200 M records, 50 k barcodes x 36 601 genes, --cell 0.5 --depth 0.5,
+    log-normal cells, Zipf genes, 12-bp UMIs, 5 % without CB, 15 % bad xf, 0.1 % UMIs with N (SURVEY 8d 'C3').
+    Size-independent properties: counters against closed forms computed on the host, strict (cell, feature) order,
+    count sums, idempotence, and the -u rows as a checksum of the matrix."""
+    import torch  # noqa: F401
+    N = 200_000_000
+    bt, ft, bar, genes = synth.make_lists(50_000, 36_601, seed=77)
+    lists = F.Lists(bt, ft, 0.5, 926)
+    alld = F.Lists(bt, ft, 1.0, 926)                       # keys of every barcode, sampled or not
+    sampled_key = np.zeros(0, dtype=np.uint64)
+    sampled_key = np.sort(lists.cell_keys)
+    rng = np.random.default_rng(5)
+    w = rng.lognormal(0, 1, 50_000); w /= w.sum()
+    gw = 1.0 / np.arange(1, 36_602) ** 1.1; gw /= gw.sum()
+    mol_cell, mol_gene, mol_umi = _molecule_stream(rng, N, 50_000, 36_601, w, gw, 24, 4.0)
+    eng = F.Engine.from_lists(lists, rate_depth=0.5, seed=926, umi_max_bases=12, batch_records=8 << 20)
+    T = F.draw_threshold(0.5)
+    draws_kept = F.mt_draws(926, lists.mt_skip, N) < T     # draw i belongs to the i-th CB hit of the whole stream
+    hits = sampled = valid = 0
+    try:
+        B = 20_000_000
+        for off in range(0, N, B):
+            n = min(B, N - off)
+            src = rng.integers(0, len(mol_cell), size=n)
+            cbk = alld.cell_keys[mol_cell[src]]
+            gxk = alld.feature_keys[mol_gene[src]]
+            umi = (mol_umi[src] << np.uint32(8)).astype(np.uint32)
+            meta = np.full(n, 1 | 2 | 4 | (3 << 4), dtype=np.uint32)
+            r = rng.random(n)
+            cbk[r < 0.05] = 0
+            meta[(r > 0.05) & (r < 0.20)] &= ~np.uint32(1)
+            meta[r > 0.999] &= ~np.uint32(4)
+            # closed forms on the host: hit = CB is a sampled barcode; kept = its draw (by hit rank) is below T
+            pos = np.searchsorted(sampled_key, cbk)
+            hit = (cbk != 0) & (sampled_key[np.minimum(pos, len(sampled_key) - 1)] == cbk)
+            h = int(hit.sum())
+            kept = np.zeros(n, dtype=bool)
+            kept[hit] = draws_kept[hits:hits + h]
+            hits += h
+            sampled += int(kept.sum())
+            valid += int((kept & ((meta & 1) != 0)).sum())    # every gene is listed and every record has a UB
+            eng.push(cbk, gxk, umi, meta)
+        res = eng.finish()
+        assert (res["total"], res["sampled"], res["valid"]) == (N, sampled, valid)
+        key = res["cell"].astype(np.int64) * (1 << 20) + res["feature"].astype(np.int64)
+        assert (np.diff(key) > 0).all()
+        assert res["cell"].min() >= 1 and res["cell"].max() <= lists.n_cells and res["feature"].max() <= lists.n_features
+        assert 0 < int(res["count"].sum()) <= res["valid"]
+        r2 = eng.finish()
+        assert r2["nnz"] == res["nnz"] and np.array_equal(r2["count"], res["count"])
+        rows = eng.umi_rows()
+        assert int(rows["n_copy"].sum()) == res["valid"]                      # every valid read is in exactly one -u row
+        assert int(rows["nonnull"].sum()) == int(res["count"].sum())          # distinct non-NULL UMIs == sum of the matrix
+    finally:
+        eng.close()
+
+
+def test_adversarial_share_of_config5():
+    """One GPU's share of BASELINE configs[4] (1 B records / 8 GPUs = 125 M, 12 500 of the 100 k barcodes), keep-all,
+    UMIs Zipf(1.5)-drawn from a 4 096-value pool per gene: most keys are duplicates and a few radix digits dominate.
+    Exact check of the matrix against numpy's unique over packed (cell, gene, umi) codes."""
+    import torch  # noqa: F401
+    N = 125_000_000
+    n_cells, n_genes = 12_500, 36_601
+    bt, ft, bar, genes = synth.make_lists(n_cells, n_genes, seed=99)
+    lists = F.Lists(bt, ft, 1.0, 926)
+    rng = np.random.default_rng(9)
+    gw = 1.0 / np.arange(1, n_genes + 1) ** 1.1; gw /= gw.sum()
+    uw = 1.0 / np.arange(1, 4097) ** 1.5; uw /= uw.sum()
+    eng = F.Engine.from_lists(lists, rate_depth=1.0, seed=926, umi_max_bases=12, batch_records=8 << 20)
+    codes = []
+    try:
+        B = 25_000_000
+        for off in range(0, N, B):
+            n = min(B, N - off)
+            c = rng.integers(0, n_cells, size=n).astype(np.int64)
+            g = rng.choice(n_genes, size=n, p=gw).astype(np.int64)
+            u = rng.choice(4096, size=n, p=uw).astype(np.int64)
+            umi = (((u * 2654435761) ^ (g * 40503)) & 0xFFFFFF).astype(np.uint32)   # the gene's own pool of 4 096 UMIs
+            codes.append((c << 40) | (g << 24) | umi.astype(np.int64))
+            meta = np.full(n, 1 | 2 | 4 | (3 << 4), dtype=np.uint32)
+            eng.push(lists.cell_keys[c], lists.feature_keys[g], (umi << np.uint32(8)).astype(np.uint32), meta)
+        res = eng.finish()
+        assert (res["total"], res["sampled"], res["valid"]) == (N, N, N)
+        u = np.unique(np.concatenate(codes))
+        del codes
+        grp, cnt = np.unique(u >> 24, return_counts=True)
+        assert res["nnz"] == len(grp)
+        np.testing.assert_array_equal(res["cell"].astype(np.int64), (grp >> 16) + 1)
+        np.testing.assert_array_equal(res["feature"].astype(np.int64), (grp & 0xFFFF) + 1)
+        np.testing.assert_array_equal(res["count"].astype(np.int64), cnt)
+    finally:
+        eng.close()
