@@ -148,7 +148,7 @@ def main():
                                    "--cell 1.0 --depth 1.0 --seed 926, uniform cells/genes, 10-bp UMIs"
                                    % (N, G, args.barcodes, args.genes),
                        "records_per_gpu": N, "key_bits": eng.key_bits, "radix_passes": passes,
-                       "radix_passes_executed": passes - (eng.skip_bits // 8 if sp.st.skip_low else 0),
+                       "radix_passes_executed": eng.sort_passes(sp.st.skip_low),
                        "sharding": "cell-hash, one all-to-all" if G > 1 else "single GPU",
                        "lookup_tables": eng.table_modes},
             "roofline": {"bound": "hbm", "kernel": "scatter_kernel (one 8-bit LSD radix pass)",

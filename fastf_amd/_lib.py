@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "fastf_keydict_pack_many",
     "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
-    "fastf_engine_skip_bits", "fastf_engine_table_modes",
+    "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes",
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_hist_reset", "fastf_dev_error_bits",
     "fastf_dev_clear_error_bits", "fastf_kernel_names",
@@ -152,6 +152,7 @@ def lib():
     L.fastf_dev_hist_reset.argtypes = [vp, u32, vp]
     L.fastf_dev_reduce.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, u32, vp]
     L.fastf_engine_skip_bits.argtypes = [vp, C.POINTER(u32)]
+    L.fastf_engine_sort_passes.argtypes = [vp, u32, C.POINTER(u32)]
     L.fastf_engine_table_modes.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fastf_dev_umi_rows.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.fastf_dev_reserve.argtypes = [vp, u64, u64]

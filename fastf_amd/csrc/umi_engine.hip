@@ -43,6 +43,8 @@ static u32 bits_for(u64 max_value) {   // bits needed to hold 0..max_value
     return b ? b : 1;
 }
 
+static u32 sort_passes(u32 key_bits, u32 low_bit) { return key_bits > low_bit ? (key_bits - low_bit + 7) / 8 : 0; }
+
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     int ensure(size_t need) {
@@ -296,11 +298,16 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         delete e; return 1;
     }
     e->threshold = cfg->draw_threshold;
-    {   // keep >= 10 bits of the UMI field in the sorted part; everything below a multiple of 8 is skipped
+    {   // Matrix path: the sorted part must hold (cell, feature, NULL flag) and at least 7 bits of the UMI field, i.e. the
+        // key bits from feat_shift - 8 upwards; the digit grid is anchored at the TOP of the key, so the number of 8-bit
+        // passes is the minimum for that range whatever the key width (a byte-aligned grid spends a whole pass on the
+        // one or two top bits of a 57/58-bit key).  Everything below the grid stays unsorted (K3 resolves those runs).
         const char* sk = getenv("FASTF_SORT_SKIP_BITS");
-        const u32 fs = e->L.feat_shift;
-        e->skip_bits = sk ? (u32)atoi(sk) : (fs > 10 ? 8 * ((fs - 10) / 8) : 0);
-        if (e->skip_bits % 8 || e->skip_bits >= fs) e->skip_bits = 0;
+        const u32 fs = e->L.feat_shift, kb = e->L.total_bits;
+        const u32 need_from = fs > 8 ? fs - 8 : 0;
+        const u32 passes = (kb - need_from + 7) / 8;
+        e->skip_bits = sk ? (u32)atoi(sk) : (kb > 8 * passes ? kb - 8 * passes : 0);
+        if (e->skip_bits >= fs) e->skip_bits = 0;
     }
     e->n_shards = cfg->n_shards; e->shard_rank = cfg->shard_rank;
     fastf_mt_seed(&e->mt, cfg->mt_seed);
@@ -364,6 +371,12 @@ extern "C" int fastf_engine_table_modes(const fastf_engine_t* e, int* cells_in_l
     if (!e) return set_err("null engine");
     if (cells_in_lds) *cells_in_lds = e->use_lds_cells;
     if (genes_in_lds) *genes_in_lds = e->use_lds_genes ? (e->lds_genes.direct ? 2 : 1) : 0;
+    return 0;
+}
+
+extern "C" int fastf_engine_sort_passes(const fastf_engine_t* e, uint32_t flags, uint32_t* passes) {
+    if (!e || !passes) return set_err("null argument");
+    *passes = sort_passes(e->L.total_bits, (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0);
     return 0;
 }
 
@@ -541,46 +554,50 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
 
 static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
 extern "C" void fastf_debug_set_stamps(void* p) { g_stamps = (u64*)p; }
-static void launch_scatter(u32 pass, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt,
+static void launch_scatter(u32 shift, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt,
                            const u32* bin_tot, u32 ipt) {
-#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, g_stamps)
-    switch (pass) {
-    case 0: SC(0); break;  case 1: SC(8); break;  case 2: SC(16); break; case 3: SC(24); break;
-    case 4: SC(32); break; case 5: SC(40); break; case 6: SC(48); break; default: SC(56); break;
+#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, g_stamps)
+    const bool rt = (shift & 7u) != 0 || getenv("FASTF_SORT_RUNTIME_SHIFT");
+    switch (rt ? 64u : shift) {
+    case 0: SC(0); break;  case 8: SC(8); break;  case 16: SC(16); break; case 24: SC(24); break;
+    case 32: SC(32); break; case 40: SC(40); break; case 48: SC(48); break; case 56: SC(56); break;
+    default: SC(-1); break;
     }
 #undef SC
 }
 
 static int set_scatter_lds_limit() {
-    const void* fns[8] = {(const void*)scatter_kernel<0>, (const void*)scatter_kernel<8>, (const void*)scatter_kernel<16>,
+    const void* fns[9] = {(const void*)scatter_kernel<0>, (const void*)scatter_kernel<8>, (const void*)scatter_kernel<16>,
                           (const void*)scatter_kernel<24>, (const void*)scatter_kernel<32>, (const void*)scatter_kernel<40>,
-                          (const void*)scatter_kernel<48>, (const void*)scatter_kernel<56>};
+                          (const void*)scatter_kernel<48>, (const void*)scatter_kernel<56>, (const void*)scatter_kernel<-1>};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) return 1;
     return 0;
 }
 
+// 8-bit LSD passes over the key bits [low_bit, key_bits): pass q sorts the digit at low_bit + 8q (the last one may reach
+// past key_bits, where every key holds zeros).  low_bit = 0 is the full sort.
 static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits, u32 low_bit,
                        int* sorted_in_tmp, hipStream_t s) {
-    const u32 passes = (key_bits + 7) / 8;
-    const u32 first = std::min(low_bit / 8, passes);           // digit passes below low_bit are skipped
-    *sorted_in_tmp = (int)((passes - first) & 1);
+    if (key_bits > 64) return set_err("key_bits %u > 64", key_bits);
+    const u32 passes = sort_passes(key_bits, low_bit);
+    *sorted_in_tmp = (int)(passes & 1);
     if (max_n == 0) return 0;
-    if (passes > 8) return set_err("key_bits %u > 64", key_bits);
     if (max_n >= (1ull << 32)) return set_err("sort of %llu keys: limit is 2^32-1 per shard", (unsigned long long)max_n);
     if (reserve_workspace(e, 0, max_n)) return 1;
     const u32 ipt = choose_sort_ipt(max_n);
     const u32 T = (u32)((max_n + (u64)ipt * SORT_THREADS - 1) / ((u64)ipt * SORT_THREADS));
     u32* bintot = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
-    for (u32 q = first; q < passes; ++q) {
-        const u64* src = ((q - first) & 1) ? tmp : keys;
-        u64* dst = ((q - first) & 1) ? keys : tmp;
+    for (u32 q = 0; q < passes; ++q) {
+        const u64* src = (q & 1) ? tmp : keys;
+        u64* dst = (q & 1) ? keys : tmp;
+        const u32 shift = low_bit + 8 * q;
         t_begin(e, s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
         hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         t_begin(e, s);
-        launch_scatter(q, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt);
+        launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt);
         t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
     }
     HIP_OK(hipGetLastError());

@@ -489,14 +489,16 @@ __global__ __launch_bounds__(K1B_THREADS, LDS_GENES ? FASTF_K1B_MINWAVES : FASTF
         }
         emit[j] = alive;
         // order inside a shard list is irrelevant: the keys are sorted next
-        for (u32 s = 0; s < p.n_shards; ++s) {
-            const u64 m = __ballot(alive && shard[j] == s);
+        if (p.n_shards == 1) {
+            const u64 m = __ballot(alive);
             if (m) {
                 u32 b = 0;
-                if (lane == 0) b = atomicAdd(&s_shard_cnt[s], (u32)__popcll(m));
+                if (lane == 0) b = atomicAdd(&s_shard_cnt[0], (u32)__popcll(m));
                 b = __shfl(b, 0, WAVE);
-                if (alive && shard[j] == s) pos[j] = b + rank_below(m);
+                if (alive) pos[j] = b + rank_below(m);
             }
+        } else if (alive) {
+            pos[j] = atomicAdd(&s_shard_cnt[shard[j]], 1u);          // one returning LDS atomic per key (8 ballot rounds cost more)
         }
     }
 
@@ -637,13 +639,20 @@ __device__ __forceinline__ void match_digit(u32 d, u32& mlo, u32& mhi) {
     }
 }
 
-// scatter: stable within the tile (wave-major, item, lane == memory order).  SHIFT is a
-// template parameter so the digit is one v_bfe on the right key half; FULL tiles skip every
+// digit of a pass: byte-aligned shifts are template parameters (one v_bfe on the right key half); SHIFT < 0 takes the
+// shift at run time (digit grids that do not start on a byte boundary, see sort_low_bit() in umi_engine.hip)
+template <int SHIFT>
+__device__ __forceinline__ u32 digit_of(u64 key, u32 rshift) {
+    if (SHIFT >= 0) return (u32)(key >> SHIFT) & 255u;
+    return (u32)(key >> rshift) & 255u;
+}
+
+// scatter: stable within the tile (wave-major, item, lane == memory order).  FULL tiles skip every
 // bounds check (only the last tile of a pass is partial).
 template <int SHIFT, bool FULL>
 __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
                                              u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                             const int ipt, unsigned char* smem, u64* stamps = nullptr) {
+                                             const int ipt, unsigned char* smem, const u32 rshift, u64* stamps = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -684,7 +693,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     for (int j = 0; j < SORT_IPT; ++j) {
         if (j >= ipt) break;                               // wave-uniform
         const u32 li = wbase + j * WAVE + lane;
-        const u32 d = (FULL || li < n_valid) ? ((u32)(key[j] >> SHIFT) & 255u) : 255u;
+        const u32 d = (FULL || li < n_valid) ? digit_of<SHIFT>(key[j], rshift) : 255u;
         u32 mlo, mhi;
         match_digit(d, mlo, mhi);
         const u32 before = wh[d];
@@ -722,7 +731,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     for (int j = 0; j < SORT_IPT; ++j) {
         if (j >= ipt) break;
         const u32 li = wbase + j * WAVE + lane;
-        const u32 d = (FULL || li < n_valid) ? ((u32)(key[j] >> SHIFT) & 255u) : 255u;
+        const u32 d = (FULL || li < n_valid) ? digit_of<SHIFT>(key[j], rshift) : 255u;
         const u32 p = s_start[d] + wh[d] + rnk[j];
         s_keys[p] = key[j];
     }
@@ -736,7 +745,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         const u32 pidx = j * SORT_THREADS + tid;
         if (FULL || pidx < n_valid) {
             const u64 k = s_keys[pidx];
-            const u32 d = (u32)(k >> SHIFT) & 255u;
+            const u32 d = digit_of<SHIFT>(k, rshift);
             out[(u64)(u32)(s_delta[d] + pidx)] = k;
         }
     }
@@ -752,7 +761,7 @@ template <int SHIFT>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
                                                                const u64* __restrict__ n_ptr,
                                                                const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                                               u32 ipt, u64* stamps) {
+                                                               u32 ipt, u32 rshift, u64* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u64 n = *n_ptr;
     const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
@@ -760,8 +769,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
     const u32 tile_keys = ipt * SORT_THREADS;
     const u64 base = (u64)tile * tile_keys;
     const u32 n_valid = (u32)((n - base) < (u64)tile_keys ? (n - base) : (u64)tile_keys);
-    if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, stamps);
-    else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, stamps);
+    if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, stamps);
+    else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, stamps);
 }
 
 

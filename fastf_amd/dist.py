@@ -10,7 +10,8 @@ runs K1 on it; a key belongs to shard hash(cell_index) mod G, so all UMIs of a
   2. K1 probe/filter/pack, keys written straight into one buffer per destination shard;
   3. ONE exchange: all_to_all of the per-destination counts, then of the keys (xGMI);
   4. local K2 sort + K3 reduce on the received keys;
-  5. counters all_reduce(sum); COO rows stay on their shard (gather_coo() merges them).
+  5. COO rows stay on their shard (gather_coo() merges them); the three counters are summed over ranks on demand
+     (global_counters(): one all_reduce, outside the data path).
 
 The device stages are injected (``stages``): the default is the HIP engine; the CPU test
 suite drives the same orchestration over gloo with test doubles.
@@ -110,6 +111,7 @@ class ShardedPass:
         self.n_recv = 0
         self.sorted = None
         self._verified = False     # the group-only sort was checked against its run cap for the current result
+        self._counters_reduced = True
 
     def run(self, cb, gx, umi, meta, n, draws):
         """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident)."""
@@ -142,7 +144,7 @@ class ShardedPass:
                 self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
             self.d_n.fill_(self.n_recv)
             keys = self.recv
-            self._all_reduce(self.counters[:3])
+            self._counters_reduced = False              # summed over ranks on demand (global_counters), not per step
         else:
             self.d_n.copy_(self.key_counts[:1])
             self.n_recv = n                             # upper bound; the device reads d_n
@@ -221,6 +223,10 @@ class ShardedPass:
         return F[order], Cc[order], K[order]
 
     def global_counters(self):
+        """{hits, sampled, sampled_valid, error bits} of the whole job (collective when G > 1: every rank must call it)"""
         self.ensure_exact()
+        if self.G > 1 and not self._counters_reduced:
+            self._all_reduce(self.counters[:3])
+            self._counters_reduced = True
         c = self.counters.cpu().numpy()
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])

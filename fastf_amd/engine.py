@@ -259,6 +259,11 @@ class Engine:
         check(self._L.fastf_engine_skip_bits(self._h, C.byref(b)))
         return b.value
 
+    def sort_passes(self, skip_low=False) -> int:
+        b = C.c_uint32()
+        check(self._L.fastf_engine_sort_passes(self._h, 2 if skip_low else 0, C.byref(b)))
+        return b.value
+
     def dev_umi_rows(self, d_sorted, d_n, max_n, d_ukeys, d_ncopy, d_nrows, stream=0):
         check(self._L.fastf_dev_umi_rows(self._h, d_sorted, d_n, max_n, d_ukeys, d_ncopy, d_nrows, stream))
 

@@ -245,6 +245,9 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
                                       (equal keys stay neighbours of their (cell, feature, top-UMI-bits) run);
                                       pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
 int fastf_engine_skip_bits(const fastf_engine_t *e, uint32_t *bits);
+/* number of 8-bit LSD passes fastf_dev_sort runs for this engine's keys with the given flags: the digit grid starts at
+ * the skip bit (not necessarily a byte boundary) when FASTF_SORT_SKIP_LOW is set, at bit 0 otherwise */
+int fastf_engine_sort_passes(const fastf_engine_t *e, uint32_t flags, uint32_t *passes);
 /* which lookup structure the lists qualified for: 1 = LDS-resident (barcodes: perfect hash of 32-bit codes; genes:
  * bitmap + rank + permutation over one id family; genes: 2 = direct index table over a dense id range),
  * 0 = open-addressed table in L2 */

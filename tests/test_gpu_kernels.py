@@ -98,7 +98,7 @@ def test_group_only_sort_plus_run_aware_reduce(env, n, n_groups, low_values, see
     (one group, thousands of distinct low parts sharing the sorted prefix) and heavy duplication."""
     torch, F, eng = env
     skip = eng.skip_bits
-    assert skip == 16                       # this engine: feat_shift 27 → two low digit passes skipped
+    assert 0 < skip < 27 and eng.sort_passes(True) == (46 - skip + 7) // 8      # 46-bit keys: the digit grid ends at the top bit
     rng = np.random.default_rng(seed)
     fs, cs = 27, 36
     cell = rng.integers(1, 1001, size=n_groups, dtype=np.uint64)

@@ -90,7 +90,7 @@ def test_long_unsorted_runs_fall_back_to_the_full_sort():
     lists = F.Lists(bt, ft, 1.0, 926)
     eng = F.Engine.from_lists(lists, umi_max_bases=12)
     try:
-        assert eng.skip_bits == 16
+        assert 0 < eng.skip_bits < 27 and eng.sort_passes(True) < eng.sort_passes(False)
         eng.push(*F.pack_records(lists, flags, xf, cb, gx, ub))
         res = eng.finish()
         case = Case(n=1, n_bar=2, n_gene=2); case.rate_cell, case.rate_depth, case.label = 1.0, 1.0, b"synthetic.bam"
