@@ -556,6 +556,7 @@ static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): pe
 extern "C" void fastf_debug_set_stamps(void* p) { g_stamps = (u64*)p; }
 static void launch_scatter(u32 shift, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt,
                            const u32* bin_tot, u32 ipt) {
+    T = (T + 7u) & ~7u;                 // whole rounds over the 8 XCDs (see the tile swizzle in scatter_kernel)
 #define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, g_stamps)
     const bool rt = (shift & 7u) != 0 || getenv("FASTF_SORT_RUNTIME_SHIFT");
     switch (rt ? 64u : shift) {

@@ -764,7 +764,16 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
                                                                u32 ipt, u32 rshift, u64* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u64 n = *n_ptr;
-    const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
+    const u32 T = num_tiles(n, ipt);
+#ifdef FASTF_NO_XCD_SWIZZLE
+    const u32 tile = blockIdx.x;
+#else
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  Consecutive tiles write consecutive runs of every
+    // bin, so neighbouring tiles share the cache lines at their run boundaries: give each XCD a contiguous range of
+    // tiles and those partial lines merge in that XCD's L2 instead of going to HBM twice.  (grid = 8 x ceil(T / 8))
+    const u32 chunk = (gridDim.x + 7u) >> 3;
+    const u32 tile = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+#endif
     if (tile >= T) return;
     const u32 tile_keys = ipt * SORT_THREADS;
     const u64 base = (u64)tile * tile_keys;
