@@ -401,14 +401,14 @@ extern "C" int fastf_engine_key_bits(const fastf_engine_t* e, uint32_t* cell_bit
 // ------------------------------------------------------------------------------------
 static u64 max_tiles_for(u64 n, u64 tile) { return (n + tile - 1) / tile + 1; }
 
-// keys per thread of the sort tiles (tile = ipt x 512 keys).  At most 10, so that the scatter kernel's LDS
-// (tile x 8 B + 10 KB) lets three workgroups share a CU, and the smallest value that needs no more rounds over
-// those 3 x CU slots than ipt = 10 would, so every round is full (measured at 10 M keys: 42.2 us vs 44.5 us
-// per pass for fixed 8192-key tiles).
+// keys per thread of the sort tiles (tile = ipt x 512 keys).  At most 7, so that the scatter kernel's LDS
+// (tile x 8 B + 10 KB) lets four workgroups share a CU (8 waves per SIMD), and the smallest value that needs no more
+// rounds over those 4 x CU slots than ipt = 7 would, so every round is full.  Measured at 10 M keys with the
+// XCD-contiguous tile mapping: 34.4-35.5 us per scatter pass for ipt 6-7, 37 us for 9-10 (three workgroups per CU).
 static u32 choose_sort_ipt(u64 n) {
     const char* f = getenv("FASTF_SORT_IPT");
     if (f) { int v = atoi(f); if (v >= 1 && v <= SORT_IPT) return (u32)v; }
-    const u64 max_ipt = 10, slots = 3ull * g_cu_count;
+    const u64 max_ipt = std::min<u64>(7, SORT_IPT), slots = 4ull * g_cu_count;
     const u64 per_round_max = slots * SORT_THREADS * max_ipt;
     const u64 rounds = std::max<u64>(1, (n + per_round_max - 1) / per_round_max);
     const u64 per_thread = (n + rounds * slots * SORT_THREADS - 1) / (rounds * slots * SORT_THREADS);
@@ -594,7 +594,7 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         u64* dst = (q & 1) ? keys : tmp;
         const u32 shift = low_bit + 8 * q;
         t_begin(e, s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3(T), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt);
+        hipLaunchKernelGGL(tile_count_kernel, dim3((T + 7u) & ~7u), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
         hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         t_begin(e, s);

@@ -547,8 +547,9 @@ __global__ __launch_bounds__(K1B_THREADS, LDS_GENES ? FASTF_K1B_MINWAVES : FASTF
 // K2: LSD radix sort, 8-bit digits.  Per pass: tile_count → row_scan → scatter.
 // ------------------------------------------------------------------------------------
 constexpr int RADIX = 256;
+// keys per thread of a sort tile, compile-time bound: 8 keeps the scatter at 47 VGPRs (8 waves per SIMD)
 #ifndef FASTF_SORT_IPT_MAX
-#define FASTF_SORT_IPT_MAX 16
+#define FASTF_SORT_IPT_MAX 8
 #endif
 #ifndef FASTF_SORT_THREADS
 #define FASTF_SORT_THREADS 512
@@ -567,7 +568,11 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
                                                                   u32 shift, u32* __restrict__ cnt, u32 ipt) {
     __shared__ u32 s_h[4 * RADIX];
     const u64 n = *n_ptr;
-    const u32 T = num_tiles(n, ipt), tile = blockIdx.x;
+    const u32 T = num_tiles(n, ipt);
+    // same XCD-contiguous tile mapping as the scatter: the 4-byte counts of neighbouring tiles share cache lines in
+    // every digit row of cnt[][]
+    const u32 chunk = (gridDim.x + 7u) >> 3;
+    const u32 tile = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
     if (tile >= T) return;
     for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) s_h[i] = 0;
     __syncthreads();
