@@ -422,7 +422,11 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
         e->cells_cached_for = nullptr;
         if (e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
     }
-    if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
+    if (e->d_tilecnt.bytes < std::max(t1, t3) * sizeof(u32)) {       // (re)allocated: establish the all-zero invariant
+        if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemset(e->d_tilecnt.p, 0, e->d_tilecnt.bytes));
+    }
     if (e->d_tilebase.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
@@ -475,8 +479,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     if (reserve_workspace(e, n, 0)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     t_begin(e, s);
-    if (e->use_lds_cells) {
-        HIP_OK(hipMemsetAsync(e->d_tilecnt.p, 0, (size_t)tiles * sizeof(u32), s));
+    if (e->use_lds_cells) {                          // tile counts are all-zero here: scan_tiles_kernel clears what it reads
         const u32 grid = std::min<u32>(2 * g_cu_count, (tiles + 1) / 2);
         hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
                            (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
@@ -485,7 +488,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
                            (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
                        (u64*)e->d_tilebase.p, tiles, d_total_out);
     HIP_OK(hipGetLastError());
     e->cells_cached_for = cb; e->cells_cached_n = n;
@@ -630,7 +633,7 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
     t_begin(e, s);
     hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_tilecnt.p,
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
                        (u64*)e->d_tilebase.p, tiles, nrows);
     hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,

@@ -174,24 +174,31 @@ __device__ __forceinline__ void table_probe_batch(const Table t, const u64 (&key
 }
 
 // ------------------------------------------------------------------------------------
-// exclusive scan of per-tile counts (one workgroup; T is a few thousand entries)
+// exclusive scan of per-tile counts (one workgroup; T is a few thousand entries, four per thread).
+// The input is cleared once read: K1a accumulates its hit counts with atomics and needs zeros there, so the buffer
+// returns to all-zero after every use and no memset is launched per step.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(const u32* __restrict__ in, u64* __restrict__ out, u32 T,
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, u64* __restrict__ out, u32 T,
                                                           u64* __restrict__ total_out) {
     __shared__ u32 s_w[16];
     __shared__ u64 s_carry;
     const int lane = lane_id(), w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (u32 t0 = 0; t0 < T; t0 += 1024) {
-        const u32 t = t0 + threadIdx.x;
-        const u32 v = t < T ? in[t] : 0;
-        const u32 inc = wave_incl_scan32(v, lane);
+    for (u32 t0 = 0; t0 < T; t0 += 4096) {
+        const u32 t = t0 + 4 * threadIdx.x;
+        u32 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = t + k < T ? in[t + k] : 0; if (t + k < T) in[t + k] = 0; }
+        const u32 sum = v[0] + v[1] + v[2] + v[3];
+        const u32 inc = wave_incl_scan32(sum, lane);
         if (lane == WAVE - 1) s_w[w] = inc;
         __syncthreads();
         u64 off = s_carry;
         for (int i = 0; i < w; ++i) off += s_w[i];
-        if (t < T) out[t] = off + inc - v;
+        u64 e = off + inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (t + k < T) out[t + k] = e; e += v[k]; }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();

@@ -103,7 +103,8 @@ class ShardedPass:
         self.recv_cap = G * n
         self.recv = torch.empty(self.recv_cap, dtype=i64, device=device)
         self.tmp = torch.empty(self.recv_cap, dtype=i64, device=device)
-        self.d_n = torch.zeros(1, dtype=i64, device=device)
+        self._d_n_buf = torch.zeros(1, dtype=i64, device=device)
+        self.d_n = self._d_n_buf
         self.feature = torch.empty(self.recv_cap, dtype=i32, device=device)
         self.cell = torch.empty(self.recv_cap, dtype=i32, device=device)
         self.count = torch.empty(self.recv_cap, dtype=i32, device=device)
@@ -142,12 +143,13 @@ class ShardedPass:
             else:                                       # gloo: contiguous send buffer
                 flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
                 self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
+            self.d_n = self._d_n_buf
             self.d_n.fill_(self.n_recv)
             keys = self.recv
             self._counters_reduced = False              # summed over ranks on demand (global_counters), not per step
         else:
-            self.d_n.copy_(self.key_counts[:1])
-            self.n_recv = n                             # upper bound; the device reads d_n
+            self.d_n = self.key_counts[:1]              # the device reads the key count where K1b accumulated it
+            self.n_recv = n                             # upper bound
             keys = self.keys_out.view(-1)
         # 4. local sort + reduce
         self.sorted = st.sort_reduce(keys, self.tmp, self.d_n, self.n_recv, self.feature, self.cell,
