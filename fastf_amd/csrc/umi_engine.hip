@@ -259,7 +259,7 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes; e->lds_genes.direct = direct ? 1u : 0u;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess) return 0;
-    const size_t per_block = bytes + 10 * 1024;                      // + the kernel's static LDS
+    const size_t per_block = bytes + 1024;                           // + the kernel's static LDS (about 0.5 KB)
     e->genes_blocks_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / per_block));
     e->use_lds_genes = true;
     return 0;
