@@ -74,6 +74,7 @@ struct fastf_engine {
     DevBuf tab_cells, tab_feats;
     Table cells{}, feats{};
     DevBuf img_cells, img_genes;         // LDS table images (fast path, when the lists allow it)
+    DevBuf d_cell_filter; MissFilter cell_filter{nullptr, 0};        // miss filter in front of the L2 cell table
     CellLds lds_cells{}; GeneLds lds_genes{};
     bool use_lds_cells = false, use_lds_genes = false; u32 genes_blocks_per_cu = 1;
     // draw stream
@@ -153,6 +154,26 @@ static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char
 }
 
 // LDS images (see umi_kernels.hpp "LDS-resident tables"); both return 0 and leave use_* false when not eligible
+static u32 h_filter_bit(u64 key) {          // host mirror of filter_bit() in umi_kernels.hpp
+    const u32 h = (u32)key * 0x85EBCA77u + (u32)(key >> 32) * 0xC2B2AE3Du;
+    return h ^ (h >> 13);
+}
+
+// bit set over the listed barcode keys, about 10 bits per key (a tenth of the unlisted keys still reach the table), 4-32 KB
+static int build_cell_filter(fastf_engine* e, const u64* keys, u32 n) {
+    if (n == 0 || getenv("FASTF_NO_CELL_FILTER")) return 0;
+    u32 bits = 1u << 15;
+    while (bits < 10ull * n && bits < (1u << 18)) bits <<= 1;
+    std::vector<u32> w(bits / 32, 0u);
+    for (u32 i = 0; i < n; ++i) { const u32 b = h_filter_bit(keys[i]) & (bits - 1); w[b >> 5] |= 1u << (b & 31); }
+    if (e->d_cell_filter.ensure(bits / 8)) return 1;
+    HIP_OK(hipMemcpy(e->d_cell_filter.p, w.data(), bits / 8, hipMemcpyHostToDevice));
+    e->cell_filter.bits = (const u32*)e->d_cell_filter.p; e->cell_filter.mask = bits - 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_filtered_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(bits / 8)) != hipSuccess) { e->cell_filter.bits = nullptr; }
+    return 0;
+}
+
 static u32 h_fmix32(u32 h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
 
 // compress-hash-displace perfect hash of the 32-bit barcode codes (host mirror of chd_bucket / chd_slot)
@@ -329,6 +350,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
             if (!(lt && lt[0] == '0')) {
                 const char* lc = getenv("FASTF_LDS_CELLS");
                 if (!(lc && lc[0] == '0') && (rc = build_cell_lds(e, (const u64*)cfg->cell_keys, cfg->n_cells))) break;
+                if (!e->use_lds_cells && (rc = build_cell_filter(e, (const u64*)cfg->cell_keys, cfg->n_cells))) break;
                 if ((rc = build_gene_lds(e, (const u64*)cfg->feature_keys, cfg->n_features))) break;
             }
         }
@@ -359,7 +381,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
         if (e->t_ev[i]) (void)hipEventDestroy(e->t_ev[i]);
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
-    DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
+    DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -483,6 +505,10 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
         const u32 grid = std::min<u32>(2 * g_cu_count, (tiles + 1) / 2);
         hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
                            (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
+    } else if (e->cell_filter.bits) {
+        const u32 grid = std::min<u32>(tiles, 4 * g_cu_count);
+        hipLaunchKernelGGL(probe_cells_filtered_kernel, dim3(grid), dim3(K1_THREADS), (e->cell_filter.mask + 1u) / 8u, s, cb, n,
+                           e->cells, e->cell_filter, (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
     } else {
         hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
                            (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
@@ -681,7 +707,7 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 }
 
 extern "C" const char* fastf_kernel_names(void) {
-    return "probe_cells_kernel,probe_cells_lds_kernel,scan_tiles_kernel,filter_pack_kernel,"
+    return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,"
            "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
 }
 

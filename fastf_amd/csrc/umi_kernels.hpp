@@ -272,6 +272,62 @@ __device__ __forceinline__ u32 chd_bucket(u32 code, u32 buckets) { return (u32)(
 __device__ __forceinline__ u32 chd_slot(u32 code, u32 disp, u32 m) { return (u32)(((u64)fmix32(code ^ (disp * 0x9E3779B1u + 0x7F4A7C15u)) * m) >> 32); }
 
 
+// K1a with a miss filter (barcode lists too large for the LDS perfect hash): a bit set over a second hash of the listed
+// keys sits in LDS (persistent workgroups, four per CU); a key whose bit is clear cannot be listed and never reaches the
+// L2 table.  Every listed key passes, so the result is the table's; what changes is the number of L2 lines gathered:
+// with --cell 0.5 half of the CB tags are unsampled barcodes, and BAMs carry reads of unlisted barcodes anyway.
+struct MissFilter { const u32* bits; u32 mask; };          // mask = number of bits - 1 (power of two)
+__device__ __forceinline__ u32 filter_bit(u64 key) {
+    const u32 h = (u32)key * 0x85EBCA77u + (u32)(key >> 32) * 0xC2B2AE3Du;
+    return h ^ (h >> 13);
+}
+
+__global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(const u64* __restrict__ cb, u64 n, Table cells, MissFilter f,
+                                                                             u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                                             u32 n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 s_w[K1_WAVES];
+    u32* s_bits = reinterpret_cast<u32*>(smem);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(f.bits);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (u32 i = threadIdx.x; i < (f.mask + 1u) / 128u; i += K1_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u64 base = (u64)tile * K1_TILE;
+        u64 key[K1_IPT]; u32 cell[K1_IPT];
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            const u64 idx = base + (u64)j * K1_THREADS + tid;
+            key[j] = idx < n ? cb[idx] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            const u32 b = filter_bit(key[j]) & f.mask;
+            if (!((s_bits[b >> 5] >> (b & 31u)) & 1u)) key[j] = 0;        // not listed: no probe (dead lanes share slot 0)
+        }
+        table_probe_batch<K1_IPT, 0>(cells, key, cell);
+        u32 hits = 0;
+#pragma unroll
+        for (int j = 0; j < K1_IPT; ++j) {
+            const u64 idx = base + (u64)j * K1_THREADS + tid;
+            if (idx < n) cell_out[idx] = cell[j];
+            hits += cell[j] != 0;
+        }
+        hits = wave_sum32(hits);
+        if (lane == 0) s_w[w] = hits;
+        __syncthreads();
+        if (tid == 0) {
+            u32 t = 0;
+            for (int i = 0; i < K1_WAVES; ++i) t += s_w[i];
+            tile_hits[tile] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // K1a, LDS mode: persistent 1024-thread workgroups (two per CU); each 512-thread half walks its own tiles,
 // hit counts go to tile_hits[] (zeroed before) with one atomic per wave.
 __global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
