@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--genes", type=int, default=30_000)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gene-stride", type=int, default=1, help="spacing of the synthetic gene ids (8 ~ a real Ensembl list)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,7 +65,7 @@ def main():
     seed, rate_cell, rate_depth = 926, 1.0, 1.0
 
     # ---- synthetic job: G slices of N records; this rank owns slice `rank` ----
-    bt, ft, bar, genes = synth.make_lists(args.barcodes, args.genes, seed=4242)
+    bt, ft, bar, genes = synth.make_lists(args.barcodes, args.genes, seed=4242, gene_stride=args.gene_stride)
     lists = F.Lists(bt, ft, rate_cell, seed)
     fl, xf, cb, gx, ub = synth.make_records(N, bar, genes, seed=100 + rank, umi_len=10)
     cbs, gxs, ubs = synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)

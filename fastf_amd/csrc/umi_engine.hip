@@ -257,7 +257,10 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     const size_t direct_bytes = ((size_t)range * 2 + 15) & ~(size_t)15;
     const bool direct = direct_bytes <= bytes + bytes / 8 && !getenv("FASTF_GENES_NO_DIRECT");
     if (direct) bytes = direct_bytes;
-    if (bytes > 120 * 1024) return 0;
+    {   // FASTF_GENES_LDS_MAX_KB: largest LDS image (default 120 KB)
+        const char* mk = getenv("FASTF_GENES_LDS_MAX_KB");
+        if (bytes > (size_t)(mk ? atoi(mk) : 120) * 1024) return 0;
+    }
     std::vector<u32> img(bytes / 4 + 4, 0u);
     if (direct) {
         unsigned short* tab = reinterpret_cast<unsigned short*>(img.data());
