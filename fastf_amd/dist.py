@@ -63,13 +63,10 @@ class HipStages:
                                 key_counts.data_ptr(), counters.data_ptr(), self._s(),
                                 d_draw_base=draw_base.data_ptr())
 
-    def hist_reset(self):
-        self.eng.dev_hist_reset(self._s(), skip_low=self.skip_low)
-
     def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, hist_ready=False):
         # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs
         in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
-                                   hist_ready=hist_ready and self.skip_low, skip_low=self.skip_low)
+                                   skip_low=self.skip_low)
         src = tmp if in_tmp else keys
         self.eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, feature.data_ptr(), cell.data_ptr(),
                             count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=self.skip_low)
@@ -123,8 +120,6 @@ class ShardedPass:
             st.count_hits(cb, n, self.hits)
             self._all_gather(self.all_hits, self.hits)
             self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
-        else:
-            st.hist_reset()                             # single shard: K1b accumulates the digit histograms
         # 2. K1
         st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
                       self.key_counts, self.counters)

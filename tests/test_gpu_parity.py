@@ -222,3 +222,47 @@ def test_survey_edge_case_fixture():
         assert eng.format_umi_rows(eng.umi_rows()).decode().splitlines() == fx["umi_rows"]
     finally:
         eng.close()
+
+
+# key widths around the byte boundaries: the matrix sort's digit grid is anchored at the top key bit, so its shifts are
+# run-time values (non-byte-aligned) for most of these; -u rows take the full, byte-aligned sort of the same keys
+WIDTHS = [
+    # (n_bar, n_gene, umi_max_bases, expected key bits)
+    (3, 1, 16, 2 + 1 + 36),
+    (200, 100, 16, 8 + 7 + 36),
+    (1000, 500, 10, 10 + 9 + 23),
+    (5000, 3000, 12, 13 + 12 + 27),
+    (20_000, 40_000, 12, 15 + 16 + 27),
+    (40_000, 40_000, 12, 16 + 16 + 27),
+    (70_000, 40_000, 12, 17 + 16 + 27),
+    (70_000, 70_000, 12, 17 + 17 + 27),
+    (2000, 1500, 16, 11 + 11 + 36),
+    (260_000, 600, 16, 18 + 10 + 36),                       # 64 bits exactly
+]
+
+
+@pytest.mark.parametrize("n_bar,n_gene,umi_max,bits", WIDTHS)
+def test_key_widths(n_bar, n_gene, umi_max, bits):
+    case = Case(n=150_000, n_bar=n_bar, n_gene=n_gene, rate_cell=0.9, rate_depth=0.7, umi_len=min(umi_max, 12), dup_factor=3.0,
+                cell_dist="lognormal", gene_dist="zipf", p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.01, data_seed=bits)
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=umi_max)
+    try:
+        if case.rate_cell == 0.9 and lists.n_cells == int(np.float32(n_bar) * np.float32(0.9)):
+            cb = max(1, int(lists.n_cells).bit_length())
+            assert eng.key_bits == bits - max(1, n_bar.bit_length()) + cb      # sampled cells set the cell field
+        assert eng.sort_passes(True) <= eng.sort_passes(False)
+        eng.push(*case.packed(lists))
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
+def test_key_wider_than_64_bits_is_refused():
+    case = Case(n=10, n_bar=70_000, n_gene=70_000)
+    lists = case.lists()
+    with pytest.raises(F.FastfError) as ei:
+        F.Engine.from_lists(lists, umi_max_bases=16)
+    assert "bits" in str(ei.value)
