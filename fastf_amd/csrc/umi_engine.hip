@@ -257,9 +257,9 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     const size_t direct_bytes = ((size_t)range * 2 + 15) & ~(size_t)15;
     const bool direct = direct_bytes <= bytes + bytes / 8 && !getenv("FASTF_GENES_NO_DIRECT");
     if (direct) bytes = direct_bytes;
-    {   // FASTF_GENES_LDS_MAX_KB: largest LDS image (default 120 KB)
+    {   // FASTF_GENES_LDS_MAX_KB: largest LDS image (default 152 KB: one workgroup per CU; a real human Ensembl list needs ~128 KB)
         const char* mk = getenv("FASTF_GENES_LDS_MAX_KB");
-        if (bytes > (size_t)(mk ? atoi(mk) : 120) * 1024) return 0;
+        if (bytes > (size_t)(mk ? atoi(mk) : 152) * 1024) return 0;
     }
     std::vector<u32> img(bytes / 4 + 4, 0u);
     if (direct) {
@@ -281,7 +281,9 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     HIP_OK(hipMemcpy(e->img_genes.p, img.data(), bytes, hipMemcpyHostToDevice));
     e->lds_genes.image = (const u32*)e->img_genes.p; e->lds_genes.words = words; e->lds_genes.n_perm = (u32)best_n;
     e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes; e->lds_genes.direct = direct ? 1u : 0u;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess) return 0;
     const size_t per_block = bytes + 1024;                           // + the kernel's static LDS (about 0.5 KB)
     e->genes_blocks_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / per_block));
@@ -556,7 +558,8 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     t_begin(e, s);
     if (e->use_lds_genes) {
         const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
-        hipLaunchKernelGGL(filter_pack_kernel<true>, dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);
+        if (e->genes_blocks_per_cu >= 2) hipLaunchKernelGGL((filter_pack_kernel<true, false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);
+        else hipLaunchKernelGGL((filter_pack_kernel<true, true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);
     } else {
         hipLaunchKernelGGL(filter_pack_kernel<false>, dim3(tiles), dim3(K1B_THREADS), 0, s, p);
     }

@@ -411,8 +411,10 @@ struct PackParams {
 #define K1STAMP(i) do { } while (0)
 #endif
 
-template <bool LDS_GENES>
-__global__ __launch_bounds__(K1B_THREADS, LDS_GENES ? FASTF_K1B_MINWAVES : FASTF_K1B_MINWAVES_L2) void filter_pack_kernel(const PackParams p) {
+// ROOMY: the gene image leaves room for one workgroup per CU only (sparse id ranges of real lists: >78 KB) — then four
+// waves per SIMD is all there is, and the kernel may as well use 128 VGPRs (112 us vs 125 us with the 64-VGPR build)
+template <bool LDS_GENES, bool ROOMY = false>
+__global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MINWAVES : FASTF_K1B_MINWAVES_L2)) void filter_pack_kernel(const PackParams p) {
     __shared__ u32 s_cnt[K1B_IPT * K1B_WAVES];       // hits per (item, wave), then exclusive
     __shared__ u32 s_red[3][K1B_WAVES];
     __shared__ u32 s_shard_cnt[8];

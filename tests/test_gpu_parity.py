@@ -26,6 +26,11 @@ CASES = {
     "one_group_null_umis": dict(n=30_000, n_bar=1, n_gene=1, umi_pool=3, p_n_umi=0.9),
     # BASELINE config 5 shape, scaled: 100 k barcodes, Zipf-skewed UMI reuse from a 4096-pool per gene
     "c5_like": dict(n=1_500_000, n_bar=100_000, n_gene=400, umi_len=12, umi_pool=4096, zipf_umi=1.5, data_seed=9),
+    # sparse gene id ranges (real Ensembl lists): bitmap + rank + permutation image; the second needs > 78 KB of LDS
+    # (one workgroup per CU, the 128-VGPR build of K1b)
+    "sparse_gene_ids": dict(n=200_000, n_bar=800, n_gene=5000, gene_stride=7, gene_dist="zipf", umi_pool=2048, p_bad_xf=0.1),
+    "sparse_gene_ids_big_image": dict(n=300_000, n_bar=2000, n_gene=30_000, gene_stride=8, umi_pool=4096, rate_depth=0.8,
+                                      p_unlisted_cb=0.05),
     "every_record_misses": dict(n=20_000, n_bar=50, n_gene=20, p_unlisted_cb=1.0),
     "no_cb_at_all": dict(n=20_000, n_bar=50, n_gene=20, p_no_cb=1.0),
 }
