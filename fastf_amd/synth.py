@@ -152,8 +152,13 @@ def _bgzf_block(payload: bytes) -> bytes:
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def bam_record(name: bytes, aux: bytes) -> bytes:
-    body = struct.pack("<iiBBHHHiiii", -1, -1, len(name) + 1, 0, 4680, 0, 4, 0, -1, -1, 0) + name + b"\0" + aux
+def bam_record(name: bytes, aux: bytes, seq_len: int = 0, n_cigar: int = 0, ref_id: int = -1, pos: int = -1) -> bytes:
+    """one alignment record; seq_len / n_cigar > 0 give the shape of a mapped read (CIGAR words, packed bases, qualities
+    between the read name and the tags)"""
+    flag = 4 if ref_id < 0 else 0
+    body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(name) + 1, 255 if ref_id >= 0 else 0, 4680, n_cigar, flag, seq_len, -1, -1, 0)
+    body += name + b"\0" + struct.pack("<%dI" % n_cigar, *([(seq_len << 4) | 0] * n_cigar))
+    body += bytes([0x12] * ((seq_len + 1) // 2)) + bytes([30] * seq_len) + aux
     return struct.pack("<i", len(body)) + body
 
 
@@ -167,8 +172,9 @@ def aux_int(tag: bytes, val: int, typ: bytes = b"C") -> bytes:
 
 
 def write_bam(path: str, flags, xf, cb, gx, ub, xf_type: bytes = b"C", extra_aux=None, header_text: bytes = b"@HD\tVN:1.6\n",
-              refs=(("chr1", 1000),)):
-    """records → BGZF BAM file.  extra_aux(i) may return bytes inserted BEFORE the tags of record i."""
+              refs=(("chr1", 1000),), shape=None):
+    """records → BGZF BAM file.  extra_aux(i) may return bytes inserted BEFORE the tags of record i;
+    shape(i) may return (seq_len, n_cigar, ref_id, pos) for a mapped-read layout."""
     out = bytearray()
     payload = bytearray(b"BAM\1" + struct.pack("<i", len(header_text)) + header_text + struct.pack("<i", len(refs)))
     for nm, ln in refs:
@@ -195,7 +201,7 @@ def write_bam(path: str, flags, xf, cb, gx, ub, xf_type: bytes = b"C", extra_aux
             aux += aux_Z(b"GX", gxl[i])
         if f & HAS_UB:
             aux += aux_Z(b"UB", ubl[i])
-        payload += bam_record(b"r%d" % i, bytes(aux))
+        payload += bam_record(b"r%d" % i, bytes(aux), *(shape(i) if shape is not None else ()))
         if len(payload) >= 0xff00:
             flush()
     flush(force=True)

@@ -45,6 +45,19 @@ def test_bam_roundtrip_equals_direct_packing(tmp_path, xf_type):
         np.testing.assert_array_equal(g, w)
 
 
+def test_bam_mapped_read_layout(tmp_path):
+    """records shaped like Cell Ranger's: CIGAR words, packed bases and qualities of varying length before the tags,
+    mapped and unmapped reads mixed, names of varying length"""
+    case = Case(n=20000, n_bar=100, n_gene=50, umi_pool=64, p_no_cb=0.05, p_bad_xf=0.1)
+    lists = case.lists()
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub,
+                    shape=lambda i: ((28 + 7 * (i % 19)) if i % 11 else 0, i % 4, (i % 3) - 1, 1000 + i))
+    got = read_all(bam, lists, cap=4099)
+    for g, w in zip(got, case.packed(lists)):
+        np.testing.assert_array_equal(g, w)
+
+
 def test_bam_other_aux_types_and_tag_order(tmp_path):
     """tags of every aux type before/between the ones we need; first occurrence wins (bam_aux_get)"""
     case = Case(n=500, n_bar=20, n_gene=10, umi_pool=8)
