@@ -101,7 +101,7 @@ struct fastf_engine {
     u32 skip_bits = 0;           // low key bits the matrix path leaves unsorted (dedup needs adjacency of equal keys only)
     bool fully_sorted = false;
     // workspace
-    DevBuf d_cellidx, d_mthits, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
+    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
     const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
     // timing
     bool timing = false;
@@ -387,7 +387,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_mthits, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt};
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -449,7 +449,6 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
         e->cells_cached_for = nullptr;
         if (e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
     }
-    if (max_records && e->d_mthits.ensure(t1 * K1_MT_PER_TILE * sizeof(u32))) return 1;
     if (e->d_tilecnt.bytes < std::max(t1, t3) * sizeof(u32)) {       // (re)allocated: establish the all-zero invariant
         if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
         HIP_OK(hipDeviceSynchronize());
@@ -510,14 +509,14 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     if (e->use_lds_cells) {                          // tile counts are all-zero here: scan_tiles_kernel clears what it reads
         const u32 grid = std::min<u32>(2 * g_cu_count, (tiles + 1) / 2);
         hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_mthits.p, tiles);
+                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
     } else if (e->cell_filter.bits) {
         const u32 grid = std::min<u32>(tiles, 4 * g_cu_count);
         hipLaunchKernelGGL(probe_cells_filtered_kernel, dim3(grid), dim3(K1_THREADS), (e->cell_filter.mask + 1u) / 8u, s, cb, n,
-                           e->cells, e->cell_filter, (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_mthits.p, tiles);
+                           e->cells, e->cell_filter, (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
     } else {
         hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
-                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_mthits.p);
+                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,

@@ -213,11 +213,8 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, 
 //   tile_base[tile] (scan of K1a's counts) + rank inside the tile (ballots, record order).
 // ------------------------------------------------------------------------------------
 constexpr int K1_THREADS = FASTF_K1_THREADS, K1_IPT = FASTF_K1_IPT, K1_TILE = K1_THREADS * K1_IPT, K1_WAVES = K1_THREADS / WAVE;
-// Mini-tiles: 256 consecutive records, 16 per tile.  K1a lays a tile out wave by wave (wave w of a 512-thread group owns
-// records [512 w, 512 w + 512) = mini-tiles 2w and 2w+1), so a wave knows the hit counts of its two mini-tiles by itself
-// and writes them without atomics; K1b's waves each take one mini-tile and need no workgroup barrier for the hit rank.
-constexpr int K1_MT = 256, K1_MT_PER_TILE = K1_TILE / K1_MT;
-static_assert(K1_THREADS == 512 && K1_IPT == 8 && K1_MT_PER_TILE == 16, "K1a layout: 8 waves x 8 items x 64 lanes per tile");
+// K1a lays a tile out wave by wave: wave w of a 512-thread group owns the records [512 w, 512 w + 512) of its tile
+static_assert(K1_THREADS == 512 && K1_IPT == 8, "K1a layout: 8 waves x 8 items x 64 lanes per tile");
 
 __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
@@ -225,8 +222,7 @@ __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
 
 template <int AUX>
 __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __restrict__ cb, u64 n, Table cells,
-                                                                 u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                                 u32* __restrict__ mt_hits) {
+                                                                 u32* __restrict__ cell_out, u32* __restrict__ tile_hits) {
     __shared__ u32 s_w[K1_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u64 base = (u64)blockIdx.x * K1_TILE + (u64)w * (K1_IPT * WAVE);
@@ -237,19 +233,14 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
         key[j] = idx < n ? cb[idx] : 0;
     }
     table_probe_batch<K1_IPT, AUX>(cells, key, cell);
-    u32 h0 = 0, h1 = 0;
+    u32 hits = 0;
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
         const u64 idx = base + (u64)j * WAVE + lane;
         if (idx < n) cell_out[idx] = cell[j];
-        const u32 c = (u32)__popcll(__ballot(cell[j] != 0));
-        if (j < K1_IPT / 2) h0 += c; else h1 += c;
+        hits += (u32)__popcll(__ballot(cell[j] != 0));
     }
-    if (lane == 0) {
-        mt_hits[(u64)blockIdx.x * K1_MT_PER_TILE + 2 * w] = h0;
-        mt_hits[(u64)blockIdx.x * K1_MT_PER_TILE + 2 * w + 1] = h1;
-        s_w[w] = h0 + h1;
-    }
+    if (lane == 0) s_w[w] = hits;
     __syncthreads();
     if (tid == 0) {
         u32 t = 0;
@@ -294,7 +285,7 @@ __device__ __forceinline__ u32 filter_bit(u64 key) {
 
 __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(const u64* __restrict__ cb, u64 n, Table cells, MissFilter f,
                                                                              u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                                             u32* __restrict__ mt_hits, u32 n_tiles) {
+                                                                             u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u32 s_w[K1_WAVES];
     u32* s_bits = reinterpret_cast<u32*>(smem);
@@ -319,19 +310,14 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
             if (!((s_bits[b >> 5] >> (b & 31u)) & 1u)) key[j] = 0;        // not listed: no probe (dead lanes share slot 0)
         }
         table_probe_batch<K1_IPT, 0>(cells, key, cell);
-        u32 h0 = 0, h1 = 0;
+        u32 hits = 0;
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const u64 idx = base + (u64)j * WAVE + lane;
             if (idx < n) cell_out[idx] = cell[j];
-            const u32 c = (u32)__popcll(__ballot(cell[j] != 0));
-            if (j < K1_IPT / 2) h0 += c; else h1 += c;
+            hits += (u32)__popcll(__ballot(cell[j] != 0));
         }
-        if (lane == 0) {
-            mt_hits[(u64)tile * K1_MT_PER_TILE + 2 * w] = h0;
-            mt_hits[(u64)tile * K1_MT_PER_TILE + 2 * w + 1] = h1;
-            s_w[w] = h0 + h1;
-        }
+        if (lane == 0) s_w[w] = hits;
         __syncthreads();
         if (tid == 0) {
             u32 t = 0;
@@ -342,11 +328,11 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
     }
 }
 
-// K1a, LDS mode: persistent 1024-thread workgroups (two per CU); every wave walks its own 512-record chunks (two
-// mini-tiles), writes their hit counts itself and adds its sum to tile_hits[] (all-zero on entry) with one atomic.
+// K1a, LDS mode: persistent 1024-thread workgroups (two per CU); every wave walks its own 512-record chunks and adds
+// its hit count to tile_hits[] (all-zero on entry) with one atomic — no barrier after the table image is in LDS.
 __global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
                                                                   u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                                  u32* __restrict__ mt_hits, u32 n_tiles) {
+                                                                  u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 m_even = (c.m + 1u) & ~1u;
     const u32* s_code = reinterpret_cast<const u32*>(smem);
@@ -368,7 +354,7 @@ __global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __r
             const u64 idx = base + (u64)j * WAVE + lane;
             key[j] = idx < n ? cb[idx] : 0;
         }
-        u32 h0 = 0, h1 = 0;
+        u32 hits = 0;
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const u32 code = (u32)(key[j] >> 16);
@@ -376,19 +362,14 @@ __global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __r
             const u32 sl = chd_slot(code, s_disp[chd_bucket(code, c.buckets)], c.m);
             const u32 v = (fam && s_code[sl] == code) ? s_idx[sl] : 0u;       // empty slots carry index 0
             cell[j] = v;
-            const u32 cnt = (u32)__popcll(__ballot(v != 0));
-            if (j < K1_IPT / 2) h0 += cnt; else h1 += cnt;
+            hits += (u32)__popcll(__ballot(v != 0));
         }
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const u64 idx = base + (u64)j * WAVE + lane;
             if (idx < n) cell_out[idx] = cell[j];
         }
-        if (lane == 0) {
-            mt_hits[2ull * chunk] = h0;
-            mt_hits[2ull * chunk + 1] = h1;
-            if (h0 + h1) atomicAdd(&tile_hits[chunk / (u32)K1_WAVES], h0 + h1);
-        }
+        if (lane == 0 && hits) atomicAdd(&tile_hits[chunk / (u32)K1_WAVES], hits);
     }
 }
 
