@@ -265,6 +265,7 @@ static void par_run(int n_threads, void (*fn)(void *, int), void *arg)
 
 /* ---- step 2: parallel inflate ---- */
 int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);   /* inflate_fast.c */
+uint32_t fastf_crc32(const unsigned char *buf, size_t len);                               /* crc32_fast.c */
 
 typedef struct { fastf_bam_t *b; size_t next; int err; int use_zlib; pthread_mutex_t mu; } inflate_job;
 
@@ -285,14 +286,14 @@ static void inflate_worker(void *vp, int widx)
             const unsigned char *tail = b->cbuf + k->coff + k->clen;       /* crc32, isize */
             /* own decoder first (about 3x zlib); zlib is the referee whenever it declines or the CRC disagrees */
             if (!j->use_zlib && fastf_inflate_raw(b->cbuf + k->coff, k->clen, b->nbuf + k->uoff, k->isize) == 0 &&
-                (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->nbuf + k->uoff, k->isize) == rd32(tail))
+                fastf_crc32(b->nbuf + k->uoff, k->isize) == rd32(tail))
                 continue;
             inflateReset(&z);
             z.next_in = b->cbuf + k->coff; z.avail_in = k->clen;
             z.next_out = b->nbuf + k->uoff; z.avail_out = k->isize;
             int r = inflate(&z, Z_FINISH);
             if (r != Z_STREAM_END || z.avail_out != 0 ||
-                (uint32_t)crc32(crc32(0L, Z_NULL, 0), b->nbuf + k->uoff, k->isize) != rd32(tail)) { j->err = 1; break; }
+                fastf_crc32(b->nbuf + k->uoff, k->isize) != rd32(tail)) { j->err = 1; break; }
         }
     }
     inflateEnd(&z);

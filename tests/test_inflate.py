@@ -93,3 +93,20 @@ def test_corrupted_streams_fail_cleanly():
     for _ in range(300):                                             # pure noise
         junk = rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8).tobytes()
         inflate(junk, int(rng.integers(0, 5000)))
+
+
+def test_crc32_matches_zlib():
+    """the carry-less-multiplication CRC-32 of the BGZF reader (crc32_fast.c) against zlib on every length class"""
+    import ctypes as C
+    import zlib as Z
+    L = _lib.lib()
+    L.fastf_crc32.argtypes = [C.c_char_p, C.c_size_t]
+    L.fastf_crc32.restype = C.c_uint32
+    L.fastf_crc32_selftest.restype = C.c_int
+    assert L.fastf_crc32_selftest() in (0, 1)
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes()
+    for n in list(range(0, 200)) + [255, 256, 1000, 4095, 4096, 65280, 65535, 65536, 299_999]:
+        for off in (0, 1, 7):
+            b = data[off:off + n]
+            assert L.fastf_crc32(b, len(b)) == Z.crc32(b)

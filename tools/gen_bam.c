@@ -1,5 +1,8 @@
 /* gen_bam.c — fast synthetic BAM generator for end-to-end benchmarks (test tooling, not product).
- *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len]
+ *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len]
+ * seq_len > 0 gives records the size and content mix of a Cell Ranger BAM: mapped reads with one CIGAR word, seq_len
+ * packed bases, binned qualities (long runs of 'F' with ':' and ','), and the CR/CY/UR/UY/NH/AS/RG tags in front of
+ * CB/xf/GX/UB; blocks are then deflated at level 6 as samtools does.
  * Every record: unmapped, tags CB:Z (95 % from the list, 5 % random), xf:C (85 % 25/17), GX:Z, UB:Z.
  * gcc -O2 -o gen_bam gen_bam.c -lz */
 #include <stdint.h>
@@ -19,11 +22,11 @@ static char **read_col1(const char *path, size_t *n)
     fclose(f); return v;
 }
 
-static FILE *out; static unsigned char blk[0xff00]; static size_t blen;
+static FILE *out; static unsigned char blk[0xff00]; static size_t blen; static int g_level = 1;
 static void flush_block(void)
 {
     unsigned char comp[0x10000 + 64]; z_stream z; memset(&z, 0, sizeof z);
-    deflateInit2(&z, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    deflateInit2(&z, g_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
     z.next_in = blk; z.avail_in = (uInt)blen; z.next_out = comp + 18; z.avail_out = sizeof comp - 26;
     deflate(&z, Z_FINISH); size_t clen = z.total_out; deflateEnd(&z);
     static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
@@ -43,17 +46,36 @@ int main(int argc, char **argv)
     if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len]\n"); return 1; }
     size_t nb, ng; char **bar = read_col1(argv[2], &nb), **gen = read_col1(argv[3], &ng);
     size_t n = strtoull(argv[4], NULL, 10); uint64_t seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 1; int ul = argc > 6 ? atoi(argv[6]) : 10;
+    int sl = argc > 7 ? atoi(argv[7]) : 0; if (sl > 150) sl = 150; if (sl > 0) g_level = 6;
     s[0] = seed * 0x9E3779B97F4A7C15ull + 1; s[1] = seed ^ 0xD1B54A32D192ED03ull; for (int i = 0; i < 8; i++) rnd();
     out = fopen(argv[1], "wb"); if (!out) { perror(argv[1]); return 1; }
     static char obuf[1 << 22]; setvbuf(out, obuf, _IOFBF, sizeof obuf);
     const char *text = "@HD\tVN:1.6\tSO:unsorted\n"; int32_t lt = (int32_t)strlen(text), nref = 0;
     put("BAM\1", 4); put(&lt, 4); put(text, lt); put(&nref, 4);
-    unsigned char rec[512];
+    unsigned char rec[1024];
     for (size_t i = 0; i < n; i++) {
         unsigned char *p = rec + 4; int32_t m1 = -1, z = 0; char name[24]; int nl = snprintf(name, sizeof name, "r%zu", i) + 1;
         memcpy(p, &m1, 4); memcpy(p + 4, &m1, 4); p[8] = (unsigned char)nl; p[9] = 0; uint16_t bin = 4680, nc = 0, fl = 4;
         memcpy(p + 10, &bin, 2); memcpy(p + 12, &nc, 2); memcpy(p + 14, &fl, 2); memcpy(p + 16, &z, 4);
-        memcpy(p + 20, &m1, 4); memcpy(p + 24, &m1, 4); memcpy(p + 28, &z, 4); p += 32; memcpy(p, name, nl); p += nl;
+        memcpy(p + 20, &m1, 4); memcpy(p + 24, &m1, 4); memcpy(p + 28, &z, 4);
+        if (sl > 0) {                               /* mapped read: refID 0, a position, one CIGAR word, bases, qualities */
+            int32_t ref = 0, pos = (int32_t)(i * 37 % 100000000); uint16_t one = 1, f0 = (uint16_t)((rnd() & 1) ? 16 : 0); int32_t lseq = sl;
+            memcpy(p, &ref, 4); memcpy(p + 4, &pos, 4); p[9] = 255; memcpy(p + 12, &one, 2); memcpy(p + 14, &f0, 2); memcpy(p + 16, &lseq, 4);
+        }
+        p += 32; memcpy(p, name, nl); p += nl;
+        if (sl > 0) {
+            uint32_t cig = ((uint32_t)sl << 4) | 0; memcpy(p, &cig, 4); p += 4;
+            for (int k = 0; k < (sl + 1) / 2; k++) { uint64_t q = rnd(); *p++ = (unsigned char)(((1 << (q & 3)) << 4) | (1 << ((q >> 2) & 3))); }
+            for (int k = 0; k < sl;) { uint64_t q = rnd(); int run = 1 + (int)(q & 31); unsigned char qv = (q >> 5) % 10 < 8 ? 37 : ((q >> 9) & 1 ? 25 : 11);
+                                       while (run-- && k < sl) { *p++ = qv; k++; } }
+            uint64_t q = rnd();
+            memcpy(p, "NHC\1HIC\1ASC", 11); p += 11; *p++ = (unsigned char)(sl - (q & 3)); memcpy(p, "nMC", 3); p += 3; *p++ = (unsigned char)(q >> 4 & 1);
+            memcpy(p, "RGZsample:0:1:HXXXXXXXX:1", 26); p += 26;
+            *p++ = 'C'; *p++ = 'R'; *p++ = 'Z'; for (int k = 0; k < 16; k++) *p++ = "ACGT"[(q >> (8 + 2 * k)) & 3]; *p++ = 0;
+            *p++ = 'C'; *p++ = 'Y'; *p++ = 'Z'; memset(p, 'F', 16); p += 16; *p++ = 0;
+            q = rnd(); *p++ = 'U'; *p++ = 'R'; *p++ = 'Z'; for (int k = 0; k < ul; k++) *p++ = "ACGT"[(q >> (2 * k)) & 3]; *p++ = 0;
+            *p++ = 'U'; *p++ = 'Y'; *p++ = 'Z'; memset(p, 'F', ul); p += ul; *p++ = 0;
+        }
         uint64_t r = rnd();
         *p++ = 'C'; *p++ = 'B'; *p++ = 'Z';
         if ((r & 1023) < 51) { for (int k = 0; k < 16; k++) *p++ = "ACGT"[(rnd() >> 7) & 3]; memcpy(p, "-1", 3); p += 3; }

@@ -1,5 +1,5 @@
 /* diagnostic: the BAM tag reader + registering key dictionary under sanitizers (CPU build only):
- *   gcc -O1 -g -fsanitize=address,undefined -Iinclude -Ifastf_amd/csrc tools/san_tags.c fastf_amd/csrc/{host_io,host_prims,inflate_fast}.c -lz -lpthread -o build/san_tags
+ *   gcc -O1 -g -fsanitize=address,undefined -Iinclude -Ifastf_amd/csrc tools/san_tags.c fastf_amd/csrc/{host_io,host_prims,inflate_fast,crc32_fast}.c -lz -lpthread -o build/san_tags
  *   (and -fsanitize=thread);  build/san_tags file.bam CB CR */
 #include "host_io.h"
 #include <stdio.h>
