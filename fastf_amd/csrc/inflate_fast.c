@@ -203,7 +203,57 @@ int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
         } else return 1;
 
         /* ---- symbols of one block ---- */
-        for (;;) {
+        /* Fast loop: while at least 16 input bytes and 320 output bytes remain, a refill always delivers >= 56 bits and
+         * no symbol can overrun the output (a match is at most 258 bytes, its word copy may run 7 bytes past it, and up to
+         * three literals precede it), so nothing inside checks a bound.  56 bits cover a whole length/distance pair
+         * (15 + 5 + 15 + 13 = 48), so one refill per iteration is enough. */
+        int eob = 0;
+        while (b.in_end - b.in >= 16 && oend - op >= 320) {
+            refill(&b);
+            uint32_t e = L[peek(&b, LIT_BITS)];
+            int kind = (e >> 4) & 15;
+            if (kind == K_LIT) {                                 /* up to three literals per refill (3 x 15 bits at most) */
+                drop(&b, e & 15); *op++ = (uint8_t)(e >> 16);
+                e = L[peek(&b, LIT_BITS)]; kind = (e >> 4) & 15;
+                if (kind == K_LIT) {
+                    drop(&b, e & 15); *op++ = (uint8_t)(e >> 16);
+                    e = L[peek(&b, LIT_BITS)]; kind = (e >> 4) & 15;
+                    if (kind == K_LIT) { drop(&b, e & 15); *op++ = (uint8_t)(e >> 16); continue; }
+                }
+                if (b.cnt < 48) refill(&b);                      /* a length/distance pair may follow */
+            }
+            if (kind == K_SUB) {
+                drop(&b, LIT_BITS);
+                e = L[(e >> 16) + peek(&b, (e >> 8) & 255)];
+                kind = (e >> 4) & 15;
+            }
+            drop(&b, e & 15);
+            if (kind == K_LIT) { *op++ = (uint8_t)(e >> 16); continue; }
+            if (kind == K_EOB) { eob = 1; break; }
+            if (kind != K_LEN) return 1;
+            const int xb = (e >> 8) & 255;
+            const uint32_t len = (e >> 16) + peek(&b, xb); drop(&b, xb);
+            uint32_t d = D[peek(&b, DIST_BITS)];
+            int dk = (d >> 4) & 15;
+            if (dk == K_SUB) { drop(&b, DIST_BITS); d = D[(d >> 16) + peek(&b, (d >> 8) & 255)]; dk = (d >> 4) & 15; }
+            if (dk != K_DIST) return 1;
+            drop(&b, d & 15);
+            const int dxb = (d >> 8) & 255;
+            const uint32_t dist = (d >> 16) + peek(&b, dxb); drop(&b, dxb);
+            if (b.cnt < 0 || dist > (size_t)(op - out)) return 1;
+            const uint8_t *src = op - dist;
+            if (dist >= 8) {
+                uint8_t *q = op; const uint8_t *sp = src; uint32_t left = len;
+                do { uint64_t w; memcpy(&w, sp, 8); memcpy(q, &w, 8); q += 8; sp += 8; left = left > 8 ? left - 8 : 0; } while (left);
+            } else if (dist == 1) {
+                memset(op, *src, len);
+            } else {
+                for (uint32_t i = 0; i < len; i++) op[i] = src[i];
+            }
+            op += len;
+        }
+        /* careful loop: the ends of the buffers */
+        while (!eob) {
             refill(&b);                                          /* >= 56 bits unless the input is nearly exhausted */
             uint32_t e = L[peek(&b, LIT_BITS)];
             int kind = (e >> 4) & 15;
@@ -218,9 +268,6 @@ int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
             if (kind == K_LIT) {
                 if (op >= oend) return 1;
                 *op++ = (uint8_t)(e >> 16);
-                /* a second literal out of the same refill, the common case in text-like data */
-                uint32_t e2 = L[peek(&b, LIT_BITS)];
-                if (((e2 >> 4) & 15) == K_LIT && (int)(e2 & 15) <= b.cnt && op < oend) { drop(&b, e2 & 15); *op++ = (uint8_t)(e2 >> 16); }
                 continue;
             }
             if (kind == K_EOB) break;
