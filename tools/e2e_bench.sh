@@ -1,7 +1,9 @@
 #!/bin/bash
-# End-to-end CLI throughput (BAM file -> three .gz outputs) on the GPU box.  usage: tools/e2e_bench.sh [n_records]
+# End-to-end CLI throughput (BAM file -> three .gz outputs) on the GPU box.
+# usage: tools/e2e_bench.sh [n_records] [seq_len]     seq_len > 0: records shaped like Cell Ranger's (bases, qualities, 14 tags)
 set -e
 N=${1:-10000000}
+SL=${2:-0}
 R=$(cd "$(dirname "$0")/.." && pwd)
 W=${TMPDIR:-/tmp}/fastf_e2e; mkdir -p $W/out
 python3 - <<PY
@@ -10,8 +12,8 @@ from fastf_amd import synth
 bt, ft, _, _ = synth.make_lists(10000, 30000, seed=4242)
 open("$W/bar.tsv", "wb").write(bt); open("$W/feat.tsv", "wb").write(ft)
 PY
-[ -x $R/build/gen_bam ] || gcc -O2 -o $R/build/gen_bam $R/tools/gen_bam.c -lz
-$R/build/gen_bam $W/in.bam $W/bar.tsv $W/feat.tsv $N 7
+gcc -O2 -o $R/build/gen_bam $R/tools/gen_bam.c -lz
+$R/build/gen_bam $W/in.bam $W/bar.tsv $W/feat.tsv $N 7 10 $SL
 ls -la $W/in.bam | awk '{print "BAM bytes", $5}'
 echo "host cores visible: $(nproc)"
 run() {
