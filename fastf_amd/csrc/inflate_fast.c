@@ -113,7 +113,7 @@ static int build_table(const uint8_t *lens, int n_sym, int is_dist, int tbits, u
 
 typedef struct { const uint8_t *in, *in_end; uint64_t buf; int cnt; } bitrd;
 
-static inline void refill(bitrd *b)
+static inline __attribute__((always_inline)) void refill(bitrd *b)
 {
     if (b->in_end - b->in >= 8) {
         uint64_t w; memcpy(&w, b->in, 8);
@@ -124,10 +124,10 @@ static inline void refill(bitrd *b)
         while (b->cnt <= 56 && b->in < b->in_end) { b->buf |= (uint64_t)*b->in++ << b->cnt; b->cnt += 8; }
     }
 }
-static inline uint32_t peek(const bitrd *b, int n) { return (uint32_t)(b->buf & ((1ull << n) - 1)); }
-static inline void drop(bitrd *b, int n) { b->buf >>= n; b->cnt -= n; }
+static inline __attribute__((always_inline)) uint32_t peek(const bitrd *b, int n) { return (uint32_t)(b->buf & ((1ull << n) - 1)); }
+static inline __attribute__((always_inline)) void drop(bitrd *b, int n) { b->buf >>= n; b->cnt -= n; }
 
-int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+static inline __attribute__((always_inline)) int inflate_body(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 {
     bitrd b = { in, in + in_len, 0, 0 };
     uint8_t *op = out, *const oend = out + out_len;
@@ -242,7 +242,17 @@ int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
             const uint32_t dist = (d >> 16) + peek(&b, dxb); drop(&b, dxb);
             if (b.cnt < 0 || dist > (size_t)(op - out)) return 1;
             const uint8_t *src = op - dist;
-            if (dist >= 8) {
+            if (dist >= 16) {                                    /* 16 bytes at a time, the first two without a loop test */
+                uint8_t *q = op; const uint8_t *sp = src;
+                uint64_t w0, w1;
+                memcpy(&w0, sp, 8); memcpy(&w1, sp + 8, 8); memcpy(q, &w0, 8); memcpy(q + 8, &w1, 8);
+                if (len > 16) {
+                    memcpy(&w0, sp + 16, 8); memcpy(&w1, sp + 24, 8); memcpy(q + 16, &w0, 8); memcpy(q + 24, &w1, 8);
+                    for (uint32_t done = 32; done < len; done += 16) {
+                        memcpy(&w0, sp + done, 8); memcpy(&w1, sp + done + 8, 8); memcpy(q + done, &w0, 8); memcpy(q + done + 8, &w1, 8);
+                    }
+                }
+            } else if (dist >= 8) {
                 uint8_t *q = op; const uint8_t *sp = src; uint32_t left = len;
                 do { uint64_t w; memcpy(&w, sp, 8); memcpy(q, &w, 8); q += 8; sp += 8; left = left > 8 ? left - 8 : 0; } while (left);
             } else if (dist == 1) {
@@ -298,4 +308,27 @@ int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
         }
     }
     return op == oend ? 0 : 1;
+}
+
+/* The same body compiled twice: with BMI2 the variable shifts and masks of the bit reader are single instructions
+ * (shrx / bzhi); picked once per process by CPUID. */
+#if defined(__x86_64__)
+__attribute__((target("bmi2"))) static int inflate_bmi2(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+    return inflate_body(in, in_len, out, out_len);
+}
+#endif
+static int inflate_generic(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+    return inflate_body(in, in_len, out, out_len);
+}
+
+int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+#if defined(__x86_64__)
+    static int have_bmi2 = -1;
+    if (have_bmi2 < 0) have_bmi2 = __builtin_cpu_supports("bmi2") ? 1 : 0;
+    if (have_bmi2) return inflate_bmi2(in, in_len, out, out_len);
+#endif
+    return inflate_generic(in, in_len, out, out_len);
 }
