@@ -102,6 +102,7 @@ struct fastf_engine {
     bool fully_sorted = false;
     // workspace
     DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
+    DevBuf d_heads, d_rowbase;           // K3's tile counts / bases: not shared with K1, so K1 of the next batch may run beside K3 (other stream)
     const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
     // timing
     bool timing = false;
@@ -387,7 +388,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt};
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -449,12 +450,13 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
         e->cells_cached_for = nullptr;
         if (e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
     }
-    if (e->d_tilecnt.bytes < std::max(t1, t3) * sizeof(u32)) {       // (re)allocated: establish the all-zero invariant
-        if (e->d_tilecnt.ensure(std::max(t1, t3) * sizeof(u32))) return 1;
+    if (e->d_heads.ensure(t3 * sizeof(u32)) || e->d_rowbase.ensure(t3 * sizeof(u64))) return 1;
+    if (e->d_tilecnt.bytes < t1 * sizeof(u32)) {                     // (re)allocated: establish the all-zero invariant
+        if (e->d_tilecnt.ensure(t1 * sizeof(u32))) return 1;
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemset(e->d_tilecnt.p, 0, e->d_tilecnt.bytes));
     }
-    if (e->d_tilebase.ensure(std::max(t1, t3) * sizeof(u64))) return 1;
+    if (e->d_tilebase.ensure(t1 * sizeof(u64))) return 1;
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
@@ -659,20 +661,19 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
     p.low_skip = UMI_ROWS ? 0 : low_skip;
-    p.tile_heads = (u32*)e->d_tilecnt.p; p.row_base = (const u64*)e->d_tilebase.p;
+    p.tile_heads = (u32*)e->d_heads.p; p.row_base = (const u64*)e->d_rowbase.p;
     p.tile_carry = (u32*)e->d_tilecarry.p;
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
     p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
     t_begin(e, s);
     hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
-                       (u64*)e->d_tilebase.p, tiles, nrows);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_heads.p,
+                       (u64*)e->d_rowbase.p, tiles, nrows);
     hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,
-                       (const u64*)e->d_tilebase.p, count, d_n);
+                       (const u64*)e->d_rowbase.p, count, d_n);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
-    e->cells_cached_for = nullptr;          // d_tilecnt / d_tilebase were reused
     return 0;
 }
 

@@ -13,9 +13,20 @@ runs K1 on it; a key belongs to shard hash(cell_index) mod G, so all UMIs of a
   5. COO rows stay on their shard (gather_coo() merges them); the three counters are summed over ranks on demand
      (global_counters(): one all_reduce, outside the data path).
 
+With more than one shard on GPUs the pass is software-pipelined over two HIP streams: the K1 stage of step i+1
+(hit count, draw-rank base, probe/filter/pack, count exchange) runs on a side stream while the key exchange, sort and
+reduce of step i run on the caller's stream — K1 is HBM-bound, the exchange is xGMI-bound, so the two overlap; the
+per-step buffers K1 writes (shard buffers, counters) are double-buffered and an event keeps K1 from overwriting a shard
+buffer its exchange is still sending.  In that mode the two tiny collectives of the K1 stage travel as host integers over
+a gloo side group (RCCL would queue them behind the running key exchange, and the host needs the counts anyway).
+``FASTF_DIST_PIPELINE=0`` runs everything on one stream with every collective on the default group.
+
 The device stages are injected (``stages``): the default is the HIP engine; the CPU test
 suite drives the same orchestration over gloo with test doubles.
 """
+import os
+import sys
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -76,24 +87,45 @@ class HipStages:
 class ShardedPass:
     """Buffers + orchestration of one sharded pass; reusable across steps (bench loop)."""
 
-    def __init__(self, stages, n_local_max, device, group=None):
+    def __init__(self, stages, n_local_max, device, group=None, world=None, rank=None):
         self.st, self.dev, self.group = stages, device, group
-        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.G = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         # gloo has no all_to_all on device tensors: with that backend and HBM buffers every collective is staged
         # through host memory (rehearsal of the N>1 path on a box whose ranks share one GPU; RCCL refuses that)
         self.host_staged = (dist.is_initialized() and dist.get_backend(group) != "nccl"
                             and torch.device(device).type == "cuda")
+        self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
         G, n = self.G, int(n_local_max)
         i64, i32 = torch.int64, torch.int32
         self.stride = n
-        self.keys_out = torch.empty((G, n), dtype=i64, device=device)
-        # per-step scalars live in one buffer so a step clears them with a single fill, but 512 B apart:
-        # atomics (key_counts, counters) and the plain loads of draw_base must not share a cache line
-        self._small = torch.zeros(192, dtype=i64, device=device)
-        self.key_counts = self._small[:G]
-        self.counters = self._small[64:68]
-        self.draw_base = self._small[128:129]
+        self.pipelined = (G > 1 and torch.device(device).type == "cuda"
+                          and os.environ.get("FASTF_DIST_PIPELINE", "1") != "0")
+        self.k1_stream = torch.cuda.Stream(device) if self.pipelined else None
+        # The two tiny collectives of the K1 stage (one u64 per rank, G counts per rank) go over a gloo side group on host
+        # integers when the pass is pipelined: RCCL runs the collectives of one communicator in issue order, so on it
+        # they would queue behind the previous step's key exchange — the very transfer the K1 stage is meant to overlap —
+        # and their results are needed on the host anyway (the exchange sizes).
+        self.small_group = None
+        if self.pipelined and dist.is_initialized():
+            if dist.get_backend(group) == "gloo":
+                self.small_group = group
+            else:
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: loopback (the host name may not resolve)
+                try:
+                    self.small_group = dist.new_group(backend="gloo")
+                except Exception as exc:                               # same image on every rank: fails everywhere or nowhere
+                    print("fastf_amd.dist: no gloo side group (%s); running the pass on one stream" % exc, file=sys.stderr)
+                    self.pipelined, self.k1_stream = False, None
+        nb = 2 if self.pipelined else 1
+        # what K1 writes per step, one set per pipeline slot.  The per-step scalars live in one buffer so a step clears
+        # them with a single fill, but 512 B apart: atomics (key_counts, counters) and the plain loads of draw_base
+        # must not share a cache line
+        self._keys_out_slots = [torch.empty((G, n), dtype=i64, device=device) for _ in range(nb)]
+        self._small_slots = [torch.zeros(192, dtype=i64, device=device) for _ in range(nb)]
+        self._slot_free = [None] * nb          # event: the exchange that read this slot's shard buffers has finished
+        self._step = 0
+        self._use_slot(0)
         self.recv_counts = torch.zeros(G, dtype=i64, device=device)
         self.hits = torch.zeros(1, dtype=i64, device=device)
         self.all_hits = torch.zeros(G, dtype=i64, device=device)
@@ -111,38 +143,76 @@ class ShardedPass:
         self._verified = False     # the group-only sort was checked against its run cap for the current result
         self._counters_reduced = True
 
+    def _use_slot(self, b):
+        G = self.G
+        self.keys_out = self._keys_out_slots[b]
+        self._small = self._small_slots[b]
+        self.key_counts = self._small[:G]
+        self.counters = self._small[64:68]
+        self.draw_base = self._small[128:129]
+
+    def _k1_stage(self, cb, gx, umi, meta, n, draws):
+        """hit count → draw-rank base → probe/filter/pack → count exchange; returns (send, recv) counts on the host"""
+        G, st = self.G, self.st
+        self._small.zero_()
+        st.count_hits(cb, n, self.hits)
+        if self.pipelined:                                                   # host integers over the gloo side group
+            all_h = torch.empty(G, dtype=torch.int64)
+            self._gather_small(all_h, self.hits.cpu())
+            self.draw_base.fill_(int(all_h[:self.rank].sum()))
+            st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
+                          self.key_counts, self.counters)
+            send = self.key_counts.cpu()
+            recv = torch.empty(G, dtype=torch.int64)
+            self._exchange_small(recv, send)
+            return send.tolist(), recv.tolist()
+        self._all_gather(self.all_hits, self.hits)
+        self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
+        st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
+                      self.key_counts, self.counters)
+        self._all_to_all_single(self.recv_counts, self.key_counts)
+        both = torch.cat([self.key_counts, self.recv_counts]).tolist()       # the one host sync of the pass
+        return both[:G], both[G:]
+
+    def _gather_small(self, out_cpu, inp_cpu):
+        dist.all_gather_into_tensor(out_cpu, inp_cpu, group=self.small_group)
+
+    def _exchange_small(self, out_cpu, inp_cpu):
+        dist.all_to_all_single(out_cpu, inp_cpu, group=self.small_group)
+
     def run(self, cb, gx, umi, meta, n, draws):
         """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident)."""
         G, st = self.G, self.st
-        self._small.zero_()
-        # 1. draw-rank base
         if G > 1:
-            st.count_hits(cb, n, self.hits)
-            self._all_gather(self.all_hits, self.hits)
-            self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
-        # 2. K1
-        st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
-                      self.key_counts, self.counters)
-        # 3. the exchange
-        if G > 1:
-            self._all_to_all_single(self.recv_counts, self.key_counts)
-            both = torch.cat([self.key_counts, self.recv_counts]).tolist()   # the one host sync of the pass
-            send, recv = both[:G], both[G:]
+            b = self._step % len(self._small_slots)
+            self._step += 1
+            self._use_slot(b)
+            if self.pipelined:
+                main = torch.cuda.current_stream(self.dev)
+                k1 = self.k1_stream
+                if self._step == 1:
+                    k1.wait_stream(main)                 # the inputs were produced on the caller's stream
+                with torch.cuda.stream(k1):
+                    if self._slot_free[b] is not None:
+                        k1.wait_event(self._slot_free[b])
+                    send, recv = self._k1_stage(cb, gx, umi, meta, n, draws)
+                main.wait_stream(k1)                     # (the host has already waited for the counts)
+            else:
+                send, recv = self._k1_stage(cb, gx, umi, meta, n, draws)
             self.n_recv = int(sum(recv))
-            if dist.get_backend(self.group) == "nccl":
-                outs, o = [], 0
-                for c in recv:
-                    outs.append(self.recv[o:o + c]); o += c
-                ins = [self.keys_out[g, :send[g]] for g in range(G)]
-                dist.all_to_all(outs, ins, group=self.group)
-            else:                                       # gloo: contiguous send buffer
-                flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
-                self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
+            self._exchange_keys(send, recv)
+            if self.pipelined:                          # this slot's shard buffers may be written again after this point
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.dev))
+                self._slot_free[b] = ev
             self.d_n = self._d_n_buf
             self.d_n.fill_(self.n_recv)
             keys = self.recv
             self._counters_reduced = False              # summed over ranks on demand (global_counters), not per step
         else:
+            self._small.zero_()
+            st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
+                          self.key_counts, self.counters)
             self.d_n = self.key_counts[:1]              # the device reads the key count where K1b accumulated it
             self.n_recv = n                             # upper bound
             keys = self.keys_out.view(-1)
@@ -151,6 +221,19 @@ class ShardedPass:
                                      self.count, self.nnz, hist_ready=(G == 1))
         self._keys_buf = keys
         self._verified = False
+
+    def _exchange_keys(self, send, recv):
+        """the one exchange of the pass: shard buffer g of this rank → rank g; what arrives lands in self.recv"""
+        G = self.G
+        if self._nccl:
+            outs, o = [], 0
+            for c in recv:
+                outs.append(self.recv[o:o + c]); o += c
+            ins = [self.keys_out[g, :send[g]] for g in range(G)]
+            dist.all_to_all(outs, ins, group=self.group)
+        else:                                           # gloo: contiguous send buffer
+            flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
+            self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
 
     # ---- collectives: direct on RCCL (and on CPU tensors over gloo), staged through the host otherwise ----
     def _all_gather(self, out, inp):

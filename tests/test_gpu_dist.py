@@ -77,3 +77,65 @@ def test_sharded_pass_ranks_share_one_gpu(world, kw):
         np.testing.assert_array_equal(k, ora["count"].astype(np.int64))
         hits, sampled, valid, _ = counters
         assert (sampled, valid) == (ora["sampled"], ora["valid"])
+
+
+def test_pipelined_pass_with_asynchronous_loopback_exchange():
+    """The two-stream pipeline of ShardedPass under real asynchrony: one process plays shard 0 of 2, the collectives
+    are device-side copies on the current stream (nothing synchronises the host but the count read-back), and the
+    input alternates between two different record slices from step to step — a shard buffer or counter slot reused
+    too early shows up as a wrong matrix.  Each step's rows are checked against the oracle restricted to shard 0's cells."""
+    import torch
+    import fastf_amd as F
+    from fastf_amd.dist import HipStages, ShardedPass, owner_of_cell
+
+    class Loopback(ShardedPass):
+        def _all_gather(self, out, inp):
+            out.zero_(); out[self.rank:self.rank + 1].copy_(inp)          # the other shard holds no records
+
+        def _all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+            out.zero_(); out[:1].copy_(inp[:1])                           # only my own shard-0 count comes back
+
+        def _exchange_keys(self, send, recv):
+            self.recv[:send[0]].copy_(self.keys_out[0, :send[0]])
+
+        def _gather_small(self, out_cpu, inp_cpu):
+            out_cpu.zero_(); out_cpu[self.rank] = inp_cpu[0]
+
+        def _exchange_small(self, out_cpu, inp_cpu):
+            out_cpu.zero_(); out_cpu[0] = inp_cpu[0]
+
+    dev = torch.device("cuda", 0)
+    kws = [dict(n=400_000, n_bar=600, n_gene=300, rate_cell=0.9, rate_depth=0.7, umi_pool=1024, cell_dist="lognormal",
+                p_unlisted_cb=0.1, p_bad_xf=0.1, data_seed=s) for s in (21, 22)]
+    cases = [Case(**kw) for kw in kws]
+    # the same lists for both slices (same list seed is part of data_seed): rebuild the second case on the first's lists
+    cases[1].bt, cases[1].ft, cases[1].bar, cases[1].genes = cases[0].bt, cases[0].ft, cases[0].bar, cases[0].genes
+    from fastf_amd import synth
+    fl, xf, cb, gx, ub = synth.make_records(cases[1].n, cases[0].bar, cases[0].genes, seed=22, umi_pool=1024,
+                                            cell_dist="lognormal", p_unlisted_cb=0.1, p_bad_xf=0.1)
+    cases[1].flags, cases[1].xf = fl, xf
+    cases[1].cb, cases[1].gx, cases[1].ub = synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)
+    lists = cases[0].lists()
+    oras = [c.oracle() for c in cases]
+    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+    packed = [[t(a) for a in c.packed(lists)] for c in cases]
+    n = cases[0].n
+    draws = t(F.mt_draws(cases[0].seed, lists.mt_skip, n))
+    eng = F.Engine.from_lists(lists, rate_depth=cases[0].rate_depth, seed=cases[0].seed, n_shards=2, shard_rank=0, device=0)
+    eng.reserve(n, n)
+    try:
+        sp = Loopback(HipStages(eng, dev), n, dev, world=2, rank=0)
+        assert sp.pipelined
+        for step in range(12):
+            k = step % 2
+            sp.run(packed[k][0], packed[k][1], packed[k][2], packed[k][3], n, draws)
+            if step in (5, 10, 11):                                   # mid-stream and final results
+                f, c, cnt = sp.local_coo()
+                ora = oras[k]
+                mine = owner_of_cell(ora["cell"].astype(np.int64), 2) == 0
+                np.testing.assert_array_equal(c, ora["cell"].astype(np.int64)[mine])
+                np.testing.assert_array_equal(f, ora["feature"].astype(np.int64)[mine])
+                np.testing.assert_array_equal(cnt, ora["count"].astype(np.int64)[mine])
+        assert eng.dev_error_bits() == 0
+    finally:
+        eng.close()
