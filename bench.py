@@ -150,7 +150,7 @@ def main():
                                    % (N, G, args.barcodes, args.genes),
                        "records_per_gpu": N, "key_bits": eng.key_bits, "radix_passes": passes,
                        "radix_passes_executed": eng.sort_passes(sp.st.skip_low),
-                       "sharding": "cell-hash, one all-to-all" if G > 1 else "single GPU",
+                       "sharding": ("cell-hash, one all-to-all, %s" % ("3-stream pipeline" if sp.pipelined else "single stream")) if G > 1 else "single GPU",
                        "lookup_tables": eng.table_modes},
             "roofline": {"bound": "hbm", "kernel": "scatter_kernel (one 8-bit LSD radix pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

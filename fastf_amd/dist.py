@@ -13,11 +13,12 @@ runs K1 on it; a key belongs to shard hash(cell_index) mod G, so all UMIs of a
   5. COO rows stay on their shard (gather_coo() merges them); the three counters are summed over ranks on demand
      (global_counters(): one all_reduce, outside the data path).
 
-With more than one shard on GPUs the pass is software-pipelined over two HIP streams: the K1 stage of step i+1
-(hit count, draw-rank base, probe/filter/pack, count exchange) runs on a side stream while the key exchange, sort and
-reduce of step i run on the caller's stream — K1 is HBM-bound, the exchange is xGMI-bound, so the two overlap; the
-per-step buffers K1 writes (shard buffers, counters) are double-buffered and an event keeps K1 from overwriting a shard
-buffer its exchange is still sending.  In that mode the two tiny collectives of the K1 stage travel as host integers over
+With more than one shard on GPUs the pass is software-pipelined over three HIP streams: the K1 stage of step i+1
+(hit count, draw-rank base, probe/filter/pack, count exchange) on one, the key exchange of step i on another, sort and
+reduce on the caller's stream — K1 and the sort are HBM-bound, the exchange is xGMI-bound, so the exchange overlaps
+both; the buffers K1 writes (shard buffers, counters) and the receive buffer are double-buffered, and events keep K1
+from overwriting a shard buffer that is still being sent and the exchange from landing in a receive buffer that is still
+being sorted.  In that mode the two tiny collectives of the K1 stage travel as host integers over
 a gloo side group (RCCL would queue them behind the running key exchange, and the host needs the counts anyway).
 ``FASTF_DIST_PIPELINE=0`` runs everything on one stream with every collective on the default group.
 
@@ -102,6 +103,7 @@ class ShardedPass:
         self.pipelined = (G > 1 and torch.device(device).type == "cuda"
                           and os.environ.get("FASTF_DIST_PIPELINE", "1") != "0")
         self.k1_stream = torch.cuda.Stream(device) if self.pipelined else None
+        self.x_stream = torch.cuda.Stream(device) if self.pipelined else None     # the key exchange
         # The two tiny collectives of the K1 stage (one u64 per rank, G counts per rank) go over a gloo side group on host
         # integers when the pass is pipelined: RCCL runs the collectives of one communicator in issue order, so on it
         # they would queue behind the previous step's key exchange — the very transfer the K1 stage is meant to overlap —
@@ -116,7 +118,7 @@ class ShardedPass:
                     self.small_group = dist.new_group(backend="gloo")
                 except Exception as exc:                               # same image on every rank: fails everywhere or nowhere
                     print("fastf_amd.dist: no gloo side group (%s); running the pass on one stream" % exc, file=sys.stderr)
-                    self.pipelined, self.k1_stream = False, None
+                    self.pipelined, self.k1_stream, self.x_stream = False, None, None
         nb = 2 if self.pipelined else 1
         # what K1 writes per step, one set per pipeline slot.  The per-step scalars live in one buffer so a step clears
         # them with a single fill, but 512 B apart: atomics (key_counts, counters) and the plain loads of draw_base
@@ -130,7 +132,10 @@ class ShardedPass:
         self.hits = torch.zeros(1, dtype=i64, device=device)
         self.all_hits = torch.zeros(G, dtype=i64, device=device)
         self.recv_cap = G * n
-        self.recv = torch.empty(self.recv_cap, dtype=i64, device=device)
+        # the exchange of step i+1 may land while step i is still being sorted: two receive buffers when pipelined
+        self._recv_slots = [torch.empty(self.recv_cap, dtype=i64, device=device) for _ in range(nb)]
+        self._recv_free = [None] * nb          # event: sort + reduce of the step that used this receive buffer are done
+        self.recv = self._recv_slots[0]
         self.tmp = torch.empty(self.recv_cap, dtype=i64, device=device)
         self._d_n_buf = torch.zeros(1, dtype=i64, device=device)
         self.d_n = self._d_n_buf
@@ -196,15 +201,23 @@ class ShardedPass:
                     if self._slot_free[b] is not None:
                         k1.wait_event(self._slot_free[b])
                     send, recv = self._k1_stage(cb, gx, umi, meta, n, draws)
-                main.wait_stream(k1)                     # (the host has already waited for the counts)
             else:
                 send, recv = self._k1_stage(cb, gx, umi, meta, n, draws)
             self.n_recv = int(sum(recv))
-            self._exchange_keys(send, recv)
-            if self.pipelined:                          # this slot's shard buffers may be written again after this point
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.dev))
-                self._slot_free[b] = ev
+            self.recv = self._recv_slots[b]
+            if self.pipelined:
+                x = self.x_stream
+                with torch.cuda.stream(x):
+                    x.wait_stream(k1)                    # this step's shard buffers are complete
+                    if self._recv_free[b] is not None:
+                        x.wait_event(self._recv_free[b])  # the step that last used this receive buffer is sorted and reduced
+                    self._exchange_keys(send, recv)
+                    ev = torch.cuda.Event()
+                    ev.record(x)
+                self._slot_free[b] = ev                   # K1 may write this slot's shard buffers again after the exchange
+                main.wait_event(ev)
+            else:
+                self._exchange_keys(send, recv)
             self.d_n = self._d_n_buf
             self.d_n.fill_(self.n_recv)
             keys = self.recv
@@ -219,6 +232,10 @@ class ShardedPass:
         # 4. local sort + reduce
         self.sorted = st.sort_reduce(keys, self.tmp, self.d_n, self.n_recv, self.feature, self.cell,
                                      self.count, self.nnz, hist_ready=(G == 1))
+        if G > 1 and self.pipelined:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._recv_free[b] = ev
         self._keys_buf = keys
         self._verified = False
 
