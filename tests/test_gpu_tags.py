@@ -181,3 +181,33 @@ def test_large_bam(tmp_path):
         want, total, valid = O.run_extract(np.ones(c.n), vals=c.S(vals))
         got, n, nv = extract_text(path, tag, 0)
         assert got == want and nv == valid
+
+
+def test_records_the_reference_cannot_handle_are_skipped_not_fatal(tmp_path):
+    """CB without CR is a NULL dereference in the reference (extract.c:102-103); an integer-typed tag read as a string
+    is one too (extract.c:189); -T values other than 0/1 fall through its switch.  Defined behaviour here: skip + warn."""
+    from fastf_amd import synth
+    n = 5000
+    rng = np.random.default_rng(8)
+    cbs = [b"ACGTACGTACGTAC%s-1" % (b"AC", b"GT", b"TT")[i % 3] for i in range(n)]
+    crs = [b"ACGTACGTACGTAC%s" % (b"AC", b"GT", b"NN")[int(x)] for x in rng.integers(0, 3, n)]
+    has_cr = rng.random(n) > 0.2
+    z = np.zeros(n, dtype=np.uint8); e = np.array([b""] * n, dtype="S1")
+
+    def aux(i):
+        a = synth.aux_Z(b"CB", cbs[i]) + synth.aux_int(b"xf", 25, b"C")
+        if has_cr[i]:
+            a += synth.aux_Z(b"CR", crs[i])
+        return a
+    path = str(tmp_path / "u.bam")
+    synth.write_bam(path, z, z.astype(np.int32), e, e, e, extra_aux=aux)
+    want, n_read, undef = O.run_crb(np.ones(n), has_cr, TagCase.S(cbs), TagCase.S(crs))
+    got, nr = crb_text(path)
+    assert nr == n_read == n and undef == int((~has_cr).sum())
+    assert got == want
+    # string mode on the integer tag xf: every record is "valid" (the tag exists) but nothing can be inserted
+    got, nr, nv = extract_text(path, b"xf", 0)
+    assert got == b"" and (nr, nv) == (n, n)
+    # -T 7: the reference's switch has no such case → counts only
+    got, nr, nv = extract_text(path, b"CB", 7)
+    assert got == b"" and (nr, nv) == (n, n)
