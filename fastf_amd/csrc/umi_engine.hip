@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -778,10 +779,18 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     char* hs = (char*)e->h_stage[cur];
     char* ds = (char*)e->d_stage[cur].p;
     const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_draw = cap * 24;
+    // staging: three streams of 8 bytes per record, copied side by side (the caller's thread also fills the draws)
+    std::thread t_gx, t_um;
+    const bool par = n >= (1u << 18);
+    if (par) {
+        t_gx = std::thread([=] { memcpy(hs + o_gx, b->gx_key + off, n * 8); });
+        t_um = std::thread([=] { memcpy(hs + o_umi, b->umi + off, n * 4); memcpy(hs + o_meta, b->meta + off, n * 4); });
+    } else {
+        memcpy(hs + o_gx, b->gx_key + off, n * 8);
+        memcpy(hs + o_umi, b->umi + off, n * 4);
+        memcpy(hs + o_meta, b->meta + off, n * 4);
+    }
     memcpy(hs, b->cb_key + off, n * 8);
-    memcpy(hs + o_gx, b->gx_key + off, n * 8);
-    memcpy(hs + o_umi, b->umi + off, n * 4);
-    memcpy(hs + o_meta, b->meta + off, n * 4);
     size_t nd;
     if (draws) { nd = std::min(n_draws, n); memcpy(hs + o_draw, draws, nd * 4); }
     else {
@@ -793,6 +802,7 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
         nd = n;
         memcpy(hs + o_draw, e->pending_draws.data(), n * 4);
     }
+    if (par) { t_gx.join(); t_um.join(); }
     hipStream_t sc = e->s_copy, sk = e->s_compute;
     HIP_OK(hipMemcpyAsync(ds, hs, n * 8, hipMemcpyHostToDevice, sc));
     HIP_OK(hipMemcpyAsync(ds + o_gx, hs + o_gx, n * 8, hipMemcpyHostToDevice, sc));
