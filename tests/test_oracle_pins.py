@@ -137,3 +137,16 @@ def test_mixed_length_blobs_collapse_like_sqlite():
         assert (O.encode_dna(a) == O.encode_dna(b)) == same
     assert O.encode_dna(b"ACGTN") is None
     assert O.encode_dna(b"") == b""
+
+
+def test_config0_digest_fixture():
+    """BASELINE configs[0] through the oracle: counters, row count and output digests are stable (tests/golden)"""
+    import hashlib
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config0_digest.json")))
+    for name, want in fx.items():
+        o = Case(**want["kw"]).oracle()
+        assert [o["total"], o["sampled"], o["valid"]] == want["counters"] and o["nnz"] == want["nnz"]
+        assert hashlib.md5(o["matrix"]).hexdigest() == want["matrix_md5"]
+        assert hashlib.md5(o["barcodes"]).hexdigest() == want["barcodes_md5"]
+        assert hashlib.md5(o["features"]).hexdigest() == want["features_md5"]
+        assert hashlib.md5(o["umi"]).hexdigest() == want["umi_md5"]
