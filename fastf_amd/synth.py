@@ -25,7 +25,8 @@ def _as_S(mat_u8: np.ndarray, width: int) -> np.ndarray:
     return out.view("S%d" % width).reshape(n)
 
 
-def make_lists(n_barcodes: int, n_genes: int, seed: int = 926, gene_prefix: str = "ENSG", gene_stride: int = 1):
+def make_lists(n_barcodes: int, n_genes: int, seed: int = 926, gene_prefix: str = "ENSG", gene_stride: int = 1,
+               gene_start: int = 1):
     """distinct random 16-mer barcodes + '-1'; genes '<prefix>%011d' (ids i * gene_stride + 1: a stride above 1 gives
     the sparse id range of real Ensembl lists).  Returns (barcodes_text, features_text, barcodes 'S19', genes 'S<k>')."""
     rng = np.random.default_rng(seed)
@@ -36,7 +37,7 @@ def make_lists(n_barcodes: int, n_genes: int, seed: int = 926, gene_prefix: str 
     m = _kmers(codes, 16)
     suffix = np.tile(np.frombuffer(b"-1", dtype=np.uint8), (n_barcodes, 1))
     bar = _as_S(np.concatenate([m, suffix], axis=1), 19)
-    genes = np.array([("%s%011d" % (gene_prefix, i * gene_stride + 1)).encode() for i in range(n_genes)])
+    genes = np.array([("%s%011d" % (gene_prefix, i * gene_stride + gene_start)).encode() for i in range(n_genes)])
     glen = genes.dtype.itemsize + 1
     genes = genes.astype("S%d" % glen)
     barcodes_text = b"".join(b + b"\n" for b in bar.tolist())

@@ -7,9 +7,9 @@ from oracle import oracle as O
 
 
 class Case:
-    def __init__(self, n, n_bar, n_gene, rate_cell=1.0, rate_depth=1.0, seed=926, data_seed=1, umi_copies=True, gene_stride=1, **kw):
+    def __init__(self, n, n_bar, n_gene, rate_cell=1.0, rate_depth=1.0, seed=926, data_seed=1, umi_copies=True, gene_stride=1, gene_start=1, **kw):
         self.rate_cell, self.rate_depth, self.seed = rate_cell, rate_depth, seed
-        self.bt, self.ft, self.bar, self.genes = synth.make_lists(n_bar, n_gene, seed=data_seed + 1000, gene_stride=gene_stride)
+        self.bt, self.ft, self.bar, self.genes = synth.make_lists(n_bar, n_gene, seed=data_seed + 1000, gene_stride=gene_stride, gene_start=gene_start)
         fl, xf, cb, gx, ub = synth.make_records(n, self.bar, self.genes, seed=data_seed, **kw)
         self.flags, self.xf = fl, xf
         self.cb, self.gx, self.ub = synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)

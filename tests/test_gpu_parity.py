@@ -31,6 +31,13 @@ CASES = {
     "sparse_gene_ids": dict(n=200_000, n_bar=800, n_gene=5000, gene_stride=7, gene_dist="zipf", umi_pool=2048, p_bad_xf=0.1),
     "sparse_gene_ids_big_image": dict(n=300_000, n_bar=2000, n_gene=30_000, gene_stride=8, umi_pool=4096, rate_depth=0.8,
                                       p_unlisted_cb=0.05),
+    # gene ids that start far from zero (direct table and bitmap are indexed relative to the smallest listed id)
+    "gene_ids_offset_dense": dict(n=100_000, n_bar=500, n_gene=4000, gene_start=123_456_789, umi_pool=512, p_bad_xf=0.1),
+    "gene_ids_offset_sparse": dict(n=100_000, n_bar=500, n_gene=4000, gene_start=99_000_000, gene_stride=13, umi_pool=512),
+    # a barcode list too large for the LDS perfect hash: L2 table behind the LDS miss filter, most CB tags not sampled
+    # or not listed (the filter's false positives reach the table and must miss there)
+    "big_barcode_list_mostly_misses": dict(n=400_000, n_bar=30_000, n_gene=300, rate_cell=0.3, rate_depth=0.9, umi_pool=2048,
+                                           p_unlisted_cb=0.3, p_no_cb=0.05, data_seed=13),
     "every_record_misses": dict(n=20_000, n_bar=50, n_gene=20, p_unlisted_cb=1.0),
     "no_cb_at_all": dict(n=20_000, n_bar=50, n_gene=20, p_no_cb=1.0),
 }
