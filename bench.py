@@ -84,6 +84,27 @@ def main():
     def step():
         sp.run(d_cb, d_gx, d_umi, d_meta, N, d_draws)
 
+    if world > 1 and sp.pipelined:
+        # self-check of the multi-stream pipeline against the single-stream pass on the same input (one step each);
+        # on any difference the timed loop uses the single-stream pass
+        ref = ShardedPass(HipStages(eng, dev), N, dev, pipeline=False)
+        ref.run(d_cb, d_gx, d_umi, d_meta, N, d_draws)
+        ref.ensure_exact()
+        want = (int(ref.d_n.item()), int(ref.nnz.item()), ref.global_counters())
+        for _ in range(2):
+            step()
+        sp.ensure_exact()
+        got = (int(sp.d_n.item()), int(sp.nnz.item()), sp.global_counters())
+        same = torch.tensor([1 if got == want else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        if int(same.item()) != 1:
+            if rank == 0:
+                print("bench: pipelined pass differs from the single-stream pass (%r vs %r): timing the single-stream pass"
+                      % (got, want), file=sys.stderr)
+            sp = ref
+        else:
+            del ref
+            torch.cuda.empty_cache()
     for _ in range(args.warmup):
         step()
         sp.ensure_exact()      # data with very deep (cell, feature) groups switches the sort to all digits here, once

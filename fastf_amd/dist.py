@@ -88,7 +88,7 @@ class HipStages:
 class ShardedPass:
     """Buffers + orchestration of one sharded pass; reusable across steps (bench loop)."""
 
-    def __init__(self, stages, n_local_max, device, group=None, world=None, rank=None):
+    def __init__(self, stages, n_local_max, device, group=None, world=None, rank=None, pipeline=None):
         self.st, self.dev, self.group = stages, device, group
         self.G = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
@@ -100,8 +100,9 @@ class ShardedPass:
         G, n = self.G, int(n_local_max)
         i64, i32 = torch.int64, torch.int32
         self.stride = n
-        self.pipelined = (G > 1 and torch.device(device).type == "cuda"
-                          and os.environ.get("FASTF_DIST_PIPELINE", "1") != "0")
+        if pipeline is None:
+            pipeline = os.environ.get("FASTF_DIST_PIPELINE", "1") != "0"
+        self.pipelined = bool(pipeline) and G > 1 and torch.device(device).type == "cuda"
         self.k1_stream = torch.cuda.Stream(device) if self.pipelined else None
         self.x_stream = torch.cuda.Stream(device) if self.pipelined else None     # the key exchange
         # The two tiny collectives of the K1 stage (one u64 per rank, G counts per rank) go over a gloo side group on host
