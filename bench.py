@@ -195,7 +195,10 @@ def main():
         cpu_dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": S / cpu_dt, "unit": "records/s", "cores": 1, "kind": "port",
                                "sample": "first %d records of the same workload through oracle/fastf_oracle.c "
-                                         "(hash probe + MT draw + qsort aggregate), %.1f s" % (S, cpu_dt)}
+                                         "(hash probe + MT draw + qsort aggregate), %.1f s" % (S, cpu_dt),
+                               "note": "the reference's own bam2db (SQLite INSERT + GROUP BY, gz writers) ran at 0.24 M records/s on "
+                                       "1 core in the survey session (BASELINE.md section 2, 2 M records of this shape); the port has "
+                                       "no SQLite and no file I/O"}
         # parity of the GPU path on that very sample (bit-exact COO + counters)
         e2 = F.Engine.from_lists(lists, rate_depth=rate_depth, seed=seed, umi_max_bases=12, device=local)
         e2.push(cbk[:S], gxk[:S], umi[:S], meta[:S])
