@@ -159,6 +159,7 @@ def main():
         # algorithmic bytes of one step on this rank: 24N + 4H + 8K(3+2P) + 12Z
         H, K, Z, P = hits // G, n_keys_local, nnz_local, passes
         B = 24 * N + 4 * H + 8 * K * (3 + 2 * P) + 12 * Z
+        B_read = 24 * N + 4 * H + 8 * K * (2 + P)          # the read-only share
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "BAM records/sec -> deduped UMI matrix (device path, inputs resident in HBM)",
@@ -180,7 +181,8 @@ def main():
             "kernels_ms": {"probe_cells": t_k1 / max(n_k1, 1), "filter_pack": t_k1b / max(n_k1b, 1),
                            "tile_count_per_pass": t_ct / max(n_ct, 1), "scatter_per_pass": sc_ms,
                            "head_count+scan+reduce": t_k3 / max(n_k3, 1)},
-            "whole_path": {"algorithmic_bytes_per_step": B, "achieved_GBs": B / (ms_step * 1e-3) / 1e9,
+            "whole_path": {"algorithmic_bytes_per_step": B, "algorithmic_read_bytes_per_step": B_read,
+                           "achieved_read_GBs": B_read / (ms_step * 1e-3) / 1e9, "achieved_GBs": B / (ms_step * 1e-3) / 1e9,
                            "frac_of_peak": B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "counters": {"total": N * G, "hits": hits, "sampled": sampled, "valid": valid,
                          "keys_rank0": n_keys_local, "rows_rank0": nnz_local, "device_error_bits": err},
