@@ -225,7 +225,7 @@ struct fastf_bam {
     size_t *rec; size_t reccap;                   /* offsets (into ubuf) of the records of one batch   */
     uint64_t n_records, n_no_xf, n_no_gx;
     int failed;
-    double t_read, t_inflate, t_hop, t_pack;      /* FASTF_BAM_PROFILE=1 prints these at close */
+    double t_read, t_inflate, t_hop, t_pack, t_wait;   /* FASTF_BAM_PROFILE=1 prints these at close; t_wait: consumer blocked on the filler */
 };
 
 #include <time.h>
@@ -394,10 +394,12 @@ static int bam_fill(fastf_bam_t *b)
 {
     if (b->failed) return -1;
     if (b->drained) return 1;
+    const double t_w0 = now_s();
     pthread_mutex_lock(&b->mu);
     while (!b->fill_done) pthread_cond_wait(&b->cv, &b->mu);
     const int r = b->fill_result;
     pthread_mutex_unlock(&b->mu);
+    b->t_wait += now_s() - t_w0;
     if (r < 0) { b->failed = 1; return -1; }
     if (r == 1) { b->drained = 1; return 1; }
     const size_t tail = b->ulen - b->upos;
@@ -468,8 +470,9 @@ void fastf_bam_close(fastf_bam_t *b)
 {
     if (!b) return;
     if (getenv("FASTF_BAM_PROFILE"))
-        fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s, record hop %.3f s, tag pack %.3f s\n",
-                (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack);
+        fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s (both on the prefetch thread), record hop %.3f s, "
+                "tag pack %.3f s, waited for the prefetch %.3f s\n",
+                (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack, b->t_wait);
     if (b->filler_started) {
         pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv); pthread_mutex_unlock(&b->mu);
         pthread_join(b->filler, NULL);
@@ -598,7 +601,7 @@ static long bam_hop_records(fastf_bam_t *b, size_t cap)
 {
     if (b->reccap < cap) { b->reccap = cap; b->rec = (size_t *)realloc(b->rec, cap * sizeof *b->rec); }
     size_t n = 0;
-    double t_hop0 = now_s(), t_fill0 = b->t_read + b->t_inflate;
+    double t_hop0 = now_s(), t_wait0 = b->t_wait;
     while (n < cap) {
         if (b->ulen - b->upos < 4 || b->ulen - b->upos < 4 + (size_t)rd32(b->ubuf + b->upos)) {
             if (n) break;                                       /* hand out what this window had */
@@ -621,7 +624,7 @@ static long bam_hop_records(fastf_bam_t *b, size_t cap)
         b->rec[n++] = b->upos;
         b->upos += 4 + (size_t)bs;
     }
-    b->t_hop += (now_s() - t_hop0) - (b->t_read + b->t_inflate - t_fill0);
+    b->t_hop += (now_s() - t_hop0) - (b->t_wait - t_wait0);          /* the hop itself, without the time blocked on the next window */
     return (long)n;
 }
 
