@@ -205,6 +205,8 @@ void fastf_lists_free(fastf_lists_t *l)
  * Record order is preserved: slot i of the output is the i-th record of the file.
  */
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 typedef struct { size_t coff; uint32_t clen, isize; size_t uoff; } bgzf_blk;
@@ -214,6 +216,7 @@ struct fastf_bam {
     int n_threads;
     int file_eof;
     unsigned char *cbuf; size_t ccap, clen;      /* compressed window (whole blocks + a partial tail) */
+    unsigned char *map; size_t map_len, map_pos; unsigned char *cbuf_own;   /* the file mapped read-only: windows are views, nothing is copied */
     unsigned char *ubuf; size_t ucap, ulen, upos;/* inflated window; [upos, ulen) not yet consumed     */
     bgzf_blk *blk; size_t nblk, blkcap;
     /* prefetch: a filler thread reads + inflates the NEXT window into nbuf[NX_RESERVE ...) while the caller
@@ -304,7 +307,15 @@ static void inflate_worker(void *vp, int widx)
 static int fill_next(fastf_bam_t *b)
 {
     for (;;) {
-        if (!b->file_eof) {
+        if (b->map) {                                         /* window = a view of the mapping; the inflate workers fault the pages in */
+            b->cbuf = b->map + b->map_pos;
+            b->clen = b->map_len - b->map_pos < b->ccap ? b->map_len - b->map_pos : b->ccap;
+            if (b->map_pos + b->clen == b->map_len) b->file_eof = 1;
+            if (!b->file_eof) {                               /* read-ahead hint for the window after this one */
+                size_t a = (b->map_pos + b->clen) & ~(size_t)4095, l = b->map_len - a < b->ccap ? b->map_len - a : b->ccap;
+                (void)madvise(b->map + a, l, MADV_WILLNEED);
+            }
+        } else if (!b->file_eof) {
             double t0 = now_s();
             size_t want = b->ccap - b->clen;
             size_t got = fread(b->cbuf + b->clen, 1, want, b->fp);
@@ -355,8 +366,8 @@ static int fill_next(fastf_bam_t *b)
         b->t_inflate += now_s() - t0;
         if (job.err) { io_err("BGZF inflate/CRC failure"); return -1; }
         b->nlen = NX_RESERVE + utotal;
-        memmove(b->cbuf, b->cbuf + pos, b->clen - pos);       /* keep the partial block for the next round */
-        b->clen -= pos;
+        if (b->map) b->map_pos += pos;                        /* the partial block stays where it is */
+        else { memmove(b->cbuf, b->cbuf + pos, b->clen - pos); b->clen -= pos; }   /* keep the partial block for the next round */
         return 0;
     }
 }
@@ -444,7 +455,15 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     const char *w = getenv("FASTF_BAM_WINDOW");
     b->ccap = w ? (size_t)strtoull(w, NULL, 0) : ((size_t)32 << 20);
     if (b->ccap < (1 << 17)) b->ccap = 1 << 17;
-    b->cbuf = (unsigned char *)malloc(b->ccap);
+    {   /* regular files are mapped (FASTF_BAM_MMAP=0: read() into a buffer, as for anything that cannot be mapped) */
+        const char *mm = getenv("FASTF_BAM_MMAP");
+        struct stat st;
+        if (!(mm && mm[0] == '0') && fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+            if (m != MAP_FAILED) { b->map = (unsigned char *)m; b->map_len = (size_t)st.st_size; (void)madvise(m, b->ccap < b->map_len ? b->ccap : b->map_len, MADV_WILLNEED); }
+        }
+    }
+    if (!b->map) { b->cbuf_own = (unsigned char *)malloc(b->ccap); b->cbuf = b->cbuf_own; }
     b->ucap = 1 << 16; b->ubuf = (unsigned char *)malloc(b->ucap);
     b->ncap = NX_RESERVE + b->ccap * 4; b->nbuf = (unsigned char *)malloc(b->ncap);
     pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv, NULL);
@@ -479,7 +498,8 @@ void fastf_bam_close(fastf_bam_t *b)
         pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv);
     }
     if (b->fp) fclose(b->fp);
-    free(b->cbuf); free(b->ubuf); free(b->nbuf); free(b->blk); free(b->rec); free(b);
+    if (b->map) munmap(b->map, b->map_len);
+    free(b->cbuf_own); free(b->ubuf); free(b->nbuf); free(b->blk); free(b->rec); free(b);
 }
 
 void fastf_bam_stats(const fastf_bam_t *b, uint64_t *n_records, uint64_t *n_no_xf, uint64_t *n_no_gx)

@@ -58,6 +58,21 @@ def test_bam_mapped_read_layout(tmp_path):
         np.testing.assert_array_equal(g, w)
 
 
+def test_mapped_and_buffered_reads_agree(tmp_path, monkeypatch):
+    """the reader maps regular files and falls back to read() (FASTF_BAM_MMAP=0): same records either way"""
+    case = Case(n=40000, n_bar=200, n_gene=80, umi_pool=64, p_no_cb=0.05)
+    lists = case.lists()
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub)
+    monkeypatch.setenv("FASTF_BAM_WINDOW", str(1 << 17))
+    a = read_all(bam, lists, cap=9001)
+    monkeypatch.setenv("FASTF_BAM_MMAP", "0")
+    b = read_all(bam, lists, cap=9001)
+    for x, y, w in zip(a, b, case.packed(lists)):
+        np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(x, w)
+
+
 def test_bam_other_aux_types_and_tag_order(tmp_path):
     """tags of every aux type before/between the ones we need; first occurrence wins (bam_aux_get)"""
     case = Case(n=500, n_bar=20, n_gene=10, umi_pool=8)
