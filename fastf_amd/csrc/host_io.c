@@ -226,6 +226,11 @@ struct fastf_bam {
     pthread_mutex_t mu; pthread_cond_t cv;
     int want_fill, fill_done, fill_result, quit, drained;
     size_t *rec; size_t reccap;                   /* offsets (into ubuf) of the records of one batch   */
+    /* parallel record hop: offsets of every complete record of the current window, handed out batch by batch */
+    size_t *wrec; size_t wreccap, wn, wi;
+    size_t *spec; size_t speccap;                 /* the segments' speculative chains, back to back */
+    uint32_t n_ref; int serial_hop;               /* FASTF_BAM_SERIAL_HOP=1 */
+    uint64_t hop_adopted, hop_walked;             /* records taken over from speculative chains / found by the serial walk */
     uint64_t n_records, n_no_xf, n_no_gx;
     int failed;
     double t_read, t_inflate, t_hop, t_pack, t_wait;   /* FASTF_BAM_PROFILE=1 prints these at close; t_wait: consumer blocked on the filler */
@@ -451,6 +456,7 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     fastf_bam_t *b = (fastf_bam_t *)calloc(1, sizeof *b);
     b->fp = fp;
     b->n_threads = host_threads(n_threads);
+    { const char *sh = getenv("FASTF_BAM_SERIAL_HOP"); b->serial_hop = sh && sh[0] == '1'; }
     setvbuf(fp, NULL, _IONBF, 0);
     const char *w = getenv("FASTF_BAM_WINDOW");
     b->ccap = w ? (size_t)strtoull(w, NULL, 0) : ((size_t)32 << 20);
@@ -475,6 +481,7 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     uint32_t l_text = rd32(b->ubuf + b->upos + 4);
     if (bam_need(b, 12 + (size_t)l_text)) { io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
     uint32_t n_ref = rd32(b->ubuf + b->upos + 8 + l_text);
+    b->n_ref = n_ref;
     b->upos += 12 + (size_t)l_text;
     for (uint32_t i = 0; i < n_ref; i++) {
         if (bam_need(b, 4)) { io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
@@ -492,6 +499,9 @@ void fastf_bam_close(fastf_bam_t *b)
         fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s (both on the prefetch thread), record hop %.3f s, "
                 "tag pack %.3f s, waited for the prefetch %.3f s\n",
                 (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack, b->t_wait);
+    if (getenv("FASTF_BAM_PROFILE") && (b->hop_adopted || b->hop_walked))
+        fprintf(stderr, "[bam] parallel hop: %llu records adopted from speculative chains, %llu found by the serial walk\n",
+                (unsigned long long)b->hop_adopted, (unsigned long long)b->hop_walked);
     if (b->filler_started) {
         pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv); pthread_mutex_unlock(&b->mu);
         pthread_join(b->filler, NULL);
@@ -499,7 +509,7 @@ void fastf_bam_close(fastf_bam_t *b)
     }
     if (b->fp) fclose(b->fp);
     if (b->map) munmap(b->map, b->map_len);
-    free(b->cbuf_own); free(b->ubuf); free(b->nbuf); free(b->blk); free(b->rec); free(b);
+    free(b->cbuf_own); free(b->ubuf); free(b->nbuf); free(b->blk); free(b->rec); free(b->wrec); free(b->spec); free(b);
 }
 
 void fastf_bam_stats(const fastf_bam_t *b, uint64_t *n_records, uint64_t *n_no_xf, uint64_t *n_no_gx)
@@ -614,6 +624,124 @@ static void pack_worker(void *vp, int widx)
     j->no_xf[widx] = nxf; j->no_gx[widx] = ngx;
 }
 
+/* ---- step 3, parallel form -------------------------------------------------------------------------------------
+ * The record chain is serial by nature (an offset follows from the previous record's length) and on real BAMs every hop
+ * is a cache miss into data other cores just inflated: 31 ns per record, more than the 16-thread inflate of the same
+ * window.  So the window is cut into segments; every worker guesses the first record start in its segment (an offset
+ * where HOP_PLAUSIBLE consecutive records look like alignment records) and hops from there; afterwards the TRUE chain is
+ * followed from the window's known start and every segment's speculative chain is adopted from the first offset the true
+ * chain shares with it (two chains that meet once are identical from there on).  A wrong guess costs a serial hop over
+ * that segment, never a wrong answer. */
+#define HOP_PLAUSIBLE 3
+typedef struct { size_t lo, hi, first, n, exit_off; } hop_seg;     /* [lo, hi) bytes; chain in spec[first, first + n); offset after its last record */
+typedef struct { fastf_bam_t *b; hop_seg *seg; size_t n_seg, next, end; } hop_job;
+
+/* offset just past the record at o if a whole, structurally valid record starts there; 0 otherwise */
+static inline size_t rec_end(const fastf_bam_t *b, size_t o, size_t end)
+{
+    if (end - o < 36) return 0;
+    const unsigned char *p = b->ubuf + o;
+    const uint32_t bs = rd32(p);
+    if (bs < 32 || (size_t)bs + 4 > end - o) return 0;
+    const uint64_t fixed = 32ull + p[12] + 4ull * rd16(p + 16) + ((uint64_t)rd32(p + 20) + 1) / 2 + rd32(p + 20);
+    return fixed <= bs ? o + 4 + (size_t)bs : 0;
+}
+
+/* does the record at o look like an alignment record (stricter than rec_end: used only to GUESS chain starts) */
+static inline int rec_plausible(const fastf_bam_t *b, size_t o, size_t end)
+{
+    if (!rec_end(b, o, end)) return 0;
+    const unsigned char *p = b->ubuf + o;
+    const int32_t ref = (int32_t)rd32(p + 4), pos = (int32_t)rd32(p + 8), nref = (int32_t)rd32(p + 24), npos = (int32_t)rd32(p + 28);
+    const uint32_t l_name = p[12];
+    if (ref < -1 || (uint32_t)(ref + 1) > b->n_ref || nref < -1 || (uint32_t)(nref + 1) > b->n_ref || pos < -1 || npos < -1) return 0;
+    if (l_name < 1 || p[36 + l_name - 1] != 0) return 0;
+    for (uint32_t i = 0; i + 1 < l_name; i++) if (p[36 + i] < 33 || p[36 + i] > 126) return 0;     /* [!-~]: SAM read names */
+    return 1;
+}
+
+static void hop_seg_worker(void *vp, int widx)
+{
+    (void)widx;
+    hop_job *j = (hop_job *)vp;
+    fastf_bam_t *b = j->b;
+    for (;;) {
+        const size_t si = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (si >= j->n_seg) break;
+        hop_seg *s = &j->seg[si];
+        size_t o = s->lo, found = 0;
+        s->n = 0; s->exit_off = s->lo;
+        for (; o < s->hi && !found; o++) {                     /* guess: first offset with HOP_PLAUSIBLE plausible records in a row */
+            size_t q = o; int k = 0;
+            while (k < HOP_PLAUSIBLE && rec_plausible(b, q, j->end)) { q = rec_end(b, q, j->end); k++; }
+            if (k == HOP_PLAUSIBLE || (k > 0 && q >= j->end - 36)) { found = 1; break; }     /* fewer only at the very end of the window */
+        }
+        if (!found) continue;
+        size_t *out = b->spec + s->first;
+        while (o < s->hi) {                                    /* hop to the end of the segment (the last record may cross it) */
+            const size_t e = rec_end(b, o, j->end);
+            if (!e) break;
+            out[s->n++] = o;
+            o = e;
+        }
+        s->exit_off = o;
+    }
+}
+
+/* offsets of all complete records of the window from upos on → wrec[0, wn); returns 0, or -1 on a corrupt record */
+static int hop_window(fastf_bam_t *b)
+{
+    const size_t start = b->upos, end = b->ulen;
+    b->wn = 0; b->wi = 0;
+    if (end - start < 36) return 0;
+    size_t n_seg = (size_t)b->n_threads * 4, bytes = end - start;
+    if (bytes / n_seg < (1u << 16)) n_seg = bytes / (1u << 16) ? bytes / (1u << 16) : 1;
+    const size_t max_rec = bytes / 36 + n_seg + 16;            /* a record is at least 36 bytes */
+    if (b->wreccap < max_rec) { b->wreccap = max_rec; free(b->wrec); b->wrec = (size_t *)malloc(max_rec * sizeof *b->wrec); }
+    if (b->speccap < max_rec) { b->speccap = max_rec; free(b->spec); b->spec = (size_t *)malloc(max_rec * sizeof *b->spec); }
+    hop_seg *seg = (hop_seg *)calloc(n_seg, sizeof *seg);
+    for (size_t i = 0; i < n_seg; i++) {
+        seg[i].lo = start + bytes * i / n_seg; seg[i].hi = start + bytes * (i + 1) / n_seg;
+        seg[i].first = (seg[i].lo - start) / 36 + i;           /* disjoint slices of spec[] */
+    }
+    hop_job job; memset(&job, 0, sizeof job);
+    job.b = b; job.seg = seg; job.n_seg = n_seg; job.end = end; job.next = 1;      /* segment 0 starts at the true chain: followed below */
+    if (n_seg > 1) par_run(b->n_threads, hop_seg_worker, &job);
+    /* the true chain, adopting speculative chains where it meets them */
+    size_t cur = start, n = 0;
+    int rc = 0;
+    for (size_t si = 0; si < n_seg && cur < end; si++) {
+        const hop_seg *s = &seg[si];
+        const size_t *chain = b->spec + s->first;
+        size_t k = 0;
+        while (cur < s->hi) {
+            while (k < s->n && chain[k] < cur) k++;
+            if (si > 0 && k < s->n && chain[k] == cur) {       /* met the speculative chain: the rest of it is the true chain */
+                memcpy(b->wrec + n, chain + k, (s->n - k) * sizeof *chain);
+                n += s->n - k;
+                b->hop_adopted += s->n - k;
+                cur = s->exit_off;
+                break;
+            }
+            const size_t e = rec_end(b, cur, end);
+            if (!e) {                                          /* incomplete at the end of the window, or corrupt */
+                if (end - cur >= 4 && rd32(b->ubuf + cur) < 32) { io_err("corrupt BAM record (block_size %u)", rd32(b->ubuf + cur)); rc = -1; }
+                else if (end - cur >= 36 && (size_t)rd32(b->ubuf + cur) + 4 <= end - cur) { io_err("corrupt BAM record (fields exceed block_size)"); rc = -1; }
+                goto out;
+            }
+            b->wrec[n++] = cur;
+            b->hop_walked++;
+            cur = e;
+        }
+    }
+out:
+    free(seg);
+    if (rc) { b->failed = 1; return -1; }
+    b->wn = n;
+    b->upos = cur;                                             /* the carry-over tail starts behind the last complete record */
+    return 0;
+}
+
 /* step 3: offsets of up to cap records into b->rec; the window is refilled only when it runs dry, so one batch
  * never spans a refill (offsets stay valid) unless the window holds no complete record at all.
  * Returns the count, 0 at EOF, -1 on error. */
@@ -622,6 +750,30 @@ static long bam_hop_records(fastf_bam_t *b, size_t cap)
     if (b->reccap < cap) { b->reccap = cap; b->rec = (size_t *)realloc(b->rec, cap * sizeof *b->rec); }
     size_t n = 0;
     double t_hop0 = now_s(), t_wait0 = b->t_wait;
+    if (b->n_threads > 1 && !b->serial_hop) {
+        for (;;) {
+            if (b->wi == b->wn && hop_window(b) < 0) return -1;   /* every record of the last hopped stretch is handed out */
+            if (b->wi < b->wn) {
+                n = b->wn - b->wi < cap ? b->wn - b->wi : cap;
+                memcpy(b->rec, b->wrec + b->wi, n * sizeof *b->rec);
+                b->wi += n;
+                b->t_hop += (now_s() - t_hop0) - (b->t_wait - t_wait0);
+                return (long)n;
+            }
+            /* no complete record in what is left of this window: bring in the next one */
+            const size_t have = b->ulen - b->upos;
+            const size_t need = have < 4 ? 4 : 4 + (size_t)rd32(b->ubuf + b->upos);
+            if (have >= 4 && rd32(b->ubuf + b->upos) < 32) { io_err("corrupt BAM record (block_size %u)", rd32(b->ubuf + b->upos)); b->failed = 1; return -1; }
+            const int r = bam_need(b, need > have ? need : have + 1);
+            if (r == 1) return 0;                               /* clean EOF */
+            if (r < 0) {
+                if (b->failed) return -1;
+                fprintf(stderr, "Warning: truncated BAM stream after %llu records\n", (unsigned long long)b->n_records);
+                b->upos = b->ulen;
+                return 0;
+            }
+        }
+    }
     while (n < cap) {
         if (b->ulen - b->upos < 4 || b->ulen - b->upos < 4 + (size_t)rd32(b->ubuf + b->upos)) {
             if (n) break;                                       /* hand out what this window had */

@@ -11,9 +11,9 @@ from fastf_amd import synth, _lib
 from helpers import Case
 
 
-def read_all(path, lists, cap=1000):
+def read_all(path, lists, cap=1000, threads=0):
     L = _lib.lib()
-    h = L.fastf_bam_open(str(path).encode(), 0)
+    h = L.fastf_bam_open(str(path).encode(), threads)
     assert h, L.fastf_last_error()
     outs = [[], [], [], []]
     try:
@@ -166,3 +166,30 @@ def test_reader_rejects_corrupt_block(tmp_path):
         n = L.fastf_bam_read_batch(h, lists.cell_dict, lists.feat_dict, cb.ctypes.data, gx.ctypes.data, um.ctypes.data, me.ctypes.data, 9000)
         L.fastf_bam_close(h)
         assert n == -1 and b"BGZF" in L.fastf_last_error()
+
+
+@pytest.mark.parametrize("window,threads", [(1 << 17, 8), (1 << 20, 4), (32 << 20, 8)])
+def test_parallel_record_hop_survives_decoy_records(tmp_path, monkeypatch, window, threads):
+    """The parallel hop guesses a record start per segment and verifies it against the true chain.  Here most of the file
+    is decoy: every record carries a byte array whose content is itself a run of perfectly plausible BAM records, so
+    the guesses usually land in decoys; the result must still be the serial hop's."""
+    case = Case(n=6000, n_bar=50, n_gene=20, umi_pool=32, p_no_cb=0.1, p_bad_xf=0.1)
+    lists = case.lists()
+    decoy_rec = synth.bam_record(b"decoy", synth.aux_Z(b"CB", b"AAAAAAAAAAAAAAAA-1") + synth.aux_int(b"xf", 25) +
+                                 synth.aux_Z(b"GX", b"ENSG00000000001") + synth.aux_Z(b"UB", b"ACGTACGTAC"), seq_len=20, n_cigar=1,
+                                 ref_id=0, pos=5)
+
+    def extra(i):
+        payload = decoy_rec * (3 + i % 9) + bytes([i % 251] * (i % 7))           # misaligned runs of whole decoy records
+        return b"ZBBC" + struct.pack("<i", len(payload)) + payload
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, extra_aux=extra)
+    monkeypatch.setenv("FASTF_BAM_WINDOW", str(window))
+    want = case.packed(lists)
+    got = read_all(bam, lists, cap=2500, threads=threads)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    monkeypatch.setenv("FASTF_BAM_SERIAL_HOP", "1")
+    got = read_all(bam, lists, cap=2500, threads=threads)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)

@@ -51,7 +51,9 @@ int main(int argc, char **argv)
     out = fopen(argv[1], "wb"); if (!out) { perror(argv[1]); return 1; }
     static char obuf[1 << 22]; setvbuf(out, obuf, _IOFBF, sizeof obuf);
     const char *text = "@HD\tVN:1.6\tSO:unsorted\n"; int32_t lt = (int32_t)strlen(text), nref = 0;
-    put("BAM\1", 4); put(&lt, 4); put(text, lt); put(&nref, 4);
+    put("BAM\1", 4); put(&lt, 4); put(text, lt);
+    if (sl > 0) { nref = 1; put(&nref, 4); int32_t ln = 5, lref = 248956422; put(&ln, 4); put("chr1", 5); put(&lref, 4); }   /* mapped reads name refID 0 */
+    else put(&nref, 4);
     unsigned char rec[1024];
     for (size_t i = 0; i < n; i++) {
         unsigned char *p = rec + 4; int32_t m1 = -1, z = 0; char name[24]; int nl = snprintf(name, sizeof name, "r%zu", i) + 1;
