@@ -346,7 +346,13 @@ static int fill_next(fastf_bam_t *b)
             size_t total = (size_t)bsize + 1;
             if (total < 12 + (size_t)xlen + 8) { io_err("bad BGZF block size"); return -1; }
             if (b->clen - pos < total) break;
-            if (b->nblk == b->blkcap) { b->blkcap = b->blkcap ? b->blkcap * 2 : 4096; b->blk = (bgzf_blk *)realloc(b->blk, b->blkcap * sizeof *b->blk); }
+            if (b->nblk == b->blkcap) {
+                size_t nc = b->blkcap ? b->blkcap * 2 : 4096;
+                bgzf_blk *nb = (bgzf_blk *)realloc(b->blk, nc * sizeof *b->blk);
+                if (!nb) { io_err("out of memory (BGZF block index)"); return -1; }
+                b->blk = nb; b->blkcap = nc;
+            }
+            if (rd32(h + total - 4) > 65536) { io_err("bad BGZF block (ISIZE %u above the format's 64 KiB)", rd32(h + total - 4)); return -1; }
             bgzf_blk *k = &b->blk[b->nblk++];
             k->coff = pos + 12 + xlen;
             k->clen = (uint32_t)(total - 12 - xlen - 8);
@@ -363,7 +369,10 @@ static int fill_next(fastf_bam_t *b)
             if (b->clen == b->ccap) { io_err("BGZF block larger than the read window"); return -1; }
             continue;
         }
-        if (NX_RESERVE + utotal > b->ncap) { b->ncap = (NX_RESERVE + utotal) * 5 / 4 + (1 << 20); free(b->nbuf); b->nbuf = (unsigned char *)malloc(b->ncap); }
+        if (NX_RESERVE + utotal > b->ncap) {
+            b->ncap = (NX_RESERVE + utotal) * 5 / 4 + (1 << 20); free(b->nbuf); b->nbuf = (unsigned char *)malloc(b->ncap);
+            if (!b->nbuf) { b->ncap = 0; io_err("out of memory (inflate window of %zu bytes)", NX_RESERVE + utotal); return -1; }
+        }
         inflate_job job; memset(&job, 0, sizeof job); job.b = b;
         { const char *iv = getenv("FASTF_INFLATE"); job.use_zlib = iv && !strcmp(iv, "zlib"); }
         double t0 = now_s();
@@ -426,6 +435,7 @@ static int bam_fill(fastf_bam_t *b)
     } else {                                                  /* a record longer than the reserve: make room */
         const size_t data = b->nlen - NX_RESERVE;
         unsigned char *nb = (unsigned char *)malloc(tail + data + (1 << 20));
+        if (!nb) { io_err("out of memory (record of %zu bytes)", tail); b->failed = 1; return -1; }
         memcpy(nb, b->ubuf + b->upos, tail);
         memcpy(nb + tail, b->nbuf + NX_RESERVE, data);
         free(b->nbuf); b->nbuf = nb; b->ncap = tail + data + (1 << 20); b->nlen = tail + data;
@@ -473,20 +483,22 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     b->ucap = 1 << 16; b->ubuf = (unsigned char *)malloc(b->ucap);
     b->ncap = NX_RESERVE + b->ccap * 4; b->nbuf = (unsigned char *)malloc(b->ncap);
     pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv, NULL);
+    if ((!b->map && !b->cbuf_own) || !b->ubuf || !b->nbuf) { io_err("out of memory (BAM read windows)"); fastf_bam_close(b); return NULL; }
     if (pthread_create(&b->filler, NULL, filler_main, b) != 0) { io_err("cannot start the BAM prefetch thread"); fastf_bam_close(b); return NULL; }
     b->filler_started = 1;
     request_fill(b);
     /* header: magic, l_text, text, n_ref, {l_name, name, l_ref}* — what sam_hdr_read() consumes (bam2db_ds.c:340) */
-    if (bam_need(b, 12) || memcmp(b->ubuf + b->upos, "BAM\1", 4) != 0) { io_err("%s is not a BAM file", path); fastf_bam_close(b); return NULL; }
+    /* a failed refill has already said why (bad BGZF block, CRC, ...): keep that message */
+    if (bam_need(b, 12) || memcmp(b->ubuf + b->upos, "BAM\1", 4) != 0) { if (!b->failed) io_err("%s is not a BAM file", path); fastf_bam_close(b); return NULL; }
     uint32_t l_text = rd32(b->ubuf + b->upos + 4);
-    if (bam_need(b, 12 + (size_t)l_text)) { io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
+    if (bam_need(b, 12 + (size_t)l_text)) { if (!b->failed) io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
     uint32_t n_ref = rd32(b->ubuf + b->upos + 8 + l_text);
     b->n_ref = n_ref;
     b->upos += 12 + (size_t)l_text;
     for (uint32_t i = 0; i < n_ref; i++) {
-        if (bam_need(b, 4)) { io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
+        if (bam_need(b, 4)) { if (!b->failed) io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
         uint32_t l_name = rd32(b->ubuf + b->upos);
-        if (bam_need(b, 8 + (size_t)l_name)) { io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
+        if (bam_need(b, 8 + (size_t)l_name)) { if (!b->failed) io_err("truncated BAM header"); fastf_bam_close(b); return NULL; }
         b->upos += 8 + (size_t)l_name;
     }
     return b;
@@ -697,9 +709,10 @@ static int hop_window(fastf_bam_t *b)
     size_t n_seg = (size_t)b->n_threads * 4, bytes = end - start;
     if (bytes / n_seg < (1u << 16)) n_seg = bytes / (1u << 16) ? bytes / (1u << 16) : 1;
     const size_t max_rec = bytes / 36 + n_seg + 16;            /* a record is at least 36 bytes */
-    if (b->wreccap < max_rec) { b->wreccap = max_rec; free(b->wrec); b->wrec = (size_t *)malloc(max_rec * sizeof *b->wrec); }
-    if (b->speccap < max_rec) { b->speccap = max_rec; free(b->spec); b->spec = (size_t *)malloc(max_rec * sizeof *b->spec); }
+    if (b->wreccap < max_rec) { free(b->wrec); b->wrec = (size_t *)malloc(max_rec * sizeof *b->wrec); b->wreccap = b->wrec ? max_rec : 0; }
+    if (b->speccap < max_rec) { free(b->spec); b->spec = (size_t *)malloc(max_rec * sizeof *b->spec); b->speccap = b->spec ? max_rec : 0; }
     hop_seg *seg = (hop_seg *)calloc(n_seg, sizeof *seg);
+    if (!b->wrec || !b->spec || !seg) { free(seg); io_err("out of memory (record offsets of a %zu-byte window)", bytes); b->failed = 1; return -1; }
     for (size_t i = 0; i < n_seg; i++) {
         seg[i].lo = start + bytes * i / n_seg; seg[i].hi = start + bytes * (i + 1) / n_seg;
         seg[i].first = (seg[i].lo - start) / 36 + i;           /* disjoint slices of spec[] */
@@ -747,7 +760,11 @@ out:
  * Returns the count, 0 at EOF, -1 on error. */
 static long bam_hop_records(fastf_bam_t *b, size_t cap)
 {
-    if (b->reccap < cap) { b->reccap = cap; b->rec = (size_t *)realloc(b->rec, cap * sizeof *b->rec); }
+    if (b->reccap < cap) {
+        size_t *nr = (size_t *)realloc(b->rec, cap * sizeof *b->rec);
+        if (!nr) { io_err("out of memory (record offsets)"); b->failed = 1; return -1; }
+        b->rec = nr; b->reccap = cap;
+    }
     size_t n = 0;
     double t_hop0 = now_s(), t_wait0 = b->t_wait;
     if (b->n_threads > 1 && !b->serial_hop) {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -21,15 +22,27 @@ extern "C" {
 
 using namespace fastf;
 
-static thread_local char g_err[512] = "";
+// The last error of the process, whichever thread raised it: the BAM reader's prefetch and inflate workers and the
+// decoder thread of bam2db() fail on their own threads, and the caller of fastf_last_error() must still see why.
+// Readers get a thread-local snapshot, so the returned pointer stays valid while other threads keep working.
+static std::mutex g_err_mu;
+static char g_err[512] = "";
 
 static int set_err(const char* fmt, ...) {
-    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    char buf[sizeof g_err];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    memcpy(g_err, buf, sizeof g_err);
     return 1;
 }
-extern "C" const char* fastf_last_error(void) { return g_err; }
-extern "C" const char* fastf_version(void) { return "fastf_amd 0.1 (gfx950)"; }
-extern "C" void fastf_set_error_(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+extern "C" const char* fastf_last_error(void) {
+    static thread_local char snap[sizeof g_err];
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    memcpy(snap, g_err, sizeof snap);
+    return snap;
+}
+extern "C" const char* fastf_version(void) { return "fastf_amd 0.2 (gfx950)"; }
+extern "C" void fastf_set_error_(const char* msg) { set_err("%s", msg); }
 
 #define HIP_OK(call)                                                                        \
     do {                                                                                    \
@@ -104,7 +117,6 @@ struct fastf_engine {
     // workspace
     DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
     DevBuf d_heads, d_rowbase;           // K3's tile counts / bases: not shared with K1, so K1 of the next batch may run beside K3 (other stream)
-    const void* cells_cached_for = nullptr; u64 cells_cached_n = 0;   // K1a result reusable by the next K1b
     // timing
     bool timing = false;
     hipEvent_t t_ev[2] = {nullptr, nullptr};
@@ -447,10 +459,7 @@ static u32 choose_sort_ipt(u64 n) {
 static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     const u64 t1 = max_tiles_for(max_records, K1_TILE), t3 = max_tiles_for(max_keys, K3_TILE);
     const u64 ts = max_tiles_for(max_keys, (u64)choose_sort_ipt(max_keys) * SORT_THREADS);
-    if (max_records && e->d_cellidx.bytes < max_records * sizeof(u32)) {
-        e->cells_cached_for = nullptr;
-        if (e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
-    }
+    if (max_records && e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
     if (e->d_heads.ensure(t3 * sizeof(u32)) || e->d_rowbase.ensure(t3 * sizeof(u64))) return 1;
     if (e->d_tilecnt.bytes < t1 * sizeof(u32)) {                     // (re)allocated: establish the all-zero invariant
         if (e->d_tilecnt.ensure(t1 * sizeof(u32))) return 1;
@@ -525,7 +534,6 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
                        (u64*)e->d_tilebase.p, tiles, d_total_out);
     HIP_OK(hipGetLastError());
-    e->cells_cached_for = cb; e->cells_cached_n = n;
     return 0;
 }
 
@@ -540,12 +548,10 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
-                        u64* counters, hipStream_t s) {
+                        u64* counters, bool reuse_hits, hipStream_t s) {
     if (n == 0) return 0;
-    // K1a (skipped when fastf_dev_count_hits just ran on the very same records, same stream order)
-    if (!(e->cells_cached_for == cb && e->cells_cached_n == n))
-        if (launch_probe_cells(e, cb, n, nullptr, s)) return 1;
-    e->cells_cached_for = nullptr;
+    // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order)
+    if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     PackParams p{};
     p.cell = (const u32*)e->d_cellidx.p; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
@@ -571,23 +577,16 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     return 0;
 }
 
-extern "C" int fastf_dev_hist_reset(fastf_engine_t* e, uint32_t flags, void* stream) {
-    if (!e) return set_err("null engine");
-    HIP_OK(hipSetDevice(e->device));
-    (void)flags; (void)stream;      // kept for ABI compatibility: the sort derives its bin bases from the per-tile counts now
-    return 0;
-}
-
 extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key, const uint64_t* d_gx_key,
                                     const uint32_t* d_umi, const uint32_t* d_meta, uint64_t n,
                                     const uint32_t* d_draws, uint64_t n_draws, const uint64_t* d_draw_base,
                                     uint64_t* d_keys_out, uint64_t shard_stride, uint64_t* d_key_counts,
-                                    uint64_t* d_counters, void* stream) {
+                                    uint64_t* d_counters, uint32_t flags, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
-                        (hipStream_t)stream);
+                        (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream);
 }
 
 static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
@@ -706,11 +705,9 @@ extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
 extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
-    u64 cur = 0;
-    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-    HIP_OK(hipMemcpy(&cur, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64), hipMemcpyDeviceToHost));
-    cur &= ~mask;
-    HIP_OK(hipMemcpy((u64*)e->d_small.p + SM_COUNTERS + 3, &cur, sizeof(u64), hipMemcpyHostToDevice));
+    // stream-ordered atomicAnd on the device: kernels raise bits with atomicOr, a host read-modify-write would race them
+    hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (u64*)e->d_small.p + SM_COUNTERS + 3, (u64)mask);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 
@@ -725,7 +722,7 @@ extern "C" const char* fastf_kernel_names(void) {
 static const char* err_bits_text(u64 bits) {
     static thread_local char buf[256];
     snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s%s", (unsigned long long)bits,
-             (bits & ERR_RESERVED) ? " (reserved bit 0);" : "",
+             (bits & 1) ? " (unknown bit 0);" : "",
              (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
              (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it; key must still fit 64 bits);" : "",
              (bits & ERR_KEYS_FULL) ? " key store full;" : "",
@@ -814,7 +811,7 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     u64* small = (u64*)e->d_small.p;
     if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
                      (const u32*)(ds + o_draw), nd, nullptr, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
-                     small + SM_COUNTERS, sk))
+                     small + SM_COUNTERS, false, sk))
         return 1;
     HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
     e->batch_in_flight = true;

@@ -29,7 +29,6 @@ typedef unsigned int u32;
 constexpr int WAVE = 64;
 
 // error bits accumulated in counters[3]
-constexpr u64 ERR_RESERVED = 1;            // (was: inter-workgroup wait timeout; no kernel waits on another now)
 constexpr u64 ERR_DRAWS_SHORT  = 2;
 constexpr u64 ERR_UMI_TOOLONG  = 4;
 constexpr u64 ERR_KEYS_FULL    = 8;
@@ -75,6 +74,8 @@ __device__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 33;
     return x;
 }
+
+__global__ void clear_bits_kernel(u64* word, u64 mask) { atomicAnd(word, ~mask); }
 
 // ------------------------------------------------------------------------------------
 // device-resident open-addressed table: 16-byte slots {key lo, key hi, value, 0},

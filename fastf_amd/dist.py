@@ -69,13 +69,13 @@ class HipStages:
     def count_hits(self, cb, n, out_hits):
         self.eng.dev_count_hits(cb.data_ptr(), n, out_hits.data_ptr(), self._s())
 
-    def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters):
+    def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters, reuse_hits=False):
         self.eng.dev_probe_pack(cb.data_ptr(), gx.data_ptr(), umi.data_ptr(), meta.data_ptr(), n,
                                 draws.data_ptr(), draws.numel(), keys_out.data_ptr(), stride,
                                 key_counts.data_ptr(), counters.data_ptr(), self._s(),
-                                d_draw_base=draw_base.data_ptr())
+                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits)
 
-    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, hist_ready=False):
+    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz):
         # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs
         in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
                                    skip_low=self.skip_low)
@@ -167,7 +167,7 @@ class ShardedPass:
             self._gather_small(all_h, self.hits.cpu())
             self.draw_base.fill_(int(all_h[:self.rank].sum()))
             st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
-                          self.key_counts, self.counters)
+                          self.key_counts, self.counters, reuse_hits=True)
             send = self.key_counts.cpu()
             recv = torch.empty(G, dtype=torch.int64)
             self._exchange_small(recv, send)
@@ -175,7 +175,7 @@ class ShardedPass:
         self._all_gather(self.all_hits, self.hits)
         self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
         st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
-                      self.key_counts, self.counters)
+                      self.key_counts, self.counters, reuse_hits=True)
         self._all_to_all_single(self.recv_counts, self.key_counts)
         both = torch.cat([self.key_counts, self.recv_counts]).tolist()       # the one host sync of the pass
         return both[:G], both[G:]
@@ -186,8 +186,13 @@ class ShardedPass:
     def _exchange_small(self, out_cpu, inp_cpu):
         dist.all_to_all_single(out_cpu, inp_cpu, group=self.small_group)
 
-    def run(self, cb, gx, umi, meta, n, draws):
-        """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident)."""
+    def run(self, cb, gx, umi, meta, n, draws, inputs_ready=None):
+        """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident).
+
+        Pipelined mode runs K1 on its own stream so that it overlaps the previous step's sort on the caller's stream;
+        it therefore cannot wait for everything the caller has queued.  A caller that REWRITES the input tensors between
+        steps must pass `inputs_ready`, an event recorded on its stream after the writes: K1 waits for it.  Without it
+        the inputs must be ready when the first step starts and stay untouched afterwards (bench.py: resident inputs)."""
         G, st = self.G, self.st
         if G > 1:
             b = self._step % len(self._small_slots)
@@ -196,7 +201,9 @@ class ShardedPass:
             if self.pipelined:
                 main = torch.cuda.current_stream(self.dev)
                 k1 = self.k1_stream
-                if self._step == 1:
+                if inputs_ready is not None:
+                    k1.wait_event(inputs_ready)          # the caller refilled the inputs on its own stream
+                elif self._step == 1:
                     k1.wait_stream(main)                 # the inputs were produced on the caller's stream
                 with torch.cuda.stream(k1):
                     if self._slot_free[b] is not None:
@@ -232,7 +239,7 @@ class ShardedPass:
             keys = self.keys_out.view(-1)
         # 4. local sort + reduce
         self.sorted = st.sort_reduce(keys, self.tmp, self.d_n, self.n_recv, self.feature, self.cell,
-                                     self.count, self.nnz, hist_ready=(G == 1))
+                                     self.count, self.nnz)
         if G > 1 and self.pipelined:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
@@ -290,7 +297,7 @@ class ShardedPass:
             src = self.sorted
             other = self.tmp if src.data_ptr() != self.tmp.data_ptr() else self._keys_buf
             self.sorted = st.sort_reduce(src, other, self.d_n, self.n_recv, self.feature, self.cell,
-                                         self.count, self.nnz, hist_ready=False)
+                                         self.count, self.nnz)
 
     def local_coo(self):
         self.ensure_exact()

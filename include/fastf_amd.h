@@ -22,7 +22,9 @@
  *      fastf_amd/dist.py, kernel parity tests).
  *
  * Every function returns 0 on success and non-zero on failure unless stated;
- * the message is available from fastf_last_error() (thread-local).
+ * the message is available from fastf_last_error() — the last error of the process, whichever
+ * thread raised it (reader workers fail on their own threads); the returned pointer is a
+ * per-thread snapshot.
  * The reference convention "0 ok / 1 fail + message on stderr" (bam2db_ds.h:60)
  * is kept by the outer layer.
  */
@@ -219,8 +221,10 @@ int  fastf_taghist_finish(fastf_taghist_t *h, fastf_taghist_result_t *result);
 /* 3. device-level entry points (all pointers are device pointers)        */
 /* ===================================================================== */
 
-/* number of CB hits in a record range (multi-GPU: draw-rank base of each shard).  Runs K1a;
- * a fastf_dev_probe_pack on the same d_cb_key/n right after reuses its result. */
+/* number of CB hits in a record range (multi-GPU: draw-rank base of each shard).  Runs K1a and leaves the cell
+ * index of every record in the engine's scratch: a fastf_dev_probe_pack over the very same records, next on the same
+ * stream, may pass FASTF_PROBE_REUSE_HITS to skip its own K1a.  The caller vouches for "same records": nothing is
+ * cached by pointer. */
 int fastf_dev_count_hits(fastf_engine_t *e, const uint64_t *d_cb_key, uint64_t n,
                          uint64_t *d_hits_out, void *stream);
 
@@ -234,13 +238,12 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
                          const uint32_t *d_umi, const uint32_t *d_meta, uint64_t n,
                          const uint32_t *d_draws, uint64_t n_draws, const uint64_t *d_draw_base,
                          uint64_t *d_keys_out, uint64_t shard_stride,
-                         uint64_t *d_key_counts, uint64_t *d_counters, void *stream);
+                         uint64_t *d_key_counts, uint64_t *d_counters, uint32_t flags, void *stream);
+#define FASTF_PROBE_REUSE_HITS 1u  /* fastf_dev_count_hits(e, d_cb_key, n, …) was the previous call on this stream */
 
 /* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
  * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
  * *sorted_in_tmp tells where the result landed. */
-#define FASTF_SORT_HIST_READY 1u   /* accepted and ignored (earlier builds pre-computed digit histograms in K1b; the
-                                      sort now takes its bin bases from the per-tile counts of each pass)        */
 #define FASTF_SORT_SKIP_LOW   2u   /* leave the low fastf_engine_skip_bits() bits unsorted: enough for the matrix
                                       (equal keys stay neighbours of their (cell, feature, top-UMI-bits) run);
                                       pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
@@ -252,7 +255,6 @@ int fastf_engine_sort_passes(const fastf_engine_t *e, uint32_t flags, uint32_t *
  * bitmap + rank + permutation over one id family; genes: 2 = direct index table over a dense id range),
  * 0 = open-addressed table in L2 */
 int fastf_engine_table_modes(const fastf_engine_t *e, int *cells_in_lds, int *genes_in_lds);
-int fastf_dev_hist_reset(fastf_engine_t *e, uint32_t flags, void *stream);   /* no-op, kept for ABI compatibility */
 int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
                    const uint64_t *d_n, uint64_t max_n, uint32_t key_bits, uint32_t flags,
                    int *sorted_in_tmp, void *stream);
@@ -278,6 +280,7 @@ int fastf_dev_reserve(fastf_engine_t *e, uint64_t max_records, uint64_t max_keys
  * (fastf_engine_finish does this by itself). */
 #define FASTF_ERR_RUN_TOO_LONG 16u
 int fastf_dev_error_bits(fastf_engine_t *e, uint64_t *bits);
+/* stream-ordered (an atomicAnd on the device; no synchronisation) */
 int fastf_dev_clear_error_bits(fastf_engine_t *e, uint64_t mask, void *stream);
 
 /* name of the dominant kernel symbols, for profile post-processing */

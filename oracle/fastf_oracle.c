@@ -6,7 +6,7 @@
  * reference stores rows in SQLite and lets it aggregate; SQLite is a third-
  * party dependency (unpinned system library, 3.3x), so the aggregate is
  * restated from its documented semantics and cross-checked against the real
- * library in tests/test_oracle_sqlite.py.
+ * library in tests/test_oracle_pins.py::test_aggregate_matches_sqlite.
  */
 #define _GNU_SOURCE
 #include "fastf_oracle.h"

@@ -27,10 +27,7 @@ class NumpyStages:
     def count_hits(self, cb, n, out_hits):
         out_hits[0] = int((self._cells_of(cb, n) != 0).sum())
 
-    def hist_reset(self):
-        pass
-
-    def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters):
+    def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters, reuse_hits=False):
         cell = self._cells_of(cb, n)
         hit = cell != 0
         rank = np.cumsum(hit) - 1 + int(draw_base[0])
@@ -56,7 +53,7 @@ class NumpyStages:
             key_counts[s] = c + len(ks)
         counters[0] += int(hit.sum()); counters[1] += int(keep.sum()); counters[2] += int(valid.sum())
 
-    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, hist_ready=False):
+    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz):
         n = int(d_n[0])
         k = np.sort(keys[:n].numpy().view(np.uint64))
         keys[:n] = torch.from_numpy(k.view(np.int64))

@@ -151,21 +151,45 @@ def test_reader_windows_and_threads_are_invisible(tmp_path, monkeypatch, window,
         np.testing.assert_array_equal(g, w)
 
 
-def test_reader_rejects_corrupt_block(tmp_path):
-    case = Case(n=5000, n_bar=20, n_gene=10)
+def test_reader_rejects_corrupt_block(tmp_path, monkeypatch):
+    """a byte flipped late in a multi-window file: the open succeeds, a later refill fails on the prefetch thread,
+    and the calling thread still reads the cause from fastf_last_error()"""
+    case = Case(n=60000, n_bar=20, n_gene=10)
     lists = case.lists()
     p = tmp_path / "c.bam"
     synth.write_bam(str(p), case.flags, case.xf, case.cb, case.gx, case.ub)
     data = bytearray(p.read_bytes())
-    data[len(data) // 2] ^= 0xFF                      # flip a byte inside a deflate stream
+    assert len(data) > 4 * (1 << 17)
+    data[len(data) * 3 // 4] ^= 0xFF                  # inside a deflate stream of a late block
+    p.write_bytes(bytes(data))
+    monkeypatch.setenv("FASTF_BAM_WINDOW", str(1 << 17))
+    L = _lib.lib()
+    L.fastf_set_error_.argtypes = [C.c_char_p]
+    L.fastf_set_error_(b"stale text from an earlier call")
+    h = L.fastf_bam_open(str(p).encode(), 2)
+    assert h, L.fastf_last_error()
+    cb = np.empty(9000, np.uint64); gx = np.empty(9000, np.uint64); um = np.empty(9000, np.uint32); me = np.empty(9000, np.uint32)
+    n, total = 1, 0
+    while n > 0:
+        n = L.fastf_bam_read_batch(h, lists.cell_dict, lists.feat_dict, cb.ctypes.data, gx.ctypes.data, um.ctypes.data, me.ctypes.data, 9000)
+        total += max(n, 0)
+    L.fastf_bam_close(h)
+    assert n == -1 and 0 < total < case.n
+    assert b"BGZF" in L.fastf_last_error() or b"corrupt BAM record" in L.fastf_last_error()
+
+
+def test_reader_rejects_oversized_isize(tmp_path):
+    """BGZF caps a block's inflated size at 64 KiB: a crafted ISIZE near 4 GiB must be refused, not allocated"""
+    case = Case(n=2000, n_bar=20, n_gene=10)
+    p = tmp_path / "i.bam"
+    synth.write_bam(str(p), case.flags, case.xf, case.cb, case.gx, case.ub)
+    data = bytearray(p.read_bytes())
+    bsize = struct.unpack_from("<H", data, 16)[0] + 1          # first block: ISIZE is its last 4 bytes
+    struct.pack_into("<I", data, bsize - 4, 0xFFFFFF00)
     p.write_bytes(bytes(data))
     L = _lib.lib()
     h = L.fastf_bam_open(str(p).encode(), 2)
-    if h:
-        cb = np.empty(9000, np.uint64); gx = np.empty(9000, np.uint64); um = np.empty(9000, np.uint32); me = np.empty(9000, np.uint32)
-        n = L.fastf_bam_read_batch(h, lists.cell_dict, lists.feat_dict, cb.ctypes.data, gx.ctypes.data, um.ctypes.data, me.ctypes.data, 9000)
-        L.fastf_bam_close(h)
-        assert n == -1 and b"BGZF" in L.fastf_last_error()
+    assert not h and b"BGZF" in L.fastf_last_error()
 
 
 @pytest.mark.parametrize("window,threads", [(1 << 17, 8), (1 << 20, 4), (32 << 20, 8)])

@@ -25,7 +25,7 @@ stamps = torch.zeros(T * 8, dtype=torch.int64, device=dev)
 L = _lib.lib(); L.fastf_debug_set_k1_stamps.argtypes = [ctypes.c_void_p]
 s = torch.cuda.current_stream().cuda_stream
 def run():
-    kc.zero_(); cnt.zero_(); eng.dev_hist_reset(s)
+    kc.zero_(); cnt.zero_()
     eng.dev_probe_pack(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), N, d[4].data_ptr(), N, keys.data_ptr(), N, kc.data_ptr(), cnt.data_ptr(), s)
 for _ in range(3): run()
 L.fastf_debug_set_k1_stamps(stamps.data_ptr()); run(); torch.cuda.synchronize()
