@@ -90,7 +90,7 @@ struct fastf_engine {
     DevBuf img_cells, img_genes;         // LDS table images (fast path, when the lists allow it)
     DevBuf d_cell_filter; MissFilter cell_filter{nullptr, 0};        // miss filter in front of the L2 cell table
     CellLds lds_cells{}; GeneLds lds_genes{};
-    bool use_lds_cells = false, use_lds_genes = false; u32 genes_blocks_per_cu = 1;
+    bool use_lds_cells = false, use_lds_genes = false; u32 genes_blocks_per_cu = 1, cells_blocks_per_cu = 1;
     // draw stream
     fastf_mt_t mt{};
     std::vector<u32> pending_draws;      // generated, not yet consumed
@@ -188,66 +188,99 @@ static int build_cell_filter(fastf_engine* e, const u64* keys, u32 n) {
     return 0;
 }
 
-static u32 h_fmix32(u32 h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
-
-// compress-hash-displace perfect hash of the 32-bit barcode codes (host mirror of chd_bucket / chd_slot)
-static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
-    if (n == 0 || n > 12000) return 0;
+// hash-and-displace with quotienting over the 32-bit barcode codes (see "LDS-resident tables" in umi_kernels.hpp):
+// buckets by the low bits of the mixed code, largest first; a bucket's displacement is any value that puts all of its
+// keys on free slots (a single key goes straight to a free slot).  Two keys of one bucket with the same hi part can
+// never be placed — about one such pair is expected at 25 k keys, so the mix is re-seeded until there is none.
+struct CellImage { std::vector<unsigned char> img; u32 slot_bits = 0, bucket_mask = 0, family = 0, bytes = 0, seed = 0; };
+// pure host code (no HIP): true when the list qualifies and a displacement set was found
+static bool make_cell_image(const u64* keys, u32 n, CellImage& out) {
+    u32 max_n = 32767;
+    { const char* mx = getenv("FASTF_LDS_CELLS_MAX"); if (mx) max_n = std::min<u32>(max_n, (u32)atoi(mx)); }
+    if (n == 0 || n > max_n) return false;
     const u64 fam = keys[0] >> 49;
     std::vector<u32> code(n);
     for (u32 i = 0; i < n; ++i) {
         const u64 k = keys[i];
-        if ((k >> 62) != 1 || (k >> 49) != fam || (k & 0xFFFFu) != 0 || ((k >> 57) & 31) > 16) return 0;
+        if ((k >> 62) != 1 || (k >> 49) != fam || (k & 0xFFFFu) != 0 || ((k >> 57) & 31) > 16) return false;
         code[i] = (u32)(k >> 16);
     }
-    const u32 B = std::max<u32>(1, (n + 3) / 4);
-    for (u32 attempt = 0; attempt < 8; ++attempt) {
-        const u32 m = n + n / 50 * attempt + (attempt ? 8 : 0);         // minimal first, +2 % slots per retry
-        const u32 m_even = (m + 1u) & ~1u;
-        std::vector<std::vector<u32>> bucket(B);
-        for (u32 i = 0; i < n; ++i) bucket[(u32)(((u64)h_fmix32(code[i]) * B) >> 32)].push_back(i);
-        std::vector<u32> order(B);
-        for (u32 i = 0; i < B; ++i) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return bucket[a].size() > bucket[b].size(); });
-        std::vector<u32> slot_code(m, 0); std::vector<unsigned short> slot_idx(m_even, 0), disp(B, 0);
-        bool ok = true;
-        std::vector<u32> trial;
-        for (u32 bi : order) {
-            const auto& items = bucket[bi];
-            if (items.empty()) continue;
-            bool placed = false;
-            for (u32 d = 0; d < 65536 && !placed; ++d) {
-                trial.clear();
-                bool fits = true;
-                for (u32 it : items) {
-                    const u32 sl = (u32)(((u64)h_fmix32(code[it] ^ (d * 0x9E3779B1u + 0x7F4A7C15u)) * m) >> 32);
-                    if (slot_idx[sl] || std::find(trial.begin(), trial.end(), sl) != trial.end()) { fits = false; break; }
-                    trial.push_back(sl);
-                }
-                if (!fits) continue;
-                for (size_t t = 0; t < items.size(); ++t) { slot_code[trial[t]] = code[items[t]]; slot_idx[trial[t]] = (unsigned short)(items[t] + 1); }
-                disp[bi] = (unsigned short)d;
-                placed = true;
+    u32 S = 10;
+    while ((1u << S) <= n) ++S;                                          // n <= 2^S - 1: index 0 marks an empty slot
+    const u32 slots = 1u << S, smask = slots - 1u, lo_mask = (1u << (32u - S)) - 1u;
+    u32 B = 256;
+    while (B * 3u < n && B < 8192u) B <<= 1;                            // about 2-4 keys per bucket; 16 KB of displacements at most
+    const size_t bytes = (size_t)slots * 4 + (size_t)B * 2;
+    std::vector<u32> h(n), order(B), head(B + 1), items(n), free_list; std::vector<u32> slot(slots);
+    std::vector<unsigned short> disp(B);
+    for (u32 attempt = 0; attempt < 64; ++attempt) {
+        const u32 seed = attempt * 0x632BE5ABu;
+        std::fill(head.begin(), head.end(), 0u);
+        for (u32 i = 0; i < n; ++i) { h[i] = cell_mix(code[i], seed); head[(h[i] & lo_mask & (B - 1u)) + 1]++; }
+        for (u32 b = 0; b < B; ++b) head[b + 1] += head[b];
+        { std::vector<u32> fill(head.begin(), head.end() - 1); for (u32 i = 0; i < n; ++i) items[fill[h[i] & lo_mask & (B - 1u)]++] = i; }
+        for (u32 b = 0; b < B; ++b) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](u32 x, u32 y) { const u32 sx = head[x + 1] - head[x], sy = head[y + 1] - head[y]; return sx != sy ? sx > sy : x < y; });
+        std::fill(slot.begin(), slot.end(), 0u); std::fill(disp.begin(), disp.end(), (unsigned short)0);
+        bool ok = true; u32 placed_keys = 0, rover = 0;
+        for (u32 oi = 0; oi < B && ok; ++oi) {
+            const u32 b = order[oi], lo_i = head[b], sz = head[b + 1] - lo_i;
+            if (sz == 0) break;
+            if (sz == 1) {                                               // any free slot will do: walk a rover over the table
+                while (slot[rover]) rover = (rover + 1) & smask;
+                const u32 it = items[lo_i], hi = h[it] >> (32u - S);
+                disp[b] = (unsigned short)((rover - hi) & smask);
+                slot[rover] = ((h[it] & lo_mask) << S) | (it + 1);
+                placed_keys++;
+                continue;
             }
-            if (!placed) { ok = false; break; }
+            for (u32 x = lo_i; x < lo_i + sz && ok; ++x)                 // equal hi parts inside a bucket collide for every displacement
+                for (u32 y = x + 1; y < lo_i + sz; ++y)
+                    if ((h[items[x]] >> (32u - S)) == (h[items[y]] >> (32u - S))) { ok = false; break; }
+            if (!ok) break;
+            bool placed = false;
+            u32 d = (b * 0x9E3779B1u) >> (32u - S);                      // spread the starting points
+            for (u32 t = 0; t < slots && !placed; ++t, d = (d + 1) & smask) {
+                bool fits = true;
+                for (u32 x = lo_i; x < lo_i + sz; ++x) if (slot[((h[items[x]] >> (32u - S)) + d) & smask]) { fits = false; break; }
+                if (!fits) continue;
+                for (u32 x = lo_i; x < lo_i + sz; ++x) { const u32 it = items[x]; slot[((h[it] >> (32u - S)) + d) & smask] = ((h[it] & lo_mask) << S) | (it + 1); }
+                disp[b] = (unsigned short)d; placed = true; placed_keys += sz;
+            }
+            if (!placed) ok = false;
         }
-        if (!ok) continue;
-        const size_t bytes = (((size_t)m * 4 + (size_t)m_even * 2 + (size_t)B * 2) + 15) & ~(size_t)15;
-        if (bytes > 78 * 1024) return 0;
-        std::vector<unsigned char> img(bytes + 16, 0);
-        memcpy(img.data(), slot_code.data(), (size_t)m * 4);
-        memcpy(img.data() + (size_t)m * 4, slot_idx.data(), (size_t)m_even * 2);
-        memcpy(img.data() + (size_t)m * 4 + (size_t)m_even * 2, disp.data(), (size_t)B * 2);
-        if (e->img_cells.ensure(bytes)) return 1;
-        HIP_OK(hipMemcpy(e->img_cells.p, img.data(), bytes, hipMemcpyHostToDevice));
-        e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.m = m; e->lds_cells.buckets = B;
-        e->lds_cells.family = (u32)fam; e->lds_cells.bytes = (u32)bytes;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes) != hipSuccess) return 0;
-        e->use_lds_cells = true;
-        return 0;
+        if (!ok || placed_keys != n) continue;
+        out.img.assign(((bytes + 15) & ~(size_t)15) + 16, 0);
+        memcpy(out.img.data(), slot.data(), (size_t)slots * 4);
+        memcpy(out.img.data() + (size_t)slots * 4, disp.data(), (size_t)B * 2);
+        out.slot_bits = S; out.bucket_mask = B - 1u; out.family = (u32)fam; out.bytes = (u32)bytes; out.seed = seed;
+        return true;
     }
-    return 0;                                                            // no displacement set found: stay on the L2 table
+    return false;                                                        // no displacement set found: stay on the L2 table
+}
+
+static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
+    CellImage ci;
+    if (!make_cell_image(keys, n, ci)) return 0;
+    if (e->img_cells.ensure(ci.img.size())) return 1;
+    HIP_OK(hipMemcpy(e->img_cells.p, ci.img.data(), ci.img.size(), hipMemcpyHostToDevice));
+    e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.slot_bits = ci.slot_bits; e->lds_cells.bucket_mask = ci.bucket_mask;
+    e->lds_cells.family = ci.family; e->lds_cells.bytes = ci.bytes; e->lds_cells.seed = ci.seed;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ci.bytes) != hipSuccess) return 0;
+    e->cells_blocks_per_cu = ci.bytes + 64 <= 80 * 1024 ? 2u : 1u;
+    e->use_lds_cells = true;
+    return 0;
+}
+
+// test hook (host only, no device needed): the LDS image of a barcode list and its parameters; returns the image size
+// in bytes (0: the list does not qualify), copies at most cap bytes
+extern "C" size_t fastf_debug_cell_image(const uint64_t* cell_keys, uint32_t n, void* image_out, size_t cap, uint32_t params[5]) {
+    CellImage ci;
+    if (!make_cell_image((const u64*)cell_keys, n, ci)) return 0;
+    if (image_out) memcpy(image_out, ci.img.data(), std::min(cap, (size_t)ci.bytes));
+    if (params) { params[0] = ci.slot_bits; params[1] = ci.bucket_mask; params[2] = ci.family; params[3] = ci.bytes; params[4] = ci.seed; }
+    return ci.bytes;
 }
 
 static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
@@ -519,7 +552,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     t_begin(e, s);
     if (e->use_lds_cells) {                          // tile counts are all-zero here: scan_tiles_kernel clears what it reads
-        const u32 grid = std::min<u32>(2 * g_cu_count, (tiles + 1) / 2);
+        const u32 grid = std::min<u32>(e->cells_blocks_per_cu * g_cu_count, (tiles + 1) / 2);
         hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
                            (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
     } else if (e->cell_filter.bits) {

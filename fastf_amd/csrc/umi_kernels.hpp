@@ -255,23 +255,29 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
 // general path).  Exactness rests on the key packing, not on hashing:
 //   cells: every registered barcode is of the DNA form with the same length (<= 16 bases) and the
 //          same "-N" suffix, so key bits 63:49 are one constant ("family") and bits 47:16 hold the
-//          bases: a 32-bit code identifies the barcode.  A perfect hash (compress-hash-displace:
-//          bucket → 16-bit displacement → slot, no empty probing) keeps (code, index) for 12 k
-//          cells in 78 KB, so two 1024-thread workgroups share a CU.  A tag key outside the family
-//          cannot be a registered barcode.
+//          bases: a 32-bit code identifies the barcode.  The table is hash-and-displace with
+//          quotienting: h = a BIJECTIVE 32-bit mix of the code, split into hi (S bits) and lo
+//          (32 - S bits); slot = (hi + disp[bucket(lo)]) mod 2^S, and the slot keeps lo next to
+//          the cell index.  A probe that finds its lo in its slot has the same bucket, hence the
+//          same displacement, hence the same hi — the whole code is verified by the 32 - S stored
+//          bits, so a slot is 4 bytes: (lo << S) | index, 0 = empty.  32 767 cells fit 128 KB of
+//          slots + 16 KB of displacements (one 1024-thread workgroup per CU), 16 383 cells 72 KB
+//          (two per CU).  A tag key outside the family cannot be a registered barcode.
 //   genes: registered feature ids of one ID-form family (<prefix><n digits>, key bits 63:44) map
 //          through a bitmap over [vmin, vmax] + per-word rank + permutation to the feature index:
 //          exact hit or exact miss with three LDS reads; keys of other families use the L2 table.
 // ------------------------------------------------------------------------------------
-struct CellLds { const u32* image; u32 m; u32 buckets; u32 family; u32 bytes; };
-                                                                      // image: u32 code[m] | u16 index[m'] | u16 disp[buckets]  (m' = m rounded up to even)
+struct CellLds { const u32* image; u32 slot_bits; u32 bucket_mask; u32 family; u32 bytes; u32 seed; };
+                                                                      // image: u32 slot[1 << slot_bits] | u16 disp[bucket_mask + 1]
 struct GeneLds { const u32* image; u32 words; u32 n_perm; u32 family; u64 vmin; u64 range; u32 bytes; u32 direct; };
                                                                       // image: u32 bitmap[words] | u16 rank[words] (padded) | u16 perm[n_perm]
                                                                       // direct (dense id range): u16 index[range], 0 = not a listed id
 
-__device__ __forceinline__ u32 fmix32(u32 h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
-__device__ __forceinline__ u32 chd_bucket(u32 code, u32 buckets) { return (u32)(((u64)fmix32(code) * buckets) >> 32); }
-__device__ __forceinline__ u32 chd_slot(u32 code, u32 disp, u32 m) { return (u32)(((u64)fmix32(code ^ (disp * 0x9E3779B1u + 0x7F4A7C15u)) * m) >> 32); }
+// bijection on 32 bits (odd multipliers and xor-shifts are invertible): distinct codes have distinct mixes
+__host__ __device__ __forceinline__ u32 cell_mix(u32 code, u32 seed) {
+    u32 h = (code ^ seed) * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+    return h;
+}
 
 
 // K1a with a miss filter (barcode lists too large for the LDS perfect hash): a bit set over a second hash of the listed
@@ -329,16 +335,17 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
     }
 }
 
-// K1a, LDS mode: persistent 1024-thread workgroups (two per CU); every wave walks its own 512-record chunks and adds
-// its hit count to tile_hits[] (all-zero on entry) with one atomic — no barrier after the table image is in LDS.
-__global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
-                                                                  u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                                  u32 n_tiles) {
+// K1a, LDS mode: persistent 1024-thread workgroups (one or two per CU, by the size of the table image); every wave
+// walks its own 512-record chunks — each lane loads and stores PAIRS of neighbouring records (16-byte loads, 8-byte
+// stores) — and adds its hit count to tile_hits[] (all-zero on entry) with one atomic: no barrier after the image is
+// in LDS.
+__global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
+                                                               u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                               u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 m_even = (c.m + 1u) & ~1u;
-    const u32* s_code = reinterpret_cast<const u32*>(smem);
-    const unsigned short* s_idx = reinterpret_cast<const unsigned short*>(smem + (size_t)c.m * 4);
-    const unsigned short* s_disp = s_idx + m_even;
+    const u32 S = c.slot_bits, smask = (1u << S) - 1u, lo_mask = (1u << (32u - S)) - 1u;
+    const u32* s_slot = reinterpret_cast<const u32*>(smem);
+    const unsigned short* s_disp = reinterpret_cast<const unsigned short*>(smem + ((size_t)4 << S));
     {
         const uint4* src = reinterpret_cast<const uint4*>(c.image);
         uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -346,29 +353,47 @@ __global__ __launch_bounds__(1024, 8) void probe_cells_lds_kernel(const u64* __r
     }
     __syncthreads();
     const int lane = lane_id();
-    const u32 n_chunks = n_tiles * (u32)K1_WAVES;                       // 512-record chunks
+    constexpr int PAIRS = K1_IPT / 2;                                    // 4 x 64 lanes x 2 records = one 512-record chunk
+    const u32 n_chunks = n_tiles * (u32)K1_WAVES;
+    const bool even = (n & 1ull) == 0 && (reinterpret_cast<uintptr_t>(cb) & 15u) == 0 && (reinterpret_cast<uintptr_t>(cell_out) & 7u) == 0;
     for (u32 chunk = blockIdx.x * 16u + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 16u) {
         const u64 base = (u64)chunk * (K1_IPT * WAVE);
         u64 key[K1_IPT]; u32 cell[K1_IPT];
+        const bool whole = even && base + K1_IPT * WAVE <= n;            // wave-uniform
+        if (whole) {
 #pragma unroll
-        for (int j = 0; j < K1_IPT; ++j) {
-            const u64 idx = base + (u64)j * WAVE + lane;
-            key[j] = idx < n ? cb[idx] : 0;
+            for (int j = 0; j < PAIRS; ++j) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(cb + base + 2ull * (j * WAVE + lane));
+                key[2 * j] = v.x; key[2 * j + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K1_IPT; ++j) {
+                const u64 idx = base + 2ull * ((j >> 1) * WAVE + lane) + (j & 1);
+                key[j] = idx < n ? cb[idx] : 0;
+            }
         }
         u32 hits = 0;
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
-            const u32 code = (u32)(key[j] >> 16);
             const bool fam = (u32)(key[j] >> 49) == c.family && (key[j] & 0xFFFFu) == 0;
-            const u32 sl = chd_slot(code, s_disp[chd_bucket(code, c.buckets)], c.m);
-            const u32 v = (fam && s_code[sl] == code) ? s_idx[sl] : 0u;       // empty slots carry index 0
+            const u32 h = cell_mix((u32)(key[j] >> 16), c.seed);
+            const u32 lo = h & lo_mask;
+            const u32 e = s_slot[((h >> (32u - S)) + s_disp[lo & c.bucket_mask]) & smask];
+            const u32 v = (fam && (e >> S) == lo) ? (e & smask) : 0u;          // empty slots carry index 0
             cell[j] = v;
             hits += (u32)__popcll(__ballot(v != 0));
         }
+        if (whole) {
 #pragma unroll
-        for (int j = 0; j < K1_IPT; ++j) {
-            const u64 idx = base + (u64)j * WAVE + lane;
-            if (idx < n) cell_out[idx] = cell[j];
+            for (int j = 0; j < PAIRS; ++j)
+                *reinterpret_cast<uint2*>(cell_out + base + 2ull * (j * WAVE + lane)) = make_uint2(cell[2 * j], cell[2 * j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < K1_IPT; ++j) {
+                const u64 idx = base + 2ull * ((j >> 1) * WAVE + lane) + (j & 1);
+                if (idx < n) cell_out[idx] = cell[j];
+            }
         }
         if (lane == 0 && hits) atomicAdd(&tile_hits[chunk / (u32)K1_WAVES], hits);
     }
