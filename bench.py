@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — device-path throughput of the bam2db hot path on MI355X.
+"""bench.py — the bam2db hot path on MI355X, measured on BASELINE.json configs[2].
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (K1 probe/filter/pack → [all-to-all] → K2 LSD radix sort →
-K3 segmented unique/reduce → COO) over one batch of synthetic packed records that is already
-resident in HBM.  Workload = BASELINE.json configs[1]: 10 M records, 10 k barcodes x 30 k genes,
-keep-all, per GPU (weak scaling: N GPUs process N x 10 M records of one job, sharded by cell).
-Prints ONE JSON line on rank 0.
+Workload (fastf_amd/workload.py): 200 M synthetic records, 50 k barcodes x 36 601 genes,
+--cell 0.5 --depth 0.5 --seed 926 (the shape of the reference's own benchmark/fastF_disk.sh).
+A step = one pass of the hot path over the whole job: K1 probe/filter/pack -> [all-to-all] -> K2 LSD
+radix sort -> K3 segmented unique/reduce -> COO.  With N GPUs the SAME job is split over the ranks
+(strong scaling): rank r owns a contiguous slice of the record stream, keys travel to their cell's
+owner in one all-to-all.
+
+The one JSON line carries
+  value            records/s of the timed steps, inputs resident in HBM when the clock starts
+  roofline         the kernel that takes most of the step: algorithmic bytes / its HIP-event time
+  whole_path       SURVEY 8d's B and B_read over the step time (nominal and executed radix passes)
+  device_path      N=1: pinned host SoA -> hipMemcpyAsync -> kernels -> COO on the host (PCIe-inclusive)
+  e2e              N=1: the real CLI on generated BAM files, process start to the .gz files closed
+  cpu_baseline     N=1: the CPU oracle on a bounded sample of the same records, 1 core (+ parity check)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,23 +36,43 @@ import torch  # noqa: E402  (before fastf_amd: one shared HIP runtime)
 import torch.distributed as dist  # noqa: E402
 
 import fastf_amd as F  # noqa: E402
-from fastf_amd import synth  # noqa: E402
+from fastf_amd import workload  # noqa: E402
 from fastf_amd.dist import HipStages, ShardedPass  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PCIE_GBS = 55.0                # Gen5 x16, what a pinned hipMemcpyAsync reaches
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_table(eng, N, H, K, Z):
+    """per-kernel HIP-event averages (ms) with each kernel's algorithmic bytes per launch"""
+    names = {0: ("probe_cells (K1a)", 12 * N), 4: ("filter_pack (K1b)", 20 * N + 4 * H + 8 * K),
+             3: ("tile_count (K2, per pass)", 8 * K), 1: ("scatter (K2, per pass)", 16 * K),
+             2: ("head_count+scan+reduce+carry (K3)", 16 * K + 12 * Z)}
+    out = {}
+    for which, (nm, b) in names.items():
+        ms, n = eng.get_timing(which)
+        if n:
+            avg = ms / n
+            out[nm] = {"avg_ms": avg, "launches_timed": int(n), "bytes_per_launch": b,
+                       "GBs": b / (avg * 1e-3) / 1e9, "frac": b / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU per step")
-    ap.add_argument("--barcodes", type=int, default=10_000)
-    ap.add_argument("--genes", type=int, default=30_000)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--records", type=int, default=200_000_000, help="records of the whole job (all GPUs together)")
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--gene-stride", type=int, default=1, help="spacing of the synthetic gene ids (8 ~ a real Ensembl list)")
+    ap.add_argument("--no-devpath", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-records", type=str, default="40000000,20000000", help="records of the skinny and the Cell-Ranger-shaped BAM")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -49,9 +80,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("FASTF_BENCH_ONE_DEVICE"):      # rehearsal of the N>1 code path on a 1-GPU box
         local = 0
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -60,52 +90,40 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    G = world
+    if workload.SEGMENTS % G:
+        sys.exit("the job is cut into %d segments: --gpus must divide it" % workload.SEGMENTS)
 
-    N, G = args.records, world
-    seed, rate_cell, rate_depth = 926, 1.0, 1.0
+    # ---- the job: every rank builds the same lists and molecule pool, then its own slice of the record stream ----
+    t_gen = time.perf_counter()
+    job = workload.C3(args.records)
+    N_total, seg_per_rank = job.n_total, workload.SEGMENTS // G
+    n_local = seg_per_rank * job.seg_len
+    lists = job.lists
+    cb = torch.empty(n_local, dtype=torch.int64, device=dev); gx = torch.empty_like(cb)
+    umi = torch.empty(n_local, dtype=torch.int32, device=dev); meta = torch.empty_like(umi)
+    for i in range(seg_per_rank):
+        a = i * job.seg_len
+        c, g, u, m = job.segment_packed(rank * seg_per_rank + i, dev)
+        cb[a:a + job.seg_len], gx[a:a + job.seg_len], umi[a:a + job.seg_len], meta[a:a + job.seg_len] = c, g, u, m
+    del c, g, u, m
+    job._pool = None
+    torch.cuda.empty_cache()
+    draws_h = F.mt_draws(workload.SEED, lists.mt_skip, N_total)      # job-wide draw stream: draw i belongs to the i-th CB hit
+    d_draws = torch.from_numpy(draws_h.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("bench: job generated in %.1f s (%d records per rank)" % (time.perf_counter() - t_gen, n_local))
 
-    # ---- synthetic job: G slices of N records; this rank owns slice `rank` ----
-    bt, ft, bar, genes = synth.make_lists(args.barcodes, args.genes, seed=4242, gene_stride=args.gene_stride)
-    lists = F.Lists(bt, ft, rate_cell, seed)
-    fl, xf, cb, gx, ub = synth.make_records(N, bar, genes, seed=100 + rank, umi_len=10)
-    cbs, gxs, ubs = synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)
-    cbk, gxk, umi, meta = F.pack_records(lists, fl, xf, cbs, gxs, ubs)
-    draws = F.mt_draws(seed, lists.mt_skip, N * G)
-
-    eng = F.Engine.from_lists(lists, rate_depth=rate_depth, seed=seed, umi_max_bases=12,
+    eng = F.Engine.from_lists(lists, rate_depth=workload.RATE_DEPTH, seed=workload.SEED, umi_max_bases=workload.UMI_LEN,
                               n_shards=G, shard_rank=rank, device=local)
-    eng.reserve(N, N * G)
-
-    def dev_t(a):
-        return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32)).to(dev)
-    d_cb, d_gx, d_umi, d_meta, d_draws = dev_t(cbk), dev_t(gxk), dev_t(umi), dev_t(meta), dev_t(draws)
-    sp = ShardedPass(HipStages(eng, dev), N, dev)
+    eng.reserve(n_local, n_local)
+    sp = ShardedPass(HipStages(eng, dev), n_local, dev)
 
     def step():
-        sp.run(d_cb, d_gx, d_umi, d_meta, N, d_draws)
+        sp.run(cb, gx, umi, meta, n_local, d_draws)
 
-    if world > 1 and sp.pipelined:
-        # self-check of the multi-stream pipeline against the single-stream pass on the same input (one step each);
-        # on any difference the timed loop uses the single-stream pass
-        ref = ShardedPass(HipStages(eng, dev), N, dev, pipeline=False)
-        ref.run(d_cb, d_gx, d_umi, d_meta, N, d_draws)
-        ref.ensure_exact()
-        want = (int(ref.d_n.item()), int(ref.nnz.item()), ref.global_counters())
-        for _ in range(2):
-            step()
-        sp.ensure_exact()
-        got = (int(sp.d_n.item()), int(sp.nnz.item()), sp.global_counters())
-        same = torch.tensor([1 if got == want else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        if int(same.item()) != 1:
-            if rank == 0:
-                print("bench: pipelined pass differs from the single-stream pass (%r vs %r): timing the single-stream pass"
-                      % (got, want), file=sys.stderr)
-            sp = ref
-        else:
-            del ref
-            torch.cuda.empty_cache()
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         step()
         sp.ensure_exact()      # data with very deep (cell, feature) groups switches the sort to all digits here, once
     torch.cuda.synchronize()
@@ -127,98 +145,208 @@ def main():
 
     err = eng.dev_error_bits()
     hits, sampled, valid, _ = sp.global_counters()
-    n_keys_local = int(sp.d_n.item())
-    nnz_local = int(sp.nnz.item())
+    K_local = int(sp.d_n.item())
+    Z_local = int(sp.nnz.item())
+    tot = torch.tensor([K_local, Z_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    K_job, Z_job = int(tot[0].item()), int(tot[1].item())
 
-    # ---- per-kernel HIP-event timing of the dominant kernel (scatter pass of the radix sort) ----
+    # ---- per-kernel HIP-event timing (events on the launch stream, a few extra steps after the timed region) ----
     eng.set_timing(True)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    t_k1, n_k1 = eng.get_timing(0)
-    t_k1b, n_k1b = eng.get_timing(4)
-    t_sc, n_sc = eng.get_timing(1)
-    t_k3, n_k3 = eng.get_timing(2)
-    t_ct, n_ct = eng.get_timing(3)
+    H_local = hits // G
+    ktab = kernel_table(eng, n_local, H_local, K_local, Z_local)
     eng.set_timing(False)
-    passes = (eng.key_bits + 7) // 8
-    sc_ms = t_sc / max(n_sc, 1)
-    sc_bytes = 16.0 * n_keys_local                     # read 8 B + write 8 B per key per launch
-    achieved = sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
+    P_nom = (eng.key_bits + 7) // 8
+    P_exe = eng.sort_passes(sp.st.skip_low)
+    per_step = {k: v["avg_ms"] * (P_exe if "per pass" in k else 1) for k, v in ktab.items()}
+    dom = max(per_step, key=per_step.get)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("scatter_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            short = dom.split(" ")[0] + "_kernel"
+            if tj.get("workload_records") == N_total:
+                traffic = tj.get("kernels", {}).get(short, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
     out = None
     if rank == 0:
-        total_records = N * G * args.steps
-        # algorithmic bytes of one step on this rank: 24N + 4H + 8K(3+2P) + 12Z
-        H, K, Z, P = hits // G, n_keys_local, nnz_local, passes
-        B = 24 * N + 4 * H + 8 * K * (3 + 2 * P) + 12 * Z
-        B_read = 24 * N + 4 * H + 8 * K * (2 + P)          # the read-only share
         ms_step = dt / args.steps * 1e3
+        d = ktab[dom]
+        # algorithmic bytes of one step of the whole job: B = 24N + 4H + 8K(3+2P) + 12Z
+        def B_of(P):
+            return 24 * N_total + 4 * hits + 8 * K_job * (3 + 2 * P) + 12 * Z_job
+
+        def Bread_of(P):
+            return 24 * N_total + 4 * hits + 8 * K_job * (2 + P)
+        gbs = lambda b: b / (ms_step * 1e-3) / 1e9 / G      # per GPU
         out = {
-            "metric": "BAM records/sec -> deduped UMI matrix (device path, inputs resident in HBM)",
-            "value": total_records / dt, "unit": "records/s",
+            "metric": "BAM records/sec -> deduped UMI matrix; achieved HBM GB/s vs roofline",
+            "value": N_total * args.steps / dt, "unit": "records/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if G > 1 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic records x %d GPU(s), %d barcodes x %d genes, "
-                                   "--cell 1.0 --depth 1.0 --seed 926, uniform cells/genes, 10-bp UMIs"
-                                   % (N, G, args.barcodes, args.genes),
-                       "records_per_gpu": N, "key_bits": eng.key_bits, "radix_passes": passes,
-                       "radix_passes_executed": eng.sort_passes(sp.st.skip_low),
+            "config": {"workload": workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (packed SoA + draw stream)",
+                       "records_per_gpu": n_local, "key_bits": eng.key_bits, "radix_passes_nominal": P_nom,
+                       "radix_passes_executed": P_exe,
                        "sharding": ("cell-hash, one all-to-all, %s" % ("3-stream pipeline" if sp.pipelined else "single stream")) if G > 1 else "single GPU",
                        "lookup_tables": eng.table_modes},
-            "roofline": {"bound": "hbm", "kernel": "scatter_kernel (one 8-bit LSD radix pass)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": sc_bytes, "avg_launch_ms": sc_ms, "launches_timed": int(n_sc)},
-            "kernels_ms": {"probe_cells": t_k1 / max(n_k1, 1), "filter_pack": t_k1b / max(n_k1b, 1),
-                           "tile_count_per_pass": t_ct / max(n_ct, 1), "scatter_per_pass": sc_ms,
-                           "head_count+scan+reduce": t_k3 / max(n_k3, 1)},
-            "whole_path": {"algorithmic_bytes_per_step": B, "algorithmic_read_bytes_per_step": B_read,
-                           "achieved_read_GBs": B_read / (ms_step * 1e-3) / 1e9, "achieved_GBs": B / (ms_step * 1e-3) / 1e9,
-                           "frac_of_peak": B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "counters": {"total": N * G, "hits": hits, "sampled": sampled, "valid": valid,
-                         "keys_rank0": n_keys_local, "rows_rank0": nnz_local, "device_error_bits": err},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["frac"], "traffic": traffic, "bytes_per_launch": d["bytes_per_launch"],
+                         "avg_launch_ms": d["avg_ms"], "launches_timed": d["launches_timed"],
+                         "share_of_step": per_step[dom] / sum(per_step.values())},
+            "kernels": ktab,
+            "whole_path": {"per_gpu": True,
+                           "B_nominal_P%d" % P_nom: B_of(P_nom), "B_executed_P%d" % P_exe: B_of(P_exe),
+                           "B_read_nominal": Bread_of(P_nom), "B_read_executed": Bread_of(P_exe),
+                           "GBs_nominal": gbs(B_of(P_nom)), "GBs_executed": gbs(B_of(P_exe)),
+                           "frac_of_peak_nominal": gbs(B_of(P_nom)) / HBM_PEAK_GBS,
+                           "frac_of_peak": gbs(B_of(P_exe)) / HBM_PEAK_GBS,
+                           "read_GBs_executed": gbs(Bread_of(P_exe)), "read_frac_of_peak": gbs(Bread_of(P_exe)) / HBM_PEAK_GBS,
+                           "read_frac_of_peak_nominal": gbs(Bread_of(P_nom)) / HBM_PEAK_GBS},
+            "counters": {"total": N_total, "hits": hits, "sampled": sampled, "valid": valid,
+                         "keys": K_job, "rows": Z_job, "device_error_bits": err},
         }
 
-    # ---- CPU baseline: the oracle (port of the reference algorithm), 1 core, bounded sample ----
-    if rank == 0 and G == 1 and not args.no_cpu:
-        from oracle import oracle as O
-        S = min(args.cpu_sample, N)
-        t1 = time.perf_counter()
-        ora = O.run_bam2db(bt, ft, fl[:S], xf[:S], cbs[:S], gxs[:S], ubs[:S], rate_cell, rate_depth, seed)
-        cpu_dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": S / cpu_dt, "unit": "records/s", "cores": 1, "kind": "port",
-                               "sample": "first %d records of the same workload through oracle/fastf_oracle.c "
-                                         "(hash probe + MT draw + qsort aggregate), %.1f s" % (S, cpu_dt),
-                               "note": "the reference's own bam2db (SQLite INSERT + GROUP BY, gz writers) ran at 0.24 M records/s on "
-                                       "1 core in the survey session (BASELINE.md section 2, 2 M records of this shape); the port has "
-                                       "no SQLite and no file I/O"}
-        # parity of the GPU path on that very sample (bit-exact COO + counters)
-        e2 = F.Engine.from_lists(lists, rate_depth=rate_depth, seed=seed, umi_max_bases=12, device=local)
-        e2.push(cbk[:S], gxk[:S], umi[:S], meta[:S])
-        res = e2.finish()
-        ok = (res["total"], res["sampled"], res["valid"], res["nnz"]) == (ora["total"], ora["sampled"], ora["valid"], ora["nnz"]) \
-            and np.array_equal(res["cell"], ora["cell"].astype(np.uint32)) \
-            and np.array_equal(res["feature"], ora["feature"].astype(np.uint32)) \
-            and np.array_equal(res["count"], ora["count"].astype(np.uint32))
-        out["parity_vs_cpu"] = "bit-exact" if ok else "MISMATCH"
-        e2.close()
+    # free the resident job before the host-side legs
+    del sp, cb, gx, umi, meta, d_draws
+    eng.close()
+    torch.cuda.empty_cache()
+
+    if rank == 0 and G == 1:
+        if not args.no_devpath:
+            out["device_path"] = device_path_leg(job, dev, local, N_total, out["counters"])
+        if not args.no_cpu:
+            out["cpu_baseline"], out["parity_vs_cpu"] = cpu_leg(job, dev, local, min(args.cpu_sample, job.seg_len))
+        else:
+            out["cpu_baseline"] = None
+        if not args.no_e2e:
+            out["e2e"] = e2e_leg(job, [int(x) for x in args.e2e_records.split(",")])
     elif rank == 0:
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out))
-    eng.close()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def device_path_leg(job, dev, local, N_total, want):
+    """SURVEY 8d 'device-path': packed SoA batches in pinned host memory -> hipMemcpyAsync -> kernels -> COO on the host.
+    The clock starts at the first push and stops when finish() has returned the COO arrays."""
+    lists = job.lists
+    pb = F.PinnedBatch(N_total)
+    off = 0
+    for s in range(workload.SEGMENTS):
+        c, g, u, m = job.segment_packed(s, dev)
+        pb.fill(off, c, g, u, m)
+        off += job.seg_len
+    del c, g, u, m
+    job._pool = None
+    torch.cuda.empty_cache()
+    eng = F.Engine.from_lists(lists, rate_depth=workload.RATE_DEPTH, seed=workload.SEED, umi_max_bases=workload.UMI_LEN,
+                              device=local, batch_records=8 << 20, key_capacity=N_total // 4)
+    runs = []
+    res = None
+    try:
+        for rep in range(3):
+            eng.reset(); eng.reseed(workload.SEED, lists.mt_skip)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.push_pinned(pb)
+            t1 = time.perf_counter()
+            res = eng.finish()
+            t2 = time.perf_counter()
+            runs.append((t2 - t0, t1 - t0, t2 - t1))
+    finally:
+        eng.close()
+        pb.close()
+    same = (res["total"], res["sampled"], res["valid"], res["nnz"]) == (want["total"], want["sampled"], want["valid"], want["rows"])
+    best = min(runs)
+    bytes_h2d = 24 * N_total + 4 * want["hits"]
+    return {"value": N_total / best[0], "unit": "records/s", "seconds": best[0], "push_s": best[1], "finish_s": best[2],
+            "runs_s": [r[0] for r in runs], "h2d_bytes": bytes_h2d, "h2d_GBs": bytes_h2d / best[1] / 1e9,
+            "frac_of_pcie": (bytes_h2d / best[0] / 1e9) / PCIE_GBS, "pcie_peak_GBs_assumed": PCIE_GBS,
+            "scope": "pinned host SoA (8 M-record chunks) -> hipMemcpyAsync on the copy stream -> K1 per chunk -> sort + reduce -> COO D2H",
+            "same_result_as_resident_steps": bool(same)}
+
+
+def cpu_leg(job, dev, local, S):
+    """the CPU oracle (port of the reference algorithm: hash probe + MT draw + sort/aggregate, no SQLite, no file I/O) on
+    the first S records of the job, 1 core; the GPU result on that sample must equal it bit for bit"""
+    from oracle import oracle as O
+    lists = job.lists
+    fl, xf, cbs, gxs, ubs = job.segment_strings(0, dev, S)
+    t1 = time.perf_counter()
+    ora = O.run_bam2db(job.bt, job.ft, fl, xf, cbs, gxs, ubs, workload.RATE_CELL, workload.RATE_DEPTH, workload.SEED)
+    cpu_dt = time.perf_counter() - t1
+    base = {"value": S / cpu_dt, "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": "first %d records of the same workload through oracle/fastf_oracle.c, %.1f s" % (S, cpu_dt),
+            "note": "the reference's own bam2db (htslib + SQLite INSERT + GROUP BY + gz writers) ran at 0.24 M records/s on 1 core "
+                    "in the survey session (BASELINE.md section 2); it cannot be built here (htslib absent)"}
+    # the product's own packer on the strings, against the generator's direct packing, then the device result
+    cbk, gxk, umi, meta = F.pack_records(lists, fl, xf, cbs, gxs, ubs)
+    c, g, u, m = (t.cpu().numpy() for t in job.segment_packed(0, dev, S))
+    nn = (meta & 4) != 0
+    pack_ok = (np.array_equal(cbk.view(np.int64), c) and np.array_equal(gxk.view(np.int64), g) and np.array_equal(meta.view(np.int32), m)
+               and np.array_equal(umi.view(np.int32)[nn], u[nn]))
+    e2 = F.Engine.from_lists(lists, rate_depth=workload.RATE_DEPTH, seed=workload.SEED, umi_max_bases=workload.UMI_LEN, device=local)
+    try:
+        e2.push(cbk, gxk, umi, meta)
+        res = e2.finish()
+    finally:
+        e2.close()
+    ok = pack_ok and (res["total"], res["sampled"], res["valid"], res["nnz"]) == (ora["total"], ora["sampled"], ora["valid"], ora["nnz"]) \
+        and np.array_equal(res["cell"], ora["cell"].astype(np.uint32)) \
+        and np.array_equal(res["feature"], ora["feature"].astype(np.uint32)) \
+        and np.array_equal(res["count"], ora["count"].astype(np.uint32))
+    return base, ("bit-exact" if ok else "MISMATCH")
+
+
+def e2e_leg(job, sizes):
+    """the real CLI (fastF bam2db -c .5 -r .5) on generated BAM files: process start -> the three .gz files closed"""
+    threads = int(os.environ.get("FASTF_HOST_THREADS", "16"))
+    gen = os.path.join(ROOT, "build", "gen_bam")
+    os.makedirs(os.path.dirname(gen), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-o", gen, os.path.join(ROOT, "tools", "gen_bam.c"), "-lz", "-lpthread"])
+    cli = os.path.join(ROOT, "fastf_amd", "bin", "fastF")
+    out = {"host_threads": threads, "flags": "-c 0.5 -r 0.5 -s 926", "lists": "%d barcodes x %d genes" % (workload.N_BARCODES, workload.N_GENES)}
+    tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=tmp_root) as td:
+        open(os.path.join(td, "bar.tsv"), "wb").write(job.bt)
+        open(os.path.join(td, "feat.tsv"), "wb").write(job.ft)
+        for label, n, seq_len in (("skinny", sizes[0], 0), ("cell_ranger_shaped", sizes[1], 91)):
+            bam = os.path.join(td, "in.bam")
+            t0 = time.perf_counter()
+            subprocess.check_call([gen, bam, os.path.join(td, "bar.tsv"), os.path.join(td, "feat.tsv"), str(n), "7", "12", str(seq_len), str(threads)])
+            t_gen = time.perf_counter() - t0
+            best = None
+            for rep in range(2):
+                od = os.path.join(td, "out"); os.makedirs(od, exist_ok=True)
+                for f in os.listdir(od):
+                    os.unlink(os.path.join(od, f))
+                env = dict(os.environ, FASTF_HOST_THREADS=str(threads), FASTF_PROFILE="1")
+                t0 = time.perf_counter()
+                p = subprocess.run([cli, "bam2db", "-b", bam, "-a", os.path.join(td, "bar.tsv"), "-f", os.path.join(td, "feat.tsv"),
+                                    "-o", od, "-c", "0.5", "-r", "0.5", "-s", "926"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                wall = time.perf_counter() - t0
+                if p.returncode != 0:
+                    out[label] = {"error": p.stderr.decode(errors="replace")[-400:]}
+                    break
+                prof = [l for l in p.stderr.decode(errors="replace").splitlines() if l.startswith("[bam2db]")]
+                if best is None or wall < best["seconds"]:
+                    best = {"value": n / wall, "unit": "records/s", "seconds": wall, "records": n, "bam_bytes": os.path.getsize(bam),
+                            "bam_generated_in_s": t_gen, "stages": prof[-1] if prof else ""}
+            if best:
+                out[label] = best
+            os.unlink(bam)
+    return out
 
 
 if __name__ == "__main__":

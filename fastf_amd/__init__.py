@@ -6,7 +6,7 @@ thin Python host mirror used by the tests, bench.py and the multi-GPU launcher; 
 only plumbing here (device memory, streams, torch.distributed over RCCL).
 """
 from ._lib import build, lib, lib_path, FastfError  # noqa: F401
-from .engine import Engine, Lists, pack_records, draw_threshold, mt_draws  # noqa: F401
+from .engine import Engine, Lists, PinnedBatch, pack_records, draw_threshold, mt_draws  # noqa: F401
 
-__all__ = ["build", "lib", "lib_path", "FastfError", "Engine", "Lists", "pack_records",
+__all__ = ["build", "lib", "lib_path", "FastfError", "Engine", "Lists", "PinnedBatch", "pack_records",
            "draw_threshold", "mt_draws"]

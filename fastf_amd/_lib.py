@@ -90,6 +90,8 @@ ABI_SYMBOLS = [
     "fastf_keydict_create", "fastf_keydict_destroy", "fastf_keydict_add", "fastf_keydict_pack",
     "fastf_keydict_pack_many",
     "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",
+    "fastf_engine_push_pinned", "fastf_engine_wait_input",
+    "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes",
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
@@ -116,6 +118,13 @@ def lib():
     L.fastf_last_error.restype = C.c_char_p
     L.fastf_version.restype = C.c_char_p
     L.fastf_kernel_names.restype = C.c_char_p
+    L.fastf_engine_push_pinned.argtypes = [vp, vp]
+    L.fastf_engine_wait_input.argtypes = [vp]
+    L.fastf_pinned_alloc.argtypes = [sz]
+    L.fastf_pinned_alloc.restype = vp
+    L.fastf_pinned_free.argtypes = [vp]
+    L.fastf_pinned_register.argtypes = [vp, sz]
+    L.fastf_pinned_unregister.argtypes = [vp]
     L.fastf_mt_seed.argtypes = [C.POINTER(MT), u32]
     L.fastf_mt_next.argtypes = [C.POINTER(MT)]
     L.fastf_mt_next.restype = u32

@@ -11,6 +11,7 @@
 #define _GNU_SOURCE
 #include "host_io.h"
 
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,6 +68,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     fastf_bam_t *bam = NULL;
     fastf_engine_t *eng = NULL;
     dec_ctx dec; pthread_t dec_thread; int dec_started = 0; double t_wait = 0;
+    unsigned char *slab = NULL; int slab_pinned = 0;
     memset(&dec, 0, sizeof dec);
 
     bam = fastf_bam_open(bam_file, 0);
@@ -90,10 +92,13 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     memset(&dec, 0, sizeof dec);
     dec.bam = bam; dec.lists = &lists; dec.cap = cap;
     pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
+    /* one slab for both decoder slots: pinned once the HIP runtime is up (below), so that the engine copies the
+     * packed records to the device straight from where the decoder wrote them */
+    if (posix_memalign((void **)&slab, 4096, 2 * cap * 24) != 0) { slab = NULL; fprintf(stderr, "out of memory\n"); goto done; }
     for (int k = 0; k < 2; k++) {
-        dec.slot[k].cb = (uint64_t *)malloc(cap * 8); dec.slot[k].gx = (uint64_t *)malloc(cap * 8);
-        dec.slot[k].umi = (uint32_t *)malloc(cap * 4); dec.slot[k].meta = (uint32_t *)malloc(cap * 4);
-        if (!dec.slot[k].cb || !dec.slot[k].gx || !dec.slot[k].umi || !dec.slot[k].meta) { fprintf(stderr, "out of memory\n"); goto done; }
+        unsigned char *base = slab + (size_t)k * cap * 24;
+        dec.slot[k].cb = (uint64_t *)base; dec.slot[k].gx = (uint64_t *)(base + cap * 8);
+        dec.slot[k].umi = (uint32_t *)(base + cap * 16); dec.slot[k].meta = (uint32_t *)(base + cap * 20);
     }
     printf("Start to convert bam file to UMI keys on the device...\n");
     if (pthread_create(&dec_thread, NULL, decoder_main, &dec) != 0) { fprintf(stderr, "cannot start decoder thread\n"); goto done; }
@@ -114,6 +119,9 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     cfg.batch_records = cap;
     tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    {   const char *zc = getenv("FASTF_ZERO_COPY");                 /* "0": stage every batch through the engine's own pinned buffers */
+        if (!(zc && zc[0] == '0') && fastf_pinned_register(slab, 2 * cap * 24) == 0) slab_pinned = 1;
+    }
     t_engine = now_s() - tt;
 
     for (int k = 0;; k ^= 1) {
@@ -127,7 +135,10 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         if (n == 0) break;
         fastf_batch_t batch = { dec.slot[k].cb, dec.slot[k].gx, dec.slot[k].umi, dec.slot[k].meta, (size_t)n };
         tt = now_s();
-        if (fastf_engine_push(eng, &batch)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+        /* pinned slots: queue the copies, and hand the slot back to the decoder once they have left it */
+        if (slab_pinned ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
+            fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
+        }
         t_push += now_s() - tt;
         pthread_mutex_lock(&dec.mu);
         dec.filled[k] = 0;
@@ -168,8 +179,9 @@ done:
         pthread_cond_broadcast(&dec.cv); pthread_mutex_unlock(&dec.mu);
         pthread_join(dec_thread, NULL);
     }
-    for (int k = 0; k < 2; k++) { free(dec.slot[k].cb); free(dec.slot[k].gx); free(dec.slot[k].umi); free(dec.slot[k].meta); }
     if (eng) fastf_engine_destroy(eng);
+    if (slab_pinned) fastf_pinned_unregister(slab);
+    free(slab);
     if (bam) fastf_bam_close(bam);
     fastf_lists_free(&lists);
     return rc;
@@ -223,9 +235,13 @@ int cmd_bam2db(int argc, const char **argv)
             for (const struct opt *k = k_opts; k->l; k++) if (k->s == a[1]) { o = k; break; }
             if (o && o->has_arg && a[2]) val = a + 2;          /* -xVALUE */
         }
-        if (!o) { fprintf(stderr, "error: unknown option `%s`\n", a); usage_bam2db(stderr); exit(129); }
+        /* messages and exit status as argparse.c:36-46, 274-277: the option is named by its own spelling (`--cell`,
+         * `-c`), never with the value glued to it, and the process ends with EXIT_FAILURE */
+        if (!o) { fprintf(stderr, "error: unknown option `%s`\n", a); usage_bam2db(stderr); exit(EXIT_FAILURE); }
+        char oname[32];
+        if (a[1] == '-') snprintf(oname, sizeof oname, "--%s", o->l); else snprintf(oname, sizeof oname, "-%c", o->s);
         if (o->has_arg && !val) {
-            if (i + 1 >= argc) { fprintf(stderr, "error: option `%s` requires a value\n", a); exit(129); }
+            if (i + 1 >= argc) { fprintf(stderr, "error: option `%s` requires a value\n", oname); exit(EXIT_FAILURE); }
             val = argv[++i];
         }
         char *end = NULL;
@@ -236,9 +252,10 @@ int cmd_bam2db(int argc, const char **argv)
         case 'a': bar = val; break;
         case 'd': db = val; break;
         case 'o': out = val; break;
-        case 'c': rate_cell = strtof(val, &end); if (!*val || *end) { fprintf(stderr, "error: option `%s` expects a numerical value\n", a); exit(129); } break;
-        case 'r': rate_depth = strtof(val, &end); if (!*val || *end) { fprintf(stderr, "error: option `%s` expects a numerical value\n", a); exit(129); } break;
-        case 's': seed = (unsigned int)strtol(val, &end, 0); if (!*val || *end) { fprintf(stderr, "error: option `%s` expects an integer value\n", a); exit(129); } break;
+        /* argparse.c:88-108: ERANGE first, then trailing characters; an empty value parses as 0 */
+        case 'c': errno = 0; rate_cell = strtof(val, &end); if (errno == ERANGE) { fprintf(stderr, "error: option `%s` numerical result out of range\n", oname); exit(EXIT_FAILURE); } if (*end) { fprintf(stderr, "error: option `%s` expects a numerical value\n", oname); exit(EXIT_FAILURE); } break;
+        case 'r': errno = 0; rate_depth = strtof(val, &end); if (errno == ERANGE) { fprintf(stderr, "error: option `%s` numerical result out of range\n", oname); exit(EXIT_FAILURE); } if (*end) { fprintf(stderr, "error: option `%s` expects a numerical value\n", oname); exit(EXIT_FAILURE); } break;
+        case 's': errno = 0; seed = (unsigned int)strtol(val, &end, 0); if (errno == ERANGE) { fprintf(stderr, "error: option `%s` numerical result out of range\n", oname); exit(EXIT_FAILURE); } if (*end) { fprintf(stderr, "error: option `%s` expects an integer value\n", oname); exit(EXIT_FAILURE); } break;
         case 'u': _umi_copies_flag = 1; break;
         }
     }

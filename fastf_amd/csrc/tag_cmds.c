@@ -448,9 +448,14 @@ static const struct topt *next_opt(const struct topt *opts, int argc, const char
         for (const struct topt *k = opts; k->l; k++) if (k->s == a[1]) { o = k; break; }
         if (o && o->has_arg && a[2]) *val = a + 2;
     }
-    if (!o) { fprintf(stderr, "error: unknown option `%s`\n", a); exit(129); }
+    /* messages and exit status as argparse.c:36-46, 274-277 */
+    if (!o) { fprintf(stderr, "error: unknown option `%s`\n", a); exit(EXIT_FAILURE); }
     if (o->has_arg && !*val) {
-        if (*i + 1 >= argc) { fprintf(stderr, "error: option `%s` requires a value\n", a); exit(129); }
+        if (*i + 1 >= argc) {
+            if (a[1] == '-') fprintf(stderr, "error: option `--%s` requires a value\n", o->l);
+            else fprintf(stderr, "error: option `-%c` requires a value\n", o->s);
+            exit(EXIT_FAILURE);
+        }
         *val = argv[++*i];
     }
     return o;
@@ -508,6 +513,7 @@ int cmd_extract(int argc, const char **argv)                  /* main.c:364-402 
         const struct topt *o = next_opt(opts, argc, argv, &i, &val);
         if (!o) break;
         char *end = NULL;
+        const int o_long = argv[i][1] == '-' || (i > 1 && val == argv[i] && argv[i - 1][1] == '-');
         switch (o->s) {
         case 'h':
             printf("Usage: fastF extract [options]\n\nExtract the tag of bam file.\n\n"
@@ -520,7 +526,7 @@ int cmd_extract(int argc, const char **argv)                  /* main.c:364-402 
         case 't': tag = val; break;
         case 'T':
             type = (int)strtol(val, &end, 0);                  /* argparse.c:88-92 */
-            if (!*val || *end) { fprintf(stderr, "error: option `%s` expects an integer value\n", argv[i]); exit(129); }
+            if (*end) { fprintf(stderr, "error: option `%s` expects an integer value\n", o_long ? "--type" : "-T"); exit(EXIT_FAILURE); }
             break;
         }
     }

@@ -80,7 +80,6 @@ struct KernelTimer {           // optional per-kernel HIP-event timing (bench ro
 struct fastf_engine {
     int device = 0;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
-    hipEvent_t ev_copy[2] = {nullptr, nullptr};
     KeyLayout L{};
     u32 cell_bits = 0, feat_bits = 0, n_cells = 0, n_features = 0;
     u64 threshold = 0;
@@ -91,25 +90,38 @@ struct fastf_engine {
     DevBuf d_cell_filter; MissFilter cell_filter{nullptr, 0};        // miss filter in front of the L2 cell table
     CellLds lds_cells{}; GeneLds lds_genes{};
     bool use_lds_cells = false, use_lds_genes = false; u32 genes_blocks_per_cu = 1, cells_blocks_per_cu = 1;
-    // draw stream
+    // draw stream: draws live in a device ring indexed by the ABSOLUTE hit rank since the last reset; the hit-rank
+    // base of a chunk is a device-side running total, so a push never waits for the counts of the chunk before it
     fastf_mt_t mt{};
-    std::vector<u32> pending_draws;      // generated, not yet consumed
-    // staging (double buffered)
+    u32 mt_seed0 = 0; u64 mt_skip0 = 0;  // where the engine-owned stream starts (create / reseed)
+    u64 mt_hits = 0;                     // hits served from the engine-owned stream so far
+    u64 mt_abs0 = 0;                     // absolute hit rank a  <->  draw number a - mt_abs0 of the engine-owned stream
+    bool mt_live = false;                // the generator stands at draw number draws_up - mt_abs0
+    DevBuf d_ring; u64 ring_len = 0;     // u32[ring_len], power of two
+    u64 draws_up = 0;                    // absolute ranks below this are (being) uploaded
+    u64 draws_valid = 0;                 // ranks below this carry a real draw (caller-supplied streams can run short)
+    // staging: chunks in flight, double buffered
     u64 batch_cap = 0;
-    void* h_stage[2] = {nullptr, nullptr};       // pinned: cb | gx | umi | meta | draws
-    DevBuf d_stage[2];
+    struct Slot {
+        void* h_stage = nullptr;         // pinned: cb | gx | umi | meta  (only pageable input is staged)
+        void* h_draws = nullptr;         // pinned: the draws uploaded with this chunk
+        DevBuf d_stage;
+        hipEvent_t ev_copy = nullptr, ev_done = nullptr;
+        u64* h_small = nullptr;          // pinned: d_small as it stood when this chunk's K1 had finished
+        bool busy = false; u64 n = 0; bool external = false;
+    } slot[2];
     int cur = 0;
-    bool batch_in_flight = false, in_flight_external = false;
-    u64 in_flight_n = 0;
+    u64 inflight_records = 0;            // records of the chunks not yet retired
     // key store + results
     u64 key_cap = 0;
     DevBuf d_keys, d_tmp;
     DevBuf d_small;              // key_counts[8] | counters[4] | nnz | nrows_u | n_tmp  (u64 each)
     u64* h_small = nullptr;      // pinned mirror
     DevBuf d_feature, d_cell, d_count, d_ukeys, d_ncopy;
-    std::vector<u32> h_feature, h_cell, h_count, h_ufeature, h_ucell, h_uumi, h_ncopy;
+    u32* h_coo = nullptr; u64 h_coo_cap = 0, h_nnz = 0;      // pinned: feature | cell | count, h_coo_cap rows each
+    std::vector<u32> h_ufeature, h_ucell, h_uumi, h_ncopy;
     std::vector<uint8_t> h_unonnull;
-    u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;
+    u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;      // hits / keys: as of the last retired chunk
     u64 c_sampled = 0, c_valid = 0;
     bool finished = false; int sorted_in_tmp = 0; u64 n_sorted = 0;
     u32 skip_bits = 0;           // low key bits the matrix path leaves unsorted (dedup needs adjacency of equal keys only)
@@ -128,7 +140,7 @@ struct fastf_engine {
 };
 
 // key_counts (one returning atomic per tile) and counters (three atomics per tile) sit on different 256-B segments
-enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 66, SM_WORDS = 80 };
+enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 66, SM_RUNNING = 96, SM_DRAWBASE = 128, SM_WORDS = 160 };
 
 static int set_scatter_lds_limit();
 static u32 g_cu_count = 256;
@@ -383,15 +395,16 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         if (e->skip_bits >= fs) e->skip_bits = 0;
     }
     e->n_shards = cfg->n_shards; e->shard_rank = cfg->shard_rank;
-    fastf_mt_seed(&e->mt, cfg->mt_seed);
-    fastf_mt_skip(&e->mt, cfg->mt_skip);
+    e->mt_seed0 = cfg->mt_seed; e->mt_skip0 = cfg->mt_skip;
 
     int rc = 0;
     do {
         if (hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_copy[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_copy[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->slot[0].ev_copy, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->slot[1].ev_copy, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->slot[0].ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->slot[1].ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreate(&e->t_ev[0]) != hipSuccess || hipEventCreate(&e->t_ev[1]) != hipSuccess) {
             rc = set_err("stream/event creation failed"); break;
         }
@@ -427,12 +440,18 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) {
-        if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
-        e->d_stage[i].release();
-        if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
+        fastf_engine::Slot& sl = e->slot[i];
+        if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+        if (sl.h_draws) (void)hipHostFree(sl.h_draws);
+        if (sl.h_small) (void)hipHostFree(sl.h_small);
+        sl.d_stage.release();
+        if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (e->t_ev[i]) (void)hipEventDestroy(e->t_ev[i]);
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
+    if (e->h_coo) (void)hipHostFree(e->h_coo);
+    e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase};
     for (DevBuf* b : all) b->release();
@@ -547,7 +566,8 @@ static u64* g_k1_stamps = nullptr;   // diagnostic builds only
 extern "C" void fastf_debug_set_k1_stamps(void* p) { g_k1_stamps = (u64*)p; }
 
 // K1a + scan: cell index per record, hit-rank base per tile, total hits
-static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s) {
+static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s,
+                              u64* d_running = nullptr, u64* d_base_out = nullptr) {
     if (reserve_workspace(e, n, 0)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     t_begin(e, s);
@@ -565,7 +585,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
-                       (u64*)e->d_tilebase.p, tiles, d_total_out);
+                       (u64*)e->d_tilebase.p, tiles, d_total_out, d_running, d_base_out);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -581,15 +601,16 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
-                        u64* counters, bool reuse_hits, hipStream_t s) {
+                        u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr) {
     if (n == 0) return 0;
-    // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order)
-    if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s)) return 1;
+    // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order).
+    // d_running: the scan leaves the running hit total of the earlier chunks at draw_base and adds this chunk's hits.
+    if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s, d_running, d_running ? const_cast<u64*>(draw_base) : nullptr)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     PackParams p{};
     p.cell = (const u32*)e->d_cellidx.p; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
     p.tile_base = (const u64*)e->d_tilebase.p;
-    p.draws = draws; p.n_draws = n_draws; p.draw_base = draw_base;
+    p.draws = draws; p.n_draws = n_draws; p.draw_base = draw_base; p.draw_mask = draw_mask;
     p.feats = e->feats;
     p.threshold = e->threshold; p.L = e->L;
     p.n_shards = e->n_shards;
@@ -701,7 +722,7 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     t_begin(e, s);
     hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_heads.p,
-                       (u64*)e->d_rowbase.p, tiles, nrows);
+                       (u64*)e->d_rowbase.p, tiles, nrows, (u64*)nullptr, (u64*)nullptr);
     hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,
                        (const u64*)e->d_rowbase.p, count, d_n);
@@ -763,10 +784,48 @@ static const char* err_bits_text(u64 bits) {
     return buf;
 }
 
-static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4 + 4); }
+static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4); }
+
+// Streaming push path.
+//   chunk i:  [host staging, pageable input only]  ->  H2D on s_copy  ->  K1a + scan + K1b on s_compute
+// Nothing in it waits for the chunk before: the hit-rank base of a chunk is a device-side running total (the scan
+// kernel hands it to K1b), the draws live in a device ring addressed by absolute hit rank, and the host keeps that ring
+// filled up to the highest rank the chunk could possibly reach (hits retired so far + every record still in flight).
+// A chunk is retired — its counters read — only when its slot is needed again, two chunks later.
+
+static int slot_alloc(fastf_engine* e, fastf_engine::Slot& sl, bool need_host_stage) {
+    if (!sl.h_small) HIP_OK(hipHostMalloc((void**)&sl.h_small, SM_WORDS * sizeof(u64), hipHostMallocDefault));
+    if (!sl.h_draws) HIP_OK(hipHostMalloc(&sl.h_draws, e->batch_cap * 4, hipHostMallocDefault));
+    if (sl.d_stage.ensure(stage_bytes(e->batch_cap))) return 1;
+    if (need_host_stage && !sl.h_stage) HIP_OK(hipHostMalloc(&sl.h_stage, stage_bytes(e->batch_cap), hipHostMallocDefault));
+    return 0;
+}
+
+// wait for a chunk and fold its counters into the host-side running state
+static int retire_slot(fastf_engine* e, fastf_engine::Slot& sl) {
+    if (!sl.busy) return 0;
+    HIP_OK(hipEventSynchronize(sl.ev_done));
+    sl.busy = false;
+    e->inflight_records -= sl.n;
+    const u64* c = sl.h_small + SM_COUNTERS;
+    if (!sl.external) e->mt_hits += c[0] - e->hits_so_far;
+    e->hits_so_far = c[0];
+    e->c_sampled = c[1]; e->c_valid = c[2];
+    e->keys_so_far = sl.h_small[SM_KEYCOUNT];
+    if (c[3]) return set_err("%s", err_bits_text(c[3]));
+    return 0;
+}
+static int retire_all(fastf_engine* e) {
+    // oldest first: the running state must end at the newest chunk's counters
+    const int first = e->cur;              // slot[cur] holds the older of the two chunks in flight
+    if (retire_slot(e, e->slot[first])) return 1;
+    return retire_slot(e, e->slot[first ^ 1]);
+}
 
 static int grow_keys(fastf_engine* e, u64 need) {
     if (need <= e->key_cap && e->d_keys.p) return 0;
+    if (retire_all(e)) return 1;           // the copy below needs the exact key count and a quiet key store
+    HIP_OK(hipStreamSynchronize(e->s_compute));
     u64 ncap = std::max<u64>(need, std::max<u64>(e->key_cap * 2, 1u << 20));
     void* np = nullptr;
     HIP_OK(hipMalloc(&np, ncap * sizeof(u64)));
@@ -778,119 +837,161 @@ static int grow_keys(fastf_engine* e, u64 need) {
     return 0;
 }
 
-// wait for the batch in flight, fold its counters into the host-side running state
-static int retire_batch(fastf_engine* e) {
-    if (!e->batch_in_flight) return 0;
-    HIP_OK(hipStreamSynchronize(e->s_compute));
-    e->batch_in_flight = false;
-    const u64* c = e->h_small + SM_COUNTERS;
-    const u64 hits_total = c[0];
-    const u64 consumed = hits_total - e->hits_so_far;
-    if (!e->in_flight_external) {
-        if (consumed > e->pending_draws.size()) return set_err("internal: consumed more draws than staged");
-        e->pending_draws.erase(e->pending_draws.begin(), e->pending_draws.begin() + (size_t)consumed);
+// the draw source of the chunks being pushed: the engine-owned MT19937 stream, or an array the caller supplied
+struct DrawSource { const u32* ext; u64 ext_abs0; u64 ext_n; };
+
+// make the ring hold every absolute rank below `upto`
+static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSource& src, u64 upto) {
+    while (e->draws_up < upto) {
+        const u64 n = std::min<u64>(upto - e->draws_up, e->batch_cap);
+        u32* h = (u32*)sl.h_draws;
+        if (src.ext) {
+            const u64 a = e->draws_up - src.ext_abs0;                  // index into the caller's array
+            const u64 have = a < src.ext_n ? std::min<u64>(src.ext_n - a, n) : 0;
+            if (have) memcpy(h, src.ext + a, have * 4);
+            if (have < n) memset(h + have, 0, (n - have) * 4);
+        } else {
+            fastf_mt_fill(&e->mt, h, n);
+        }
+        const u64 pos = e->draws_up & (e->ring_len - 1), first = std::min<u64>(n, e->ring_len - pos);
+        HIP_OK(hipMemcpyAsync((u32*)e->d_ring.p + pos, h, first * 4, hipMemcpyHostToDevice, e->s_copy));
+        if (first < n) HIP_OK(hipMemcpyAsync((u32*)e->d_ring.p, h + first, (n - first) * 4, hipMemcpyHostToDevice, e->s_copy));
+        e->draws_up += n;
+        if (e->draws_up < upto) HIP_OK(hipStreamSynchronize(e->s_copy));   // the staging buffer is about to be refilled (uneven chunk sizes only)
     }
-    e->hits_so_far = hits_total;
-    e->c_sampled = c[1]; e->c_valid = c[2];
-    e->keys_so_far = e->h_small[SM_KEYCOUNT];
-    if (c[3]) return set_err("%s", err_bits_text(c[3]));
     return 0;
 }
 
-static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_t n, const u32* draws, size_t n_draws) {
-    if (retire_batch(e)) return 1;
-    if (grow_keys(e, e->keys_so_far + n)) return 1;
-    const int cur = e->cur;
-    if (!e->h_stage[cur]) {
-        HIP_OK(hipHostMalloc(&e->h_stage[cur], stage_bytes(e->batch_cap), hipHostMallocDefault));
-        if (e->d_stage[cur].ensure(stage_bytes(e->batch_cap))) return 1;
-    }
+// pinned == true: the batch arrays are pinned host memory and go to the device straight from where they are
+static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_t n, const DrawSource& src, bool pinned) {
+    fastf_engine::Slot& sl = e->slot[e->cur];
+    if (retire_slot(e, sl)) return 1;                                   // the chunk pushed two chunks ago
+    if (slot_alloc(e, sl, !pinned)) return 1;
+    // upper bounds for what the device will have seen when this chunk's K1 starts
+    const u64 hits_ub = e->hits_so_far + e->inflight_records, keys_ub = e->keys_so_far + e->inflight_records;
+    if (grow_keys(e, keys_ub + n)) return 1;
     const u64 cap = e->batch_cap;
-    char* hs = (char*)e->h_stage[cur];
-    char* ds = (char*)e->d_stage[cur].p;
-    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_draw = cap * 24;
-    // staging: three streams of 8 bytes per record, copied side by side (the caller's thread also fills the draws)
-    std::thread t_gx, t_um;
-    const bool par = n >= (1u << 18);
-    if (par) {
-        t_gx = std::thread([=] { memcpy(hs + o_gx, b->gx_key + off, n * 8); });
-        t_um = std::thread([=] { memcpy(hs + o_umi, b->umi + off, n * 4); memcpy(hs + o_meta, b->meta + off, n * 4); });
-    } else {
-        memcpy(hs + o_gx, b->gx_key + off, n * 8);
-        memcpy(hs + o_umi, b->umi + off, n * 4);
-        memcpy(hs + o_meta, b->meta + off, n * 4);
-    }
-    memcpy(hs, b->cb_key + off, n * 8);
-    size_t nd;
-    if (draws) { nd = std::min(n_draws, n); memcpy(hs + o_draw, draws, nd * 4); }
-    else {
-        if (e->pending_draws.size() < n) {
-            const size_t have = e->pending_draws.size();
-            e->pending_draws.resize(n);
-            fastf_mt_fill(&e->mt, e->pending_draws.data() + have, n - have);
+    char* ds = (char*)sl.d_stage.p;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
+    const void *s_cb = b->cb_key + off, *s_gx = b->gx_key + off, *s_umi = b->umi + off, *s_meta = b->meta + off;
+    if (!pinned) {
+        // staging: three streams of 8 bytes per record, copied side by side
+        char* hs = (char*)sl.h_stage;
+        std::thread t_gx, t_um;
+        const bool par = n >= (1u << 18);
+        if (par) {
+            t_gx = std::thread([=] { memcpy(hs + o_gx, s_gx, n * 8); });
+            t_um = std::thread([=] { memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4); });
+        } else {
+            memcpy(hs + o_gx, s_gx, n * 8); memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4);
         }
-        nd = n;
-        memcpy(hs + o_draw, e->pending_draws.data(), n * 4);
+        memcpy(hs, s_cb, n * 8);
+        if (par) { t_gx.join(); t_um.join(); }
+        s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
     }
-    if (par) { t_gx.join(); t_um.join(); }
     hipStream_t sc = e->s_copy, sk = e->s_compute;
-    HIP_OK(hipMemcpyAsync(ds, hs, n * 8, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_gx, hs + o_gx, n * 8, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_umi, hs + o_umi, n * 4, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_meta, hs + o_meta, n * 4, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_draw, hs + o_draw, nd * 4, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipEventRecord(e->ev_copy[cur], sc));
-    HIP_OK(hipStreamWaitEvent(sk, e->ev_copy[cur], 0));
+    HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyHostToDevice, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyHostToDevice, sc));
+    if (upload_draws(e, sl, src, hits_ub + n)) return 1;               // generated while the record copies are in flight
+    if (!src.ext) e->draws_valid = e->draws_up;
+    HIP_OK(hipEventRecord(sl.ev_copy, sc));
+    HIP_OK(hipStreamWaitEvent(sk, sl.ev_copy, 0));
     u64* small = (u64*)e->d_small.p;
     if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
-                     (const u32*)(ds + o_draw), nd, nullptr, (u64*)e->d_keys.p, e->key_cap, small + SM_KEYCOUNT,
-                     small + SM_COUNTERS, false, sk))
+                     (const u32*)e->d_ring.p, std::min(e->draws_up, e->draws_valid), small + SM_DRAWBASE, (u64*)e->d_keys.p, e->key_cap,
+                     small + SM_KEYCOUNT, small + SM_COUNTERS, false, sk, e->ring_len - 1, small + SM_RUNNING))
         return 1;
-    HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
-    e->batch_in_flight = true;
-    e->in_flight_external = draws != nullptr;
-    e->in_flight_n = n;
+    HIP_OK(hipMemcpyAsync(sl.h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, sk));
+    HIP_OK(hipEventRecord(sl.ev_done, sk));
+    sl.busy = true; sl.n = n; sl.external = src.ext != nullptr;
+    e->inflight_records += n;
     e->total_records += n;
     e->cur ^= 1;
     e->finished = false;
     return 0;
 }
 
-static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws) {
+static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws, bool pinned) {
     if (!e || !batch) return set_err("null argument");
     if (e->n_shards != 1) return set_err("fastf_engine_push drives a single shard; use the fastf_dev_* calls for sharded runs");
     HIP_OK(hipSetDevice(e->device));
-    if (retire_batch(e)) return 1;
-    const u64 hits_start = e->hits_so_far;
+    if (batch->n == 0) return 0;
+    if (!e->d_ring.p) {
+        u64 r = 1; while (r < 4 * e->batch_cap) r <<= 1;               // three chunks of ranks can be live at once
+        if (e->d_ring.ensure(r * 4)) return 1;
+        e->ring_len = r;
+    }
+    DrawSource src{nullptr, 0, 0};
+    if (draws) {
+        // caller-supplied draws: draws[i] belongs to the i-th CB hit of this batch.  The ring restarts at the exact hit count.
+        if (retire_all(e)) return 1;
+        HIP_OK(hipStreamSynchronize(e->s_copy));
+        src.ext = draws; src.ext_abs0 = e->hits_so_far; src.ext_n = n_draws;
+        e->draws_up = e->hits_so_far; e->draws_valid = e->hits_so_far + n_draws;
+        e->mt_live = false;
+    } else if (!e->mt_live) {
+        // (re)position the engine-owned stream: rank a takes draw number a - mt_abs0, and mt_hits draws are spent
+        if (retire_all(e)) return 1;
+        HIP_OK(hipStreamSynchronize(e->s_copy));
+        fastf_mt_seed(&e->mt, e->mt_seed0);
+        fastf_mt_skip(&e->mt, e->mt_skip0 + e->mt_hits);
+        e->mt_abs0 = e->hits_so_far - e->mt_hits;
+        e->draws_up = e->hits_so_far; e->draws_valid = e->hits_so_far;
+        e->mt_live = true;
+    }
     size_t off = 0;
     while (off < batch->n) {
         const size_t n = std::min<size_t>(batch->n - off, e->batch_cap);
-        if (draws) {
-            // caller-supplied draws: a chunk starts at the hits consumed by the chunks before it
-            if (retire_batch(e)) return 1;
-            const size_t doff = (size_t)(e->hits_so_far - hits_start);
-            if (push_chunk(e, batch, off, n, draws + std::min(doff, n_draws), n_draws > doff ? n_draws - doff : 0)) return 1;
-        } else {
-            if (push_chunk(e, batch, off, n, nullptr, 0)) return 1;
-        }
+        if (push_chunk(e, batch, off, n, src, pinned)) return 1;
         off += n;
+    }
+    if (draws) {                                                        // the caller's array must not be needed after return
+        if (retire_all(e)) return 1;
+        HIP_OK(hipStreamSynchronize(e->s_copy));
+    } else if (!pinned) {
+        // the batch may be reused as soon as the call returns: every chunk was staged, nothing left to wait for
     }
     return 0;
 }
 
 extern "C" int fastf_engine_push(fastf_engine_t* e, const fastf_batch_t* batch) {
-    return push_impl(e, batch, nullptr, 0);
+    return push_impl(e, batch, nullptr, 0, false);
 }
 
 extern "C" int fastf_engine_push_draws(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws) {
     if (!draws && batch && batch->n) return set_err("null draws");
-    return push_impl(e, batch, draws, n_draws);
+    return push_impl(e, batch, draws, n_draws, false);
 }
+
+extern "C" int fastf_engine_push_pinned(fastf_engine_t* e, const fastf_batch_t* batch) {
+    return push_impl(e, batch, nullptr, 0, true);
+}
+
+extern "C" int fastf_engine_wait_input(fastf_engine_t* e) {
+    if (!e) return set_err("null engine");
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize(e->s_copy));
+    return 0;
+}
+
+extern "C" void* fastf_pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void fastf_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" int fastf_pinned_register(void* p, size_t bytes) {
+    HIP_OK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return 0;
+}
+extern "C" void fastf_pinned_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
 
 extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) {
     if (!e || !coo) return set_err("null argument");
     HIP_OK(hipSetDevice(e->device));
-    if (retire_batch(e)) return 1;
+    if (retire_all(e)) return 1;
     hipStream_t s = e->s_compute;
     u64* small = (u64*)e->d_small.p;
     const u64 n = e->keys_so_far;
@@ -933,17 +1034,25 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         }
         if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
         const u64 nnz = e->h_small[SM_NNZ];
-        e->h_feature.resize(nnz); e->h_cell.resize(nnz); e->h_count.resize(nnz);
-        if (nnz) {
-            HIP_OK(hipMemcpy(e->h_feature.data(), e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(e->h_cell.data(), e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(e->h_count.data(), e->d_count.p, nnz * 4, hipMemcpyDeviceToHost));
+        if (nnz > e->h_coo_cap) {                                       // pinned: the rows come back at PCIe rate
+            if (e->h_coo) (void)hipHostFree(e->h_coo);
+            e->h_coo = nullptr; e->h_coo_cap = 0;
+            const u64 cap = nnz + nnz / 8 + 1024;
+            HIP_OK(hipHostMalloc((void**)&e->h_coo, cap * 12, hipHostMallocDefault));
+            e->h_coo_cap = cap;
         }
+        if (nnz) {
+            HIP_OK(hipMemcpyAsync(e->h_coo, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(e->h_coo + e->h_coo_cap, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipMemcpyAsync(e->h_coo + 2 * e->h_coo_cap, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+        }
+        e->h_nnz = nnz;
         e->n_sorted = n;
         e->finished = true;
     }
-    coo->feature = e->h_feature.data(); coo->cell = e->h_cell.data(); coo->count = e->h_count.data();
-    coo->nnz = e->h_feature.size();
+    coo->feature = e->h_coo; coo->cell = e->h_coo ? e->h_coo + e->h_coo_cap : nullptr; coo->count = e->h_coo ? e->h_coo + 2 * e->h_coo_cap : nullptr;
+    coo->nnz = e->h_nnz;
     if (counters) { counters[0] = e->total_records; counters[1] = e->c_sampled; counters[2] = e->c_valid; }
     return 0;
 }
@@ -1006,19 +1115,22 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) {
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemset(e->d_small.p, 0, SM_WORDS * sizeof(u64)));
     memset(e->h_small, 0, SM_WORDS * sizeof(u64));
-    e->batch_in_flight = false;
+    for (auto& sl : e->slot) sl.busy = false;
+    e->inflight_records = 0;
     e->total_records = e->hits_so_far = e->keys_so_far = e->c_sampled = e->c_valid = 0;
-    e->finished = false;
-    e->pending_draws.clear();
+    e->finished = false; e->h_nnz = 0;
+    e->draws_up = e->draws_valid = 0;
+    e->mt_live = false;                  // the engine-owned stream goes on after the last draw a hit consumed
     return 0;
 }
 
 // re-position the engine-owned draw stream (tests; bam2db() sets it through the config)
 extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t skip) {
     if (!e) return set_err("null engine");
-    fastf_mt_seed(&e->mt, seed);
-    fastf_mt_skip(&e->mt, skip);
-    e->pending_draws.clear();
+    HIP_OK(hipSetDevice(e->device));
+    if (retire_all(e)) return 1;
+    e->mt_seed0 = seed; e->mt_skip0 = skip; e->mt_hits = 0;
+    e->mt_live = false;
     return 0;
 }
 

@@ -179,8 +179,11 @@ __device__ __forceinline__ void table_probe_batch(const Table t, const u64 (&key
 // The input is cleared once read: K1a accumulates its hit counts with atomics and needs zeros there, so the buffer
 // returns to all-zero after every use and no memset is launched per step.
 // ------------------------------------------------------------------------------------
+// running / base_out (optional): a device-side running total across launches — *base_out = *running before this
+// launch's total is added (the streaming push path: hit-rank base of a chunk without a host round trip).
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, u64* __restrict__ out, u32 T,
-                                                          u64* __restrict__ total_out) {
+                                                          u64* __restrict__ total_out, u64* __restrict__ running = nullptr,
+                                                          u64* __restrict__ base_out = nullptr) {
     __shared__ u32 s_w[16];
     __shared__ u64 s_carry;
     const int lane = lane_id(), w = threadIdx.x >> 6;
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, 
         __syncthreads();
     }
     if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+    if (threadIdx.x == 0 && running) { const u64 r = *running; *base_out = r; *running = r + s_carry; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -416,8 +420,9 @@ static_assert(K1B_THREADS * K1B_IPT == K1_TILE, "K1b walks K1a's tiles");
 struct PackParams {
     const u32* cell; const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
-    const u32* draws; u64 n_draws;
-    const u64* draw_base;          // optional device-side offset into draws (sharded runs)
+    const u32* draws; u64 n_draws; // draw of hit rank r: draws[r & draw_mask], valid while r < n_draws
+    u64 draw_mask;                 // ~0 for a linear array; ring size - 1 for the streaming push path
+    const u64* draw_base;          // optional device-side offset into draws (sharded runs, streaming pushes)
     Table feats;
     GeneLds genes;                 // LDS fast path of the feature lookup (LDS_GENES instantiation)
     u32 n_tiles;
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
         draw[j] = 0;
         if (cell[j] != 0) {
             const u64 r = tile_base + s_cnt[j * K1B_WAVES + w] + hrank[j];
-            if (r < p.n_draws) draw[j] = p.draws[r];
+            if (r < p.n_draws) draw[j] = p.draws[r & p.draw_mask];
             else { cell[j] = 0; n_hit++; errs |= (u32)ERR_DRAWS_SHORT; }
         }
     }
@@ -652,6 +657,14 @@ __device__ __forceinline__ u32 num_tiles(u64 n, u32 ipt) { const u64 t = (u64)ip
 // rows of cnt[d][tile] are padded to a multiple of 4 tiles so a row scan can use 16-byte accesses
 __device__ __forceinline__ u32 row_stride(u32 T) { return (T + 3u) & ~3u; }
 
+// XCD-contiguous tile of this workgroup.  The ranges are cut from the ACTUAL tile count T (the grid is sized for the
+// caller's upper bound on the key count and may be several times larger: cutting the ranges from gridDim would leave
+// most XCDs without a tile when the bound is loose).  Returns a value >= T for workgroups without a tile.
+__device__ __forceinline__ u32 xcd_tile(u32 T) {
+    const u32 chunk = (T + 7u) >> 3, r = blockIdx.x >> 3;
+    return r < chunk ? (blockIdx.x & 7u) * chunk + r : ~0u;
+}
+
 // per-tile digit counts: cnt[d * T + tile].  Four LDS copies of the histogram (lane & 3) keep the
 // same-address atomic conflicts of skewed digits (e.g. the constant length bits) four times shorter.
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
@@ -661,8 +674,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
     const u32 T = num_tiles(n, ipt);
     // same XCD-contiguous tile mapping as the scatter: the 4-byte counts of neighbouring tiles share cache lines in
     // every digit row of cnt[][]
-    const u32 chunk = (gridDim.x + 7u) >> 3;
-    const u32 tile = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    const u32 tile = xcd_tile(T);
     if (tile >= T) return;
     for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) s_h[i] = 0;
     __syncthreads();
@@ -865,9 +877,8 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
 #else
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  Consecutive tiles write consecutive runs of every
     // bin, so neighbouring tiles share the cache lines at their run boundaries: give each XCD a contiguous range of
-    // tiles and those partial lines merge in that XCD's L2 instead of going to HBM twice.  (grid = 8 x ceil(T / 8))
-    const u32 chunk = (gridDim.x + 7u) >> 3;
-    const u32 tile = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    // tiles and those partial lines merge in that XCD's L2 instead of going to HBM twice.
+    const u32 tile = xcd_tile(T);
 #endif
     if (tile >= T) return;
     const u32 tile_keys = ipt * SORT_THREADS;

@@ -107,6 +107,53 @@ def pack_records(lists: Lists, flags, xf, cb, gx, ub):
     return cb_key, gx_key, umi, meta
 
 
+class PinnedBatch:
+    """n packed records in pinned host memory (fastf_pinned_alloc): cb_key u64 | gx_key u64 | umi u32 | meta u32,
+    as numpy views.  What fastf_engine_push_pinned sends to the device without a staging copy."""
+
+    def __init__(self, n):
+        self._L = _lib.lib()
+        self.n = int(n)
+        self._p = self._L.fastf_pinned_alloc(max(self.n, 1) * 24)
+        if not self._p:
+            raise FastfError(self._L.fastf_last_error().decode())
+        buf = (C.c_uint8 * (max(self.n, 1) * 24)).from_address(self._p)
+        raw = np.frombuffer(buf, dtype=np.uint8)
+        self.cb_key = raw[:8 * n].view(np.uint64)
+        self.gx_key = raw[8 * n:16 * n].view(np.uint64)
+        self.umi = raw[16 * n:20 * n].view(np.uint32)
+        self.meta = raw[20 * n:24 * n].view(np.uint32)
+
+    def fill(self, off, cb, gx, umi, meta):
+        """copy torch device tensors (int64/int32 bit patterns) or numpy arrays into [off, off + len)"""
+        def put(dst, src, dt):
+            if hasattr(src, "cpu"):
+                import torch
+                view = torch.from_numpy(dst[off:off + src.numel()].view(dt))
+                view.copy_(src)                       # device -> pinned host, no intermediate
+            else:
+                dst[off:off + len(src)] = src
+        put(self.cb_key, cb, np.int64); put(self.gx_key, gx, np.int64)
+        put(self.umi, umi, np.int32); put(self.meta, meta, np.int32)
+
+    def batch(self, a=0, b=None):
+        b = self.n if b is None else b
+        return Batch(self.cb_key[a:b].ctypes.data, self.gx_key[a:b].ctypes.data, self.umi[a:b].ctypes.data,
+                     self.meta[a:b].ctypes.data, b - a)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.cb_key = self.gx_key = self.umi = self.meta = None
+            self._L.fastf_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """fastf_engine_* (host buffers) and fastf_dev_* (device pointers) of include/fastf_amd.h."""
 
@@ -156,6 +203,14 @@ class Engine:
             d = np.ascontiguousarray(draws, dtype=np.uint32)
             check(self._L.fastf_engine_push_draws(self._h, C.byref(b), d.ctypes.data, len(d)))
         del keep
+
+    def push_pinned(self, pb: PinnedBatch, a=0, b=None):
+        """zero-copy push of pinned records [a, b); the memory must stay untouched until wait_input() / finish()"""
+        bt = pb.batch(a, b)
+        check(self._L.fastf_engine_push_pinned(self._h, C.byref(bt)))
+
+    def wait_input(self):
+        check(self._L.fastf_engine_wait_input(self._h))
 
     def finish(self):
         coo = Coo()

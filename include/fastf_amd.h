@@ -183,6 +183,18 @@ int  fastf_engine_push(fastf_engine_t *e, const fastf_batch_t *batch);
 /* Same, with caller-supplied draws (draws[i] belongs to the i-th CB hit of this batch). */
 int  fastf_engine_push_draws(fastf_engine_t *e, const fastf_batch_t *batch,
                              const uint32_t *draws, size_t n_draws);
+/* Zero-copy variant: the four arrays of the batch are PINNED host memory (fastf_pinned_alloc, or any memory passed
+ * through fastf_pinned_register) and go to the device straight from where they are — no staging copy.  The call
+ * returns once the copies are queued; the arrays must stay untouched until fastf_engine_wait_input() or
+ * fastf_engine_finish() has returned.  This is the path SURVEY 8d calls "device-path": pinned SoA batches ->
+ * hipMemcpyAsync on the copy stream -> kernels.  No push waits for the result of an earlier one: the hit-rank base
+ * of a chunk (bam2db_ds.c:385 consumes one draw per CB hit) is carried on the device. */
+int  fastf_engine_push_pinned(fastf_engine_t *e, const fastf_batch_t *batch);
+int  fastf_engine_wait_input(fastf_engine_t *e);   /* every host-to-device copy queued so far has completed */
+void *fastf_pinned_alloc(size_t bytes);            /* hipHostMalloc; NULL on failure */
+void  fastf_pinned_free(void *p);
+int   fastf_pinned_register(void *p, size_t bytes);/* pin memory the caller allocated (hipHostRegister) */
+void  fastf_pinned_unregister(void *p);
 /* Sort + segmented unique/reduce over everything pushed; results stay valid until
  * reset/destroy.  counters = {total, sampled, sampled_valid} (bam2db_ds.c:342-344). */
 int  fastf_engine_finish(fastf_engine_t *e, fastf_coo_t *coo, uint64_t counters[3]);

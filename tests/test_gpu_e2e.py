@@ -58,6 +58,29 @@ def test_cli_outputs_equal_oracle_bytes(tmp_path, name, kw, args, gz):
     assert not (tmp_path / "unused.db").exists()
 
 
+REFMAIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "fastF_refmain")
+
+
+@pytest.mark.skipif(not os.path.exists(REFMAIN), reason="oracle/_ref/fastF_refmain not built (needs /root/reference at build time)")
+def test_reference_main_drives_the_engine(tmp_path):
+    """the reference's OWN main.c + argparse.c (compiled in place, `make -C oracle refcli`) with libfastf_amd.so linked in
+    place of bam2db_ds.c: `fastF bam2db ...` through the reference's dispatch table and option parser lands in the
+    MI355X engine and writes the oracle's bytes"""
+    case = Case(n=80_000, n_bar=400, n_gene=150, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=3.0,
+                p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.005)
+    bam, b, f = _write_inputs(tmp_path, case)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    r = subprocess.run([REFMAIN, "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out),
+                        "-d", str(tmp_path / "unused.db"), "--cell=0.5", "-r", "0.5", "-s", "926", "-u"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
+    assert _read_gz(out / "barcodes.tsv.gz") == ora["barcodes"]
+    assert _read_gz(out / "features.tsv.gz") == ora["features"]
+    assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
+
+
 def test_bam2db_symbol_in_process(tmp_path):
     """the drop-in C symbol itself (what the reference's main.c would call)"""
     import torch  # noqa: F401

@@ -12,8 +12,8 @@ from fastf_amd import synth
 bt, ft, _, _ = synth.make_lists(10000, 30000, seed=4242)
 open("$W/bar.tsv", "wb").write(bt); open("$W/feat.tsv", "wb").write(ft)
 PY
-gcc -O2 -o $R/build/gen_bam $R/tools/gen_bam.c -lz
-$R/build/gen_bam $W/in.bam $W/bar.tsv $W/feat.tsv $N 7 10 $SL
+gcc -O2 -o $R/build/gen_bam $R/tools/gen_bam.c -lz -lpthread
+$R/build/gen_bam $W/in.bam $W/bar.tsv $W/feat.tsv $N 7 10 $SL 16
 ls -la $W/in.bam | awk '{print "BAM bytes", $5}'
 echo "host cores visible: $(nproc)"
 run() {

@@ -1,17 +1,22 @@
 /* gen_bam.c — fast synthetic BAM generator for end-to-end benchmarks (test tooling, not product).
- *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len]
+ *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len] [threads]
+ * The record stream is cut into 64 pieces, each with its own generator state and its own run of BGZF blocks, so the
+ * file is the same for every thread count.
  * seq_len > 0 gives records the size and content mix of a Cell Ranger BAM: mapped reads with one CIGAR word, seq_len
  * packed bases, binned qualities (long runs of 'F' with ':' and ','), and the CR/CY/UR/UY/NH/AS/RG tags in front of
  * CB/xf/GX/UB; blocks are then deflated at level 6 as samtools does.
  * Every record: unmapped, tags CB:Z (95 % from the list, 5 % random), xf:C (85 % 25/17), GX:Z, UB:Z.
- * gcc -O2 -o gen_bam gen_bam.c -lz */
+ * gcc -O2 -o gen_bam gen_bam.c -lz -lpthread */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <pthread.h>
 
-static uint64_t s[2];
+typedef struct { uint64_t s[2]; unsigned char blk[0xff00]; size_t blen; unsigned char *out; size_t olen, ocap; } piece_t;
+static __thread piece_t *P;
+#define s (P->s)
 static inline uint64_t rnd(void) { uint64_t a = s[0], b = s[1]; s[0] = b; a ^= a << 23; s[1] = a ^ b ^ (a >> 17) ^ (b >> 26); return s[1] + b; }
 
 static char **read_col1(const char *path, size_t *n)
@@ -22,7 +27,9 @@ static char **read_col1(const char *path, size_t *n)
     fclose(f); return v;
 }
 
-static FILE *out; static unsigned char blk[0xff00]; static size_t blen; static int g_level = 1;
+static FILE *out; static int g_level = 1;
+#define blk (P->blk)
+#define blen (P->blen)
 static void flush_block(void)
 {
     unsigned char comp[0x10000 + 64]; z_stream z; memset(&z, 0, sizeof z);
@@ -33,7 +40,8 @@ static void flush_block(void)
     memcpy(comp, hdr, 16); uint16_t bsize = (uint16_t)(clen + 25); memcpy(comp + 16, &bsize, 2);
     uint32_t crc = (uint32_t)crc32(crc32(0, NULL, 0), blk, (uInt)blen), isz = (uint32_t)blen;
     memcpy(comp + 18 + clen, &crc, 4); memcpy(comp + 22 + clen, &isz, 4);
-    fwrite(comp, 1, clen + 26, out); blen = 0;
+    if (P->olen + clen + 26 > P->ocap) { P->ocap = P->ocap ? P->ocap * 2 : (1 << 22); P->out = realloc(P->out, P->ocap); if (!P->out) { perror("realloc"); exit(1); } }
+    memcpy(P->out + P->olen, comp, clen + 26); P->olen += clen + 26; blen = 0;
 }
 static void put(const void *p, size_t n)
 {
@@ -41,21 +49,55 @@ static void put(const void *p, size_t n)
     while (n) { size_t k = sizeof blk - blen; if (k > n) k = n; memcpy(blk + blen, q, k); blen += k; q += k; n -= k; if (blen == sizeof blk) flush_block(); }
 }
 
+enum { PIECES = 64 };
+static piece_t *g_piece[PIECES + 1];
+static size_t g_n, g_nb, g_ng; static char **g_bar, **g_gen; static uint64_t g_seed; static int g_ul, g_sl; static int g_next;
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static void gen_piece(int pc);
+static void *worker(void *vp)
+{
+    (void)vp;
+    for (;;) {
+        pthread_mutex_lock(&g_mu); int pc = g_next++; pthread_mutex_unlock(&g_mu);
+        if (pc >= PIECES) return NULL;
+        gen_piece(pc);
+    }
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len]\n"); return 1; }
-    size_t nb, ng; char **bar = read_col1(argv[2], &nb), **gen = read_col1(argv[3], &ng);
-    size_t n = strtoull(argv[4], NULL, 10); uint64_t seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 1; int ul = argc > 6 ? atoi(argv[6]) : 10;
-    int sl = argc > 7 ? atoi(argv[7]) : 0; if (sl > 150) sl = 150; if (sl > 0) g_level = 6;
-    s[0] = seed * 0x9E3779B97F4A7C15ull + 1; s[1] = seed ^ 0xD1B54A32D192ED03ull; for (int i = 0; i < 8; i++) rnd();
+    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len] [seq_len] [threads]\n"); return 1; }
+    g_bar = read_col1(argv[2], &g_nb); g_gen = read_col1(argv[3], &g_ng);
+    g_n = strtoull(argv[4], NULL, 10); g_seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 1; g_ul = argc > 6 ? atoi(argv[6]) : 10;
+    g_sl = argc > 7 ? atoi(argv[7]) : 0; if (g_sl > 150) g_sl = 150; if (g_sl > 0) g_level = 6;
+    int nt = argc > 8 ? atoi(argv[8]) : 1; if (nt < 1) nt = 1; if (nt > 64) nt = 64;
     out = fopen(argv[1], "wb"); if (!out) { perror(argv[1]); return 1; }
-    static char obuf[1 << 22]; setvbuf(out, obuf, _IOFBF, sizeof obuf);
+    for (int i = 0; i <= PIECES; i++) { g_piece[i] = calloc(1, sizeof(piece_t)); if (!g_piece[i]) { perror("calloc"); return 1; } }
+    /* the header is a block run of its own (piece PIECES, written first) */
+    P = g_piece[PIECES];
     const char *text = "@HD\tVN:1.6\tSO:unsorted\n"; int32_t lt = (int32_t)strlen(text), nref = 0;
     put("BAM\1", 4); put(&lt, 4); put(text, lt);
-    if (sl > 0) { nref = 1; put(&nref, 4); int32_t ln = 5, lref = 248956422; put(&ln, 4); put("chr1", 5); put(&lref, 4); }   /* mapped reads name refID 0 */
+    if (g_sl > 0) { nref = 1; put(&nref, 4); int32_t ln = 5, lref = 248956422; put(&ln, 4); put("chr1", 5); put(&lref, 4); }   /* mapped reads name refID 0 */
     else put(&nref, 4);
+    if (blen) flush_block();
+    pthread_t th[64];
+    for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, worker, NULL);
+    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+    fwrite(g_piece[PIECES]->out, 1, g_piece[PIECES]->olen, out);
+    for (int i = 0; i < PIECES; i++) fwrite(g_piece[i]->out, 1, g_piece[i]->olen, out);
+    static const unsigned char eof[28] = {0x1f,0x8b,8,4,0,0,0,0,0,0xff,6,0,'B','C',2,0,0x1b,0,3,0,0,0,0,0,0,0,0,0};
+    fwrite(eof, 1, 28, out); fclose(out);
+    return 0;
+}
+
+static void gen_piece(int pc)
+{
+    P = g_piece[pc];
+    const size_t n0 = g_n * (size_t)pc / PIECES, n1 = g_n * (size_t)(pc + 1) / PIECES, nb = g_nb, ng = g_ng;
+    char **bar = g_bar, **gen = g_gen; const int ul = g_ul, sl = g_sl; const uint64_t seed = g_seed * 1000003ull + (uint64_t)pc;
+    s[0] = seed * 0x9E3779B97F4A7C15ull + 1; s[1] = seed ^ 0xD1B54A32D192ED03ull; for (int i = 0; i < 8; i++) rnd();
     unsigned char rec[1024];
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = n0; i < n1; i++) {
         unsigned char *p = rec + 4; int32_t m1 = -1, z = 0; char name[24]; int nl = snprintf(name, sizeof name, "r%zu", i) + 1;
         memcpy(p, &m1, 4); memcpy(p + 4, &m1, 4); p[8] = (unsigned char)nl; p[9] = 0; uint16_t bin = 4680, nc = 0, fl = 4;
         memcpy(p + 10, &bin, 2); memcpy(p + 12, &nc, 2); memcpy(p + 14, &fl, 2); memcpy(p + 16, &z, 4);
@@ -89,7 +131,4 @@ int main(int argc, char **argv)
         int32_t bs = (int32_t)(p - rec - 4); memcpy(rec, &bs, 4); put(rec, (size_t)(p - rec));
     }
     if (blen) flush_block();
-    static const unsigned char eof[28] = {0x1f,0x8b,8,4,0,0,0,0,0,0xff,6,0,'B','C',2,0,0x1b,0,3,0,0,0,0,0,0,0,0,0};
-    fwrite(eof, 1, 28, out); fclose(out);
-    return 0;
 }
