@@ -994,8 +994,19 @@ typedef struct {
     int level; size_t next; int err;
 } gz_job;
 
+/* level < 0 (FASTF_GZIP_LEVEL unset): the built-in encoder (deflate_fast.c: one-probe LZ77 + dynamic Huffman);
+ * FASTF_GZIP_LEVEL=0..9: zlib at that level (6 = what the reference's gzopen(..., "wb") uses) */
 static int gz_member(const char *text, size_t len, int level, unsigned char **out, size_t *out_len)
 {
+    if (level < 0) {
+        size_t cap = fastf_gz_bound(len);
+        unsigned char *buf = (unsigned char *)malloc(cap);
+        if (!buf) return 1;
+        size_t n = fastf_gz_member_fast((const unsigned char *)text, len, buf, cap);
+        if (n) { *out = buf; *out_len = n; return 0; }
+        free(buf);                                             /* did not fit the bound (cannot happen): zlib below */
+        level = 1;
+    }
     z_stream z; memset(&z, 0, sizeof z);
     if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 1;
     size_t cap = deflateBound(&z, (uLong)len) + 64;
@@ -1063,7 +1074,8 @@ static int write_gz_chunks_path(const char *path, const char *prefix, size_t pre
     j.out = (unsigned char **)calloc(j.n_chunks, sizeof *j.out);
     j.out_len = (size_t *)calloc(j.n_chunks, sizeof *j.out_len);
     const char *lv = getenv("FASTF_GZIP_LEVEL");
-    j.level = lv ? atoi(lv) : Z_DEFAULT_COMPRESSION;           /* gzopen(…, "wb") default, as the reference */
+    j.level = lv ? atoi(lv) : -1;                               /* unset: built-in fast encoder; parity is on the decompressed bytes */
+    if (j.level > 9) j.level = 9;
     int nt = host_threads(0);
     if ((size_t)nt > j.n_chunks) nt = (int)j.n_chunks;
     par_run(nt, gz_worker, &j);

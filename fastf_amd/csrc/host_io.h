@@ -11,6 +11,9 @@ extern "C" {
 #endif
 
 void fastf_set_error_(const char *msg);
+/* deflate_fast.c: text -> one complete gzip member; 0 when cap (>= fastf_gz_bound(len)) was too small */
+size_t fastf_gz_bound(size_t len);
+size_t fastf_gz_member_fast(const unsigned char *in, size_t len, unsigned char *out, size_t cap);
 
 /* ---- barcode / feature lists: bam2db_ds.c:229-337 ---- */
 typedef struct fastf_lists {

@@ -83,3 +83,52 @@ def test_write_outputs_empty(tmp_path):
     assert L.fastf_write_outputs(b"/nonexistent/dir", case.label, C.c_float(0.0), C.c_float(1.0), C.byref(cnt),
                                  C.byref(lists._s), C.byref(coo), None) == 1
     assert b"can not open file" in L.fastf_last_error()
+
+
+# ---- the built-in deflate encoder (deflate_fast.c): any valid stream will do, so the check is "zlib inflates it back" ----
+def _gz_fast(b):
+    L = _lib.lib()
+    L.fastf_gz_bound.restype = C.c_size_t; L.fastf_gz_bound.argtypes = [C.c_size_t]
+    L.fastf_gz_member_fast.restype = C.c_size_t
+    L.fastf_gz_member_fast.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    cap = L.fastf_gz_bound(len(b))
+    out = C.create_string_buffer(cap)
+    n = L.fastf_gz_member_fast(b, len(b), out, cap)
+    assert n > 0
+    return out.raw[:n]
+
+
+def test_fast_deflate_round_trips_edge_cases():
+    rng = np.random.default_rng(11)
+    cells = np.sort(rng.integers(1, 25_001, 300_000)); feats = rng.integers(1, 36_602, 300_000)
+    rows = b"".join(b"%d %d %d\n" % (f, c, 1 + (f % 7)) for f, c in zip(feats.tolist(), cells.tolist()))
+    cases = {
+        "empty": b"", "one byte": b"x", "three bytes": b"abc", "short repeat": b"hello hello hello hello",
+        "zeros": bytes(700_000),                                   # matches of the maximum length 258, distance 1
+        "random": rng.integers(0, 256, 400_000, dtype=np.uint8).tobytes(),      # incompressible: literal-only blocks
+        "matrix rows": rows,                                       # several 128 K-token blocks
+        "period 321": (b"abcdefgh" * 40 + b"X") * 3000,
+        "far matches": (rng.integers(0, 256, 32_768, dtype=np.uint8).tobytes()) * 3,     # distance exactly 32 768
+        "too far": (rng.integers(0, 256, 32_769, dtype=np.uint8).tobytes()) * 3,         # one beyond the window: no match allowed
+        "two symbols": bytes(rng.integers(0, 2, 100_000, dtype=np.uint8)),
+        "all bytes": bytes(range(256)) * 50,
+    }
+    import zlib
+    for name, b in cases.items():
+        z = _gz_fast(b)
+        d = zlib.decompressobj(31)
+        assert d.decompress(z) == b and d.eof and d.unused_data == b"", name
+        assert gzip.decompress(z) == b, name
+    assert len(_gz_fast(rows)) < len(rows) / 2.5                   # digit rows: in the class of zlib's fast levels
+
+
+def test_fast_deflate_fuzz():
+    rng = np.random.default_rng(12)
+    for it in range(400):
+        n = int(rng.integers(0, 6000)); alpha = int(rng.integers(1, 257))
+        b = rng.integers(0, alpha, n, dtype=np.uint8).tobytes()
+        if it % 3 == 0:
+            b = b * int(rng.integers(1, 30))
+        if it % 7 == 0:
+            b = b + b[: len(b) // 2][::-1] + b
+        assert gzip.decompress(_gz_fast(b)) == b
