@@ -110,11 +110,10 @@ static void huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len
     for (int i = next - 2; i >= 0; i--) depth[i] = depth[parent[i]] + 1;
     int bl_count[64]; memset(bl_count, 0, sizeof bl_count);
     int overflow = 0;
-    for (int i = 0; i < nl; i++) {
-        int d = depth[i];
-        if (d > max_bits) { d = max_bits; overflow++; }
-        bl_count[d]++;
-    }
+    for (int i = 0; i < nl; i++) bl_count[depth[i] > max_bits ? max_bits : depth[i]]++;
+    /* every node below the limit, leaf or internal, costs one unit: a subtree of L leaves hanging under a node at the
+     * limit holds 2L - 2 such nodes and needs L - 1 of the steps below (each step settles two units) */
+    for (int i = 0; i < next - 1; i++) overflow += depth[i] > max_bits;
     if (overflow) {
         /* Kraft sum is now too large: repeatedly take a leaf from the deepest level that still has one above max_bits-1
          * ... zlib's gen_bitlen loop */
@@ -131,6 +130,14 @@ static void huff_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len
     int i = 0;
     for (int bits = max_bits; bits >= 1; bits--)
         for (int c = bl_count[bits]; c > 0; c--) len[leaves[i++].sym] = (uint8_t)bits;
+}
+
+/* a prefix code exists for these lengths iff the Kraft sum does not exceed 1 (checked in units of 2^-15) */
+static int kraft_ok(const uint8_t *len, int n)
+{
+    uint32_t k = 0;
+    for (int i = 0; i < n; i++) if (len[i]) k += 1u << (MAX_BITS - len[i]);
+    return k <= (1u << MAX_BITS);
 }
 
 static void huff_codes(const uint8_t *len, int n, uint16_t *code)
@@ -162,6 +169,11 @@ static void write_block(bitw *w, block_t *b, int final)
     huff_lengths(b->dfreq, N_DIST, MAX_BITS, dlen);
     int nd_used = 0; for (int i = 0; i < N_DIST; i++) nd_used += dlen[i] != 0;
     if (nd_used == 0) dlen[0] = 1;                 /* at least one distance code must be described */
+#ifdef DEFLATE_DEBUG
+    { double kl = 0, kd = 0; int ml = 0; for (int i = 0; i < N_LITLEN; i++) if (llen[i]) { kl += 1.0 / (1 << llen[i]); if (llen[i] > ml) ml = llen[i]; }
+      for (int i = 0; i < N_DIST; i++) if (dlen[i]) kd += 1.0 / (1 << dlen[i]);
+      fprintf(stderr, "block n=%zu kraft litlen %.6f (max %d) dist %.6f\n", b->n, kl, ml, kd); }
+#endif
     huff_codes(llen, N_LITLEN, lcode);
     huff_codes(dlen, N_DIST, dcode);
     int hlit = N_LITLEN - 2;                       /* symbols 286, 287 never occur */
@@ -188,6 +200,12 @@ static void write_block(bitw *w, block_t *b, int final)
     }
     uint8_t cllen[19]; uint16_t clcode[19];
     huff_lengths(clfreq, 19, 7, cllen);
+    /* belt and braces: lengths that admit no prefix code make the caller fall back to zlib for this member */
+    if (!kraft_ok(llen, N_LITLEN) || !kraft_ok(dlen, N_DIST) || !kraft_ok(cllen, 19)) { w->overflow = 1; b->n = 0; return; }
+#ifdef DEFLATE_DEBUG
+    { double k = 0; for (int i = 0; i < 19; i++) if (cllen[i]) k += 1.0 / (1 << cllen[i]);
+      fprintf(stderr, "  kraft cl %.6f:", k); for (int i = 0; i < 19; i++) fprintf(stderr, " %d(%u)", cllen[i], clfreq[i]); fprintf(stderr, "\n"); }
+#endif
     huff_codes(cllen, 19, clcode);
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = 19; while (hclen > 4 && cllen[order[hclen - 1]] == 0) hclen--;

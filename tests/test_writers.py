@@ -111,6 +111,11 @@ def test_fast_deflate_round_trips_edge_cases():
         "far matches": (rng.integers(0, 256, 32_768, dtype=np.uint8).tobytes()) * 3,     # distance exactly 32 768
         "too far": (rng.integers(0, 256, 32_769, dtype=np.uint8).tobytes()) * 3,         # one beyond the window: no match allowed
         "two symbols": bytes(rng.integers(0, 2, 100_000, dtype=np.uint8)),
+        # Fibonacci-like symbol frequencies: the unrestricted Huffman tree is deeper than 15 levels (and the code-length
+        # code deeper than 7), so the length-limiting step has to rebalance it
+        "skewed": bytes(rng.permutation(np.repeat(np.arange(24, dtype=np.uint8), [1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377,
+                                                  610, 987, 1597, 2584, 4181, 6765, 10946, 17711, 28657, 46368]))),
+        "skewed wide": bytes(rng.permutation(np.repeat(np.arange(200, dtype=np.uint8), (1.09 ** np.arange(200)).astype(int) + 1))),
         "all bytes": bytes(range(256)) * 50,
     }
     import zlib
