@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes",
-    "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_sort", "fastf_dev_reduce",
+    "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_error_bits",
     "fastf_dev_clear_error_bits", "fastf_kernel_names",
     # crb / extract
@@ -118,6 +118,7 @@ def lib():
     L.fastf_last_error.restype = C.c_char_p
     L.fastf_version.restype = C.c_char_p
     L.fastf_kernel_names.restype = C.c_char_p
+    L.fastf_dev_probe_capacity.argtypes = [vp, u64, C.POINTER(u64)]
     L.fastf_engine_push_pinned.argtypes = [vp, vp]
     L.fastf_engine_wait_input.argtypes = [vp]
     L.fastf_pinned_alloc.argtypes = [sz]

@@ -3,9 +3,11 @@
 #include "fastf_amd.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
+extern int fastf_process_is_exiting_;
 struct cmd_struct { const char *cmd; int (*fn)(int, const char **); };
 static const struct cmd_struct commands[] = { {"crb", cmd_crb}, {"bam2db", cmd_bam2db}, {"extract", cmd_extract} };
 
@@ -21,6 +23,7 @@ int main(int argc, const char **argv)
     }
     for (size_t i = 0; i < sizeof commands / sizeof commands[0]; i++)
         if (!strcmp(commands[i].cmd, argv[1])) {
+            fastf_process_is_exiting_ = getenv("FASTF_FULL_TEARDOWN") == NULL;   /* this process ends with the command */
             int rc = commands[i].fn(argc - 1, argv + 1);
             /* every output is closed by now; skip the ~0.2 s the HIP runtime spends unloading at exit */
             fflush(NULL);

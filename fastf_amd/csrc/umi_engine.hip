@@ -128,6 +128,9 @@ struct fastf_engine {
     bool fully_sorted = false;
     // workspace
     DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
+    DevBuf d_halfhits;                   // K1a: hits per 256-record unit (the streaming K1b's rank bases)
+    DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
+    u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
     DevBuf d_heads, d_rowbase;           // K3's tile counts / bases: not shared with K1, so K1 of the next batch may run beside K3 (other stream)
     // timing
     bool timing = false;
@@ -278,7 +281,9 @@ static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
     HIP_OK(hipMemcpy(e->img_cells.p, ci.img.data(), ci.img.size(), hipMemcpyHostToDevice));
     e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.slot_bits = ci.slot_bits; e->lds_cells.bucket_mask = ci.bucket_mask;
     e->lds_cells.family = ci.family; e->lds_cells.bytes = ci.bytes; e->lds_cells.seed = ci.seed;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ci.bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)ci.bytes) != hipSuccess) return 0;
     e->cells_blocks_per_cu = ci.bytes + 64 <= 80 * 1024 ? 2u : 1u;
     e->use_lds_cells = true;
@@ -343,6 +348,10 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess) return 0;
     const size_t per_block = bytes + 1024;                           // + the kernel's static LDS (about 0.5 KB)
     e->genes_blocks_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / per_block));
@@ -453,7 +462,8 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     if (e->h_coo) (void)hipHostFree(e->h_coo);
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase};
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase,
+                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -519,6 +529,8 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
         HIP_OK(hipMemset(e->d_tilecnt.p, 0, e->d_tilecnt.bytes));
     }
     if (e->d_tilebase.ensure(t1 * sizeof(u64))) return 1;
+    if (e->d_halfhits.ensure(t1 * 16 * sizeof(u32))) return 1;
+    if (e->d_tileseg.ensure((ts + 8) * sizeof(u32))) return 1;
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
@@ -573,15 +585,19 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
     t_begin(e, s);
     if (e->use_lds_cells) {                          // tile counts are all-zero here: scan_tiles_kernel clears what it reads
         const u32 grid = std::min<u32>(e->cells_blocks_per_cu * g_cu_count, (tiles + 1) / 2);
-        hipLaunchKernelGGL(probe_cells_lds_kernel, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
+        if (e->cells_blocks_per_cu >= 2)
+            hipLaunchKernelGGL(probe_cells_lds_kernel<true>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
+                               (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+        else
+            hipLaunchKernelGGL(probe_cells_lds_kernel<false>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
+                               (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else if (e->cell_filter.bits) {
         const u32 grid = std::min<u32>(tiles, 4 * g_cu_count);
         hipLaunchKernelGGL(probe_cells_filtered_kernel, dim3(grid), dim3(K1_THREADS), (e->cell_filter.mask + 1u) / 8u, s, cb, n,
-                           e->cells, e->cell_filter, (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, tiles);
+                           e->cells, e->cell_filter, (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else {
         hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
-                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p);
+                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p);
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
@@ -601,7 +617,9 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
-                        u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr) {
+                        u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr,
+                        bool segmented = false) {
+    if (segmented) e->seg_n = 0;
     if (n == 0) return 0;
     // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order).
     // d_running: the scan leaves the running hit total of the earlier chunks at draw_base and adds this chunk's hits.
@@ -619,7 +637,19 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.n_tiles = tiles;
     p.genes = e->lds_genes;
     t_begin(e, s);
-    if (e->use_lds_genes) {
+    if (segmented) {
+        // streaming form: every wave on its own, keys into one private region per workgroup (see filter_pack_stream_kernel)
+        const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
+        const u64 region = (u64)((tiles + grid - 1) / grid) * K1_TILE;
+        if ((u64)grid * region > stride) return set_err("segmented key output needs %llu slots, the buffer has %llu (fastf_dev_probe_capacity)",
+                                                        (unsigned long long)((u64)grid * region), (unsigned long long)stride);
+        if (e->d_segcount.ensure(grid * sizeof(u64)) || e->d_segprefix.ensure((grid + 1) * sizeof(u64))) return 1;
+        StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
+        if (e->genes_blocks_per_cu >= 2) hipLaunchKernelGGL((filter_pack_stream_kernel<false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp);
+        else hipLaunchKernelGGL((filter_pack_stream_kernel<true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp);
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p, grid, (u64*)e->d_segprefix.p, key_counts);
+        e->seg_n = grid; e->seg_stride = region;
+    } else if (e->use_lds_genes) {
         const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
         if (e->genes_blocks_per_cu >= 2) hipLaunchKernelGGL((filter_pack_kernel<true, false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);
         else hipLaunchKernelGGL((filter_pack_kernel<true, true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);
@@ -638,17 +668,36 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
                                     uint64_t* d_counters, uint32_t flags, void* stream) {
     if (!e) return set_err("null engine");
     HIP_OK(hipSetDevice(e->device));
+    const bool seg = (flags & FASTF_PROBE_SEGMENTED) != 0;
+    if (seg && !(e->n_shards == 1 && e->use_lds_genes))
+        return set_err("FASTF_PROBE_SEGMENTED needs a single shard and the gene table in LDS (fastf_dev_probe_capacity returns 0 otherwise)");
     return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
-                        (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream);
+                        (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream, ~0ull, nullptr, seg);
+}
+
+extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uint64_t* key_slots) {
+    if (!e || !key_slots) return set_err("null argument");
+    *key_slots = 0;
+    if (!(e->n_shards == 1 && e->use_lds_genes) || getenv("FASTF_NO_STREAM_K1B")) return 0;
+    const u64 tiles = (n + K1_TILE - 1) / K1_TILE;
+    const u64 grid = std::min<u64>(std::max<u64>(tiles, 1), (u64)e->genes_blocks_per_cu * g_cu_count);
+    *key_slots = grid * ((tiles + grid - 1) / grid) * K1_TILE;
+    return 0;
 }
 
 static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
 extern "C" void fastf_debug_set_stamps(void* p) { g_stamps = (u64*)p; }
+// grid of the tile kernels: whole rounds over the 8 XCDs, capped — beyond the cap the workgroups walk their tiles
+static u32 tile_grid(u32 T) {
+    static int cap = -1;
+    if (cap < 0) { const char* c = getenv("FASTF_TILE_GRID_CAP"); cap = c ? atoi(c) : 32 * (int)g_cu_count; if (cap < 8) cap = 8; }
+    return std::min<u32>((T + 7u) & ~7u, (u32)cap & ~7u);
+}
 static void launch_scatter(u32 shift, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt,
-                           const u32* bin_tot, u32 ipt) {
-    T = (T + 7u) & ~7u;                 // whole rounds over the 8 XCDs (see the tile swizzle in scatter_kernel)
-#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, g_stamps)
+                           const u32* bin_tot, u32 ipt, const SegMap seg = SegMap{nullptr, nullptr, 0, 0}) {
+    T = tile_grid(T);
+#define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, seg, g_stamps)
     const bool rt = (shift & 7u) != 0 || getenv("FASTF_SORT_RUNTIME_SHIFT");
     switch (rt ? 64u : shift) {
     case 0: SC(0); break;  case 8: SC(8); break;  case 16: SC(16); break; case 24: SC(24); break;
@@ -670,7 +719,7 @@ static int set_scatter_lds_limit() {
 // 8-bit LSD passes over the key bits [low_bit, key_bits): pass q sorts the digit at low_bit + 8q (the last one may reach
 // past key_bits, where every key holds zeros).  low_bit = 0 is the full sort.
 static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits, u32 low_bit,
-                       int* sorted_in_tmp, hipStream_t s) {
+                       int* sorted_in_tmp, hipStream_t s, bool segmented_input = false) {
     if (key_bits > 64) return set_err("key_bits %u > 64", key_bits);
     const u32 passes = sort_passes(key_bits, low_bit);
     *sorted_in_tmp = (int)(passes & 1);
@@ -680,16 +729,26 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
     const u32 ipt = choose_sort_ipt(max_n);
     const u32 T = (u32)((max_n + (u64)ipt * SORT_THREADS - 1) / ((u64)ipt * SORT_THREADS));
     u32* bintot = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
+    SegMap seg{nullptr, nullptr, 0, 0};
+    if (segmented_input) {
+        // the keys are the segmented output of the streaming K1b: the first pass reads through the region map
+        if (!e->seg_n) return set_err("FASTF_SORT_SEGMENTED without a preceding FASTF_PROBE_SEGMENTED probe_pack");
+        if (passes == 0) return set_err("segmented keys need at least one sort pass");
+        seg = SegMap{(const u64*)e->d_segprefix.p, (const u32*)e->d_tileseg.p, e->seg_n, e->seg_stride};
+        hipLaunchKernelGGL(seg_tiles_kernel, dim3(std::min<u32>((T + 255) / 256, 1024)), dim3(256), 0, s, seg.prefix, seg.n_seg,
+                           ipt * SORT_THREADS, (u32*)e->d_tileseg.p);
+    }
+    const SegMap none{nullptr, nullptr, 0, 0};
     for (u32 q = 0; q < passes; ++q) {
         const u64* src = (q & 1) ? tmp : keys;
         u64* dst = (q & 1) ? keys : tmp;
         const u32 shift = low_bit + 8 * q;
         t_begin(e, s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3((T + 7u) & ~7u), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt, q == 0 ? seg : none);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
         hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         t_begin(e, s);
-        launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt);
+        launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt, q == 0 ? seg : none);
         t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
     }
     HIP_OK(hipGetLastError());
@@ -703,7 +762,7 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
     int dummy = 0;
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
                        (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0,
-                       sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream);
+                       sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream, (flags & FASTF_SORT_SEGMENTED) != 0);
 }
 
 template <bool UMI_ROWS>
@@ -720,10 +779,11 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
     p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
     t_begin(e, s);
-    hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
+    const u32 k3_grid = std::min<u32>(tiles, tile_grid(~0u - 8u));
+    hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(k3_grid), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_heads.p,
                        (u64*)e->d_rowbase.p, tiles, nrows, (u64*)nullptr, (u64*)nullptr);
-    hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(tiles), dim3(K3_THREADS), 0, s, p);
+    hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(k3_grid), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,
                        (const u64*)e->d_rowbase.p, count, d_n);
     HIP_OK(hipGetLastError());
@@ -766,7 +826,7 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 }
 
 extern "C" const char* fastf_kernel_names(void) {
-    return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,"
+    return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,filter_pack_stream_kernel,"
            "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
 }
 

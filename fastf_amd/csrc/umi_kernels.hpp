@@ -225,9 +225,12 @@ __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
 }
 
+// half_hits[16 t + h]: hits among records [256 h, 256 h + 256) of tile t — the hit-rank base of a 256-record unit is
+// tile_base[t] + the halves in front of it, which lets every WAVE of K1b work on its own (filter_pack_stream_kernel)
 template <int AUX>
 __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __restrict__ cb, u64 n, Table cells,
-                                                                 u32* __restrict__ cell_out, u32* __restrict__ tile_hits) {
+                                                                 u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                                 u32* __restrict__ half_hits) {
     __shared__ u32 s_w[K1_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u64 base = (u64)blockIdx.x * K1_TILE + (u64)w * (K1_IPT * WAVE);
@@ -238,14 +241,18 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
         key[j] = idx < n ? cb[idx] : 0;
     }
     table_probe_batch<K1_IPT, AUX>(cells, key, cell);
-    u32 hits = 0;
+    u32 hits = 0, hits_lo = 0;
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
         const u64 idx = base + (u64)j * WAVE + lane;
         if (idx < n) cell_out[idx] = cell[j];
         hits += (u32)__popcll(__ballot(cell[j] != 0));
+        if (j == K1_IPT / 2 - 1) hits_lo = hits;
     }
-    if (lane == 0) s_w[w] = hits;
+    if (lane == 0) {
+        s_w[w] = hits;
+        half_hits[((u64)blockIdx.x * K1_WAVES + w) * 2] = hits_lo; half_hits[((u64)blockIdx.x * K1_WAVES + w) * 2 + 1] = hits - hits_lo;
+    }
     __syncthreads();
     if (tid == 0) {
         u32 t = 0;
@@ -296,7 +303,7 @@ __device__ __forceinline__ u32 filter_bit(u64 key) {
 
 __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(const u64* __restrict__ cb, u64 n, Table cells, MissFilter f,
                                                                              u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                                             u32 n_tiles) {
+                                                                             u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u32 s_w[K1_WAVES];
     u32* s_bits = reinterpret_cast<u32*>(smem);
@@ -321,14 +328,18 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
             if (!((s_bits[b >> 5] >> (b & 31u)) & 1u)) key[j] = 0;        // not listed: no probe (dead lanes share slot 0)
         }
         table_probe_batch<K1_IPT, 0>(cells, key, cell);
-        u32 hits = 0;
+        u32 hits = 0, hits_lo = 0;
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const u64 idx = base + (u64)j * WAVE + lane;
             if (idx < n) cell_out[idx] = cell[j];
             hits += (u32)__popcll(__ballot(cell[j] != 0));
+            if (j == K1_IPT / 2 - 1) hits_lo = hits;
         }
-        if (lane == 0) s_w[w] = hits;
+        if (lane == 0) {
+            s_w[w] = hits;
+            half_hits[((u64)tile * K1_WAVES + w) * 2] = hits_lo; half_hits[((u64)tile * K1_WAVES + w) * 2 + 1] = hits - hits_lo;
+        }
         __syncthreads();
         if (tid == 0) {
             u32 t = 0;
@@ -343,9 +354,11 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
 // walks its own 512-record chunks — each lane loads and stores PAIRS of neighbouring records (16-byte loads, 8-byte
 // stores) — and adds its hit count to tile_hits[] (all-zero on entry) with one atomic: no barrier after the image is
 // in LDS.
-__global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
+// TWO_PER_CU: the image leaves room for two workgroups per CU, which takes 64 VGPRs at most
+template <bool TWO_PER_CU>
+__global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
                                                                u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
-                                                               u32 n_tiles) {
+                                                               u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 S = c.slot_bits, smask = (1u << S) - 1u, lo_mask = (1u << (32u - S)) - 1u;
     const u32* s_slot = reinterpret_cast<const u32*>(smem);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __rest
                 key[j] = idx < n ? cb[idx] : 0;
             }
         }
-        u32 hits = 0;
+        u32 hits = 0, hits_lo = 0;                                        // key[2 jj], key[2 jj + 1]: records 128 jj + 2 lane + {0, 1}
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const bool fam = (u32)(key[j] >> 49) == c.family && (key[j] & 0xFFFFu) == 0;
@@ -387,6 +400,7 @@ __global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __rest
             const u32 v = (fam && (e >> S) == lo) ? (e & smask) : 0u;          // empty slots carry index 0
             cell[j] = v;
             hits += (u32)__popcll(__ballot(v != 0));
+            if (j == K1_IPT / 2 - 1) hits_lo = hits;
         }
         if (whole) {
 #pragma unroll
@@ -399,7 +413,10 @@ __global__ __launch_bounds__(1024) void probe_cells_lds_kernel(const u64* __rest
                 if (idx < n) cell_out[idx] = cell[j];
             }
         }
-        if (lane == 0 && hits) atomicAdd(&tile_hits[chunk / (u32)K1_WAVES], hits);
+        if (lane == 0) {
+            if (hits) atomicAdd(&tile_hits[chunk / (u32)K1_WAVES], hits);
+            *reinterpret_cast<uint2*>(half_hits + 2ull * chunk) = make_uint2(hits_lo, hits - hits_lo);
+        }
     }
 }
 
@@ -446,7 +463,7 @@ struct PackParams {
 template <bool LDS_GENES, bool ROOMY = false>
 __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MINWAVES : FASTF_K1B_MINWAVES_L2)) void filter_pack_kernel(const PackParams p) {
     __shared__ u32 s_cnt[K1B_IPT * K1B_WAVES];       // hits per (item, wave), then exclusive
-    __shared__ u32 s_red[3][K1B_WAVES];
+    __shared__ u64 s_tot[3];                         // hits, sampled, valid of this workgroup's tiles so far
     __shared__ u32 s_shard_cnt[8];
     __shared__ u64 s_shard_base[8];
     __shared__ u32 s_err;
@@ -468,7 +485,6 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
     const u64 base = (u64)tile * K1_TILE;
 
     if (tid < 8) s_shard_cnt[tid] = 0;
-    if (tid == 0) s_err = 0;
 
     K1STAMP(0);
     // ---- loads; hit ranks in record order (item-major, then wave, then lane) ----
@@ -599,16 +615,16 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
 
     K1STAMP(4);
     // ---- counters + global slot reservation ----
+    // the three counters and the error bits gather in LDS; a persistent workgroup sends them to memory once, after its
+    // last tile (same-address device-scope atomics serialise at about 12 ns each: three per tile were a sixth of this kernel)
     n_hit = wave_sum32(n_hit); n_samp = wave_sum32(n_samp); n_valid = wave_sum32(n_valid);
-    if (lane == 0) { s_red[0][w] = n_hit; s_red[1][w] = n_samp; s_red[2][w] = n_valid; }
+    if (lane == 0) {
+        if (n_hit) atomicAdd(&s_tot[0], (u64)n_hit);
+        if (n_samp) atomicAdd(&s_tot[1], (u64)n_samp);
+        if (n_valid) atomicAdd(&s_tot[2], (u64)n_valid);
+    }
     if (errs) atomicOr(&s_err, errs);
     __syncthreads();
-    if (tid < 3) {
-        u64 t = 0;
-        for (int i = 0; i < K1B_WAVES; ++i) t += s_red[tid][i];
-        if (t) atomicAdd(&p.counters[tid], t);
-    }
-    if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
     if (tid >= 64 && tid < 64 + (int)p.n_shards) {
         const u32 s = tid - 64;
         const u32 c = s_shard_cnt[s];
@@ -627,6 +643,8 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
     }
     K1STAMP(6);
     };  // do_tile
+    if (tid < 3) s_tot[tid] = 0;
+    if (tid == 0) s_err = 0;
     if constexpr (LDS_GENES) {
         __syncthreads();                           // gene image is in LDS
         for (u32 tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
@@ -634,8 +652,201 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
             __syncthreads();                       // the next tile re-initialises the shared scalars
         }
     } else {
+        __syncthreads();
         do_tile(blockIdx.x);
+        __syncthreads();
     }
+    if (tid < 3 && s_tot[tid]) atomicAdd(&p.counters[tid], s_tot[tid]);
+    if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
+}
+
+// ------------------------------------------------------------------------------------
+// K1b, streaming form (single shard, gene table in LDS): every WAVE works on its own 256-record units — no barrier,
+// no workgroup-wide scan, no global atomic anywhere in the loop.
+//   hit-rank base of a unit   tile_base[t] + the half_hits in front of it inside its tile (K1a wrote both)
+//   output slot of a key      the workgroup owns a private region of the key buffer (capacity = the records it walks);
+//                             a wave takes its slots with ONE returning LDS atomic per unit
+//   counters                  kept per wave, added up in LDS once, three global atomics per workgroup at the end
+// The key buffer is therefore SEGMENTED after this kernel: region b holds seg_count[b] keys at keys + b * region_stride.
+// seg_scan_kernel turns the counts into prefix sums and the total; the first pass of the sort reads through that map
+// (SegMap below), every later pass sees a contiguous buffer again.
+// Measured motive (s_memtime stamps on the configs[2] shape, tile form): 26 % of a tile waited on the returning
+// device-scope atomic that reserved its output slots, 22 % on tile_base + the draw gather behind the workgroup scan,
+// and same-address device-scope atomics serialise at ~12 ns each.
+// ------------------------------------------------------------------------------------
+constexpr int K1S_IPT = 4, K1S_UNIT = K1S_IPT * WAVE;                       // 256 records per wave and step
+static_assert(K1_TILE % K1S_UNIT == 0 && K1_TILE / K1S_UNIT == 16, "16 units per K1a tile");
+
+struct StreamParams {
+    const u32* half_hits;          // [16 * n_tiles]
+    u64 region_stride;             // keys per workgroup region
+    u64* seg_count;                // [gridDim.x] out
+};
+
+template <bool ROOMY>
+__global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
+    __shared__ u64 s_tot[3];
+    __shared__ u32 s_cursor, s_err;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the gene image
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const u32* s_bitmap = reinterpret_cast<const u32*>(smem);
+    const unsigned short* s_rank = reinterpret_cast<const unsigned short*>(smem + (size_t)p.genes.words * 4);
+    const unsigned short* s_perm = s_rank + ((p.genes.words + 1u) & ~1u);
+    const unsigned short* s_direct = reinterpret_cast<const unsigned short*>(smem);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.genes.image);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += K1B_THREADS) dst[i] = src[i];
+    }
+    if (tid < 3) s_tot[tid] = 0;
+    if (tid == 0) { s_cursor = 0; s_err = 0; }
+    __syncthreads();
+
+    u64* const region = p.keys + (u64)blockIdx.x * sp.region_stride;
+    const u64 draw_off = p.draw_base ? *p.draw_base : 0;
+    u32 w_hit = 0, w_samp = 0, w_valid = 0, errs = 0;                      // wave-uniform running counts
+    // the workgroup's 16 waves take the 16 units of one K1a tile per round: the same locality as the tile form
+    for (u32 t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
+        const u64 base = (u64)t * K1_TILE + (u64)w * K1S_UNIT;
+        // ---- loads ----
+        u64 gxk[K1S_IPT]; u32 umi[K1S_IPT], meta[K1S_IPT], cell[K1S_IPT];
+#pragma unroll
+        for (int j = 0; j < K1S_IPT; ++j) {
+            const u64 idx = base + (u64)j * WAVE + lane;
+            const bool in = idx < p.n;
+            cell[j] = in ? p.cell[idx] : 0;
+            gxk[j]  = in ? p.gx[idx] : 0;
+            umi[j]  = in ? p.umi[idx] : 0;
+            meta[j] = in ? p.meta[idx] : 0;
+        }
+        // hit-rank base of this unit: one 64-byte line of half counts, summed over the units in front
+        const u32 hh = lane < w ? sp.half_hits[16ull * t + lane] : 0u;     // w <= 15
+        u64 rank0 = p.tile_base[t] + draw_off + wave_sum32(hh);
+        // ---- depth draw (E4/E5): ranks in record order, loads issued here and consumed after the gene lookup ----
+        u32 draw[K1S_IPT];
+#pragma unroll
+        for (int j = 0; j < K1S_IPT; ++j) {
+            const u64 hm = __ballot(cell[j] != 0);
+            draw[j] = 0;
+            if (cell[j] != 0) {
+                const u64 r = rank0 + rank_below(hm);
+                if (r < p.n_draws) draw[j] = p.draws[r & p.draw_mask];
+                else { cell[j] = 0; errs |= (u32)ERR_DRAWS_SHORT; }
+            }
+            const u32 c = (u32)__popcll(hm);
+            rank0 += c; w_hit += c;
+        }
+        // ---- E8 ahead of E5/E7: the LDS lookup runs while the draw loads are in flight ----
+        u32 feat[K1S_IPT];
+#pragma unroll
+        for (int j = 0; j < K1S_IPT; ++j) {
+            u32 f = 0;
+            const u64 k = (cell[j] != 0 && (meta[j] & META_XF_OK)) ? gxk[j] : 0;
+            if (k != 0) {
+                if ((u32)(k >> 44) == p.genes.family) {
+                    const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;                 // wraps to huge when below vmin
+                    if (v < p.genes.range) {
+                        if (p.genes.direct) f = s_direct[(u32)v];
+                        else {
+                            const u32 wd = s_bitmap[(u32)v >> 5], rk = s_rank[(u32)v >> 5], bit = (u32)v & 31u;
+                            if ((wd >> bit) & 1u) f = s_perm[rk + __popc(wd & ((1u << bit) - 1u))];
+                        }
+                    }
+                } else f = table_probe(p.feats, k);                                      // other id families / escaped strings
+            }
+            feat[j] = f;
+        }
+        // ---- E5..E12: keep/drop, key; slots of the wave inside the workgroup's region ----
+        u64 key[K1S_IPT], em[K1S_IPT];
+        u32 n_keys = 0;
+#pragma unroll
+        for (int j = 0; j < K1S_IPT; ++j) {
+            bool alive = cell[j] != 0 && (u64)draw[j] < p.threshold;
+            w_samp += (u32)__popcll(__ballot(alive));                                      // E6
+            alive = alive && feat[j] != 0 && (meta[j] & META_HAS_UB);
+            if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
+            key[j] = alive ? make_key(p.L, cell[j], feat[j], umi[j], meta[j]) : 0;
+            em[j] = __ballot(alive);
+            n_keys += (u32)__popcll(em[j]);
+        }
+        w_valid += n_keys;                                                                 // E12
+        if (n_keys) {
+            u32 pos0 = 0;
+            if (lane == 0) pos0 = atomicAdd(&s_cursor, n_keys);
+            pos0 = (u32)__builtin_amdgcn_readfirstlane((int)pos0);
+            if ((u64)pos0 + n_keys > sp.region_stride) errs |= (u32)ERR_KEYS_FULL;         // cannot happen: the region holds every record of the workgroup
+            else {
+#pragma unroll
+                for (int j = 0; j < K1S_IPT; ++j) {
+                    if ((em[j] >> lane) & 1) region[pos0 + rank_below(em[j])] = key[j];
+                    pos0 += (u32)__popcll(em[j]);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (w_hit) atomicAdd(&s_tot[0], (u64)w_hit);
+        if (w_samp) atomicAdd(&s_tot[1], (u64)w_samp);
+        if (w_valid) atomicAdd(&s_tot[2], (u64)w_valid);
+    }
+    {
+        u32 e = errs;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e |= __shfl_xor(e, o, WAVE);
+        if (lane == 0 && e) atomicOr(&s_err, e);
+    }
+    __syncthreads();
+    if (tid < 3 && s_tot[tid]) atomicAdd(&p.counters[tid], s_tot[tid]);
+    if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
+    if (tid == 4) sp.seg_count[blockIdx.x] = s_cursor;
+}
+
+// the map from the logical key index (regions back to back) to the segmented buffer
+struct SegMap { const u64* prefix; const u32* tile_seg; u32 n_seg; u64 stride; };   // prefix == nullptr: contiguous buffer
+
+// prefix[b] = keys in the regions before b, prefix[n_seg] = total, also stored to *n_out (the key count the sort reads)
+__global__ __launch_bounds__(1024) void seg_scan_kernel(const u64* __restrict__ seg_count, u32 n_seg, u64* __restrict__ prefix,
+                                                        u64* __restrict__ n_out) {
+    __shared__ u64 s_w[16];
+    __shared__ u64 s_carry;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < n_seg; b0 += 1024) {
+        const u32 b = b0 + threadIdx.x;
+        const u64 v = b < n_seg ? seg_count[b] : 0;
+        u64 inc = v;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) { const u64 x = __shfl_up(inc, o, WAVE); if (lane >= o) inc += x; }
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        u64 off = s_carry;
+        for (int i = 0; i < w; ++i) off += s_w[i];
+        if (b < n_seg) prefix[b] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { prefix[n_seg] = s_carry; *n_out = s_carry; }
+}
+
+// tile_seg[t] = region holding the first key of sort tile t (tile_keys keys per tile)
+__global__ __launch_bounds__(256) void seg_tiles_kernel(const u64* __restrict__ prefix, u32 n_seg, u32 tile_keys, u32* __restrict__ tile_seg) {
+    const u64 total = prefix[n_seg];
+    const u64 T = (total + tile_keys - 1) / tile_keys;
+    for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < T; t += (u64)gridDim.x * 256) {
+        const u64 first = t * tile_keys;
+        u32 lo = 0, hi = n_seg;                      // largest b with prefix[b] <= first
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (prefix[mid] <= first) lo = mid; else hi = mid; }
+        tile_seg[t] = lo;
+    }
+}
+
+// physical index of logical key idx, starting the search at region b (a tile rarely spans more than two regions)
+__device__ __forceinline__ u64 seg_phys(const SegMap m, u64 idx, u32 b, u64 lo, u64 hi) {
+    if (idx < hi) return (u64)b * m.stride + (idx - lo);
+    do { ++b; lo = hi; hi = m.prefix[b + 1]; } while (idx >= hi && b + 1 < m.n_seg);
+    return (u64)b * m.stride + (idx - lo);
 }
 
 // ------------------------------------------------------------------------------------
@@ -660,41 +871,56 @@ __device__ __forceinline__ u32 row_stride(u32 T) { return (T + 3u) & ~3u; }
 // XCD-contiguous tile of this workgroup.  The ranges are cut from the ACTUAL tile count T (the grid is sized for the
 // caller's upper bound on the key count and may be several times larger: cutting the ranges from gridDim would leave
 // most XCDs without a tile when the bound is loose).  Returns a value >= T for workgroups without a tile.
-__device__ __forceinline__ u32 xcd_tile(u32 T) {
-    const u32 chunk = (T + 7u) >> 3, r = blockIdx.x >> 3;
+// The grid is capped (launch_sort): a workgroup takes the tiles r, r + gridDim/8, ... of its XCD's range, so a loose
+// bound on the key count costs no empty workgroups, each of which would still have to fetch the key count.
+__device__ __forceinline__ u32 xcd_tile(u32 T, u32 r) {
+    const u32 chunk = (T + 7u) >> 3;
     return r < chunk ? (blockIdx.x & 7u) * chunk + r : ~0u;
 }
 
 // per-tile digit counts: cnt[d * T + tile].  Four LDS copies of the histogram (lane & 3) keep the
 // same-address atomic conflicts of skewed digits (e.g. the constant length bits) four times shorter.
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
-                                                                  u32 shift, u32* __restrict__ cnt, u32 ipt) {
+                                                                  u32 shift, u32* __restrict__ cnt, u32 ipt, const SegMap seg) {
     __shared__ u32 s_h[4 * RADIX];
     const u64 n = *n_ptr;
     const u32 T = num_tiles(n, ipt);
     // same XCD-contiguous tile mapping as the scatter: the 4-byte counts of neighbouring tiles share cache lines in
     // every digit row of cnt[][]
-    const u32 tile = xcd_tile(T);
-    if (tile >= T) return;
-    for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) s_h[i] = 0;
-    __syncthreads();
-    const u64 base = (u64)tile * ipt * SORT_THREADS;
-    u32* my = s_h + (threadIdx.x & 3) * RADIX;
-    u64 k[SORT_IPT];
+    for (u32 r = blockIdx.x >> 3;; r += gridDim.x >> 3) {
+        const u32 tile = xcd_tile(T, r);
+        if (tile >= T) return;                               // block-uniform
+        for (int i = threadIdx.x; i < 4 * RADIX; i += SORT_THREADS) s_h[i] = 0;
+        __syncthreads();
+        const u64 base = (u64)tile * ipt * SORT_THREADS;
+        u32* my = s_h + (threadIdx.x & 3) * RADIX;
+        u64 k[SORT_IPT];
+        if (seg.prefix) {                                    // first pass over the segmented output of the streaming K1b
+            const u32 b0 = seg.tile_seg[tile];
+            const u64 lo = seg.prefix[b0], hi = seg.prefix[b0 + 1];
 #pragma unroll
-    for (int j = 0; j < SORT_IPT; ++j) {
-        const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-        k[j] = (j < (int)ipt && idx < n) ? keys[idx] : 0;
-    }
+            for (int j = 0; j < SORT_IPT; ++j) {
+                const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
+                k[j] = (j < (int)ipt && idx < n) ? keys[seg_phys(seg, idx, b0, lo, hi)] : 0;
+            }
+        } else {
 #pragma unroll
-    for (int j = 0; j < SORT_IPT; ++j) {
-        const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-        if (j < (int)ipt && idx < n) atomicAdd(&my[(k[j] >> shift) & 255], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < RADIX) {
-        const int d = threadIdx.x;
-        cnt[(u64)d * row_stride(T) + tile] = s_h[d] + s_h[RADIX + d] + s_h[2 * RADIX + d] + s_h[3 * RADIX + d];
+            for (int j = 0; j < SORT_IPT; ++j) {
+                const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
+                k[j] = (j < (int)ipt && idx < n) ? keys[idx] : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SORT_IPT; ++j) {
+            const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
+            if (j < (int)ipt && idx < n) atomicAdd(&my[(k[j] >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < RADIX) {
+            const int d = threadIdx.x;
+            cnt[(u64)d * row_stride(T) + tile] = s_h[d] + s_h[RADIX + d] + s_h[2 * RADIX + d] + s_h[3 * RADIX + d];
+        }
+        __syncthreads();                                     // the next tile clears the histograms
     }
 }
 
@@ -759,7 +985,7 @@ __device__ __forceinline__ u32 digit_of(u64 key, u32 rshift) {
 template <int SHIFT, bool FULL>
 __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
                                              u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                             const int ipt, unsigned char* smem, const u32 rshift, u64* stamps = nullptr) {
+                                             const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, u64* stamps = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -781,10 +1007,20 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
     u64 key[SORT_IPT];
     const u32 wbase = (u32)w * (u32)ipt * WAVE;
+    if (seg.prefix) {                                          // first pass over the segmented output of the streaming K1b
+        const u32 b0 = seg.tile_seg[tile];
+        const u64 lo = seg.prefix[b0], hi = seg.prefix[b0 + 1];
 #pragma unroll
-    for (int j = 0; j < SORT_IPT; ++j) {
-        const u32 li = wbase + j * WAVE + lane;
-        key[j] = (j < ipt && (FULL || li < n_valid)) ? in[base + li] : ~0ULL;
+        for (int j = 0; j < SORT_IPT; ++j) {
+            const u32 li = wbase + j * WAVE + lane;
+            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[seg_phys(seg, base + li, b0, lo, hi)] : ~0ULL;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SORT_IPT; ++j) {
+            const u32 li = wbase + j * WAVE + lane;
+            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[base + li] : ~0ULL;
+        }
     }
     __syncthreads();
 #ifdef FASTF_STAMPS
@@ -868,24 +1104,27 @@ template <int SHIFT>
 __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
                                                                const u64* __restrict__ n_ptr,
                                                                const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                                               u32 ipt, u32 rshift, u64* stamps) {
+                                                               u32 ipt, u32 rshift, const SegMap seg, u64* stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u64 n = *n_ptr;
     const u32 T = num_tiles(n, ipt);
-#ifdef FASTF_NO_XCD_SWIZZLE
-    const u32 tile = blockIdx.x;
-#else
     // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  Consecutive tiles write consecutive runs of every
     // bin, so neighbouring tiles share the cache lines at their run boundaries: give each XCD a contiguous range of
     // tiles and those partial lines merge in that XCD's L2 instead of going to HBM twice.
-    const u32 tile = xcd_tile(T);
-#endif
-    if (tile >= T) return;
     const u32 tile_keys = ipt * SORT_THREADS;
-    const u64 base = (u64)tile * tile_keys;
-    const u32 n_valid = (u32)((n - base) < (u64)tile_keys ? (n - base) : (u64)tile_keys);
-    if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, stamps);
-    else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, stamps);
+    for (u32 r = blockIdx.x >> 3;; r += gridDim.x >> 3) {
+#ifdef FASTF_NO_XCD_SWIZZLE
+        const u32 tile = (r << 3) | (blockIdx.x & 7u);
+#else
+        const u32 tile = xcd_tile(T, r);
+#endif
+        if (tile >= T) return;                               // block-uniform
+        const u64 base = (u64)tile * tile_keys;
+        const u32 n_valid = (u32)((n - base) < (u64)tile_keys ? (n - base) : (u64)tile_keys);
+        // (no barrier between tiles: whatever a tile reads last from LDS is rewritten only after two barriers of the next)
+        if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, stamps);
+        else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, stamps);
+    }
 }
 
 
@@ -913,29 +1152,34 @@ struct ReduceParams {
 
 constexpr int K3_THREADS = 512, K3_IPT = 8, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
 
+// both K3 kernels run on a capped grid and walk their tiles (tile += gridDim): the launch is sized for the caller's
+// upper bound on the key count, and workgroups without a tile are not free
 template <bool UMI_ROWS>
 __global__ __launch_bounds__(K3_THREADS) void head_count_kernel(const ReduceParams p) {
     __shared__ u32 s_w[K3_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u64 n = *p.n_ptr;
-    const u64 base = (u64)blockIdx.x * K3_TILE;
     const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
-    u32 heads = 0;
+    for (u64 tile = blockIdx.x; tile * K3_TILE < n; tile += gridDim.x) {
+        const u64 base = tile * K3_TILE;
+        u32 heads = 0;
 #pragma unroll
-    for (int j = 0; j < K3_IPT; ++j) {
-        const u64 idx = base + (u64)j * K3_THREADS + tid;
-        if (idx < n) {
-            const u64 k = p.keys[idx];
-            heads += idx == 0 || (k >> gshift) != (p.keys[idx - 1] >> gshift);
+        for (int j = 0; j < K3_IPT; ++j) {
+            const u64 idx = base + (u64)j * K3_THREADS + tid;
+            if (idx < n) {
+                const u64 k = p.keys[idx];
+                heads += idx == 0 || (k >> gshift) != (p.keys[idx - 1] >> gshift);
+            }
         }
-    }
-    heads = wave_sum32(heads);
-    if (lane == 0) s_w[w] = heads;
-    __syncthreads();
-    if (tid == 0) {
-        u32 t = 0;
-        for (int i = 0; i < K3_WAVES; ++i) t += s_w[i];
-        p.tile_heads[blockIdx.x] = t;
+        heads = wave_sum32(heads);
+        if (lane == 0) s_w[w] = heads;
+        __syncthreads();
+        if (tid == 0) {
+            u32 t = 0;
+            for (int i = 0; i < K3_WAVES; ++i) t += s_w[i];
+            p.tile_heads[tile] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -949,12 +1193,11 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
     __shared__ u64 s_id[K3_TILE];          // UMI_ROWS: the key; else (cell << 32) | feature
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const u32 tile = blockIdx.x;
     const u64 n = *p.n_ptr;
-    const u64 base = (u64)tile * K3_TILE;
-    if (base >= n) return;
     const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
     const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
+    for (u32 tile = blockIdx.x; (u64)tile * K3_TILE < n; tile += gridDim.x) {
+    const u64 base = (u64)tile * K3_TILE;
 
     u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
     bool too_long = false;
@@ -1021,6 +1264,8 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
         p.count[row_base + r] = c;
         if (UMI_ROWS) p.ukeys[row_base + r] = id;
         else { p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32); }
+    }
+    __syncthreads();                               // the next tile restages the shared arrays
     }
 }
 

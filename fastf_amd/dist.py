@@ -69,16 +69,24 @@ class HipStages:
     def count_hits(self, cb, n, out_hits):
         self.eng.dev_count_hits(cb.data_ptr(), n, out_hits.data_ptr(), self._s())
 
+    def key_slots(self, n, n_shards):
+        """key slots per shard buffer: the streaming K1b of a single-shard pass writes one region per workgroup"""
+        if n_shards == 1:
+            return max(n, self.eng.probe_capacity(n))
+        return n
+
     def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters, reuse_hits=False):
+        self.segmented = self.eng.n_shards == 1 and self.eng.probe_capacity(n) > 0 and stride >= self.eng.probe_capacity(n)
         self.eng.dev_probe_pack(cb.data_ptr(), gx.data_ptr(), umi.data_ptr(), meta.data_ptr(), n,
                                 draws.data_ptr(), draws.numel(), keys_out.data_ptr(), stride,
                                 key_counts.data_ptr(), counters.data_ptr(), self._s(),
-                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits)
+                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, segmented=self.segmented)
 
-    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz):
-        # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs
+    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, fresh=True):
+        # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs.
+        # fresh: keys come straight from probe_pack (possibly segmented); a re-sort of already sorted keys is contiguous
         in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
-                                   skip_low=self.skip_low)
+                                   skip_low=self.skip_low, segmented=fresh and getattr(self, "segmented", False))
         src = tmp if in_tmp else keys
         self.eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, feature.data_ptr(), cell.data_ptr(),
                             count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=self.skip_low)
@@ -99,7 +107,7 @@ class ShardedPass:
         self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
         G, n = self.G, int(n_local_max)
         i64, i32 = torch.int64, torch.int32
-        self.stride = n
+        self.stride = stages.key_slots(n, G) if hasattr(stages, "key_slots") else n
         if pipeline is None:
             pipeline = os.environ.get("FASTF_DIST_PIPELINE", "1") != "0"
         self.pipelined = bool(pipeline) and G > 1 and torch.device(device).type == "cuda"
@@ -124,7 +132,7 @@ class ShardedPass:
         # what K1 writes per step, one set per pipeline slot.  The per-step scalars live in one buffer so a step clears
         # them with a single fill, but 512 B apart: atomics (key_counts, counters) and the plain loads of draw_base
         # must not share a cache line
-        self._keys_out_slots = [torch.empty((G, n), dtype=i64, device=device) for _ in range(nb)]
+        self._keys_out_slots = [torch.empty((G, self.stride), dtype=i64, device=device) for _ in range(nb)]
         self._small_slots = [torch.zeros(192, dtype=i64, device=device) for _ in range(nb)]
         self._slot_free = [None] * nb          # event: the exchange that read this slot's shard buffers has finished
         self._step = 0
@@ -297,7 +305,7 @@ class ShardedPass:
             src = self.sorted
             other = self.tmp if src.data_ptr() != self.tmp.data_ptr() else self._keys_buf
             self.sorted = st.sort_reduce(src, other, self.d_n, self.n_recv, self.feature, self.cell,
-                                         self.count, self.nnz)
+                                         self.count, self.nnz, fresh=False)
 
     def local_coo(self):
         self.ensure_exact()

@@ -283,16 +283,24 @@ class Engine:
         check(self._L.fastf_dev_count_hits(self._h, d_cb, n, d_out, stream))
 
     def dev_probe_pack(self, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_keys, shard_stride,
-                       d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False):
-        """reuse_hits: dev_count_hits ran on these very records just before, on the same stream (K1a is skipped)"""
+                       d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False, segmented=False):
+        """reuse_hits: dev_count_hits ran on these very records just before, on the same stream (K1a is skipped);
+        segmented: streaming K1b, keys land in per-workgroup regions (probe_capacity slots; sort with segmented=True)"""
         check(self._L.fastf_dev_probe_pack(self._h, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_draw_base,
-                                           d_keys, shard_stride, d_key_counts, d_counters, 1 if reuse_hits else 0, stream))
+                                           d_keys, shard_stride, d_key_counts, d_counters,
+                                           (1 if reuse_hits else 0) | (2 if segmented else 0), stream))
 
-    def dev_sort(self, d_keys, d_tmp, d_n, max_n, key_bits=None, stream=0, skip_low=False) -> bool:
+    def probe_capacity(self, n) -> int:
+        """key slots a segmented probe_pack over n records needs; 0 = the streaming form is not available"""
+        v = C.c_uint64()
+        check(self._L.fastf_dev_probe_capacity(self._h, n, C.byref(v)))
+        return int(v.value)
+
+    def dev_sort(self, d_keys, d_tmp, d_n, max_n, key_bits=None, stream=0, skip_low=False, segmented=False) -> bool:
         in_tmp = C.c_int(0)
         check(self._L.fastf_dev_sort(self._h, d_keys, d_tmp, d_n, max_n,
                                      self.key_bits if key_bits is None else key_bits,
-                                     2 if skip_low else 0, C.byref(in_tmp), stream))
+                                     (2 if skip_low else 0) | (4 if segmented else 0), C.byref(in_tmp), stream))
         return bool(in_tmp.value)
 
     def dev_reduce(self, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz, stream=0, skip_low=False):

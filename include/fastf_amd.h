@@ -252,6 +252,15 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
                          uint64_t *d_keys_out, uint64_t shard_stride,
                          uint64_t *d_key_counts, uint64_t *d_counters, uint32_t flags, void *stream);
 #define FASTF_PROBE_REUSE_HITS 1u  /* fastf_dev_count_hits(e, d_cb_key, n, …) was the previous call on this stream */
+/* Streaming form of K1b (single shard, gene list in LDS): every wave filters and packs on its own and writes into a
+ * private region of d_keys_out per workgroup — no barrier and no global atomic in the loop.  The key buffer is then
+ * SEGMENTED (regions with gaps): d_key_counts[0] is SET to the number of keys, the buffer must hold
+ * fastf_dev_probe_capacity() slots, and the next fastf_dev_sort over it must carry FASTF_SORT_SEGMENTED (its first
+ * pass reads through the region map the engine keeps; the sorted result is contiguous as always). */
+#define FASTF_PROBE_SEGMENTED 2u
+/* key slots a FASTF_PROBE_SEGMENTED call over n records needs in d_keys_out (a little more than n);
+ * 0 = this engine cannot run the streaming form (several shards, or a gene list that does not fit LDS) */
+int fastf_dev_probe_capacity(const fastf_engine_t *e, uint64_t n, uint64_t *key_slots);
 
 /* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
  * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
@@ -259,6 +268,7 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
 #define FASTF_SORT_SKIP_LOW   2u   /* leave the low fastf_engine_skip_bits() bits unsorted: enough for the matrix
                                       (equal keys stay neighbours of their (cell, feature, top-UMI-bits) run);
                                       pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
+#define FASTF_SORT_SEGMENTED  4u   /* d_keys is the output of the last FASTF_PROBE_SEGMENTED fastf_dev_probe_pack */
 int fastf_engine_skip_bits(const fastf_engine_t *e, uint32_t *bits);
 /* number of 8-bit LSD passes fastf_dev_sort runs for this engine's keys with the given flags: the digit grid starts at
  * the skip bit (not necessarily a byte boundary) when FASTF_SORT_SKIP_LOW is set, at bit 0 otherwise */

@@ -53,7 +53,7 @@ class NumpyStages:
             key_counts[s] = c + len(ks)
         counters[0] += int(hit.sum()); counters[1] += int(keep.sum()); counters[2] += int(valid.sum())
 
-    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz):
+    def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, fresh=True):
         n = int(d_n[0])
         k = np.sort(keys[:n].numpy().view(np.uint64))
         keys[:n] = torch.from_numpy(k.view(np.int64))

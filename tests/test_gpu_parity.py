@@ -1,4 +1,6 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -278,3 +280,53 @@ def test_key_wider_than_64_bits_is_refused():
     with pytest.raises(F.FastfError) as ei:
         F.Engine.from_lists(lists, umi_max_bases=16)
     assert "bits" in str(ei.value)
+
+
+# ---- the resident single-GPU pass (what bench.py times): streaming K1b -> segmented keys -> sort through the region map ----
+STREAM_CASES = {
+    "tiny": dict(n=100, n_bar=20, n_gene=10),
+    "below one unit": dict(n=255, n_bar=20, n_gene=10, rate_depth=0.5),
+    "ragged tail": dict(n=4096 * 3 + 257, n_bar=300, n_gene=80, rate_cell=0.5, rate_depth=0.5, p_unlisted_cb=0.2, p_bad_xf=0.2, p_n_umi=0.02),
+    "keep all": dict(n=300_000, n_bar=2000, n_gene=900, umi_pool=512),
+    "c3 shape": dict(n=700_000, n_bar=40_000, n_gene=5000, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=4.0,
+                     cell_dist="lognormal", gene_dist="zipf", p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.001),
+    "nothing survives": dict(n=50_000, n_bar=100, n_gene=50, rate_depth=0.0),
+    "no hits": dict(n=30_000, n_bar=100, n_gene=50, p_unlisted_cb=1.0),
+    "sparse gene ids": dict(n=200_000, n_bar=500, n_gene=3000, gene_stride=8, rate_depth=0.7, umi_pool=128),
+}
+
+
+@pytest.mark.parametrize("name", list(STREAM_CASES))
+def test_resident_pass_streaming_k1b_matches_oracle(name):
+    """fastf_dev_probe_pack(FASTF_PROBE_SEGMENTED) -> fastf_dev_sort(FASTF_SORT_SEGMENTED) -> fastf_dev_reduce through
+    ShardedPass (G = 1), two steps on the same buffers, against the oracle; then the same with the tile form forced"""
+    import torch
+    from fastf_amd.dist import HipStages, ShardedPass
+    case = Case(**STREAM_CASES[name])
+    ora = case.oracle()
+    lists = case.lists()
+    cbk, gxk, umi, meta = case.packed(lists)
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+    d = [t(x) for x in (cbk, gxk, umi, meta)]
+    draws = t(F.mt_draws(case.seed, lists.mt_skip, case.n))
+    for force_tile_form in (False, True):
+        if force_tile_form:
+            os.environ["FASTF_NO_STREAM_K1B"] = "1"
+        try:
+            eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12)
+            sp = ShardedPass(HipStages(eng, dev), case.n, dev)
+            for _ in range(2):
+                sp.run(d[0], d[1], d[2], d[3], case.n, draws)
+            f, c, k = sp.local_coo()
+            hits, sampled, valid, err = sp.global_counters()
+            assert err == 0
+            assert sp.st.segmented == (not force_tile_form and "LDS" in eng.table_modes.split("genes:")[1])
+            assert (sampled, valid) == (ora["sampled"], ora["valid"])
+            assert len(f) == ora["nnz"]
+            np.testing.assert_array_equal(c, ora["cell"].astype(np.int64))
+            np.testing.assert_array_equal(f, ora["feature"].astype(np.int64))
+            np.testing.assert_array_equal(k, ora["count"].astype(np.int64))
+            eng.close()
+        finally:
+            os.environ.pop("FASTF_NO_STREAM_K1B", None)
