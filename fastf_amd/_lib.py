@@ -37,6 +37,7 @@ class EngineConfig(C.Structure):
         ("mt_seed", C.c_uint32), ("mt_skip", C.c_uint64),
         ("n_shards", C.c_uint32), ("shard_rank", C.c_uint32),
         ("device", C.c_int32), ("batch_records", C.c_uint64), ("key_capacity", C.c_uint64),
+        ("n_devices", C.c_uint32), ("devices", C.c_void_p),
     ]
 
 

@@ -113,6 +113,20 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     cfg.n_shards = 1; cfg.shard_rank = 0;
     const char *dev = getenv("FASTF_DEVICE");
     cfg.device = dev ? atoi(dev) : 0;
+    /* FASTF_DEVICES: "4" = devices 0..3, or an explicit list "0,1,2,3" (ordinals may repeat: all shards on one GPU).
+     * Two or more entries make this one process drive that many GPUs (cell-hash shards, one key exchange). */
+    int32_t dev_list[8]; uint32_t n_dev = 0;
+    const char *dv = getenv("FASTF_DEVICES");
+    if (dv && *dv) {
+        if (strchr(dv, ',')) {
+            for (const char *q = dv; *q && n_dev < 8;) { dev_list[n_dev++] = (int32_t)strtol(q, (char **)&q, 10); while (*q == ',' || *q == ' ') q++; }
+        } else {
+            n_dev = (uint32_t)atoi(dv); if (n_dev > 8) n_dev = 8;
+            for (uint32_t i = 0; i < n_dev; i++) dev_list[i] = (int32_t)i;
+        }
+        if (n_dev >= 2) { cfg.n_devices = n_dev; cfg.devices = dev_list; }
+        else if (n_dev == 1) cfg.device = dev_list[0];
+    }
     /* widest UMI field the 64-bit key allows (16 bases need 36 bits, 12 need 27) */
     const char *ul = getenv("FASTF_UMI_MAX_BASES");
     if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);

@@ -1,0 +1,476 @@
+// multi_engine.hpp — one host process driving G devices behind the same fastf_engine_* calls
+// (fastf_engine_config_t.n_devices > 1; bam2db() reads FASTF_DEVICES).  Included by umi_engine.hip.
+//
+// The path shards by cell: GROUP BY cell_index, feature_index (bam2db_ds.c:480-483) never joins rows of
+// different cells, so every key goes to the device that owns its cell (murmur(cell_index) mod G, shard_of()).
+//
+//   push     chunks of the record stream are dealt round-robin to the devices.  Per round of G chunks:
+//              1. H2D + K1a on every device            (hit count of each chunk -> one u64 back to the host)
+//              2. the host turns the G counts into hit-rank bases in STREAM order (a draw is consumed per CB hit in
+//                 record order, bam2db_ds.c:385), generates exactly each chunk's draws and sends them
+//              3. K1b on every device: keys land in G per-destination buffers on the device that filtered them
+//   finish   ONE exchange: buffer h of device g -> device h (RCCL send/recv in one group over xGMI, or peer copies
+//            when devices alias — the one-GPU rehearsal — or FASTF_EXCHANGE=peer), then K2 + K3 locally on every
+//            device, rows back, and a merge of the G row lists by cell (each cell lives on exactly one device).
+// Nothing but the keys crosses devices; the three counters are added up on the host.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct MultiDev {
+    fastf_engine* e = nullptr;                 // sub-engine on this device: tables, workspace, streams (n_shards = G, shard_rank = g)
+    int dev = 0;
+    void* h_stage[2] = {nullptr, nullptr};     // pinned chunk staging (pageable input only)
+    DevBuf d_stage[2];
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_sent = nullptr;
+    u32* h_draws = nullptr; DevBuf d_draws;    // the draws of the chunk in flight
+    u64* h_info = nullptr;                     // pinned mirror of the sub-engine's d_small
+    DevBuf d_shard; u64 stride = 0;            // keys by destination: [G][stride]
+    u64 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // keys per destination, exact as of the last read-back
+    u64 chunk_n = 0, chunk_hits = 0;
+    // receive side
+    DevBuf d_recv, d_tmp, d_f, d_c, d_k, d_ukeys, d_ncopy;
+    u64 n_recv = 0; int sorted_in_tmp = 0; bool fully_sorted = false;
+    std::vector<u32> f, c, k;                  // this shard's rows, ascending (cell, feature)
+    std::vector<u64> ukeys; std::vector<u32> ncopy;
+};
+
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+struct fastf_multi {
+    u32 G = 0;
+    std::vector<MultiDev> d;
+    u64 cap = 0, round = 0;
+    fastf_mt_t mt{}; u32 mt_seed0 = 0; u64 mt_skip0 = 0;
+    u64 hits = 0, total_records = 0, c_sampled = 0, c_valid = 0;
+    bool finished = false, aliased = false;
+    int use_rccl = 0; RcclApi rccl; std::vector<ncclComm_t> comms;
+    std::vector<u32> feature, cell, count;                       // merged rows
+    std::vector<u32> ufeature, ucell, uumi, ncopy; std::vector<uint8_t> unonnull;
+};
+
+static int multi_load_rccl(fastf_multi* m) {
+    if (m->rccl.lib) return 0;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return set_err("cannot load librccl.so (%s); FASTF_EXCHANGE=peer uses device-to-device copies instead", dlerror());
+    RcclApi& r = m->rccl;
+    r.lib = h;
+#define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) return set_err("librccl.so lacks %s", name)
+    SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return 0;
+}
+#define NCCL_OK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return set_err("%s failed: %s", #call, (m)->rccl.GetErrorString(r_)); } while (0)
+
+static void multi_destroy(fastf_engine* e) {
+    fastf_multi* m = e->multi;
+    if (!m) return;
+    for (auto& c : m->comms) if (c && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(c);
+    for (MultiDev& md : m->d) {
+        (void)hipSetDevice(md.dev);
+        if (md.e) (void)hipStreamSynchronize(md.e->s_compute);
+        for (int i = 0; i < 2; ++i) {
+            if (md.h_stage[i]) (void)hipHostFree(md.h_stage[i]);
+            md.d_stage[i].release();
+            if (md.ev_in[i]) (void)hipEventDestroy(md.ev_in[i]);
+        }
+        if (md.ev_sent) (void)hipEventDestroy(md.ev_sent);
+        if (md.h_draws) (void)hipHostFree(md.h_draws);
+        if (md.h_info) (void)hipHostFree(md.h_info);
+        DevBuf* all[] = {&md.d_draws, &md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy};
+        for (DevBuf* b : all) b->release();
+        if (md.e) fastf_engine_destroy(md.e);
+    }
+    if (m->rccl.lib) dlclose(m->rccl.lib);
+    delete m;
+    e->multi = nullptr;
+}
+
+static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
+    const u32 G = cfg->n_devices;
+    if (G > 8) return set_err("n_devices %u: at most 8 devices (one node)", G);
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    fastf_multi* m = new fastf_multi();
+    e->multi = m;
+    m->G = G; m->d.resize(G);
+    m->cap = cfg->batch_records ? cfg->batch_records : (4ull << 20);
+    m->mt_seed0 = cfg->mt_seed; m->mt_skip0 = cfg->mt_skip;
+    fastf_mt_seed(&m->mt, cfg->mt_seed); fastf_mt_skip(&m->mt, cfg->mt_skip);
+    for (u32 g = 0; g < G; ++g) {
+        const int dev = cfg->devices ? cfg->devices[g] : (int)g;
+        if (dev < 0 || dev >= ndev) return set_err("device %d out of range (have %d)", dev, ndev);
+        for (u32 q = 0; q < g; ++q) if (m->d[q].dev == dev) m->aliased = true;
+        m->d[g].dev = dev;
+    }
+    {   // the exchange: RCCL between distinct devices, device-to-device copies when devices repeat or on request
+        const char* x = getenv("FASTF_EXCHANGE");
+        m->use_rccl = x ? (strcmp(x, "rccl") == 0) : !m->aliased;
+        if (m->use_rccl && m->aliased) return set_err("FASTF_EXCHANGE=rccl needs distinct devices");
+    }
+    for (u32 g = 0; g < G; ++g) {
+        MultiDev& md = m->d[g];
+        fastf_engine_config_t sub = *cfg;
+        sub.n_devices = 0; sub.devices = nullptr;
+        sub.n_shards = G; sub.shard_rank = g; sub.device = md.dev;
+        if (fastf_engine_create(&sub, &md.e)) return 1;
+        HIP_OK(hipSetDevice(md.dev));
+        HIP_OK(hipHostMalloc((void**)&md.h_info, SM_WORDS * sizeof(u64), hipHostMallocDefault));
+        HIP_OK(hipHostMalloc((void**)&md.h_draws, m->cap * 4, hipHostMallocDefault));
+        HIP_OK(hipEventCreateWithFlags(&md.ev_in[0], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&md.ev_in[1], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&md.ev_sent, hipEventDisableTiming));
+        if (!m->use_rccl) {                             // peer copies: let the devices reach each other's memory
+            for (u32 q = 0; q < G; ++q) {
+                const int other = cfg->devices ? cfg->devices[q] : (int)q;
+                if (other == md.dev) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, md.dev, other) == hipSuccess && can) {
+                    hipError_t pe = hipDeviceEnablePeerAccess(other, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+        }
+    }
+    if (m->use_rccl) {
+        if (multi_load_rccl(m)) return 1;
+        std::vector<int> devs(G);
+        for (u32 g = 0; g < G; ++g) devs[g] = m->d[g].dev;
+        m->comms.assign(G, nullptr);
+        NCCL_OK(m, m->rccl.CommInitAll(m->comms.data(), (int)G, devs.data()));
+    }
+    // the parent handle answers the layout queries from shard 0
+    e->L = m->d[0].e->L; e->cell_bits = m->d[0].e->cell_bits; e->feat_bits = m->d[0].e->feat_bits;
+    e->skip_bits = m->d[0].e->skip_bits; e->n_cells = cfg->n_cells; e->n_features = cfg->n_features;
+    e->use_lds_cells = m->d[0].e->use_lds_cells; e->use_lds_genes = m->d[0].e->use_lds_genes; e->lds_genes = m->d[0].e->lds_genes;
+    return 0;
+}
+
+// per-destination key buffers of one device: make room for `need` keys per destination
+static int multi_grow_shards(fastf_multi* m, MultiDev& md, u64 need) {
+    if (need <= md.stride && md.d_shard.p) return 0;
+    HIP_OK(hipStreamSynchronize(md.e->s_compute));
+    const u64 ns = std::max<u64>(need, std::max<u64>(md.stride * 2, 1u << 20));
+    void* np = nullptr;
+    HIP_OK(hipMalloc(&np, (size_t)m->G * ns * sizeof(u64)));
+    for (u32 h = 0; h < m->G && md.d_shard.p; ++h)
+        if (md.cnt[h]) HIP_OK(hipMemcpy((u64*)np + (u64)h * ns, (u64*)md.d_shard.p + (u64)h * md.stride, md.cnt[h] * sizeof(u64), hipMemcpyDeviceToDevice));
+    md.d_shard.release();
+    md.d_shard.p = np; md.d_shard.bytes = (size_t)m->G * ns * sizeof(u64);
+    md.stride = ns;
+    return 0;
+}
+
+// one round: up to G chunks, chunk j on device j
+static int multi_round(fastf_engine* e, const fastf_batch_t* b, const size_t* off, const size_t* len, u32 k, bool pinned) {
+    fastf_multi* m = e->multi;
+    const int slot = (int)(m->round & 1);
+    const u64 cap = m->cap;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
+    // 1. staging, H2D, K1a, hit count back
+    for (u32 j = 0; j < k; ++j) {
+        MultiDev& md = m->d[j];
+        fastf_engine* se = md.e;
+        const size_t n = len[j];
+        HIP_OK(hipSetDevice(md.dev));
+        if (md.d_stage[slot].ensure(stage_bytes(cap))) return 1;
+        const void *s_cb = b->cb_key + off[j], *s_gx = b->gx_key + off[j], *s_umi = b->umi + off[j], *s_meta = b->meta + off[j];
+        if (!pinned) {
+            if (!md.h_stage[slot]) HIP_OK(hipHostMalloc(&md.h_stage[slot], stage_bytes(cap), hipHostMallocDefault));
+            char* hs = (char*)md.h_stage[slot];
+            memcpy(hs, s_cb, n * 8); memcpy(hs + o_gx, s_gx, n * 8); memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4);
+            s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
+        }
+        char* ds = (char*)md.d_stage[slot].p;
+        HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyHostToDevice, se->s_copy));
+        HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyHostToDevice, se->s_copy));
+        HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyHostToDevice, se->s_copy));
+        HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyHostToDevice, se->s_copy));
+        HIP_OK(hipEventRecord(md.ev_in[slot], se->s_copy));
+        HIP_OK(hipStreamWaitEvent(se->s_compute, md.ev_in[slot], 0));
+        u64* small = (u64*)se->d_small.p;
+        if (launch_probe_cells(se, (const u64*)ds, n, small + SM_N, se->s_compute)) return 1;
+        HIP_OK(hipMemcpyAsync(md.h_info, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, se->s_compute));
+        md.chunk_n = n;
+    }
+    // 2. + 3. hit-rank bases in stream order, draws, K1b
+    for (u32 j = 0; j < k; ++j) {
+        MultiDev& md = m->d[j];
+        fastf_engine* se = md.e;
+        HIP_OK(hipSetDevice(md.dev));
+        HIP_OK(hipStreamSynchronize(se->s_compute));
+        const u64 hits = md.h_info[SM_N];
+        for (u32 h = 0; h < m->G; ++h) md.cnt[h] = md.h_info[SM_KEYCOUNT + h];       // exact: K1b of the round before is behind us
+        if (hits > md.chunk_n) return set_err("internal: more hits than records");
+        if (md.d_draws.ensure(std::max<u64>(cap, 1) * 4)) return 1;
+        fastf_mt_fill(&m->mt, md.h_draws, hits);
+        m->hits += hits;
+        if (hits) HIP_OK(hipMemcpyAsync(md.d_draws.p, md.h_draws, hits * 4, hipMemcpyHostToDevice, se->s_compute));
+        u64 most = 0;
+        for (u32 h = 0; h < m->G; ++h) most = std::max(most, md.cnt[h]);
+        if (multi_grow_shards(m, md, most + md.chunk_n)) return 1;
+        u64* small = (u64*)se->d_small.p;
+        char* ds = (char*)md.d_stage[slot].p;
+        if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), md.chunk_n,
+                         (const u32*)md.d_draws.p, hits, nullptr, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
+                         small + SM_COUNTERS, true, se->s_compute))
+            return 1;
+        m->total_records += md.chunk_n;
+    }
+    m->round++;
+    m->finished = false;
+    return 0;
+}
+
+static int multi_push(fastf_engine* e, const fastf_batch_t* b, bool pinned) {
+    fastf_multi* m = e->multi;
+    size_t off = 0;
+    while (off < b->n) {
+        size_t offs[8], lens[8]; u32 k = 0;
+        while (k < m->G && off < b->n) {
+            const size_t n = std::min<size_t>(b->n - off, m->cap);
+            offs[k] = off; lens[k] = n; off += n; ++k;
+        }
+        if (multi_round(e, b, offs, lens, k, pinned)) return 1;
+        if (pinned) {                                    // the caller's arrays may not change before the copies have left them
+            // (kept simple: the next round waits for the hit counts of this one anyway)
+        }
+    }
+    return 0;
+}
+
+// rows of G shards -> one list in (cell, feature) order: each cell lives on one shard, so whole cell runs are copied
+template <class Row>
+static void multi_merge_by_cell(u32 G, const std::vector<const u32*>& cell, const std::vector<u64>& n, Row&& copy_run) {
+    std::vector<u64> p(G, 0);
+    for (;;) {
+        u32 best = G; u32 bc = ~0u;
+        for (u32 g = 0; g < G; ++g) if (p[g] < n[g] && cell[g][p[g]] < bc) { bc = cell[g][p[g]]; best = g; }
+        if (best == G) break;
+        u64 q = p[best];
+        while (q < n[best] && cell[best][q] == bc) ++q;
+        copy_run(best, p[best], q);
+        p[best] = q;
+    }
+}
+
+static int multi_exchange(fastf_multi* m) {
+    const u32 G = m->G;
+    // exact key counts
+    for (u32 g = 0; g < G; ++g) {
+        MultiDev& md = m->d[g];
+        HIP_OK(hipSetDevice(md.dev));
+        HIP_OK(hipMemcpyAsync(md.h_info, md.e->d_small.p, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, md.e->s_compute));
+        HIP_OK(hipStreamSynchronize(md.e->s_compute));
+        for (u32 h = 0; h < G; ++h) md.cnt[h] = md.h_info[SM_KEYCOUNT + h];
+        if (md.h_info[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(md.h_info[SM_COUNTERS + 3]));
+    }
+    m->c_sampled = m->c_valid = 0;
+    for (u32 g = 0; g < G; ++g) { m->c_sampled += m->d[g].h_info[SM_COUNTERS + 1]; m->c_valid += m->d[g].h_info[SM_COUNTERS + 2]; }
+    std::vector<std::vector<u64>> at(G, std::vector<u64>(G, 0));            // at[h][g]: where g's keys start in h's receive buffer
+    for (u32 h = 0; h < G; ++h) {
+        MultiDev& mh = m->d[h];
+        u64 r = 0;
+        for (u32 g = 0; g < G; ++g) { at[h][g] = r; r += m->d[g].cnt[h]; }
+        mh.n_recv = r;
+        HIP_OK(hipSetDevice(mh.dev));
+        if (mh.d_recv.ensure(std::max<u64>(r, 1) * 8) || mh.d_tmp.ensure(std::max<u64>(r, 1) * 8)) return 1;
+    }
+    if (m->use_rccl) {
+        // the single all-to-all of the path: one group of G x G send/recv pairs, each device's calls on its own stream
+        NCCL_OK(m, m->rccl.GroupStart());
+        for (u32 g = 0; g < G; ++g) {
+            MultiDev& mg = m->d[g];
+            for (u32 h = 0; h < G; ++h) {
+                if (mg.cnt[h]) NCCL_OK(m, m->rccl.Send((const u64*)mg.d_shard.p + (u64)h * mg.stride, mg.cnt[h], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+                if (m->d[h].cnt[g]) NCCL_OK(m, m->rccl.Recv((u64*)mg.d_recv.p + at[g][h], m->d[h].cnt[g], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+            }
+        }
+        NCCL_OK(m, m->rccl.GroupEnd());
+    } else {
+        for (u32 g = 0; g < G; ++g) {
+            MultiDev& mg = m->d[g];
+            HIP_OK(hipSetDevice(mg.dev));
+            for (u32 h = 0; h < G; ++h) {
+                if (!mg.cnt[h]) continue;
+                MultiDev& mh = m->d[h];
+                const u64* src = (const u64*)mg.d_shard.p + (u64)h * mg.stride;
+                u64* dst = (u64*)mh.d_recv.p + at[h][g];
+                if (mh.dev == mg.dev) HIP_OK(hipMemcpyAsync(dst, src, mg.cnt[h] * 8, hipMemcpyDeviceToDevice, mg.e->s_compute));
+                else HIP_OK(hipMemcpyPeerAsync(dst, mh.dev, src, mg.dev, mg.cnt[h] * 8, mg.e->s_compute));
+            }
+            HIP_OK(hipEventRecord(mg.ev_sent, mg.e->s_compute));
+        }
+        for (u32 h = 0; h < G; ++h) {                                       // a receiver sorts after every sender has delivered
+            HIP_OK(hipSetDevice(m->d[h].dev));
+            for (u32 g = 0; g < G; ++g) HIP_OK(hipStreamWaitEvent(m->d[h].e->s_compute, m->d[g].ev_sent, 0));
+        }
+    }
+    return 0;
+}
+
+// K2 + K3 on every device over what it received; low_bit = bits left unsorted (0: full sort)
+static int multi_sort_reduce(fastf_multi* m, u32 low_bit, bool resort) {
+    const u32 G = m->G;
+    for (u32 h = 0; h < G; ++h) {
+        MultiDev& mh = m->d[h];
+        fastf_engine* se = mh.e;
+        HIP_OK(hipSetDevice(mh.dev));
+        u64* small = (u64*)se->d_small.p;
+        const u64 n = mh.n_recv;
+        mh.h_info[SM_N] = n;
+        HIP_OK(hipMemcpyAsync(small + SM_N, mh.h_info + SM_N, sizeof(u64), hipMemcpyHostToDevice, se->s_compute));
+        if (!n) { HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), se->s_compute)); continue; }
+        if (mh.d_f.ensure(n * 4) || mh.d_c.ensure(n * 4) || mh.d_k.ensure(n * 4)) return 1;
+        u64* from = (u64*)mh.d_recv.p; u64* other = (u64*)mh.d_tmp.p;
+        if (resort && mh.sorted_in_tmp) std::swap(from, other);
+        int in_other = 0;
+        if (launch_sort(se, from, other, small + SM_N, n, se->L.total_bits, low_bit, &in_other, se->s_compute)) return 1;
+        mh.sorted_in_tmp = resort ? (in_other ? !mh.sorted_in_tmp : mh.sorted_in_tmp) : in_other;
+        mh.fully_sorted = low_bit == 0;
+        const u64* sorted = mh.sorted_in_tmp ? (u64*)mh.d_tmp.p : (u64*)mh.d_recv.p;
+        if (launch_reduce<false>(se, sorted, small + SM_N, n, (u32*)mh.d_f.p, (u32*)mh.d_c.p, (u32*)mh.d_k.p, nullptr, small + SM_NNZ,
+                                 low_bit, se->s_compute))
+            return 1;
+    }
+    for (u32 h = 0; h < G; ++h) {
+        MultiDev& mh = m->d[h];
+        HIP_OK(hipSetDevice(mh.dev));
+        HIP_OK(hipMemcpyAsync(mh.h_info, mh.e->d_small.p, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, mh.e->s_compute));
+        HIP_OK(hipStreamSynchronize(mh.e->s_compute));
+    }
+    return 0;
+}
+
+static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3]) {
+    fastf_multi* m = e->multi;
+    const u32 G = m->G;
+    if (!m->finished) {
+        if (multi_exchange(m)) return 1;
+        const u32 skip = m->d[0].e->skip_bits;
+        if (multi_sort_reduce(m, skip, false)) return 1;
+        bool too_long = false;
+        for (u32 h = 0; h < G; ++h) too_long = too_long || (m->d[h].h_info[SM_COUNTERS + 3] & ERR_RUN_TOO_LONG);
+        if (too_long) {                                  // deep (cell, feature) groups: finish the sort everywhere and reduce exactly
+            for (u32 h = 0; h < G; ++h) {
+                MultiDev& mh = m->d[h];
+                HIP_OK(hipSetDevice(mh.dev));
+                if (fastf_dev_clear_error_bits(mh.e, ERR_RUN_TOO_LONG, mh.e->s_compute)) return 1;
+            }
+            if (multi_sort_reduce(m, 0, true)) return 1;
+        }
+        for (u32 h = 0; h < G; ++h) {
+            MultiDev& mh = m->d[h];
+            if (mh.h_info[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(mh.h_info[SM_COUNTERS + 3]));
+            const u64 nnz = mh.n_recv ? mh.h_info[SM_NNZ] : 0;
+            mh.f.resize(nnz); mh.c.resize(nnz); mh.k.resize(nnz);
+            if (nnz) {
+                HIP_OK(hipSetDevice(mh.dev));
+                HIP_OK(hipMemcpy(mh.f.data(), mh.d_f.p, nnz * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(mh.c.data(), mh.d_c.p, nnz * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(mh.k.data(), mh.d_k.p, nnz * 4, hipMemcpyDeviceToHost));
+            }
+        }
+        u64 total = 0;
+        std::vector<const u32*> cells(G); std::vector<u64> ns(G);
+        for (u32 h = 0; h < G; ++h) { cells[h] = m->d[h].c.data(); ns[h] = m->d[h].c.size(); total += ns[h]; }
+        m->feature.resize(total); m->cell.resize(total); m->count.resize(total);
+        u64 w = 0;
+        multi_merge_by_cell(G, cells, ns, [&](u32 g, u64 a, u64 b) {
+            const MultiDev& mg = m->d[g];
+            memcpy(m->feature.data() + w, mg.f.data() + a, (b - a) * 4);
+            memcpy(m->cell.data() + w, mg.c.data() + a, (b - a) * 4);
+            memcpy(m->count.data() + w, mg.k.data() + a, (b - a) * 4);
+            w += b - a;
+        });
+        m->finished = true;
+    }
+    coo->feature = m->feature.data(); coo->cell = m->cell.data(); coo->count = m->count.data(); coo->nnz = m->feature.size();
+    if (counters) { counters[0] = m->total_records; counters[1] = m->c_sampled; counters[2] = m->c_valid; }
+    return 0;
+}
+
+static int multi_umi_rows(fastf_engine* e, fastf_umi_rows_t* rows) {
+    fastf_multi* m = e->multi;
+    if (!m->finished) return set_err("call fastf_engine_finish first");
+    const u32 G = m->G;
+    for (u32 h = 0; h < G; ++h) {                         // -u rows are ordered by blob: every shard needs the full sort
+        MultiDev& mh = m->d[h];
+        fastf_engine* se = mh.e;
+        mh.ukeys.clear(); mh.ncopy.clear();
+        if (!mh.n_recv) continue;
+        HIP_OK(hipSetDevice(mh.dev));
+        u64* small = (u64*)se->d_small.p;
+        if (mh.d_ukeys.ensure(mh.n_recv * 8) || mh.d_ncopy.ensure(mh.n_recv * 4)) return 1;
+        if (!mh.fully_sorted) {
+            u64* from = mh.sorted_in_tmp ? (u64*)mh.d_tmp.p : (u64*)mh.d_recv.p;
+            u64* other = mh.sorted_in_tmp ? (u64*)mh.d_recv.p : (u64*)mh.d_tmp.p;
+            int in_other = 0;
+            if (launch_sort(se, from, other, small + SM_N, mh.n_recv, se->L.total_bits, 0, &in_other, se->s_compute)) return 1;
+            if (in_other) mh.sorted_in_tmp = !mh.sorted_in_tmp;
+            mh.fully_sorted = true;
+        }
+        const u64* sorted = mh.sorted_in_tmp ? (u64*)mh.d_tmp.p : (u64*)mh.d_recv.p;
+        if (launch_reduce<true>(se, sorted, small + SM_N, mh.n_recv, nullptr, nullptr, (u32*)mh.d_ncopy.p, (u64*)mh.d_ukeys.p,
+                                small + SM_NROWS_U, 0, se->s_compute))
+            return 1;
+        HIP_OK(hipMemcpyAsync(mh.h_info, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, se->s_compute));
+    }
+    std::vector<std::vector<u32>> ucell(G);
+    for (u32 h = 0; h < G; ++h) {
+        MultiDev& mh = m->d[h];
+        if (!mh.n_recv) continue;
+        HIP_OK(hipSetDevice(mh.dev));
+        HIP_OK(hipStreamSynchronize(mh.e->s_compute));
+        if (mh.h_info[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(mh.h_info[SM_COUNTERS + 3]));
+        const u64 nr = mh.h_info[SM_NROWS_U];
+        mh.ukeys.resize(nr); mh.ncopy.resize(nr);
+        if (nr) {
+            HIP_OK(hipMemcpy(mh.ukeys.data(), mh.d_ukeys.p, nr * 8, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(mh.ncopy.data(), mh.d_ncopy.p, nr * 4, hipMemcpyDeviceToHost));
+        }
+        ucell[h].resize(nr);
+        for (u64 i = 0; i < nr; ++i) ucell[h][i] = (u32)(mh.ukeys[i] >> e->L.cell_shift);
+    }
+    u64 total = 0;
+    std::vector<const u32*> cells(G); std::vector<u64> ns(G);
+    for (u32 h = 0; h < G; ++h) { cells[h] = ucell[h].data(); ns[h] = ucell[h].size(); total += ns[h]; }
+    m->ufeature.resize(total); m->ucell.resize(total); m->uumi.resize(total); m->unonnull.resize(total); m->ncopy.resize(total);
+    const u32 fmask = (u32)((1ull << e->feat_bits) - 1);
+    const u64 umask = e->L.umi_bits >= 64 ? ~0ull : ((1ull << e->L.umi_bits) - 1);
+    u64 w = 0;
+    multi_merge_by_cell(G, cells, ns, [&](u32 g, u64 a, u64 b) {
+        const MultiDev& mg = m->d[g];
+        for (u64 i = a; i < b; ++i, ++w) {
+            const u64 k = mg.ukeys[i];
+            m->ufeature[w] = (u32)(k >> e->L.feat_shift) & fmask;
+            m->ucell[w] = (u32)(k >> e->L.cell_shift);
+            m->unonnull[w] = (uint8_t)((k >> (e->L.umi_bits + e->L.len_bits)) & 1);
+            m->uumi[w] = (u32)(((k >> e->L.len_bits) & umask) << (32 - e->L.umi_bits));
+            m->ncopy[w] = mg.ncopy[i];
+        }
+    });
+    rows->feature = m->ufeature.data(); rows->cell = m->ucell.data(); rows->n_copy = m->ncopy.data();
+    rows->umi = m->uumi.data(); rows->nonnull = m->unonnull.data(); rows->n = total;
+    return 0;
+}
+
+static int multi_reset(fastf_engine* e, bool reseed, u32 seed, u64 skip) {
+    fastf_multi* m = e->multi;
+    if (reseed) { m->mt_seed0 = seed; m->mt_skip0 = skip; fastf_mt_seed(&m->mt, seed); fastf_mt_skip(&m->mt, skip); return 0; }
+    for (MultiDev& md : m->d) {
+        if (fastf_engine_reset(md.e)) return 1;
+        for (u64& c : md.cnt) c = 0;
+        md.n_recv = 0;
+    }
+    m->hits = m->total_records = m->c_sampled = m->c_valid = 0;
+    m->finished = false;
+    return 0;
+}

@@ -77,7 +77,9 @@ struct KernelTimer {           // optional per-kernel HIP-event timing (bench ro
     size_t used = 0;
 };
 
+struct fastf_multi;
 struct fastf_engine {
+    fastf_multi* multi = nullptr;        // n_devices > 1: this handle only dispatches (multi_engine.hpp)
     int device = 0;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
     KeyLayout L{};
@@ -147,6 +149,13 @@ enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 6
 
 static int set_scatter_lds_limit();
 static u32 g_cu_count = 256;
+// multi-device engine (multi_engine.hpp, included at the end of this file)
+static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e);
+static void multi_destroy(fastf_engine* e);
+static int multi_push(fastf_engine* e, const fastf_batch_t* b, bool pinned);
+static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3]);
+static int multi_umi_rows(fastf_engine* e, fastf_umi_rows_t* rows);
+static int multi_reset(fastf_engine* e, bool reseed, u32 seed, u64 skip);
 static size_t scatter_smem_bytes(u32 ipt = SORT_IPT) {        // LDS follows the tile size: smaller tiles → more workgroups per CU
     return (size_t)ipt * SORT_THREADS * 8 + (size_t)SORT_WAVES * RADIX * 4 + RADIX * 4 * 2 + 64;     // 64: s_wtot[8] + slack
 }
@@ -369,8 +378,14 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev == 0)
         return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
-    if (cfg->device < 0 || cfg->device >= ndev) return set_err("device %d out of range (have %d)", cfg->device, ndev);
     if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 16) return set_err("umi_max_bases must be 1..16");
+    if (cfg->n_devices > 1 || (cfg->n_devices == 1 && getenv("FASTF_FORCE_MULTI"))) {
+        fastf_engine* me = new fastf_engine();
+        if (multi_create(cfg, me)) { multi_destroy(me); delete me; return 1; }
+        *out = me;
+        return 0;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err("device %d out of range (have %d)", cfg->device, ndev);
     if (cfg->n_shards < 1 || cfg->n_shards > 8 || cfg->shard_rank >= cfg->n_shards) return set_err("bad shard config");
     HIP_OK(hipSetDevice(cfg->device));
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) g_cu_count = (u32)pr.multiProcessorCount; }
@@ -446,6 +461,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
 
 extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     if (!e) return;
+    if (e->multi) { multi_destroy(e); delete e; return; }
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) {
@@ -530,7 +546,7 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     }
     if (e->d_tilebase.ensure(t1 * sizeof(u64))) return 1;
     if (e->d_halfhits.ensure(t1 * 16 * sizeof(u32))) return 1;
-    if (e->d_tileseg.ensure((ts + 8) * sizeof(u32))) return 1;
+    if (e->d_tileseg.ensure((ts + 8) * sizeof(ulonglong2))) return 1;
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
@@ -539,6 +555,7 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
 
 extern "C" int fastf_dev_reserve(fastf_engine_t* e, uint64_t max_records, uint64_t max_keys) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_reserve: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     return reserve_workspace(e, max_records, max_keys);
 }
@@ -555,6 +572,7 @@ static void t_end(fastf_engine* e, hipStream_t s, double* acc, u64* cnt) {
 
 extern "C" int fastf_engine_set_timing(fastf_engine_t* e, int on) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_engine_set_timing: device-level calls take a single-device engine");
     e->timing = on != 0;
     e->t_scatter_ms = e->t_k1_ms = e->t_k1b_ms = e->t_k3_ms = e->t_count_ms = 0;
     e->t_scatter_n = e->t_k1_n = e->t_k1b_n = e->t_k3_n = e->t_count_n = 0;
@@ -609,6 +627,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
 extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key, uint64_t n,
                                     uint64_t* d_hits_out, void* stream) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_count_hits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s)); return 0; }
@@ -667,6 +686,7 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
                                     uint64_t* d_keys_out, uint64_t shard_stride, uint64_t* d_key_counts,
                                     uint64_t* d_counters, uint32_t flags, void* stream) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_probe_pack: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     const bool seg = (flags & FASTF_PROBE_SEGMENTED) != 0;
     if (seg && !(e->n_shards == 1 && e->use_lds_genes))
@@ -734,9 +754,9 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         // the keys are the segmented output of the streaming K1b: the first pass reads through the region map
         if (!e->seg_n) return set_err("FASTF_SORT_SEGMENTED without a preceding FASTF_PROBE_SEGMENTED probe_pack");
         if (passes == 0) return set_err("segmented keys need at least one sort pass");
-        seg = SegMap{(const u64*)e->d_segprefix.p, (const u32*)e->d_tileseg.p, e->seg_n, e->seg_stride};
+        seg = SegMap{(const u64*)e->d_segprefix.p, (const ulonglong2*)e->d_tileseg.p, e->seg_n, e->seg_stride};
         hipLaunchKernelGGL(seg_tiles_kernel, dim3(std::min<u32>((T + 255) / 256, 1024)), dim3(256), 0, s, seg.prefix, seg.n_seg,
-                           ipt * SORT_THREADS, (u32*)e->d_tileseg.p);
+                           seg.stride, ipt * SORT_THREADS, (ulonglong2*)e->d_tileseg.p);
     }
     const SegMap none{nullptr, nullptr, 0, 0};
     for (u32 q = 0; q < passes; ++q) {
@@ -758,6 +778,7 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
 extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_tmp, const uint64_t* d_n,
                               uint64_t max_n, uint32_t key_bits, uint32_t flags, int* sorted_in_tmp, void* stream) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_sort: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     int dummy = 0;
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
@@ -795,6 +816,7 @@ extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, con
                                 uint32_t* d_feature, uint32_t* d_cell, uint32_t* d_count, uint64_t* d_nnz, uint32_t flags,
                                 void* stream) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_reduce: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, d_feature, d_cell, d_count, nullptr,
                                 (u64*)d_nnz, (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0, (hipStream_t)stream);
@@ -803,6 +825,7 @@ extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, con
 extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
                                   uint64_t* d_ukeys, uint32_t* d_ncopy, uint64_t* d_nrows, void* stream) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_umi_rows: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<true>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, nullptr, nullptr, d_ncopy,
                                (u64*)d_ukeys, (u64*)d_nrows, 0, (hipStream_t)stream);
@@ -810,6 +833,7 @@ extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, c
 
 extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_error_bits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(bits, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64), hipMemcpyDeviceToHost));
@@ -818,6 +842,7 @@ extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
 
 extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void* stream) {
     if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_clear_error_bits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     // stream-ordered atomicAnd on the device: kernels raise bits with atomicOr, a host read-modify-write would race them
     hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (u64*)e->d_small.p + SM_COUNTERS + 3, (u64)mask);
@@ -975,6 +1000,10 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
 
 static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws, bool pinned) {
     if (!e || !batch) return set_err("null argument");
+    if (e->multi) {
+        if (draws) return set_err("caller-supplied draws are not supported by the multi-device engine");
+        return multi_push(e, batch, pinned);
+    }
     if (e->n_shards != 1) return set_err("fastf_engine_push drives a single shard; use the fastf_dev_* calls for sharded runs");
     HIP_OK(hipSetDevice(e->device));
     if (batch->n == 0) return 0;
@@ -1031,6 +1060,7 @@ extern "C" int fastf_engine_push_pinned(fastf_engine_t* e, const fastf_batch_t* 
 
 extern "C" int fastf_engine_wait_input(fastf_engine_t* e) {
     if (!e) return set_err("null engine");
+    if (e->multi) return 0;                  // a multi-device push returns after its rounds have consumed the input
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->s_copy));
     return 0;
@@ -1050,6 +1080,7 @@ extern "C" void fastf_pinned_unregister(void* p) { if (p) (void)hipHostUnregiste
 
 extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) {
     if (!e || !coo) return set_err("null argument");
+    if (e->multi) return multi_finish(e, coo, counters);
     HIP_OK(hipSetDevice(e->device));
     if (retire_all(e)) return 1;
     hipStream_t s = e->s_compute;
@@ -1119,6 +1150,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
 
 extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) {
     if (!e || !rows) return set_err("null argument");
+    if (e->multi) return multi_umi_rows(e, rows);
     if (!e->finished) return set_err("call fastf_engine_finish first");
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = e->s_compute;
@@ -1171,6 +1203,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
 
 extern "C" int fastf_engine_reset(fastf_engine_t* e) {
     if (!e) return set_err("null engine");
+    if (e->multi) return multi_reset(e, false, 0, 0);
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemset(e->d_small.p, 0, SM_WORDS * sizeof(u64)));
@@ -1187,6 +1220,7 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) {
 // re-position the engine-owned draw stream (tests; bam2db() sets it through the config)
 extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t skip) {
     if (!e) return set_err("null engine");
+    if (e->multi) return multi_reset(e, true, seed, skip);
     HIP_OK(hipSetDevice(e->device));
     if (retire_all(e)) return 1;
     e->mt_seed0 = seed; e->mt_skip0 = skip; e->mt_hits = 0;
@@ -1198,3 +1232,8 @@ extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t sk
 // tag histogram (crb / extract): same translation unit, reuses K2 and K3u
 // ------------------------------------------------------------------------------------
 #include "tag_hist.hpp"
+
+// ------------------------------------------------------------------------------------
+// one process, several devices: same translation unit, drives sub-engines through the launch_* functions above
+// ------------------------------------------------------------------------------------
+#include "multi_engine.hpp"

@@ -189,20 +189,40 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, 
     const int lane = lane_id(), w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (u32 t0 = 0; t0 < T; t0 += 4096) {
-        const u32 t = t0 + 4 * threadIdx.x;
-        u32 v[4];
+    constexpr u32 PER = 16;                              // entries per thread and round: 48 k tiles (200 M records) in three rounds
+    for (u32 t0 = 0; t0 < T; t0 += PER * 1024) {
+        const u32 t = t0 + PER * threadIdx.x;
+        u32 v[PER];
+        if (t + PER <= T) {                              // (in is 16-byte aligned: hipMalloc; t is a multiple of 16)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = t + k < T ? in[t + k] : 0; if (t + k < T) in[t + k] = 0; }
-        const u32 sum = v[0] + v[1] + v[2] + v[3];
+            for (u32 q = 0; q < PER / 4; ++q) {
+                const uint4 x = reinterpret_cast<const uint4*>(in + t)[q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+                reinterpret_cast<uint4*>(in + t)[q] = make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < PER; ++k) { v[k] = t + k < T ? in[t + k] : 0; if (t + k < T) in[t + k] = 0; }
+        }
+        u32 sum = 0;
+#pragma unroll
+        for (u32 k = 0; k < PER; ++k) sum += v[k];
         const u32 inc = wave_incl_scan32(sum, lane);
         if (lane == WAVE - 1) s_w[w] = inc;
         __syncthreads();
         u64 off = s_carry;
         for (int i = 0; i < w; ++i) off += s_w[i];
         u64 e = off + inc - sum;
+        if (t + PER <= T) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (t + k < T) out[t + k] = e; e += v[k]; }
+            for (u32 q = 0; q < PER / 2; ++q) {
+                reinterpret_cast<ulonglong2*>(out + t)[q] = make_ulonglong2(e, e + v[2 * q]);
+                e += (u64)v[2 * q] + v[2 * q + 1];
+            }
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < PER; ++k) { if (t + k < T) out[t + k] = e; e += v[k]; }
+        }
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();
@@ -801,8 +821,10 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
     if (tid == 4) sp.seg_count[blockIdx.x] = s_cursor;
 }
 
-// the map from the logical key index (regions back to back) to the segmented buffer
-struct SegMap { const u64* prefix; const u32* tile_seg; u32 n_seg; u64 stride; };   // prefix == nullptr: contiguous buffer
+// the map from the logical key index (regions back to back) to the segmented buffer.  Per sort tile one 16-byte
+// entry {delta, hi}: keys of the tile with logical index < hi live at index + delta (the region of the tile's first
+// key); the few tiles that run past a region boundary find the region of their later keys by a search in prefix[].
+struct SegMap { const u64* prefix; const ulonglong2* tile_seg; u32 n_seg; u64 stride; };   // prefix == nullptr: contiguous buffer
 
 // prefix[b] = keys in the regions before b, prefix[n_seg] = total, also stored to *n_out (the key count the sort reads)
 __global__ __launch_bounds__(1024) void seg_scan_kernel(const u64* __restrict__ seg_count, u32 n_seg, u64* __restrict__ prefix,
@@ -830,23 +852,28 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const u64* __restrict__ 
     if (threadIdx.x == 0) { prefix[n_seg] = s_carry; *n_out = s_carry; }
 }
 
-// tile_seg[t] = region holding the first key of sort tile t (tile_keys keys per tile)
-__global__ __launch_bounds__(256) void seg_tiles_kernel(const u64* __restrict__ prefix, u32 n_seg, u32 tile_keys, u32* __restrict__ tile_seg) {
+// largest b with prefix[b] <= idx and a non-empty region (idx < total)
+__device__ __forceinline__ u32 seg_region_of(const u64* __restrict__ prefix, u32 n_seg, u64 idx) {
+    u32 lo = 0, hi = n_seg;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (prefix[mid] <= idx) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void seg_tiles_kernel(const u64* __restrict__ prefix, u32 n_seg, u64 stride, u32 tile_keys,
+                                                        ulonglong2* __restrict__ tile_seg) {
     const u64 total = prefix[n_seg];
     const u64 T = (total + tile_keys - 1) / tile_keys;
     for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < T; t += (u64)gridDim.x * 256) {
         const u64 first = t * tile_keys;
-        u32 lo = 0, hi = n_seg;                      // largest b with prefix[b] <= first
-        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (prefix[mid] <= first) lo = mid; else hi = mid; }
-        tile_seg[t] = lo;
+        const u32 b = seg_region_of(prefix, n_seg, first);
+        tile_seg[t] = make_ulonglong2((u64)b * stride - prefix[b], prefix[b + 1]);
     }
 }
 
-// physical index of logical key idx, starting the search at region b (a tile rarely spans more than two regions)
-__device__ __forceinline__ u64 seg_phys(const SegMap m, u64 idx, u32 b, u64 lo, u64 hi) {
-    if (idx < hi) return (u64)b * m.stride + (idx - lo);
-    do { ++b; lo = hi; hi = m.prefix[b + 1]; } while (idx >= hi && b + 1 < m.n_seg);
-    return (u64)b * m.stride + (idx - lo);
+__device__ __forceinline__ u64 seg_phys(const SegMap m, u64 idx, const ulonglong2 ts) {
+    if (idx < ts.y) return idx + ts.x;
+    const u32 b = seg_region_of(m.prefix, m.n_seg, idx);
+    return (u64)b * m.stride + (idx - m.prefix[b]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -896,12 +923,11 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
         u32* my = s_h + (threadIdx.x & 3) * RADIX;
         u64 k[SORT_IPT];
         if (seg.prefix) {                                    // first pass over the segmented output of the streaming K1b
-            const u32 b0 = seg.tile_seg[tile];
-            const u64 lo = seg.prefix[b0], hi = seg.prefix[b0 + 1];
+            const ulonglong2 ts = seg.tile_seg[tile];
 #pragma unroll
             for (int j = 0; j < SORT_IPT; ++j) {
                 const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-                k[j] = (j < (int)ipt && idx < n) ? keys[seg_phys(seg, idx, b0, lo, hi)] : 0;
+                k[j] = (j < (int)ipt && idx < n) ? keys[seg_phys(seg, idx, ts)] : 0;
             }
         } else {
 #pragma unroll
@@ -1008,12 +1034,11 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     u64 key[SORT_IPT];
     const u32 wbase = (u32)w * (u32)ipt * WAVE;
     if (seg.prefix) {                                          // first pass over the segmented output of the streaming K1b
-        const u32 b0 = seg.tile_seg[tile];
-        const u64 lo = seg.prefix[b0], hi = seg.prefix[b0 + 1];
+        const ulonglong2 ts = seg.tile_seg[tile];
 #pragma unroll
         for (int j = 0; j < SORT_IPT; ++j) {
             const u32 li = wbase + j * WAVE + lane;
-            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[seg_phys(seg, base + li, b0, lo, hi)] : ~0ULL;
+            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[seg_phys(seg, base + li, ts)] : ~0ULL;
         }
     } else {
 #pragma unroll
@@ -1201,12 +1226,23 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
 
     u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
     bool too_long = false;
+    // the tile's keys go through LDS (the array that holds the row identities later): the neighbour of a key and, on the
+    // group-only path, the walk back over a run of unsorted keys are LDS reads; only what lies in front of the tile is
+    // fetched from memory
 #pragma unroll
     for (int j = 0; j < K3_IPT; ++j) {
         const u64 idx = base + (u64)j * K3_THREADS + tid;
+        key[j] = idx < n ? p.keys[idx] : 0;
+        s_id[j * K3_THREADS + tid] = key[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K3_IPT; ++j) {
+        const u32 loc = (u32)j * K3_THREADS + tid;
+        const u64 idx = base + loc;
         const bool valid = idx < n;
-        const u64 k = valid ? p.keys[idx] : 0;
-        const u64 prev = (valid && idx > 0) ? p.keys[idx - 1] : ~k;
+        const u64 k = key[j];
+        const u64 prev = (valid && idx > 0) ? (loc > 0 ? s_id[loc - 1] : p.keys[idx - 1]) : ~k;
         const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
         bool dist;
         if (UMI_ROWS) dist = valid;
@@ -1225,12 +1261,12 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
                         if (q == k) { dist = false; break; }
                         if (at == 0) break;
                         if (steps == RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
-                        q = p.keys[--at];
+                        --at;
+                        q = at >= base ? s_id[(u32)(at - base)] : p.keys[at];
                     }
                 }
             }
         }
-        key[j] = k;
         hm[j] = __ballot(head); dm[j] = __ballot(dist);
         if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }
     }

@@ -159,7 +159,7 @@ class Engine:
 
     def __init__(self, cell_keys, feature_keys, rate_depth=1.0, seed=926, mt_skip=0,
                  umi_max_bases=12, n_shards=1, shard_rank=0, device=0,
-                 batch_records=0, key_capacity=0, threshold=None):
+                 batch_records=0, key_capacity=0, threshold=None, devices=None):
         self._L = _lib.lib()
         self._cell_keys = np.ascontiguousarray(cell_keys, dtype=np.uint64)
         self._feature_keys = np.ascontiguousarray(feature_keys, dtype=np.uint64)
@@ -174,6 +174,9 @@ class Engine:
         cfg.n_shards, cfg.shard_rank = n_shards, shard_rank
         cfg.device = device
         cfg.batch_records, cfg.key_capacity = batch_records, key_capacity
+        if devices is not None:                # one engine driving several devices (ordinals may repeat: one-GPU rehearsal)
+            self._devices = np.ascontiguousarray(devices, dtype=np.int32)
+            cfg.n_devices, cfg.devices = len(self._devices), self._devices.ctypes.data
         h = C.c_void_p()
         check(self._L.fastf_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h

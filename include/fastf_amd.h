@@ -150,6 +150,15 @@ typedef struct fastf_engine_config {
     int32_t         device;        /* HIP device ordinal                                   */
     uint64_t        batch_records; /* staging capacity (records per push), 0 = default     */
     uint64_t        key_capacity;  /* initial key-store capacity, 0 = default; grows       */
+    /* One host process, several devices (SURVEY 8b inner seam / 8e): n_devices >= 2 makes this ONE engine drive that
+     * many GPUs behind the same push / finish / umi_rows calls — chunks of the record stream are dealt to the devices,
+     * keys travel to the device that owns their cell in a single exchange (RCCL send/recv group over xGMI; peer
+     * copies when devices repeat), every device sorts and reduces its cells, the rows are merged by cell on the
+     * host.  n_shards / shard_rank / device are then ignored.  0 or 1: the single-device engine.
+     * devices: n_devices HIP ordinals, NULL = 0 .. n_devices-1; ordinals may repeat (all shards on one GPU: the
+     * rehearsal the one-GPU tests run). */
+    uint32_t        n_devices;
+    const int32_t  *devices;
 } fastf_engine_config_t;
 
 /* One SoA batch of packed records (host memory; pinned is faster, any works). */

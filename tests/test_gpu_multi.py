@@ -1,0 +1,109 @@
+"""One host process driving several devices behind fastf_engine_push / _finish (fastf_engine_config_t.n_devices,
+bam2db(): FASTF_DEVICES) — SURVEY 8e through the C entry points.  The box has one GPU, so the devices alias: every
+shard lives on device 0 and the key exchange runs as device-to-device copies; the dealing of chunks, the hit-rank
+bases across devices, the per-destination buffers, the local sorts and the merge by cell are the real thing, and the
+result must be the oracle's, bit for bit."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fastf_amd as F
+from fastf_amd import synth, _lib
+from helpers import Case, assert_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "mix": dict(n=300_000, n_bar=900, n_gene=400, rate_cell=0.8, rate_depth=0.6, umi_pool=512, cell_dist="lognormal",
+                p_no_cb=0.03, p_unlisted_cb=0.1, p_bad_xf=0.1, p_n_umi=0.01),
+    "keepall": dict(n=120_000, n_bar=300, n_gene=100, umi_pool=64),
+    "c3 shape": dict(n=400_000, n_bar=30_000, n_gene=4000, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=4.0,
+                     cell_dist="lognormal", gene_dist="zipf", p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.001),
+}
+
+
+@pytest.mark.parametrize("G", [2, 3, 4, 8])
+@pytest.mark.parametrize("name", list(CASES))
+def test_multi_device_engine_matches_oracle(name, G):
+    case = Case(**CASES[name])
+    ora = case.oracle()
+    lists = case.lists()
+    cbk, gxk, umi, meta = case.packed(lists)
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12,
+                              batch_records=17_000, devices=[0] * G)          # several rounds, the last one short
+    try:
+        cuts = [0, 1, 40_000, 40_001, case.n // 2, case.n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.push(cbk[a:b], gxk[a:b], umi[a:b], meta[a:b])
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+        again = eng.finish()                                                   # idempotent
+        assert again["nnz"] == res["nnz"] and np.array_equal(again["count"], res["count"])
+        eng.reset(); eng.reseed(case.seed, lists.mt_skip)
+        eng.push(cbk, gxk, umi, meta)
+        assert_matches_oracle(eng.finish(), ora)
+    finally:
+        eng.close()
+
+
+def test_multi_device_empty_and_tiny():
+    case = Case(n=10, n_bar=4, n_gene=3)
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, devices=[0, 0, 0])
+    try:
+        res = eng.finish()
+        assert res["nnz"] == 0 and res["total"] == 0
+        eng.push(*case.packed(lists))
+        assert_matches_oracle(eng.finish(), case.oracle(), eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
+def test_multi_device_deep_groups_finish_the_sort():
+    """one cell x one gene with thousands of UMIs: the group-only sort raises its run flag on a shard and the engine
+    sorts fully everywhere"""
+    case = Case(n=60_000, n_bar=2, n_gene=1, umi_len=12)
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, umi_max_bases=12, devices=[0, 0])
+    try:
+        eng.push(*case.packed(lists))
+        assert_matches_oracle(eng.finish(), case.oracle())
+    finally:
+        eng.close()
+
+
+def test_rccl_exchange_call_sequence_on_one_device(monkeypatch):
+    """the RCCL backend of the exchange (dlopen, ncclCommInitAll, one group of send/recv on the compute stream) with a
+    single rank: the only form of it a one-GPU box can run"""
+    monkeypatch.setenv("FASTF_FORCE_MULTI", "1")
+    monkeypatch.setenv("FASTF_EXCHANGE", "rccl")
+    case = Case(n=50_000, n_bar=200, n_gene=100, rate_depth=0.5, umi_pool=64)
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=0.5, seed=case.seed, devices=[0])
+    try:
+        eng.push(*case.packed(lists))
+        assert_matches_oracle(eng.finish(), case.oracle())
+    finally:
+        eng.close()
+
+
+def test_cli_with_fastf_devices(tmp_path):
+    case = Case(n=90_000, n_bar=600, n_gene=250, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=3.0,
+                p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.005)
+    bam = tmp_path / "in.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub)
+    b, f = tmp_path / "b.tsv", tmp_path / "f.tsv"
+    b.write_bytes(case.bt); f.write_bytes(case.ft)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    env = dict(os.environ, FASTF_DEVICES="0,0,0,0", FASTF_BATCH_RECORDS="9000")
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out),
+                        "-c", "0.5", "-r", "0.5", "-u"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    rd = lambda n: gzip.decompress((out / n).read_bytes())
+    assert rd("matrix.mtx.gz") == ora["matrix"]
+    assert rd("umi.tsv.gz") == ora["umi"]
