@@ -213,6 +213,9 @@ def main():
             "counters": {"total": N_total, "hits": hits, "sampled": sampled, "valid": valid,
                          "keys": K_job, "rows": Z_job, "device_error_bits": err},
         }
+        if N_total == 200_000_000:             # the job is the same for every rank count: so are its totals
+            got = {k: out["counters"][k] for k in workload.EXPECTED_200M}
+            out["counters"]["same_as_single_gpu_reference_run"] = got == workload.EXPECTED_200M
 
     # free the resident job before the host-side legs
     del sp, cb, gx, umi, meta, d_draws

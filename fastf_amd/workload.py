@@ -20,6 +20,10 @@ N_BARCODES, N_GENES, UMI_LEN = 50_000, 36_601, 12
 RATE_CELL, RATE_DEPTH, SEED = 0.5, 0.5, 926
 P_NO_CB, P_UNLISTED, P_BAD_XF, P_N_UMI = 0.05, 0.05, 0.15, 0.001
 META_FULL = 1 | 2 | 4 | (3 << 4)          # xf ok, UB present, every base in ACGT, blob length 3 bytes
+# what the 200 M-record job comes to (single-GPU run, checked row by row against an independent torch computation in
+# tests/test_gpu_e2e.py::test_full_size_config3_exact): every rank count must reproduce these totals
+EXPECTED_200M = {"total": 200_000_000, "hits": 90_369_735, "sampled": 45_180_593, "valid": 38_401_542,
+                 "keys": 38_401_542, "rows": 8_507_596}
 
 
 def describe(n_total):

@@ -10,6 +10,7 @@ import pytest
 
 import fastf_amd as F
 from fastf_amd import synth, _lib
+from fastf_amd import workload as workload_mod
 from fastf_amd.dist import owner_of_cell
 from helpers import Case
 
@@ -210,71 +211,100 @@ def test_full_size_properties_config2():
         eng.close()
 
 
-def _molecule_stream(rng, n, n_cells_all, n_genes, cell_w, gene_w, umi_bits, dup):
-    """n reads drawn from n/dup molecules (cell, gene, umi): 10x-like duplication"""
-    n_mol = max(1, int(n / dup))
-    mol_cell = rng.choice(n_cells_all, size=n_mol, p=cell_w).astype(np.int32)
-    mol_gene = rng.choice(n_genes, size=n_mol, p=gene_w).astype(np.int32)
-    mol_umi = rng.integers(0, 1 << umi_bits, size=n_mol, dtype=np.uint32)
-    return mol_cell, mol_gene, mol_umi
+def _expected_matrix_torch(job, dev, cb, gx, umi, meta, draws_h):
+    """the matrix of a packed record stream, computed with torch ops only (sorted search, cumsum, unique) — an independent
+    route to COUNT(DISTINCT umi) GROUP BY cell, feature with the reference's draw-per-hit rule (bam2db_ds.c:374-435)"""
+    import torch
+    lists = job.lists
+    skeys = torch.from_numpy(lists.cell_keys.view(np.int64)).to(dev)            # cell_index i+1 <-> skeys[i]
+    sk, order = torch.sort(skeys)
+    pos = torch.searchsorted(sk, cb).clamp_(max=len(sk) - 1)
+    hit = (cb != 0) & (sk[pos] == cb)
+    cell_idx = (order[pos] + 1)                                                 # valid where hit
+    rank = torch.cumsum(hit.to(torch.int64), 0) - 1
+    n_hits = int(hit.sum().item())
+    T = F.draw_threshold(workload_mod.RATE_DEPTH)
+    keep_by_rank = torch.from_numpy((draws_h[:n_hits].astype(np.int64) < T)).to(dev)
+    kept = hit.clone()
+    kept[hit] = keep_by_rank[rank[hit]]
+    fkeys = torch.from_numpy(lists.feature_keys.view(np.int64)).to(dev)
+    fs, forder = torch.sort(fkeys)
+    fpos = torch.searchsorted(fs, gx).clamp_(max=len(fs) - 1)
+    feat_ok = (gx != 0) & (fs[fpos] == gx)
+    valid = kept & ((meta & 1) != 0) & feat_ok & ((meta & 2) != 0)
+    c = cell_idx[valid]; f = forder[fpos[valid]] + 1
+    nonnull = ((meta[valid] & 4) != 0).to(torch.int64)
+    u = ((umi[valid].to(torch.int64) & 0xFFFFFFFF) >> 8) * nonnull              # 12 bases = the top 24 bits
+    code = (c << 42) | (f << 26) | (nonnull << 25) | u
+    ucode = torch.unique(code)
+    grp, inv = torch.unique_consecutive(ucode >> 26, return_inverse=True)
+    cnt = torch.zeros(len(grp), dtype=torch.int64, device=dev).index_add_(0, inv, (ucode >> 25) & 1)
+    return dict(hits=n_hits, sampled=int(kept.sum().item()), valid=int(valid.sum().item()),
+                cell=(grp >> 16).cpu().numpy(), feature=(grp & 0xFFFF).cpu().numpy(), count=cnt.cpu().numpy())
 
 
-def test_full_size_properties_config3():
-    """BASELINE configs[2] at full size on one GPU: 200 M records, 50 k barcodes x 36 601 genes, --cell 0.5 --depth 0.5,
-    log-normal cells, Zipf genes, 12-bp UMIs, 5 % without CB, 15 % bad xf, 0.1 % UMIs with N (SURVEY 8d 'C3').
-    Size-independent properties: counters against closed forms computed on the host, strict (cell, feature) order,
-    count sums, idempotence, and the -u rows as a checksum of the matrix."""
-    import torch  # noqa: F401
+def test_full_size_config3_exact():
+    """BASELINE configs[2] at full size on one GPU (fastf_amd/workload.py: 200 M records, 50 k barcodes x 36 601 genes,
+    --cell 0.5 --depth 0.5, log-normal cells, Zipf genes, 12-bp UMIs, 5 % without CB, 5 % unlisted CB, 15 % bad xf,
+    0.1 % UMIs with N).  The three counters and EVERY row of the matrix — cell, feature and count — are compared with an
+    independent computation (torch sorted search / cumsum / unique), for the resident device pass bench.py times and for
+    the pinned streaming push path; the -u rows serve as a checksum of the matrix."""
+    import torch
+    from fastf_amd.dist import HipStages, ShardedPass
+    dev = torch.device("cuda", 0)
     N = 200_000_000
-    bt, ft, bar, genes = synth.make_lists(50_000, 36_601, seed=77)
-    lists = F.Lists(bt, ft, 0.5, 926)
-    alld = F.Lists(bt, ft, 1.0, 926)                       # keys of every barcode, sampled or not
-    sampled_key = np.zeros(0, dtype=np.uint64)
-    sampled_key = np.sort(lists.cell_keys)
-    rng = np.random.default_rng(5)
-    w = rng.lognormal(0, 1, 50_000); w /= w.sum()
-    gw = 1.0 / np.arange(1, 36_602) ** 1.1; gw /= gw.sum()
-    mol_cell, mol_gene, mol_umi = _molecule_stream(rng, N, 50_000, 36_601, w, gw, 24, 4.0)
-    eng = F.Engine.from_lists(lists, rate_depth=0.5, seed=926, umi_max_bases=12, batch_records=8 << 20)
-    T = F.draw_threshold(0.5)
-    draws_kept = F.mt_draws(926, lists.mt_skip, N) < T     # draw i belongs to the i-th CB hit of the whole stream
-    hits = sampled = valid = 0
+    job = workload_mod.C3(N)
+    lists = job.lists
+    parts = [job.segment_packed(s_, dev) for s_ in range(workload_mod.SEGMENTS)]
+    cb, gx, umi, meta = (torch.cat([p[i] for p in parts]) for i in range(4))
+    del parts
+    job._pool = None
+    draws_h = F.mt_draws(workload_mod.SEED, lists.mt_skip, N)
+    want = _expected_matrix_torch(job, dev, cb, gx, umi, meta, draws_h)
+    torch.cuda.empty_cache()
+    assert len(want["cell"]) > 5_000_000 and want["count"].min() == 0           # count-0 rows (N-only groups) are in
+
+    def check(res_cell, res_feature, res_count, counters):
+        assert counters == (want["sampled"], want["valid"])
+        assert len(res_cell) == len(want["cell"])
+        np.testing.assert_array_equal(np.asarray(res_cell, dtype=np.int64), want["cell"])
+        np.testing.assert_array_equal(np.asarray(res_feature, dtype=np.int64), want["feature"])
+        np.testing.assert_array_equal(np.asarray(res_count, dtype=np.int64), want["count"])
+
+    # 1. the resident pass (streaming K1b -> segmented sort -> reduce), twice on the same buffers
+    eng = F.Engine.from_lists(lists, rate_depth=workload_mod.RATE_DEPTH, seed=workload_mod.SEED, umi_max_bases=12)
     try:
-        B = 20_000_000
-        for off in range(0, N, B):
-            n = min(B, N - off)
-            src = rng.integers(0, len(mol_cell), size=n)
-            cbk = alld.cell_keys[mol_cell[src]]
-            gxk = alld.feature_keys[mol_gene[src]]
-            umi = (mol_umi[src] << np.uint32(8)).astype(np.uint32)
-            meta = np.full(n, 1 | 2 | 4 | (3 << 4), dtype=np.uint32)
-            r = rng.random(n)
-            cbk[r < 0.05] = 0
-            meta[(r > 0.05) & (r < 0.20)] &= ~np.uint32(1)
-            meta[r > 0.999] &= ~np.uint32(4)
-            # closed forms on the host: hit = CB is a sampled barcode; kept = its draw (by hit rank) is below T
-            pos = np.searchsorted(sampled_key, cbk)
-            hit = (cbk != 0) & (sampled_key[np.minimum(pos, len(sampled_key) - 1)] == cbk)
-            h = int(hit.sum())
-            kept = np.zeros(n, dtype=bool)
-            kept[hit] = draws_kept[hits:hits + h]
-            hits += h
-            sampled += int(kept.sum())
-            valid += int((kept & ((meta & 1) != 0)).sum())    # every gene is listed and every record has a UB
-            eng.push(cbk, gxk, umi, meta)
+        d_draws = torch.from_numpy(draws_h.view(np.int32)).to(dev)
+        sp = ShardedPass(HipStages(eng, dev), N, dev)
+        for _ in range(2):
+            sp.run(cb, gx, umi, meta, N, d_draws)
+        f_, c_, k_ = sp.local_coo()
+        hits, sampled, valid, err = sp.global_counters()
+        assert err == 0 and hits == want["hits"]
+        check(c_, f_, k_, (sampled, valid))
+        del sp, d_draws
+    finally:
+        eng.close()
+    torch.cuda.empty_cache()
+    # 2. the streaming push path from pinned host memory (what bam2db() and bench.py's device_path leg use)
+    pb = F.PinnedBatch(N)
+    pb.fill(0, cb, gx, umi, meta)
+    del cb, gx, umi, meta
+    torch.cuda.empty_cache()
+    eng = F.Engine.from_lists(lists, rate_depth=workload_mod.RATE_DEPTH, seed=workload_mod.SEED, umi_max_bases=12, batch_records=8 << 20)
+    try:
+        eng.push_pinned(pb)
         res = eng.finish()
-        assert (res["total"], res["sampled"], res["valid"]) == (N, sampled, valid)
-        key = res["cell"].astype(np.int64) * (1 << 20) + res["feature"].astype(np.int64)
-        assert (np.diff(key) > 0).all()
-        assert res["cell"].min() >= 1 and res["cell"].max() <= lists.n_cells and res["feature"].max() <= lists.n_features
-        assert 0 < int(res["count"].sum()) <= res["valid"]
+        assert res["total"] == N
+        check(res["cell"], res["feature"], res["count"], (res["sampled"], res["valid"]))
         r2 = eng.finish()
-        assert r2["nnz"] == res["nnz"] and np.array_equal(r2["count"], res["count"])
+        assert r2["nnz"] == res["nnz"] and np.array_equal(r2["count"], res["count"])          # idempotent
         rows = eng.umi_rows()
         assert int(rows["n_copy"].sum()) == res["valid"]                      # every valid read is in exactly one -u row
         assert int(rows["nonnull"].sum()) == int(res["count"].sum())          # distinct non-NULL UMIs == sum of the matrix
     finally:
         eng.close()
+        pb.close()
 
 
 def test_adversarial_share_of_config5():
