@@ -184,6 +184,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     }
     t_write = now_s() - tt;
     rc = 0;
+    if (prof) { struct timespec rt; clock_gettime(CLOCK_REALTIME, &rt); fprintf(stderr, "[bam2db] outputs closed at %.6f (unix time)\n", rt.tv_sec + rt.tv_nsec * 1e-9); }
     if (prof)
         fprintf(stderr, "[bam2db] lists %.3f s, engine create %.3f s, BAM decode+pack %.3f s (decoder thread; main waited %.3f s), "
                         "push (stage+H2D+K1 enqueue) %.3f s, finish (sort+reduce+D2H) %.3f s, write %.3f s, total so far %.3f s\n",
@@ -198,6 +199,7 @@ done:
     if (fastf_process_is_exiting_) {
         /* the fastF CLI leaves through _exit() right after this call: device memory, pinned pages and the BAM mapping
          * go back with the process, and unmapping them one by one first costs 0.1-0.2 s */
+        fastf_bam_print_profile(bam);
         if (prof) fprintf(stderr, "[bam2db] teardown skipped (process exits), %.3f s\n", now_s() - tt);
         return rc;
     }

@@ -504,16 +504,21 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     return b;
 }
 
+void fastf_bam_print_profile(const fastf_bam_t *b)
+{
+    if (!b || !getenv("FASTF_BAM_PROFILE")) return;
+    fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s (both on the prefetch thread), record hop %.3f s, "
+            "tag pack %.3f s, waited for the prefetch %.3f s\n",
+            (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack, b->t_wait);
+    if (b->hop_adopted || b->hop_walked)
+        fprintf(stderr, "[bam] parallel hop: %llu records adopted from speculative chains, %llu found by the serial walk\n",
+                (unsigned long long)b->hop_adopted, (unsigned long long)b->hop_walked);
+}
+
 void fastf_bam_close(fastf_bam_t *b)
 {
     if (!b) return;
-    if (getenv("FASTF_BAM_PROFILE"))
-        fprintf(stderr, "[bam] %llu records, %d threads: read %.3f s, inflate %.3f s (both on the prefetch thread), record hop %.3f s, "
-                "tag pack %.3f s, waited for the prefetch %.3f s\n",
-                (unsigned long long)b->n_records, b->n_threads, b->t_read, b->t_inflate, b->t_hop, b->t_pack, b->t_wait);
-    if (getenv("FASTF_BAM_PROFILE") && (b->hop_adopted || b->hop_walked))
-        fprintf(stderr, "[bam] parallel hop: %llu records adopted from speculative chains, %llu found by the serial walk\n",
-                (unsigned long long)b->hop_adopted, (unsigned long long)b->hop_walked);
+    fastf_bam_print_profile(b);
     if (b->filler_started) {
         pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv); pthread_mutex_unlock(&b->mu);
         pthread_join(b->filler, NULL);

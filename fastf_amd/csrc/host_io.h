@@ -40,6 +40,7 @@ void fastf_lists_free(fastf_lists_t *l);
 /* ---- BAM front end: replaces sam_open/sam_hdr_read/sam_read1/bam_aux_get/bam_aux2Z/
  *      bam_aux2i (bam2db_ds.c:141,340,360-417) for BGZF-compressed BAM ---- */
 typedef struct fastf_bam fastf_bam_t;
+void fastf_bam_print_profile(const fastf_bam_t *b);   /* FASTF_BAM_PROFILE=1: stage times of the reader on stderr */
 fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,

@@ -113,21 +113,15 @@ class ShardedPass:
         self.pipelined = bool(pipeline) and G > 1 and torch.device(device).type == "cuda"
         self.k1_stream = torch.cuda.Stream(device) if self.pipelined else None
         self.x_stream = torch.cuda.Stream(device) if self.pipelined else None     # the key exchange
-        # The two tiny collectives of the K1 stage (one u64 per rank, G counts per rank) go over a gloo side group on host
-        # integers when the pass is pipelined: RCCL runs the collectives of one communicator in issue order, so on it
-        # they would queue behind the previous step's key exchange — the very transfer the K1 stage is meant to overlap —
-        # and their results are needed on the host anyway (the exchange sizes).
-        self.small_group = None
-        if self.pipelined and dist.is_initialized():
-            if dist.get_backend(group) == "gloo":
-                self.small_group = group
-            else:
-                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: loopback (the host name may not resolve)
-                try:
-                    self.small_group = dist.new_group(backend="gloo")
-                except Exception as exc:                               # same image on every rank: fails everywhere or nowhere
-                    print("fastf_amd.dist: no gloo side group (%s); running the pass on one stream" % exc, file=sys.stderr)
-                    self.pipelined, self.k1_stream, self.x_stream = False, None, None
+        # The two tiny collectives of the K1 stage (one u64 per rank, G counts per rank):
+        #   RCCL    device tensors on the SAME communicator as the key exchange, issued from the K1 stream.  One
+        #           communicator runs its collectives in issue order, so the K1 stage of step i+1 starts behind the key
+        #           exchange of step i and overlaps that step's sort; the host synchronises once per step, to learn the
+        #           exchange sizes.  (No side group: a second communicator next to a running exchange is how RCCL jobs
+        #           deadlock, and a gloo group costs two host round trips per step.)
+        #   gloo    (CPU test suite, one-GPU rehearsal) host integers on the group itself.
+        self.small_group = group if (self.pipelined and dist.is_initialized() and dist.get_backend(group) == "gloo") else None
+        self.host_small = self.small_group is not None
         nb = 2 if self.pipelined else 1
         # what K1 writes per step, one set per pipeline slot.  The per-step scalars live in one buffer so a step clears
         # them with a single fill, but 512 B apart: atomics (key_counts, counters) and the plain loads of draw_base
@@ -170,7 +164,7 @@ class ShardedPass:
         G, st = self.G, self.st
         self._small.zero_()
         st.count_hits(cb, n, self.hits)
-        if self.pipelined:                                                   # host integers over the gloo side group
+        if self.pipelined and self.host_small:                               # gloo: host integers
             all_h = torch.empty(G, dtype=torch.int64)
             self._gather_small(all_h, self.hits.cpu())
             self.draw_base.fill_(int(all_h[:self.rank].sum()))
