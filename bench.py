@@ -48,8 +48,10 @@ def log(*a):
 
 
 def kernel_table(eng, N, H, K, Z):
-    """per-kernel HIP-event averages (ms) with each kernel's algorithmic bytes per launch"""
-    names = {0: ("probe_cells (K1a)", 12 * N), 4: ("filter_pack (K1b)", 20 * N + 4 * H + 8 * K),
+    """per-kernel HIP-event averages (ms) with each kernel's algorithmic bytes per launch (DESIGN.md section 4);
+    c = bytes per entry of the cell-index scratch between K1a and K1b (2 when n_cells <= 65535, else 4)"""
+    c = eng.cell_scratch_bytes
+    names = {0: ("probe_cells (K1a)", (8 + c) * N), 4: ("filter_pack (K1b)", (16 + c) * N + 4 * H + 8 * K),
              3: ("tile_count (K2, per pass)", 8 * K), 1: ("scatter (K2, per pass)", 16 * K),
              2: ("head_count+scan+reduce+carry (K3)", 16 * K + 12 * Z)}
     out = {}
@@ -164,14 +166,21 @@ def main():
     P_exe = eng.sort_passes(sp.st.skip_low)
     per_step = {k: v["avg_ms"] * (P_exe if "per pass" in k else 1) for k, v in ktab.items()}
     dom = max(per_step, key=per_step.get)
+    # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE in runs of
+    # their own, gfx950 corrections applied there); only a profile of this very workload counts
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    kernels_of = {"probe_cells": ["probe_cells_lds_kernel", "probe_cells_filtered_kernel", "probe_cells_kernel"],
+                  "filter_pack": ["filter_pack_stream_kernel", "filter_pack_kernel"], "tile_count": ["tile_count_kernel"],
+                  "scatter": ["scatter_kernel"], "head_count+scan+reduce+carry": ["head_count_kernel", "reduce_kernel", "carry_fix_kernel"]}
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            short = dom.split(" ")[0] + "_kernel"
-            if tj.get("workload_records") == N_total:
-                traffic = tj.get("kernels", {}).get(short, {}).get("hbm_bytes_per_launch")
+            if tj.get("workload_records") == N_total and G == 1:
+                names = kernels_of.get(dom.split(" ")[0], [])
+                got = [tj["kernels"][k]["hbm_bytes_per_launch"] for k in names if k in tj.get("kernels", {})]
+                if got:
+                    traffic = sum(got) if dom.startswith("head_count") else got[0]
         except Exception:
             traffic = None
 

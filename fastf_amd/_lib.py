@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "fastf_engine_push_pinned", "fastf_engine_wait_input",
     "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
-    "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes",
+    "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes", "fastf_engine_cell_scratch_bytes",
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_error_bits",
     "fastf_dev_clear_error_bits", "fastf_kernel_names",

@@ -91,6 +91,7 @@ struct fastf_engine {
     DevBuf img_cells, img_genes;         // LDS table images (fast path, when the lists allow it)
     DevBuf d_cell_filter; MissFilter cell_filter{nullptr, 0};        // miss filter in front of the L2 cell table
     CellLds lds_cells{}; GeneLds lds_genes{};
+    bool cell16 = false;                 // K1a -> K1b scratch holds u16 cell indices (n_cells <= 65535)
     bool use_lds_cells = false, use_lds_genes = false; u32 genes_blocks_per_cu = 1, cells_blocks_per_cu = 1;
     // draw stream: draws live in a device ring indexed by the ABSOLUTE hit rank since the last reset; the hit-rank
     // base of a chunk is a device-side running total, so a push never waits for the counts of the chunk before it
@@ -393,6 +394,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     fastf_engine* e = new fastf_engine();
     e->device = cfg->device;
     e->n_cells = cfg->n_cells; e->n_features = cfg->n_features;
+    e->cell16 = cfg->n_cells <= 65535u && !getenv("FASTF_CELL_SCRATCH_32");
     e->cell_bits = bits_for(cfg->n_cells);
     e->feat_bits = bits_for(cfg->n_features);
     e->L.umi_bits = 2 * cfg->umi_max_bases;
@@ -490,6 +492,12 @@ extern "C" int fastf_engine_table_modes(const fastf_engine_t* e, int* cells_in_l
     if (!e) return set_err("null engine");
     if (cells_in_lds) *cells_in_lds = e->use_lds_cells;
     if (genes_in_lds) *genes_in_lds = e->use_lds_genes ? (e->lds_genes.direct ? 2 : 1) : 0;
+    return 0;
+}
+
+extern "C" int fastf_engine_cell_scratch_bytes(const fastf_engine_t* e, uint32_t* bytes) {
+    if (!e || !bytes) return set_err("null argument");
+    *bytes = (e->multi ? e->n_cells <= 65535u : e->cell16) ? 2u : 4u;
     return 0;
 }
 
@@ -605,17 +613,17 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
         const u32 grid = std::min<u32>(e->cells_blocks_per_cu * g_cu_count, (tiles + 1) / 2);
         if (e->cells_blocks_per_cu >= 2)
             hipLaunchKernelGGL(probe_cells_lds_kernel<true>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                               (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
         else
             hipLaunchKernelGGL(probe_cells_lds_kernel<false>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                               (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else if (e->cell_filter.bits) {
         const u32 grid = std::min<u32>(tiles, 4 * g_cu_count);
         hipLaunchKernelGGL(probe_cells_filtered_kernel, dim3(grid), dim3(K1_THREADS), (e->cell_filter.mask + 1u) / 8u, s, cb, n,
-                           e->cells, e->cell_filter, (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+                           e->cells, e->cell_filter, e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else {
         hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
-                           (u32*)e->d_cellidx.p, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p);
+                           e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p);
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
@@ -645,7 +653,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s, d_running, d_running ? const_cast<u64*>(draw_base) : nullptr)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     PackParams p{};
-    p.cell = (const u32*)e->d_cellidx.p; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
+    p.cell = e->d_cellidx.p; p.cell16 = e->cell16; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
     p.tile_base = (const u64*)e->d_tilebase.p;
     p.draws = draws; p.n_draws = n_draws; p.draw_base = draw_base; p.draw_mask = draw_mask;
     p.feats = e->feats;

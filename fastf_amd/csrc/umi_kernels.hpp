@@ -241,6 +241,15 @@ constexpr int K1_THREADS = FASTF_K1_THREADS, K1_IPT = FASTF_K1_IPT, K1_TILE = K1
 // K1a lays a tile out wave by wave: wave w of a 512-thread group owns the records [512 w, 512 w + 512) of its tile
 static_assert(K1_THREADS == 512 && K1_IPT == 8, "K1a layout: 8 waves x 8 items x 64 lanes per tile");
 
+// the cell-index scratch between K1a and K1b holds u16 entries when every cell index fits (n_cells <= 65535): 2 instead of
+// 4 bytes written and read back per record
+__device__ __forceinline__ void put_cell(void* __restrict__ out, bool c16, u64 idx, u32 v) {
+    if (c16) reinterpret_cast<unsigned short*>(out)[idx] = (unsigned short)v; else reinterpret_cast<u32*>(out)[idx] = v;
+}
+__device__ __forceinline__ u32 get_cell(const void* __restrict__ in, bool c16, u64 idx) {
+    return c16 ? (u32)reinterpret_cast<const unsigned short*>(in)[idx] : reinterpret_cast<const u32*>(in)[idx];
+}
+
 __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
 }
@@ -249,7 +258,7 @@ __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
 // tile_base[t] + the halves in front of it, which lets every WAVE of K1b work on its own (filter_pack_stream_kernel)
 template <int AUX>
 __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __restrict__ cb, u64 n, Table cells,
-                                                                 u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                                 void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
                                                                  u32* __restrict__ half_hits) {
     __shared__ u32 s_w[K1_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __re
 #pragma unroll
     for (int j = 0; j < K1_IPT; ++j) {
         const u64 idx = base + (u64)j * WAVE + lane;
-        if (idx < n) cell_out[idx] = cell[j];
+        if (idx < n) put_cell(cell_out, c16, idx, cell[j]);
         hits += (u32)__popcll(__ballot(cell[j] != 0));
         if (j == K1_IPT / 2 - 1) hits_lo = hits;
     }
@@ -322,7 +331,7 @@ __device__ __forceinline__ u32 filter_bit(u64 key) {
 }
 
 __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(const u64* __restrict__ cb, u64 n, Table cells, MissFilter f,
-                                                                             u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                                             void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
                                                                              u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u32 s_w[K1_WAVES];
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
 #pragma unroll
         for (int j = 0; j < K1_IPT; ++j) {
             const u64 idx = base + (u64)j * WAVE + lane;
-            if (idx < n) cell_out[idx] = cell[j];
+            if (idx < n) put_cell(cell_out, c16, idx, cell[j]);
             hits += (u32)__popcll(__ballot(cell[j] != 0));
             if (j == K1_IPT / 2 - 1) hits_lo = hits;
         }
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
 // TWO_PER_CU: the image leaves room for two workgroups per CU, which takes 64 VGPRs at most
 template <bool TWO_PER_CU>
 __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
-                                                               u32* __restrict__ cell_out, u32* __restrict__ tile_hits,
+                                                               void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
                                                                u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 S = c.slot_bits, smask = (1u << S) - 1u, lo_mask = (1u << (32u - S)) - 1u;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
     const int lane = lane_id();
     constexpr int PAIRS = K1_IPT / 2;                                    // 4 x 64 lanes x 2 records = one 512-record chunk
     const u32 n_chunks = n_tiles * (u32)K1_WAVES;
-    const bool even = (n & 1ull) == 0 && (reinterpret_cast<uintptr_t>(cb) & 15u) == 0 && (reinterpret_cast<uintptr_t>(cell_out) & 7u) == 0;
+    const bool even = (reinterpret_cast<uintptr_t>(cb) & 15u) == 0 && (reinterpret_cast<uintptr_t>(cell_out) & 7u) == 0;
     for (u32 chunk = blockIdx.x * 16u + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 16u) {
         const u64 base = (u64)chunk * (K1_IPT * WAVE);
         u64 key[K1_IPT]; u32 cell[K1_IPT];
@@ -423,14 +432,20 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
             if (j == K1_IPT / 2 - 1) hits_lo = hits;
         }
         if (whole) {
+            if (c16) {
 #pragma unroll
-            for (int j = 0; j < PAIRS; ++j)
-                *reinterpret_cast<uint2*>(cell_out + base + 2ull * (j * WAVE + lane)) = make_uint2(cell[2 * j], cell[2 * j + 1]);
+                for (int j = 0; j < PAIRS; ++j)
+                    *reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(cell_out) + base + 2ull * (j * WAVE + lane)) = cell[2 * j] | (cell[2 * j + 1] << 16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PAIRS; ++j)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<u32*>(cell_out) + base + 2ull * (j * WAVE + lane)) = make_uint2(cell[2 * j], cell[2 * j + 1]);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < K1_IPT; ++j) {
                 const u64 idx = base + 2ull * ((j >> 1) * WAVE + lane) + (j & 1);
-                if (idx < n) cell_out[idx] = cell[j];
+                if (idx < n) put_cell(cell_out, c16, idx, cell[j]);
             }
         }
         if (lane == 0) {
@@ -455,7 +470,8 @@ constexpr int K1B_THREADS = FASTF_K1B_THREADS, K1B_IPT = K1_TILE / K1B_THREADS, 
 static_assert(K1B_THREADS * K1B_IPT == K1_TILE, "K1b walks K1a's tiles");
 
 struct PackParams {
-    const u32* cell; const u64* gx; const u32* umi; const u32* meta; u64 n;
+    const void* cell; bool cell16;  // K1a's scratch: u16 or u32 entries
+    const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
     const u32* draws; u64 n_draws; // draw of hit rank r: draws[r & draw_mask], valid while r < n_draws
     u64 draw_mask;                 // ~0 for a linear array; ring size - 1 for the streaming push path
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
     for (int j = 0; j < K1B_IPT; ++j) {
         const u64 idx = base + (u64)j * K1B_THREADS + tid;
         const bool in = idx < p.n;
-        cell[j] = in ? p.cell[idx] : 0;
+        cell[j] = in ? get_cell(p.cell, p.cell16, idx) : 0;
         gxk[j]  = in ? p.gx[idx] : 0;
         umi[j]  = in ? p.umi[idx] : 0;
         meta[j] = in ? p.meta[idx] : 0;
@@ -734,7 +750,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
         for (int j = 0; j < K1S_IPT; ++j) {
             const u64 idx = base + (u64)j * WAVE + lane;
             const bool in = idx < p.n;
-            cell[j] = in ? p.cell[idx] : 0;
+            cell[j] = in ? get_cell(p.cell, p.cell16, idx) : 0;
             gxk[j]  = in ? p.gx[idx] : 0;
             umi[j]  = in ? p.umi[idx] : 0;
             meta[j] = in ? p.meta[idx] : 0;
@@ -1175,7 +1191,13 @@ struct ReduceParams {
     u64* ukeys;                            // UMI_ROWS only
 };
 
-constexpr int K3_THREADS = 512, K3_IPT = 8, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
+// 4 keys per thread (2048-key tiles, 24 KB of LDS: six workgroups per CU): 324 us vs 352 us for 8 on the configs[2] shape
+#ifndef FASTF_K3_IPT
+#define FASTF_K3_IPT 4
+#endif
+constexpr int K3_THREADS = 512, K3_IPT = FASTF_K3_IPT, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
+constexpr int K3_UNITS = K3_IPT * K3_WAVES;
+static_assert(K3_UNITS <= WAVE, "one wave scans the (item, wave) units");
 
 // both K3 kernels run on a capped grid and walk their tiles (tile += gridDim): the launch is sized for the caller's
 // upper bound on the key count, and workgroups without a tile are not free
@@ -1256,13 +1278,33 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
                     // 1/2^(sorted UMI bits) of a group plus its exact duplicates — a step or two in practice.
                     const u64 run = k >> p.low_skip;
                     u64 q = prev, at = idx - 1;
-                    for (u32 steps = 0;; ++steps) {
-                        if ((q >> p.low_skip) != run) break;
-                        if (q == k) { dist = false; break; }
-                        if (at == 0) break;
-                        if (steps == RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
-                        --at;
-                        q = at >= base ? s_id[(u32)(at - base)] : p.keys[at];
+                    u32 steps = 0;
+                    bool open = true;                          // still inside the run, no equal key met yet
+                    constexpr u32 NEAR = 8;
+                    if (loc >= NEAR) {
+                        // the eight neighbours in front, read from LDS in one go (no load waits for the one before it):
+                        // most runs end within them
+                        u64 nb[NEAR];
+#pragma unroll
+                        for (u32 t = 0; t < NEAR; ++t) nb[t] = s_id[loc - 1 - t];
+#pragma unroll
+                        for (u32 t = 0; t < NEAR; ++t) {
+                            if (open) {
+                                if ((nb[t] >> p.low_skip) != run) open = false;
+                                else if (nb[t] == k) { dist = false; open = false; }
+                            }
+                        }
+                        at = idx - NEAR; q = nb[NEAR - 1]; steps = NEAR - 1;
+                    }
+                    if (open) {
+                        for (;; ++steps) {
+                            if ((q >> p.low_skip) != run) break;
+                            if (q == k) { dist = false; break; }
+                            if (at == 0) break;
+                            if (steps >= RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
+                            --at;
+                            q = at >= base ? s_id[(u32)(at - base)] : p.keys[at];
+                        }
                     }
                 }
             }
@@ -1273,10 +1315,9 @@ __global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p
     if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
     __syncthreads();
     if (w == 0) {
-        static_assert(K3_IPT * K3_WAVES == WAVE, "one wave scans the (item, wave) units");
-        const u32 h = s_h[lane], d = s_d[lane];
+        const u32 h = lane < K3_UNITS ? s_h[lane] : 0u, d = lane < K3_UNITS ? s_d[lane] : 0u;
         const u32 hi = wave_incl_scan32(h, lane), di = wave_incl_scan32(d, lane);
-        s_h[lane] = hi - h; s_d[lane] = di - d;
+        if (lane < K3_UNITS) { s_h[lane] = hi - h; s_d[lane] = di - d; }
         if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = di; }   // sentinel: all distinct flags of the tile
     }
     __syncthreads();

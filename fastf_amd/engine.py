@@ -318,6 +318,12 @@ class Engine:
                                       {0: "L2 open addressing", 1: "LDS bitmap+rank", 2: "LDS direct table"}[g.value])
 
     @property
+    def cell_scratch_bytes(self) -> int:
+        b = C.c_uint32()
+        check(self._L.fastf_engine_cell_scratch_bytes(self._h, C.byref(b)))
+        return b.value
+
+    @property
     def skip_bits(self) -> int:
         b = C.c_uint32()
         check(self._L.fastf_engine_skip_bits(self._h, C.byref(b)))

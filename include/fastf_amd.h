@@ -286,6 +286,8 @@ int fastf_engine_sort_passes(const fastf_engine_t *e, uint32_t flags, uint32_t *
  * bitmap + rank + permutation over one id family; genes: 2 = direct index table over a dense id range),
  * 0 = open-addressed table in L2 */
 int fastf_engine_table_modes(const fastf_engine_t *e, int *cells_in_lds, int *genes_in_lds);
+/* width of one entry of the cell-index scratch K1a leaves for K1b: 2 bytes when every cell index fits 16 bits, else 4 */
+int fastf_engine_cell_scratch_bytes(const fastf_engine_t *e, uint32_t *bytes);
 int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
                    const uint64_t *d_n, uint64_t max_n, uint32_t key_bits, uint32_t flags,
                    int *sorted_in_tmp, void *stream);

@@ -15,7 +15,10 @@ from collections import defaultdict
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("fastf::", "")
-    return "scatter_kernel" if n.startswith("scatter_kernel<") else n      # one kernel, 8 digit-shift instantiations
+    for k in ("scatter_kernel", "filter_pack_stream_kernel", "filter_pack_kernel", "probe_cells_lds_kernel", "reduce_kernel", "head_count_kernel"):
+        if n.startswith(k + "<"):
+            return k                                                          # template instantiations of one kernel
+    return n
 
 
 def counters(d, cname):
@@ -30,6 +33,7 @@ def counters(d, cname):
 def main():
     tag, sdir, fdir, wdir = sys.argv[1:5]
     n_keys = int(sys.argv[5]) if len(sys.argv) > 5 else 10_000_000
+    n_records = int(sys.argv[6]) if len(sys.argv) > 6 else None
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
     stats = glob.glob(os.path.join(sdir, "**", "*kernel_stats.csv"), recursive=True)[0]
@@ -54,9 +58,9 @@ def main():
     cal = (8.0 * n_keys) / (sum(tc) / len(tc) * 1024) if tc else None
     summ = {"_note": "per-launch averages; FETCH/WRITE in KiB as reported by rocprofv3 --pmc (separate passes); "
                      "hbm_bytes = FETCH*1024*2 (gfx950 correction) + WRITE*1024",
-            "fetch_factor_observed_on_tile_count_kernel": cal, "n_keys": n_keys, "kernels": {}}
+            "fetch_factor_observed_on_tile_count_kernel": cal, "n_keys": n_keys, "workload_records": n_records, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
-        if k.startswith("__amd") or k.startswith("at::"):
+        if k.startswith("__amd") or k.startswith("at::") or "at::native" in k or "void at::" in k:
             continue
         fl, wl = fetch.get(k, []), write.get(k, [])
         f = sum(fl) / len(fl) if fl else 0.0

@@ -1,15 +1,19 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/<tag>_*: kernel stats, then FETCH_SIZE and WRITE_SIZE in their own runs
-# (counters are never combined with tracing).  Run on the GPU box from the repo root:  tools/profile_round.sh r1b
+# (counters are never combined with tracing).  Run on the GPU box from the repo root:  tools/profile_round.sh r2_c3
+# The profiled command is bench.py on its default workload (BASELINE configs[2], 200 M records), device steps only.
 set -e
-tag=${1:-r1}
+tag=${1:-r2_c3}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $out/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $out/fetch --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $out/write --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu > $out/write.log 2>&1
-python3 tools/prof_summary.py $tag $out/stats $out/fetch $out/write 10000000 > $out/summary.json
+B="bench.py --no-cpu --no-e2e --no-devpath"
+rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 $B --steps 5 --warmup 1 > $out/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch --output-format csv -- python3 $B --steps 2 --warmup 1 > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $out/write --output-format csv -- python3 $B --steps 2 --warmup 1 > $out/write.log 2>&1
+keys=$(grep '^{"metric"' $out/stats.log | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['counters']['keys'])")
+recs=$(grep '^{"metric"' $out/stats.log | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['counters']['total'])")
+python3 tools/prof_summary.py $tag $out/stats $out/fetch $out/write $keys $recs > $out/summary.json
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) profiles/${tag}_rocprofv3_kernel_stats_raw.csv
-python3 bench.py --steps 20 --warmup 3 > profiles/${tag}_bench_line.json 2> $out/bench.err
+python3 bench.py --steps 40 --warmup 3 > profiles/${tag}_bench_line.json 2> $out/bench.err
 echo "profiles/${tag}_* written"
