@@ -69,7 +69,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=200_000_000, help="records of the whole job (all GPUs together)")
+    ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
+                    help="c3 = BASELINE configs[2] (the headline, default); c2 = BASELINE configs[1], 10 M keep-all records (round 1's workload)")
+    ap.add_argument("--records", type=int, default=0, help="records of the whole job (all GPUs together); default 200 M (c3) / 10 M (c2)")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-devpath", action="store_true")
@@ -98,7 +100,9 @@ def main():
 
     # ---- the job: every rank builds the same lists and molecule pool, then its own slice of the record stream ----
     t_gen = time.perf_counter()
-    job = workload.C3(args.records)
+    c2 = args.workload == "c2"
+    job = workload.C2(args.records or 10_000_000) if c2 else workload.C3(args.records or 200_000_000)
+    rate_cell, rate_depth, umi_bases = (1.0, 1.0, 12) if c2 else (workload.RATE_CELL, workload.RATE_DEPTH, workload.UMI_LEN)
     N_total, seg_per_rank = job.n_total, workload.SEGMENTS // G
     n_local = seg_per_rank * job.seg_len
     lists = job.lists
@@ -117,7 +121,7 @@ def main():
     if rank == 0:
         log("bench: job generated in %.1f s (%d records per rank)" % (time.perf_counter() - t_gen, n_local))
 
-    eng = F.Engine.from_lists(lists, rate_depth=workload.RATE_DEPTH, seed=workload.SEED, umi_max_bases=workload.UMI_LEN,
+    eng = F.Engine.from_lists(lists, rate_depth=rate_depth, seed=workload.SEED, umi_max_bases=umi_bases,
                               n_shards=G, shard_rank=rank, device=local)
     eng.reserve(n_local, n_local)
     sp = ShardedPass(HipStages(eng, dev), n_local, dev)
@@ -201,7 +205,8 @@ def main():
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong" if G > 1 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (packed SoA + draw stream)",
+            "config": {"workload": ("BASELINE configs[1]: %d synthetic records, 10000 barcodes x 30000 genes, --cell 1.0 --depth 1.0 --seed 926, "
+                                    "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (packed SoA + draw stream)",
                        "records_per_gpu": n_local, "key_bits": eng.key_bits, "radix_passes_nominal": P_nom,
                        "radix_passes_executed": P_exe,
                        "sharding": ("cell-hash, one all-to-all, %s" % ("3-stream pipeline" if sp.pipelined else "single stream")) if G > 1 else "single GPU",
@@ -222,7 +227,7 @@ def main():
             "counters": {"total": N_total, "hits": hits, "sampled": sampled, "valid": valid,
                          "keys": K_job, "rows": Z_job, "device_error_bits": err},
         }
-        if N_total == 200_000_000:             # the job is the same for every rank count: so are its totals
+        if N_total == 200_000_000 and not c2:  # the job is the same for every rank count: so are its totals
             got = {k: out["counters"][k] for k in workload.EXPECTED_200M}
             out["counters"]["same_as_single_gpu_reference_run"] = got == workload.EXPECTED_200M
 
@@ -231,7 +236,9 @@ def main():
     eng.close()
     torch.cuda.empty_cache()
 
-    if rank == 0 and G == 1:
+    if rank == 0 and G == 1 and c2:
+        out["cpu_baseline"] = None             # the legs below are defined on the headline workload
+    elif rank == 0 and G == 1:
         if not args.no_devpath:
             out["device_path"] = device_path_leg(job, dev, local, N_total, out["counters"])
         if not args.no_cpu:

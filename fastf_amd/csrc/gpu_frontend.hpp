@@ -1,0 +1,135 @@
+// gpu_frontend.hpp — device side of the BAM front end: BGZF inflate of a whole reader window on the GPU.
+// Included by umi_engine.hip; the decoder itself is gpu_inflate.hpp (one wavefront per BGZF block).
+//
+// Reference step replaced: sam_read1() -> bgzf_read -> inflate, bam2db_ds.c:360 (htslib/zlib on one core).  In the
+// host reader (host_io.c) inflate is the longest stage of an end-to-end run on real-shaped BAMs even on 16 threads;
+// the window's compressed bytes are a quarter of the inflated ones, so they cross PCIe cheaply, are decoded by as many
+// wavefronts as the window has blocks, and come back into the reader's (pinned) window buffer, where the host goes on
+// with the record hop and the tag packing.  Every block's CRC-32 is still checked on the host, and a block the device
+// declines or gets wrong is inflated again by zlib — the same referee rule as for the host's own decoder.
+//
+// The window is cut into slices that run H2D -> kernel -> D2H on alternating streams, so the three stages of
+// neighbouring slices overlap.
+#include "gpu_inflate.hpp"
+
+struct GiBlock { u64 coff; u32 clen, isize; u64 uoff; };          // offsets into the slice's compressed / inflated bytes
+
+__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const GiBlock* __restrict__ blk, u32 n_blk, const uint8_t* __restrict__ comp,
+                                                          uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+    __shared__ gi::Work w;
+    const u32 b = blockIdx.x;
+    if (b >= n_blk) return;
+    const GiBlock k = blk[b];
+    int rc = 0;
+    if (k.isize) rc = gi::inflate_block(w, comp + k.coff, k.clen, out + k.uoff, k.isize);
+    if (gi_lane0()) status[b] = (uint8_t)rc;
+}
+
+struct fastf_gpuinf {
+    int device = 0;
+    static constexpr int NS = 3;                                   // slices in flight
+    hipStream_t s[NS] = {nullptr, nullptr, nullptr};
+    void* h_comp[NS] = {nullptr, nullptr, nullptr}; size_t h_comp_cap[NS] = {0, 0, 0};      // pinned staging of compressed bytes
+    GiBlock* h_blk[NS] = {nullptr, nullptr, nullptr}; size_t h_blk_cap[NS] = {0, 0, 0};
+    uint8_t* h_status[NS] = {nullptr, nullptr, nullptr};
+    DevBuf d_comp[NS], d_out[NS], d_blk[NS], d_status[NS];
+    double t_stage = 0, t_wait = 0; u64 n_blocks = 0, n_declined = 0;
+};
+
+extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_err("no HIP device for the BGZF inflate"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    fastf_gpuinf* g = new fastf_gpuinf();
+    g->device = device;
+    for (int i = 0; i < fastf_gpuinf::NS; ++i)
+        if (hipStreamCreateWithFlags(&g->s[i], hipStreamNonBlocking) != hipSuccess) { fastf_gpuinf_destroy(g); set_err("stream creation failed"); return nullptr; }
+    return g;
+}
+
+extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (int i = 0; i < fastf_gpuinf::NS; ++i) {
+        if (g->s[i]) { (void)hipStreamSynchronize(g->s[i]); (void)hipStreamDestroy(g->s[i]); }
+        if (g->h_comp[i]) (void)hipHostFree(g->h_comp[i]);
+        if (g->h_blk[i]) (void)hipHostFree(g->h_blk[i]);
+        if (g->h_status[i]) (void)hipHostFree(g->h_status[i]);
+        g->d_comp[i].release(); g->d_out[i].release(); g->d_blk[i].release(); g->d_status[i].release();
+    }
+    delete g;
+}
+
+extern "C" void fastf_gpuinf_stats(const fastf_gpuinf_t* g, uint64_t* n_blocks, uint64_t* n_declined) {
+    if (n_blocks) *n_blocks = g ? g->n_blocks : 0;
+    if (n_declined) *n_declined = g ? g->n_declined : 0;
+}
+
+// blocks [0, n): compressed payload of block i at comp + blk[i].coff (clen bytes), inflated to out + blk[i].uoff (isize
+// bytes).  `out` must be pinned host memory (fastf_pinned_alloc).  status[i] != 0: the device declined block i (the
+// caller inflates it on the host).  Returns non-zero only when nothing could be run (the caller then inflates the
+// whole window on the host).
+extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
+                                unsigned char* out, uint8_t* status) {
+    if (!g) return set_err("null inflate handle");
+    if (n == 0) return 0;
+    HIP_OK(hipSetDevice(g->device));
+    constexpr int NS = fastf_gpuinf::NS;
+    // slices of about 1/8 of the window (at least 256 blocks), so that copies and kernels of neighbours overlap
+    const size_t per = std::max<size_t>(256, (n + 7) / 8);
+    size_t first[64]; int n_slices = 0;
+    for (size_t a = 0; a < n && n_slices < 63; a += per) first[n_slices++] = a;
+    first[n_slices] = n;
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const int q = sl % NS;
+        const size_t a = first[sl], b = first[sl + 1], nb = b - a;
+        HIP_OK(hipStreamSynchronize(g->s[q]));                      // the slice that used this slot three slices ago is done
+        if (sl >= NS) {                                              // ... and its statuses are on the host
+            const size_t pa = first[sl - NS], pb = first[sl - NS + 1];
+            memcpy(status + pa, g->h_status[q], pb - pa);
+        }
+        // compressed bytes of the slice are contiguous in the file: one staging copy, offsets relative to its start
+        const u64 c0 = blk[a].coff, c1 = blk[b - 1].coff + blk[b - 1].clen;
+        const u64 u0 = blk[a].uoff; u64 u1 = u0;
+        for (size_t i = a; i < b; ++i) u1 = std::max<u64>(u1, blk[i].uoff + blk[i].isize);
+        const size_t cbytes = (size_t)(c1 - c0) + 64, ubytes = (size_t)(u1 - u0);
+        if (cbytes > g->h_comp_cap[q]) {
+            if (g->h_comp[q]) (void)hipHostFree(g->h_comp[q]);
+            g->h_comp[q] = nullptr; g->h_comp_cap[q] = 0;
+            const size_t cap = cbytes + cbytes / 4;
+            HIP_OK(hipHostMalloc(&g->h_comp[q], cap, hipHostMallocDefault));
+            g->h_comp_cap[q] = cap;
+        }
+        if (nb > g->h_blk_cap[q]) {
+            if (g->h_blk[q]) (void)hipHostFree(g->h_blk[q]);
+            if (g->h_status[q]) (void)hipHostFree(g->h_status[q]);
+            g->h_blk[q] = nullptr; g->h_status[q] = nullptr; g->h_blk_cap[q] = 0;
+            const size_t cap = nb + nb / 4 + 64;
+            HIP_OK(hipHostMalloc((void**)&g->h_blk[q], cap * sizeof(GiBlock), hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void**)&g->h_status[q], cap, hipHostMallocDefault));
+            g->h_blk_cap[q] = cap;
+        }
+        memcpy(g->h_comp[q], comp + c0, (size_t)(c1 - c0));
+        memset((char*)g->h_comp[q] + (c1 - c0), 0, 64);               // the bit reader may look 8 bytes past a block
+        for (size_t i = a; i < b; ++i) g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0};
+        if (g->d_comp[q].ensure(cbytes) || g->d_out[q].ensure(std::max<size_t>(ubytes, 64)) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
+            g->d_status[q].ensure(nb))
+            return 1;
+        hipStream_t s = g->s[q];
+        HIP_OK(hipMemcpyAsync(g->d_comp[q].p, g->h_comp[q], cbytes, hipMemcpyHostToDevice, s));
+        HIP_OK(hipMemcpyAsync(g->d_blk[q].p, g->h_blk[q], nb * sizeof(GiBlock), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((u32)nb), dim3(64), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
+                           (const uint8_t*)g->d_comp[q].p, (uint8_t*)g->d_out[q].p, (uint8_t*)g->d_status[q].p);
+        HIP_OK(hipGetLastError());
+        if (ubytes) HIP_OK(hipMemcpyAsync(out + u0, g->d_out[q].p, ubytes, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(g->h_status[q], g->d_status[q].p, nb, hipMemcpyDeviceToHost, s));
+    }
+    for (int sl = std::max(0, n_slices - NS); sl < n_slices; ++sl) {
+        const int q = sl % NS;
+        HIP_OK(hipStreamSynchronize(g->s[q]));
+        memcpy(status + first[sl], g->h_status[q], first[sl + 1] - first[sl]);
+    }
+    g->n_blocks += n;
+    for (size_t i = 0; i < n; ++i) g->n_declined += status[i] != 0;
+    return 0;
+}

@@ -1,0 +1,274 @@
+// gpu_inflate.hpp — raw DEFLATE (RFC 1951) decode of ONE BGZF block by ONE wavefront.
+//
+// The step in front of the bam2db hot path is sam_read1() through htslib/zlib (bam2db_ds.c:360): inflate of
+// independent <= 64 KiB BGZF blocks.  On the host that is the longest stage of an end-to-end run;
+// here the blocks of a window are decoded on the device, one wavefront per block:
+//   * control flow is wave-uniform: all 64 lanes run the same symbol loop on the same bit buffer (the SIMD executes 64
+//     lanes anyway), and the lanes split the work wherever there is any — table fill, match copy, output flush;
+//   * Huffman tables live in LDS: a 10-bit (literal/length) and an 8-bit (distance) direct table of u16 entries; the rare
+//     longer codes go through the canonical count/offset walk (one bit at a time) over the sorted symbol list;
+//   * the last 8 KiB of output live in an LDS ring: literals and matches write there, every completed 64-byte line is
+//     flushed to memory by the whole wave in one store, and a match reads its source from the ring (distance <= 8128) or,
+//     for the few far ones, from memory with L2-coherent loads — those bytes left the wave at least 127 stores ago and at
+//     most 63 stores can be outstanding.
+// The same source compiles for the host (GI_HOST: one lane) so that the decoder is fuzzed against zlib on the CPU
+// (tests/test_gpu_inflate_host.py, tools/gi_host_test.cpp); the device build is checked against zlib on real BGZF blocks.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#ifdef GI_HOST
+#define GI_FN static inline
+constexpr int GI_LANES = 1;
+#define GI_LANE() 0
+#define GI_COHERENT_LOAD8(p) (*(p))
+#define GI_WAVE_SYNC() do { } while (0)
+#else
+#define GI_FN __device__ __forceinline__
+constexpr int GI_LANES = 64;
+#define GI_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+// byte read that must see what this wave stored earlier: agent-scope load of the containing dword (bypasses the CU's L1)
+__device__ __forceinline__ uint8_t gi_coherent_load8(const uint8_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint8_t)(w >> (8 * (a & 3)));
+}
+#define GI_COHERENT_LOAD8(p) gi_coherent_load8(p)
+// lanes of one wave exchange data through LDS without a workgroup barrier: keep the compiler from moving LDS accesses
+// across the hand-over (the hardware runs a wave's LDS instructions in order)
+#define GI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
+
+namespace gi {
+
+constexpr int LIT_TB = 10, DIST_TB = 8;
+constexpr uint32_t RING = 8192, RMASK = RING - 1, RING_SAFE = RING - 64;
+constexpr uint16_t LONG_CODE = 0xFFFF, NO_CODE = 0;
+
+// error codes (0 = ok)
+enum { OK = 0, E_BTYPE = 1, E_STORED = 2, E_LENS = 3, E_CODE = 4, E_DIST = 5, E_OVERRUN = 6, E_INPUT = 7, E_SIZE = 8 };
+
+// per-wave working set (LDS on the device)
+struct Work {
+    uint16_t lit_tab[1 << LIT_TB];      // (symbol << 4) | code length; 0: no code; LONG_CODE: longer than the table
+    uint16_t dist_tab[1 << DIST_TB];    // same; also holds the 7-bit table of the code-length code while a header is read
+    uint16_t lit_sorted[288], dist_sorted[32];   // symbols by (length, symbol): the canonical order, for the long-code walk
+    uint16_t lit_count[16], dist_count[16];
+    uint8_t lens[320];
+    uint8_t ring[RING];
+};
+
+struct Bits { const uint8_t* in; uint32_t pos, len; uint64_t buf; uint32_t cnt; };
+
+GI_FN uint32_t load32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+// at least 32 valid bits afterwards (reads up to 4 bytes past `len`: the caller's buffer is padded; bits beyond the end are
+// never consumed by a well-formed stream, and a malformed one is caught by the position check at the end)
+GI_FN void refill(Bits& b) {
+    if (b.cnt <= 32) { b.buf |= (uint64_t)load32(b.in + b.pos) << b.cnt; b.pos += 4; b.cnt += 32; }
+}
+GI_FN uint32_t peek(const Bits& b, int n) { return (uint32_t)b.buf & ((1u << n) - 1u); }
+GI_FN void drop(Bits& b, int n) { b.buf >>= n; b.cnt -= (uint32_t)n; }
+GI_FN uint32_t take(Bits& b, int n) { const uint32_t v = peek(b, n); drop(b, n); return v; }
+
+GI_FN uint32_t rev(uint32_t c, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; ++i) { r = (r << 1) | (c & 1u); c >>= 1; }
+    return r;
+}
+
+// canonical code -> direct table over the low `tb` stream bits + sorted symbol list and per-length counts.
+// Returns 0, or E_LENS for an over-subscribed set (or an incomplete one with more than one code).
+GI_FN int build(const uint8_t* lens, int n_sym, int tb, uint16_t* tab, uint16_t* sorted, uint16_t* count) {
+    const int lane = GI_LANE();
+    uint32_t cnt[16], next[16], offs[16];
+    for (int l = 0; l < 16; ++l) cnt[l] = 0;
+    for (int s = 0; s < n_sym; ++s) cnt[lens[s]]++;
+    const uint32_t n_codes = (uint32_t)n_sym - cnt[0];
+    cnt[0] = 0;
+    int left = 1;
+    for (int l = 1; l <= 15; ++l) { left = (left << 1) - (int)cnt[l]; if (left < 0) return E_LENS; }
+    if (left > 0 && n_codes > 1) return E_LENS;
+    uint32_t code = 0, o = 0;
+    for (int l = 1; l <= 15; ++l) { code = (code + cnt[l - 1]) << 1; next[l] = code; offs[l] = o; o += cnt[l]; }
+    for (int l = lane; l < 16; l += GI_LANES) count[l] = (uint16_t)cnt[l];
+    for (int i = lane; i < (1 << tb); i += GI_LANES) tab[i] = NO_CODE;
+    GI_WAVE_SYNC();
+    for (int s = 0; s < n_sym; ++s) {
+        const int l = lens[s];
+        if (!l) continue;
+        if (lane == 0) sorted[offs[l]] = (uint16_t)s;
+        offs[l]++;
+        const uint32_t c = next[l]++;
+        if (l <= tb) {
+            const uint32_t r = rev(c, l);
+            const uint16_t e = (uint16_t)((s << 4) | l);
+            for (uint32_t i = r + ((uint32_t)lane << l); i < (1u << tb); i += (uint32_t)GI_LANES << l) tab[i] = e;
+        } else if (lane == 0) {
+            tab[rev(c >> (l - tb), tb)] = LONG_CODE;         // the first tb bits of the code, as they arrive in the stream
+        }
+    }
+    GI_WAVE_SYNC();
+    return OK;
+}
+
+// one symbol: direct table, or the count/offset walk for codes longer than the table (RFC 1951 3.2.2; one bit per step)
+GI_FN int decode(Bits& b, const uint16_t* tab, int tb, const uint16_t* sorted, const uint16_t* count) {
+    const uint16_t e = tab[peek(b, tb)];
+    if (e != LONG_CODE) {
+        if (e == NO_CODE) return -1;
+        drop(b, e & 15);
+        return e >> 4;
+    }
+    uint32_t code = 0, first = 0, index = 0;
+    uint64_t bits = b.buf;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (uint32_t)bits & 1u; bits >>= 1;
+        const uint32_t c = count[l];
+        if (code < first + c) { drop(b, l); return sorted[index + (code - first)]; }
+        index += c; first = (first + c) << 1; code <<= 1;
+    }
+    return -1;
+}
+
+struct Out { uint8_t* out; uint32_t cap, op, flushed; };
+
+// every completed 64-byte line of the ring goes to memory, one byte per lane
+GI_FN void flush_lines(Work& w, Out& o, bool all) {
+    const int lane = GI_LANE();
+    GI_WAVE_SYNC();
+    while (o.op - o.flushed >= 64u || (all && o.op > o.flushed)) {
+        const uint32_t n = o.op - o.flushed >= 64u ? 64u : o.op - o.flushed;
+        for (uint32_t i = (uint32_t)lane; i < n; i += GI_LANES) o.out[o.flushed + i] = w.ring[(o.flushed + i) & RMASK];
+        o.flushed += n;
+    }
+}
+
+GI_FN int copy_match(Work& w, Out& o, uint32_t len, uint32_t dist) {
+    const int lane = GI_LANE();
+    if (dist == 0 || dist > o.op) return E_DIST;
+    if (o.op + len > o.cap) return E_OVERRUN;
+    while (len) {
+        const uint32_t n = len < (uint32_t)GI_LANES ? len : (uint32_t)GI_LANES;
+        for (uint32_t i = (uint32_t)lane; i < n; i += GI_LANES) {
+            const uint32_t src = o.op - dist + (dist >= n ? i : i % dist);
+            const uint8_t v = dist <= RING_SAFE ? w.ring[src & RMASK] : GI_COHERENT_LOAD8(o.out + src);
+            w.ring[(o.op + i) & RMASK] = v;
+        }
+        GI_WAVE_SYNC();
+        o.op += n; len -= n;
+        flush_lines(w, o, false);
+    }
+    return OK;
+}
+
+// out must hold `isize` bytes; `in` must be readable 8 bytes past in_len
+GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t isize) {
+    static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
+                                       4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    const int lane = GI_LANE();
+    Bits b{in, 0, in_len, 0, 0};
+    Out o{out, isize, 0, 0};
+    for (;;) {
+        refill(b);
+        const uint32_t final = take(b, 1), type = take(b, 2);
+        if (type == 0) {                                                   // stored
+            drop(b, (int)(b.cnt & 7u));
+            refill(b);
+            const uint32_t n = take(b, 16), nn = take(b, 16);
+            if ((n ^ nn) != 0xFFFFu) return E_STORED;
+            // the bit buffer holds whole bytes now: hand them back
+            uint32_t p = b.pos - b.cnt / 8u;
+            if (p + n > in_len) return E_INPUT;
+            if (o.op + n > o.cap) return E_OVERRUN;
+            uint32_t left = n;
+            while (left) {
+                const uint32_t k = left < (uint32_t)GI_LANES ? left : (uint32_t)GI_LANES;
+                for (uint32_t i = (uint32_t)lane; i < k; i += GI_LANES) w.ring[(o.op + i) & RMASK] = in[p + i];
+                o.op += k; p += k; left -= k;
+                flush_lines(w, o, false);
+            }
+            b.pos = p; b.buf = 0; b.cnt = 0;
+        } else if (type == 1 || type == 2) {
+            int n_lit, n_dist;
+            if (type == 1) {                                               // fixed code (RFC 1951 3.2.6)
+                for (int i = lane; i < 288; i += GI_LANES) w.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+                for (int i = lane; i < 32; i += GI_LANES) w.lens[288 + i] = 5;
+                GI_WAVE_SYNC();
+                n_lit = 288; n_dist = 30;
+                // (symbols 30, 31 of the fixed distance code never occur; building over 32 keeps the code complete)
+                if (build(w.lens, 288, LIT_TB, w.lit_tab, w.lit_sorted, w.lit_count)) return E_LENS;
+                if (build(w.lens + 288, 32, DIST_TB, w.dist_tab, w.dist_sorted, w.dist_count)) return E_LENS;
+            } else {                                                       // dynamic code: the header
+                n_lit = (int)take(b, 5) + 257; n_dist = (int)take(b, 5) + 1;
+                const int n_cl = (int)take(b, 4) + 4;
+                if (n_lit > 286 || n_dist > 30) return E_LENS;
+                uint8_t cl[19];
+                for (int i = 0; i < 19; ++i) cl[i] = 0;
+                for (int i = 0; i < n_cl; ++i) { refill(b); cl[CLORD[i]] = (uint8_t)take(b, 3); }
+                // the code-length code: 7-bit direct table in the distance table's space (rebuilt right after)
+                for (int i = lane; i < 19; i += GI_LANES) w.lens[i] = cl[i];
+                GI_WAVE_SYNC();
+                if (build(w.lens, 19, 7, w.dist_tab, w.dist_sorted, w.dist_count)) return E_LENS;
+                uint8_t prev = 0;
+                int i = 0;
+                uint8_t* L = w.lens;                                       // (overwrites the 19 entries just used)
+                while (i < n_lit + n_dist) {
+                    refill(b);
+                    const uint16_t e = w.dist_tab[peek(b, 7)];
+                    if (e == NO_CODE || e == LONG_CODE) return E_LENS;
+                    drop(b, e & 15);
+                    const int sym = e >> 4;
+                    if (sym < 16) { if (lane == 0) L[i] = (uint8_t)sym; prev = (uint8_t)sym; ++i; continue; }
+                    int rep; uint8_t v;
+                    if (sym == 16) { if (i == 0) return E_LENS; rep = 3 + (int)take(b, 2); v = prev; }
+                    else if (sym == 17) { rep = 3 + (int)take(b, 3); v = 0; }
+                    else { rep = 11 + (int)take(b, 7); v = 0; }
+                    if (i + rep > n_lit + n_dist) return E_LENS;
+                    for (int k = lane; k < rep; k += GI_LANES) L[i + k] = v;
+                    i += rep; prev = v;
+                }
+                GI_WAVE_SYNC();
+                if (w.lens[256] == 0) return E_LENS;                       // no end-of-block code
+                if (build(w.lens, n_lit, LIT_TB, w.lit_tab, w.lit_sorted, w.lit_count)) return E_LENS;
+                if (build(w.lens + n_lit, n_dist, DIST_TB, w.dist_tab, w.dist_sorted, w.dist_count)) return E_LENS;
+            }
+            // the symbols
+            for (;;) {
+                refill(b);
+                const int sym = decode(b, w.lit_tab, LIT_TB, w.lit_sorted, w.lit_count);
+                if (sym < 0) return E_CODE;
+                if (sym < 256) {
+                    if (o.op >= o.cap) return E_OVERRUN;
+                    if (lane == 0) w.ring[o.op & RMASK] = (uint8_t)sym;
+                    o.op++;
+                    if ((o.op & 63u) == 0) flush_lines(w, o, false);
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym >= 286) return E_CODE;
+                const int ls = sym - 257;
+                refill(b);
+                const uint32_t len = LBASE[ls] + take(b, LEXT[ls]);
+                const int ds = decode(b, w.dist_tab, DIST_TB, w.dist_sorted, w.dist_count);
+                if (ds < 0 || ds >= 30) return E_CODE;
+                refill(b);
+                const uint32_t dist = DBASE[ds] + take(b, DEXT[ds]);
+                const int rc = copy_match(w, o, len, dist);
+                if (rc) return rc;
+            }
+        } else return E_BTYPE;
+        if (final) break;
+    }
+    flush_lines(w, o, true);
+    if (o.op != isize) return E_SIZE;
+    // every consumed bit must lie inside the block's input (the bit buffer may have read ahead)
+    if (b.pos - b.cnt / 8u > in_len) return E_INPUT;
+    return OK;
+}
+
+}  // namespace gi

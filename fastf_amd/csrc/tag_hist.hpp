@@ -183,7 +183,7 @@ static int th_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 n, 
         if (!((pass_mask >> q) & 1)) continue;
         const u64* src = flip ? tmp : keys;
         u64* dst = flip ? keys : tmp;
-        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt, SegMap{nullptr, nullptr, 0, 0});
+        hipLaunchKernelGGL(tile_count_kernel<false>, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, 8 * q, cnt, ipt, SegMap{nullptr, nullptr, 0, 0});
         hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         launch_scatter(8 * q, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt);
         flip ^= 1;

@@ -554,7 +554,7 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     }
     if (e->d_tilebase.ensure(t1 * sizeof(u64))) return 1;
     if (e->d_halfhits.ensure(t1 * 16 * sizeof(u32))) return 1;
-    if (e->d_tileseg.ensure((ts + 8) * sizeof(ulonglong2))) return 1;
+    if (e->d_tileseg.ensure((ts + 8) * sizeof(TileSeg))) return 1;
     if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
@@ -726,6 +726,10 @@ static void launch_scatter(u32 shift, u32 T, hipStream_t s, const u64* src, u64*
                            const u32* bin_tot, u32 ipt, const SegMap seg = SegMap{nullptr, nullptr, 0, 0}) {
     T = tile_grid(T);
 #define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, seg, g_stamps)
+    if (seg.prefix) {                   // the one segmented pass: run-time shift, map lookup compiled in
+        hipLaunchKernelGGL((scatter_kernel<-1, true>), dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, seg, g_stamps);
+        return;
+    }
     const bool rt = (shift & 7u) != 0 || getenv("FASTF_SORT_RUNTIME_SHIFT");
     switch (rt ? 64u : shift) {
     case 0: SC(0); break;  case 8: SC(8); break;  case 16: SC(16); break; case 24: SC(24); break;
@@ -736,9 +740,10 @@ static void launch_scatter(u32 shift, u32 T, hipStream_t s, const u64* src, u64*
 }
 
 static int set_scatter_lds_limit() {
-    const void* fns[9] = {(const void*)scatter_kernel<0>, (const void*)scatter_kernel<8>, (const void*)scatter_kernel<16>,
-                          (const void*)scatter_kernel<24>, (const void*)scatter_kernel<32>, (const void*)scatter_kernel<40>,
-                          (const void*)scatter_kernel<48>, (const void*)scatter_kernel<56>, (const void*)scatter_kernel<-1>};
+    const void* fns[10] = {(const void*)scatter_kernel<0>, (const void*)scatter_kernel<8>, (const void*)scatter_kernel<16>,
+                           (const void*)scatter_kernel<24>, (const void*)scatter_kernel<32>, (const void*)scatter_kernel<40>,
+                           (const void*)scatter_kernel<48>, (const void*)scatter_kernel<56>, (const void*)scatter_kernel<-1>,
+                           (const void*)scatter_kernel<-1, true>};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) return 1;
     return 0;
@@ -762,9 +767,9 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         // the keys are the segmented output of the streaming K1b: the first pass reads through the region map
         if (!e->seg_n) return set_err("FASTF_SORT_SEGMENTED without a preceding FASTF_PROBE_SEGMENTED probe_pack");
         if (passes == 0) return set_err("segmented keys need at least one sort pass");
-        seg = SegMap{(const u64*)e->d_segprefix.p, (const ulonglong2*)e->d_tileseg.p, e->seg_n, e->seg_stride};
+        seg = SegMap{(const u64*)e->d_segprefix.p, (const TileSeg*)e->d_tileseg.p, e->seg_n, e->seg_stride};
         hipLaunchKernelGGL(seg_tiles_kernel, dim3(std::min<u32>((T + 255) / 256, 1024)), dim3(256), 0, s, seg.prefix, seg.n_seg,
-                           seg.stride, ipt * SORT_THREADS, (ulonglong2*)e->d_tileseg.p);
+                           seg.stride, ipt * SORT_THREADS, (TileSeg*)e->d_tileseg.p);
     }
     const SegMap none{nullptr, nullptr, 0, 0};
     for (u32 q = 0; q < passes; ++q) {
@@ -772,7 +777,8 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         u64* dst = (q & 1) ? keys : tmp;
         const u32 shift = low_bit + 8 * q;
         t_begin(e, s);
-        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt, q == 0 ? seg : none);
+        if (q == 0 && seg.prefix) hipLaunchKernelGGL(tile_count_kernel<true>, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt, seg);
+        else hipLaunchKernelGGL(tile_count_kernel<false>, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt, none);
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
         hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         t_begin(e, s);

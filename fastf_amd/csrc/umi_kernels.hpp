@@ -837,10 +837,12 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
     if (tid == 4) sp.seg_count[blockIdx.x] = s_cursor;
 }
 
-// the map from the logical key index (regions back to back) to the segmented buffer.  Per sort tile one 16-byte
-// entry {delta, hi}: keys of the tile with logical index < hi live at index + delta (the region of the tile's first
-// key); the few tiles that run past a region boundary find the region of their later keys by a search in prefix[].
-struct SegMap { const u64* prefix; const ulonglong2* tile_seg; u32 n_seg; u64 stride; };   // prefix == nullptr: contiguous buffer
+// the map from the logical key index (regions back to back) to the segmented buffer.  Per sort tile one 32-byte entry
+// {delta1, hi1, delta2, hi2}: keys of the tile with logical index < hi1 live at index + delta1 (the region of the tile's
+// first key), those below hi2 at index + delta2 (the next region that holds keys); only a tile that runs through more
+// than two regions (regions of a few keys) searches prefix[].
+struct TileSeg { u64 delta1, hi1, delta2, hi2; };
+struct SegMap { const u64* prefix; const TileSeg* tile_seg; u32 n_seg; u64 stride; };   // prefix == nullptr: contiguous buffer
 
 // prefix[b] = keys in the regions before b, prefix[n_seg] = total, also stored to *n_out (the key count the sort reads)
 __global__ __launch_bounds__(1024) void seg_scan_kernel(const u64* __restrict__ seg_count, u32 n_seg, u64* __restrict__ prefix,
@@ -876,18 +878,25 @@ __device__ __forceinline__ u32 seg_region_of(const u64* __restrict__ prefix, u32
 }
 
 __global__ __launch_bounds__(256) void seg_tiles_kernel(const u64* __restrict__ prefix, u32 n_seg, u64 stride, u32 tile_keys,
-                                                        ulonglong2* __restrict__ tile_seg) {
+                                                        TileSeg* __restrict__ tile_seg) {
     const u64 total = prefix[n_seg];
     const u64 T = (total + tile_keys - 1) / tile_keys;
     for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < T; t += (u64)gridDim.x * 256) {
         const u64 first = t * tile_keys;
         const u32 b = seg_region_of(prefix, n_seg, first);
-        tile_seg[t] = make_ulonglong2((u64)b * stride - prefix[b], prefix[b + 1]);
+        TileSeg ts;
+        ts.delta1 = (u64)b * stride - prefix[b]; ts.hi1 = prefix[b + 1];
+        u32 b2 = b + 1;                                   // the next region that holds keys (if any)
+        while (b2 < n_seg && prefix[b2 + 1] == ts.hi1) ++b2;
+        if (b2 < n_seg) { ts.delta2 = (u64)b2 * stride - prefix[b2]; ts.hi2 = prefix[b2 + 1]; }
+        else { ts.delta2 = 0; ts.hi2 = ts.hi1; }
+        tile_seg[t] = ts;
     }
 }
 
-__device__ __forceinline__ u64 seg_phys(const SegMap m, u64 idx, const ulonglong2 ts) {
-    if (idx < ts.y) return idx + ts.x;
+__device__ __forceinline__ u64 seg_phys(const SegMap m, u64 idx, const TileSeg ts) {
+    if (idx < ts.hi1) return idx + ts.delta1;
+    if (idx < ts.hi2) return idx + ts.delta2;
     const u32 b = seg_region_of(m.prefix, m.n_seg, idx);
     return (u64)b * m.stride + (idx - m.prefix[b]);
 }
@@ -923,6 +932,7 @@ __device__ __forceinline__ u32 xcd_tile(u32 T, u32 r) {
 
 // per-tile digit counts: cnt[d * T + tile].  Four LDS copies of the histogram (lane & 3) keep the
 // same-address atomic conflicts of skewed digits (e.g. the constant length bits) four times shorter.
+template <bool SEG>
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
                                                                   u32 shift, u32* __restrict__ cnt, u32 ipt, const SegMap seg) {
     __shared__ u32 s_h[4 * RADIX];
@@ -938,8 +948,8 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
         const u64 base = (u64)tile * ipt * SORT_THREADS;
         u32* my = s_h + (threadIdx.x & 3) * RADIX;
         u64 k[SORT_IPT];
-        if (seg.prefix) {                                    // first pass over the segmented output of the streaming K1b
-            const ulonglong2 ts = seg.tile_seg[tile];
+        if constexpr (SEG) {                                 // first pass over the segmented output of the streaming K1b
+            const TileSeg ts = seg.tile_seg[tile];
 #pragma unroll
             for (int j = 0; j < SORT_IPT; ++j) {
                 const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
@@ -1024,10 +1034,11 @@ __device__ __forceinline__ u32 digit_of(u64 key, u32 rshift) {
 
 // scatter: stable within the tile (wave-major, item, lane == memory order).  FULL tiles skip every
 // bounds check (only the last tile of a pass is partial).
-template <int SHIFT, bool FULL>
+template <int SHIFT, bool FULL, bool SEG>
 __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
                                              u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                             const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, u64* stamps = nullptr) {
+                                             const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, const int tid,
+                                             u64* stamps = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1039,7 +1050,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     u32* s_delta = s_whist + SORT_WAVES * RADIX;                                   // [256] global - local start
     u32* s_start = s_delta + RADIX;                                                // [256] local bin start
     u32* s_wtot  = s_start + RADIX;                                                // [4] tile-local, [4] global
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const int lane = tid & (WAVE - 1), w = tid >> 6;       // (tid comes in opaque, see scatter_kernel)
 
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
     // this tile's global bin offsets: issued now, needed only after the ranking
@@ -1049,8 +1060,8 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
     u64 key[SORT_IPT];
     const u32 wbase = (u32)w * (u32)ipt * WAVE;
-    if (seg.prefix) {                                          // first pass over the segmented output of the streaming K1b
-        const ulonglong2 ts = seg.tile_seg[tile];
+    if constexpr (SEG) {                                       // first pass over the segmented output of the streaming K1b
+        const TileSeg ts = seg.tile_seg[tile];
 #pragma unroll
         for (int j = 0; j < SORT_IPT; ++j) {
             const u32 li = wbase + j * WAVE + lane;
@@ -1141,8 +1152,10 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
 #undef STAMP
 }
 
-template <int SHIFT>
-__global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
+// SEG: the input is the segmented key buffer of the streaming K1b (first pass only; its own instantiation, so that the
+// map lookup does not cost the other passes registers: 47 VGPRs keep four workgroups on a CU)
+template <int SHIFT, bool SEG = false>
+__global__ __launch_bounds__(SORT_THREADS, 8) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
                                                                const u64* __restrict__ n_ptr,
                                                                const u32* __restrict__ off, const u32* __restrict__ bin_tot,
                                                                u32 ipt, u32 rshift, const SegMap seg, u64* stamps) {
@@ -1162,9 +1175,13 @@ __global__ __launch_bounds__(SORT_THREADS) void scatter_kernel(const u64* __rest
         if (tile >= T) return;                               // block-uniform
         const u64 base = (u64)tile * tile_keys;
         const u32 n_valid = (u32)((n - base) < (u64)tile_keys ? (n - base) : (u64)tile_keys);
+        // The thread index is made opaque per tile: otherwise every per-thread address of the tile body is hoisted out of
+        // the loop and stays live across it (75 VGPRs, three workgroups per CU, instead of 47 and four).
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
         // (no barrier between tiles: whatever a tile reads last from LDS is rewritten only after two barriers of the next)
-        if (n_valid == tile_keys) scatter_tile<SHIFT, true>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, stamps);
-        else scatter_tile<SHIFT, false>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, stamps);
+        if (n_valid == tile_keys) scatter_tile<SHIFT, true, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, stamps);
+        else scatter_tile<SHIFT, false, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, stamps);
     }
 }
 
@@ -1231,7 +1248,7 @@ __global__ __launch_bounds__(K3_THREADS) void head_count_kernel(const ReducePara
 }
 
 template <bool UMI_ROWS>
-__global__ __launch_bounds__(K3_THREADS) void reduce_kernel(const ReduceParams p) {
+__global__ __launch_bounds__(K3_THREADS, 8) void reduce_kernel(const ReduceParams p) {
     // (item, wave) units in tile order: heads / distinct flags per unit, then their exclusive scans
     __shared__ u32 s_h[K3_IPT * K3_WAVES], s_d[K3_IPT * K3_WAVES];
     __shared__ u32 s_tot[2];

@@ -124,3 +124,37 @@ class C3:
         xf = np.where((np.arange(n) & 3) == 0, 17, 25).astype(np.int32)
         xf[(kind & 4) != 0] = 0
         return flags, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)
+
+
+class C2:
+    """BASELINE configs[1]: 10 M synthetic records, 10 k barcodes x 30 k genes, keep-all (--cell 1 --depth 1), uniform
+    cells and genes, 10-bp UMIs — round 1's bench workload, kept for comparison (bench.py --workload c2).
+    Same interface as C3; generated on the host through the string-level generator and the product's own packer."""
+
+    def __init__(self, n_total=10_000_000):
+        import fastf_amd as F
+        self.n_total = int(n_total)
+        self.seg_len = self.n_total // SEGMENTS
+        assert self.seg_len * SEGMENTS == self.n_total
+        self.bt, self.ft, self.bar, self.genes = synth.make_lists(10_000, 30_000, seed=4242)
+        self.lists = F.Lists(self.bt, self.ft, 1.0, SEED)
+        self._cache = {}
+        self._pool = None
+        self._F = F
+
+    def _seg(self, seg):
+        if seg not in self._cache:
+            fl, xf, cb, gx, ub = synth.make_records(self.seg_len, self.bar, self.genes, seed=100 + seg, umi_len=10)
+            s = (fl, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub))
+            self._cache[seg] = (s, self._F.pack_records(self.lists, *s))
+        return self._cache[seg]
+
+    def segment_packed(self, seg, dev, n=None):
+        import torch
+        n = self.seg_len if n is None else int(n)
+        cbk, gxk, umi, meta = self._seg(seg)[1]
+        return (torch.from_numpy(cbk[:n].view(np.int64)).to(dev), torch.from_numpy(gxk[:n].view(np.int64)).to(dev),
+                torch.from_numpy(umi[:n].view(np.int32)).to(dev), torch.from_numpy(meta[:n].view(np.int32)).to(dev))
+
+    def segment_strings(self, seg, dev, n):
+        return tuple(a[:n] for a in self._seg(seg)[0])
