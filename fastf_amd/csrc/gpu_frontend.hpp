@@ -29,11 +29,12 @@ struct fastf_gpuinf {
     int device = 0;
     static constexpr int NS = 3;                                   // slices in flight
     hipStream_t s[NS] = {nullptr, nullptr, nullptr};
-    void* h_comp[NS] = {nullptr, nullptr, nullptr}; size_t h_comp_cap[NS] = {0, 0, 0};      // pinned staging of compressed bytes
     GiBlock* h_blk[NS] = {nullptr, nullptr, nullptr}; size_t h_blk_cap[NS] = {0, 0, 0};
     uint8_t* h_status[NS] = {nullptr, nullptr, nullptr};
     DevBuf d_comp[NS], d_out[NS], d_blk[NS], d_status[NS];
-    double t_stage = 0, t_wait = 0; u64 n_blocks = 0, n_declined = 0;
+    hipEvent_t ev0 = nullptr, ev_done[NS] = {nullptr, nullptr, nullptr};
+    size_t first[NS + 1] = {0, 0, 0, 0}; size_t pending_n = 0; int pending_slices = 0;
+    u64 n_blocks = 0, n_declined = 0;
 };
 
 extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) {
@@ -42,8 +43,10 @@ extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     fastf_gpuinf* g = new fastf_gpuinf();
     g->device = device;
-    for (int i = 0; i < fastf_gpuinf::NS; ++i)
-        if (hipStreamCreateWithFlags(&g->s[i], hipStreamNonBlocking) != hipSuccess) { fastf_gpuinf_destroy(g); set_err("stream creation failed"); return nullptr; }
+    bool ok = hipEventCreate(&g->ev0) == hipSuccess;
+    for (int i = 0; i < fastf_gpuinf::NS && ok; ++i)
+        ok = hipStreamCreateWithFlags(&g->s[i], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&g->ev_done[i]) == hipSuccess;
+    if (!ok) { fastf_gpuinf_destroy(g); set_err("stream/event creation failed"); return nullptr; }
     return g;
 }
 
@@ -52,11 +55,12 @@ extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) {
     (void)hipSetDevice(g->device);
     for (int i = 0; i < fastf_gpuinf::NS; ++i) {
         if (g->s[i]) { (void)hipStreamSynchronize(g->s[i]); (void)hipStreamDestroy(g->s[i]); }
-        if (g->h_comp[i]) (void)hipHostFree(g->h_comp[i]);
+        if (g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
         if (g->h_blk[i]) (void)hipHostFree(g->h_blk[i]);
         if (g->h_status[i]) (void)hipHostFree(g->h_status[i]);
         g->d_comp[i].release(); g->d_out[i].release(); g->d_blk[i].release(); g->d_status[i].release();
     }
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
     delete g;
 }
 
@@ -66,40 +70,33 @@ extern "C" void fastf_gpuinf_stats(const fastf_gpuinf_t* g, uint64_t* n_blocks, 
 }
 
 // blocks [0, n): compressed payload of block i at comp + blk[i].coff (clen bytes), inflated to out + blk[i].uoff (isize
-// bytes).  `out` must be pinned host memory (fastf_pinned_alloc).  status[i] != 0: the device declined block i (the
-// caller inflates it on the host).  Returns non-zero only when nothing could be run (the caller then inflates the
-// whole window on the host).
-extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
-                                unsigned char* out, uint8_t* status) {
+// bytes).  `comp` (readable 64 bytes past the last block) and `out` must be pinned host memory (fastf_pinned_alloc /
+// fastf_pinned_register): both directions are plain asynchronous copies.
+// submit() only queues the work — up to three slices on alternating streams, so that the H2D of one slice, the kernel of
+// another and the D2H of a third overlap — and returns; the caller is free to inflate other blocks on the host
+// meanwhile.  wait() returns when everything has landed: status[i] != 0 means the device declined block i (the caller
+// inflates it on the host); *device_ms = time from the first copy to the last.
+extern "C" int fastf_gpuinf_submit(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
+                                   unsigned char* out) {
     if (!g) return set_err("null inflate handle");
+    g->pending_n = 0;
     if (n == 0) return 0;
     HIP_OK(hipSetDevice(g->device));
     constexpr int NS = fastf_gpuinf::NS;
-    // slices of about 1/8 of the window (at least 256 blocks), so that copies and kernels of neighbours overlap
-    const size_t per = std::max<size_t>(256, (n + 7) / 8);
-    size_t first[64]; int n_slices = 0;
-    for (size_t a = 0; a < n && n_slices < 63; a += per) first[n_slices++] = a;
-    first[n_slices] = n;
+    // A block takes one wave several milliseconds (the decode is a chain of dependent table look-ups), so throughput is
+    // the number of blocks in flight over that latency: slices of at least 4096 blocks, at most NS of them.
+    const size_t per = std::max<size_t>(std::min<size_t>(4096, n), (n + NS - 1) / NS);
+    int n_slices = 0;
+    for (size_t a = 0; a < n; a += per) g->first[n_slices++] = a;
+    g->first[n_slices] = n;
+    HIP_OK(hipEventRecord(g->ev0, g->s[0]));
     for (int sl = 0; sl < n_slices; ++sl) {
-        const int q = sl % NS;
-        const size_t a = first[sl], b = first[sl + 1], nb = b - a;
-        HIP_OK(hipStreamSynchronize(g->s[q]));                      // the slice that used this slot three slices ago is done
-        if (sl >= NS) {                                              // ... and its statuses are on the host
-            const size_t pa = first[sl - NS], pb = first[sl - NS + 1];
-            memcpy(status + pa, g->h_status[q], pb - pa);
-        }
-        // compressed bytes of the slice are contiguous in the file: one staging copy, offsets relative to its start
-        const u64 c0 = blk[a].coff, c1 = blk[b - 1].coff + blk[b - 1].clen;
+        const int q = sl;
+        const size_t a = g->first[sl], b = g->first[sl + 1], nb = b - a;
+        const u64 c0 = blk[a].coff & ~(u64)63, c1 = blk[b - 1].coff + blk[b - 1].clen;
         const u64 u0 = blk[a].uoff; u64 u1 = u0;
         for (size_t i = a; i < b; ++i) u1 = std::max<u64>(u1, blk[i].uoff + blk[i].isize);
         const size_t cbytes = (size_t)(c1 - c0) + 64, ubytes = (size_t)(u1 - u0);
-        if (cbytes > g->h_comp_cap[q]) {
-            if (g->h_comp[q]) (void)hipHostFree(g->h_comp[q]);
-            g->h_comp[q] = nullptr; g->h_comp_cap[q] = 0;
-            const size_t cap = cbytes + cbytes / 4;
-            HIP_OK(hipHostMalloc(&g->h_comp[q], cap, hipHostMallocDefault));
-            g->h_comp_cap[q] = cap;
-        }
         if (nb > g->h_blk_cap[q]) {
             if (g->h_blk[q]) (void)hipHostFree(g->h_blk[q]);
             if (g->h_status[q]) (void)hipHostFree(g->h_status[q]);
@@ -109,27 +106,46 @@ extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, co
             HIP_OK(hipHostMalloc((void**)&g->h_status[q], cap, hipHostMallocDefault));
             g->h_blk_cap[q] = cap;
         }
-        memcpy(g->h_comp[q], comp + c0, (size_t)(c1 - c0));
-        memset((char*)g->h_comp[q] + (c1 - c0), 0, 64);               // the bit reader may look 8 bytes past a block
         for (size_t i = a; i < b; ++i) g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0};
         if (g->d_comp[q].ensure(cbytes) || g->d_out[q].ensure(std::max<size_t>(ubytes, 64)) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
             g->d_status[q].ensure(nb))
             return 1;
         hipStream_t s = g->s[q];
-        HIP_OK(hipMemcpyAsync(g->d_comp[q].p, g->h_comp[q], cbytes, hipMemcpyHostToDevice, s));
+        if (q) HIP_OK(hipStreamWaitEvent(s, g->ev0, 0));
+        HIP_OK(hipMemcpyAsync(g->d_comp[q].p, comp + c0, cbytes, hipMemcpyHostToDevice, s));
         HIP_OK(hipMemcpyAsync(g->d_blk[q].p, g->h_blk[q], nb * sizeof(GiBlock), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((u32)nb), dim3(64), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
                            (const uint8_t*)g->d_comp[q].p, (uint8_t*)g->d_out[q].p, (uint8_t*)g->d_status[q].p);
         HIP_OK(hipGetLastError());
         if (ubytes) HIP_OK(hipMemcpyAsync(out + u0, g->d_out[q].p, ubytes, hipMemcpyDeviceToHost, s));
         HIP_OK(hipMemcpyAsync(g->h_status[q], g->d_status[q].p, nb, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipEventRecord(g->ev_done[q], s));
     }
-    for (int sl = std::max(0, n_slices - NS); sl < n_slices; ++sl) {
-        const int q = sl % NS;
-        HIP_OK(hipStreamSynchronize(g->s[q]));
-        memcpy(status + first[sl], g->h_status[q], first[sl + 1] - first[sl]);
-    }
-    g->n_blocks += n;
-    for (size_t i = 0; i < n; ++i) g->n_declined += status[i] != 0;
+    g->pending_n = n; g->pending_slices = n_slices;
     return 0;
+}
+
+extern "C" int fastf_gpuinf_wait(fastf_gpuinf_t* g, uint8_t* status, double* device_ms) {
+    if (!g) return set_err("null inflate handle");
+    if (device_ms) *device_ms = 0;
+    if (!g->pending_n) return 0;
+    HIP_OK(hipSetDevice(g->device));
+    float worst = 0;
+    for (int sl = 0; sl < g->pending_slices; ++sl) {
+        HIP_OK(hipEventSynchronize(g->ev_done[sl]));
+        memcpy(status + g->first[sl], g->h_status[sl], g->first[sl + 1] - g->first[sl]);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g->ev0, g->ev_done[sl]) == hipSuccess && ms > worst) worst = ms;
+    }
+    if (device_ms) *device_ms = worst;
+    g->n_blocks += g->pending_n;
+    for (size_t i = 0; i < g->pending_n; ++i) g->n_declined += status[i] != 0;
+    g->pending_n = 0;
+    return 0;
+}
+
+extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
+                                unsigned char* out, uint8_t* status) {
+    if (fastf_gpuinf_submit(g, comp, blk, n, out)) return 1;
+    return fastf_gpuinf_wait(g, status, nullptr);
 }

@@ -40,6 +40,21 @@ void fastf_lists_free(fastf_lists_t *l);
 /* ---- BAM front end: replaces sam_open/sam_hdr_read/sam_read1/bam_aux_get/bam_aux2Z/
  *      bam_aux2i (bam2db_ds.c:141,340,360-417) for BGZF-compressed BAM ---- */
 typedef struct fastf_bam fastf_bam_t;
+/* gpu_frontend.hpp (HIP side of the library): BGZF inflate of a reader window on the device.  `out` is pinned host
+ * memory; status[i] != 0 = the device declined block i (the host inflates it).  FASTF_GPU_INFLATE=1 turns it on. */
+typedef struct fastf_gpuinf fastf_gpuinf_t;
+typedef struct { uint64_t coff; uint32_t clen, isize; uint64_t uoff; } fastf_gpuinf_blk_t;
+fastf_gpuinf_t *fastf_gpuinf_create(int device);
+void fastf_gpuinf_destroy(fastf_gpuinf_t *g);
+int  fastf_gpuinf_submit(fastf_gpuinf_t *g, const unsigned char *comp, const fastf_gpuinf_blk_t *blk, size_t n, unsigned char *out);
+int  fastf_gpuinf_wait(fastf_gpuinf_t *g, uint8_t *status, double *device_ms);
+int  fastf_gpuinf_run(fastf_gpuinf_t *g, const unsigned char *comp, const fastf_gpuinf_blk_t *blk, size_t n,
+                      unsigned char *out, uint8_t *status);
+void fastf_gpuinf_stats(const fastf_gpuinf_t *g, uint64_t *n_blocks, uint64_t *n_declined);
+void *fastf_pinned_alloc(size_t bytes);
+void fastf_pinned_free(void *p);
+int  fastf_pinned_register(void *p, size_t bytes);
+void fastf_pinned_unregister(void *p);
 void fastf_bam_print_profile(const fastf_bam_t *b);   /* FASTF_BAM_PROFILE=1: stage times of the reader on stderr */
 fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */

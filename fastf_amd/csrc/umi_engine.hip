@@ -18,6 +18,7 @@
 
 extern "C" {
 #include "fastf_amd.h"
+#include "host_io.h"
 }
 
 using namespace fastf;
@@ -1251,3 +1252,8 @@ extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t sk
 // one process, several devices: same translation unit, drives sub-engines through the launch_* functions above
 // ------------------------------------------------------------------------------------
 #include "multi_engine.hpp"
+
+// ------------------------------------------------------------------------------------
+// device side of the BAM front end (BGZF inflate of reader windows)
+// ------------------------------------------------------------------------------------
+#include "gpu_frontend.hpp"
