@@ -55,14 +55,14 @@ namespace gi {
 
 constexpr int LIT_TB = 10, DIST_TB = 8;
 constexpr uint32_t RING = 4096, RMASK = RING - 1, RING_SAFE = RING - 64;
-constexpr uint16_t LONG_CODE = 0xFFFF, NO_CODE = 0;
+constexpr uint16_t LONG_CODE = 0xFFFF, NO_CODE = 0xFFFE;      // both >= 0xFFFE: one compare on the symbol path
 
 // error codes (0 = ok)
 enum { OK = 0, E_BTYPE = 1, E_STORED = 2, E_LENS = 3, E_CODE = 4, E_DIST = 5, E_OVERRUN = 6, E_INPUT = 7, E_SIZE = 8 };
 
 // per-wave working set (LDS on the device)
 struct Work {
-    uint16_t lit_tab[1 << LIT_TB];      // (symbol << 4) | code length; 0: no code; LONG_CODE: longer than the table
+    uint16_t lit_tab[1 << LIT_TB];      // (symbol << 4) | code length; NO_CODE; LONG_CODE: longer than the table
     uint16_t dist_tab[1 << DIST_TB];    // same; also holds the 7-bit table of the code-length code while a header is read
     uint16_t lit_sorted[288], dist_sorted[32];   // symbols by (length, symbol): the canonical order, for the long-code walk
     uint16_t lit_count[16], dist_count[16];
@@ -164,11 +164,11 @@ GI_FN int build(Work& w, const uint8_t* lens, int n_sym, int tb, uint16_t* tab, 
 // one symbol: direct table, or the count/offset walk for codes longer than the table (RFC 1951 3.2.2; one bit per step)
 GI_FN int decode(Bits& b, const uint16_t* tab, int tb, const uint16_t* sorted, const uint16_t* count) {
     const uint32_t e = GI_UNIFORM(tab[peek(b, tb)]);
-    if (e != LONG_CODE) {
-        if (e == NO_CODE) return -1;
+    if (e < 0xFFFEu) {                                    // the common case: the code is in the table
         drop(b, (int)(e & 15u));
         return (int)(e >> 4);
     }
+    if (e == NO_CODE) return -1;
     uint32_t code = 0, first = 0, index = 0;
     uint64_t bits = b.buf;
     for (int l = 1; l <= 15; ++l) {
@@ -180,14 +180,29 @@ GI_FN int decode(Bits& b, const uint16_t* tab, int tb, const uint16_t* sorted, c
     return -1;
 }
 
-struct Out { uint8_t* out; uint32_t cap, op, flushed; };
+// base value and number of extra bits of a length symbol (257..285 -> ls = 0..28) and of a distance symbol (0..29),
+// RFC 1951 3.2.5, computed instead of looked up: a table in memory costs a load (and a wait for every store in flight)
+// per match
+GI_FN void len_code(uint32_t ls, uint32_t& base, uint32_t& extra) {
+    if (ls < 8u) { base = 3u + ls; extra = 0; }
+    else if (ls == 28u) { base = 258u; extra = 0; }
+    else { extra = (ls - 4u) >> 2; base = 3u + ((4u + (ls & 3u)) << extra); }
+}
+GI_FN void dist_code(uint32_t ds, uint32_t& base, uint32_t& extra) {
+    if (ds < 4u) { base = 1u + ds; extra = 0; }
+    else { extra = (ds >> 1) - 1u; base = 1u + ((2u + (ds & 1u)) << extra); }
+}
+
+struct Out { uint8_t* out; uint32_t cap, op, flushed; uint32_t over; };   // over: output ran past cap (nothing is stored beyond it)
 
 // every completed 64-byte line of the ring goes to memory, one byte per lane
 GI_FN void flush_lines(Work& w, Out& o, bool all) {
     const int lane = GI_LANE();
     GI_WAVE_SYNC();
+    o.op = GI_UNIFORM(o.op); o.flushed = GI_UNIFORM(o.flushed);          // (wave-uniform by construction: tell the compiler)
     while (o.op - o.flushed >= 64u || (all && o.op > o.flushed)) {
         const uint32_t n = o.op - o.flushed >= 64u ? 64u : o.op - o.flushed;
+        if (o.flushed + n > o.cap) { o.over = 1; o.flushed += n; continue; }      // malformed stream: more output than ISIZE
         for (uint32_t i = (uint32_t)lane; i < n; i += GI_LANES) o.out[o.flushed + i] = w.ring[(o.flushed + i) & RMASK];
         o.flushed += n;
     }
@@ -195,8 +210,9 @@ GI_FN void flush_lines(Work& w, Out& o, bool all) {
 
 GI_FN int copy_match(Work& w, Out& o, uint32_t len, uint32_t dist) {
     const int lane = GI_LANE();
-    if (dist == 0 || dist > o.op) return E_DIST;
-    if (o.op + len > o.cap) return E_OVERRUN;
+    len = GI_UNIFORM(len); dist = GI_UNIFORM(dist); o.op = GI_UNIFORM(o.op);   // wave-uniform by construction: scalar control flow below
+    if (dist > o.op) return E_DIST;                        // (dist >= 1 by construction)
+    if (o.over) return E_OVERRUN;
 #ifndef GI_HOST
     // The source left the ring, i.e. it went to memory at least 62 line stores ago.  Memory operations of a wave complete
     // in order, so with at most four of them still outstanding every older store has landed — in BAM payloads most matches
@@ -210,7 +226,11 @@ GI_FN int copy_match(Work& w, Out& o, uint32_t len, uint32_t dist) {
         } else if (dist >= n) {
             for (uint32_t i = (uint32_t)lane; i < n; i += GI_LANES) w.ring[(o.op + i) & RMASK] = w.ring[(o.op - dist + i) & RMASK];
         } else {                                           // the match overlaps its own output: the pattern repeats
-            for (uint32_t i = (uint32_t)lane; i < n; i += GI_LANES) w.ring[(o.op + i) & RMASK] = w.ring[(o.op - dist + i % dist) & RMASK];
+            for (uint32_t i = (uint32_t)lane; i < n; i += GI_LANES) {
+                uint32_t r = i;                            // i mod dist without a division: dist < n <= 64, a few subtractions
+                while (r >= dist) r -= dist;
+                w.ring[(o.op + i) & RMASK] = w.ring[(o.op - dist + r) & RMASK];
+            }
         }
         GI_WAVE_SYNC();
         o.op += n; len -= n;
@@ -221,11 +241,6 @@ GI_FN int copy_match(Work& w, Out& o, uint32_t len, uint32_t dist) {
 
 // out must hold `isize` bytes; `in` must be readable 8 bytes past in_len
 GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t isize) {
-    static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
-                                       4097, 6145, 8193, 12289, 16385, 24577};
-    static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     const int lane = GI_LANE();
     Bits b;
@@ -233,7 +248,7 @@ GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* ou
     uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);         // bytes in front of `in` inside its first dword
     refill(b);
     drop(b, (int)(8u * lead));
-    Out o{out, isize, 0, 0};
+    Out o{out, isize, 0, 0, 0};
     for (;;) {
         refill(b);
         const uint32_t final = take(b, 1), type = take(b, 2);
@@ -304,27 +319,27 @@ GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* ou
                 if (build(w, w.lens, n_lit, LIT_TB, w.lit_tab, w.lit_sorted, w.lit_count)) return E_LENS;
                 if (build(w, w.lens + n_lit, n_dist, DIST_TB, w.dist_tab, w.dist_sorted, w.dist_count)) return E_LENS;
             }
-            // the symbols
+            // the symbols: at most two refills per symbol (>= 33 bits after each: code <= 15 + extra <= 13 bits)
             for (;;) {
                 refill(b);
                 const int sym = decode(b, w.lit_tab, LIT_TB, w.lit_sorted, w.lit_count);
-                if (sym < 0) return E_CODE;
                 if (sym < 256) {
-                    if (o.op >= o.cap) return E_OVERRUN;
+                    if (sym < 0) return E_CODE;
                     if (lane == 0) w.ring[o.op & RMASK] = (uint8_t)sym;
                     o.op++;
-                    if ((o.op & 63u) == 0) flush_lines(w, o, false);
+                    if ((o.op & 63u) == 0) { flush_lines(w, o, false); if (o.over) return E_OVERRUN; }
                     continue;
                 }
                 if (sym == 256) break;
                 if (sym >= 286) return E_CODE;
-                const int ls = sym - 257;
+                uint32_t lb, le, db, de;
+                len_code((uint32_t)sym - 257u, lb, le);
+                const uint32_t len = lb + take(b, (int)le);
                 refill(b);
-                const uint32_t len = LBASE[ls] + take(b, LEXT[ls]);
                 const int ds = decode(b, w.dist_tab, DIST_TB, w.dist_sorted, w.dist_count);
                 if (ds < 0 || ds >= 30) return E_CODE;
-                refill(b);
-                const uint32_t dist = DBASE[ds] + take(b, DEXT[ds]);
+                dist_code((uint32_t)ds, db, de);
+                const uint32_t dist = db + take(b, (int)de);
                 const int rc = copy_match(w, o, len, dist);
                 if (rc) return rc;
             }
@@ -332,6 +347,7 @@ GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* ou
         if (final) break;
     }
     flush_lines(w, o, true);
+    if (o.over) return E_OVERRUN;
     if (o.op != isize) return E_SIZE;
     // every consumed bit must lie inside the block's input (the bit buffer may have read ahead)
     if (b.pos * 4u - b.cnt / 8u > in_len + lead) return E_INPUT;
