@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
                     help="c3 = BASELINE configs[2] (the headline, default); c2 = BASELINE configs[1], 10 M keep-all records (round 1's workload)")
     ap.add_argument("--records", type=int, default=0, help="records of the whole job (all GPUs together); default 200 M (c3) / 10 M (c2)")
-    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=75_000_000, help="records timed on the CPU oracle (rank 0, N=1): whole segments of the job, about 10 s of one core")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-devpath", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -242,7 +242,7 @@ def main():
         if not args.no_devpath:
             out["device_path"] = device_path_leg(job, dev, local, N_total, out["counters"])
         if not args.no_cpu:
-            out["cpu_baseline"], out["parity_vs_cpu"] = cpu_leg(job, dev, local, min(args.cpu_sample, job.seg_len))
+            out["cpu_baseline"], out["parity_vs_cpu"] = cpu_leg(job, dev, local, max(1, min(args.cpu_sample // job.seg_len, workload.SEGMENTS)))
         else:
             out["cpu_baseline"] = None
         if not args.no_e2e:
@@ -296,25 +296,33 @@ def device_path_leg(job, dev, local, N_total, want):
             "same_result_as_resident_steps": bool(same)}
 
 
-def cpu_leg(job, dev, local, S):
+def cpu_leg(job, dev, local, n_seg):
     """the CPU oracle (port of the reference algorithm: hash probe + MT draw + sort/aggregate, no SQLite, no file I/O) on
-    the first S records of the job, 1 core; the GPU result on that sample must equal it bit for bit"""
+    the first n_seg segments of the job, 1 core; the GPU result on that sample must equal it bit for bit"""
     from oracle import oracle as O
     lists = job.lists
-    fl, xf, cbs, gxs, ubs = job.segment_strings(0, dev, S)
+    parts = [job.segment_strings(s, dev, job.seg_len) for s in range(n_seg)]
+    fl, xf = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    w = [max(p[i].dtype.itemsize for p in parts) for i in (2, 3, 4)]
+    cbs, gxs, ubs = (np.concatenate([p[i].astype("S%d" % w[i - 2]) for p in parts]) for i in (2, 3, 4))
+    del parts
+    S = len(fl)
     t1 = time.perf_counter()
     ora = O.run_bam2db(job.bt, job.ft, fl, xf, cbs, gxs, ubs, workload.RATE_CELL, workload.RATE_DEPTH, workload.SEED)
     cpu_dt = time.perf_counter() - t1
     base = {"value": S / cpu_dt, "unit": "records/s", "cores": 1, "kind": "port",
-            "sample": "first %d records of the same workload through oracle/fastf_oracle.c, %.1f s" % (S, cpu_dt),
+            "sample": "first %d records (%d of %d segments) of the same workload through oracle/fastf_oracle.c, %.1f s" % (S, n_seg, workload.SEGMENTS, cpu_dt),
             "note": "the reference's own bam2db (htslib + SQLite INSERT + GROUP BY + gz writers) ran at 0.24 M records/s on 1 core "
                     "in the survey session (BASELINE.md section 2); it cannot be built here (htslib absent)"}
     # the product's own packer on the strings, against the generator's direct packing, then the device result
     cbk, gxk, umi, meta = F.pack_records(lists, fl, xf, cbs, gxs, ubs)
-    c, g, u, m = (t.cpu().numpy() for t in job.segment_packed(0, dev, S))
-    nn = (meta & 4) != 0
-    pack_ok = (np.array_equal(cbk.view(np.int64), c) and np.array_equal(gxk.view(np.int64), g) and np.array_equal(meta.view(np.int32), m)
-               and np.array_equal(umi.view(np.int32)[nn], u[nn]))
+    pack_ok = True
+    for s_ in range(n_seg):
+        a, b = s_ * job.seg_len, (s_ + 1) * job.seg_len
+        c, g, u, m = (t.cpu().numpy() for t in job.segment_packed(s_, dev))
+        nn = (meta[a:b] & 4) != 0
+        pack_ok = pack_ok and (np.array_equal(cbk[a:b].view(np.int64), c) and np.array_equal(gxk[a:b].view(np.int64), g)
+                               and np.array_equal(meta[a:b].view(np.int32), m) and np.array_equal(umi[a:b].view(np.int32)[nn], u[nn]))
     e2 = F.Engine.from_lists(lists, rate_depth=workload.RATE_DEPTH, seed=workload.SEED, umi_max_bases=workload.UMI_LEN, device=local)
     try:
         e2.push(cbk, gxk, umi, meta)
