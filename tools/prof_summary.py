@@ -54,7 +54,7 @@ def main():
     for r in rows:
         tot[short(r["Name"])] += float(r["TotalDurationNs"]); calls[short(r["Name"])] += int(r["Calls"])
     avg = {k: tot[k] / calls[k] for k in tot}
-    tc = fetch.get("tile_count_kernel", [])
+    tc = fetch.get("tile_count_kernel<false>") or fetch.get("tile_count_kernel") or []   # <false> = the contiguous passes
     cal = (8.0 * n_keys) / (sum(tc) / len(tc) * 1024) if tc else None
     summ = {"_note": "per-launch averages; FETCH/WRITE in KiB as reported by rocprofv3 --pmc (separate passes); "
                      "hbm_bytes = FETCH*1024*2 (gfx950 correction) + WRITE*1024",
