@@ -74,8 +74,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
 
     /* bam2db needs a device anyway: unless told otherwise (FASTF_GPU_INFLATE=0) the BGZF inflate of big windows is
      * shared between the host threads and the device (host_io.c: hybrid inflate, every block CRC-checked on the host) */
-    setenv("FASTF_GPU_INFLATE", "1", 0);
-    bam = fastf_bam_open(bam_file, 0);
+    bam = fastf_bam_open2(bam_file, 0, 1);
     if (!bam) { fprintf(stderr, "Fail to open BAM file %s (%s)\n", bam_file, fastf_last_error()); goto done; }
     fprintf(stderr, "Opened BAM file %s successfully\n", bam_file);
 

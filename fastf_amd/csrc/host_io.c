@@ -612,7 +612,11 @@ static int bam_need(fastf_bam_t *b, size_t need)
     return 0;
 }
 
-fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
+fastf_bam_t *fastf_bam_open(const char *path, int n_threads) { return fastf_bam_open2(path, n_threads, -1); }
+
+/* gpu_inflate: what the caller wants when FASTF_GPU_INFLATE is unset (-1 / 0: host threads only; 1: BGZF inflate shared
+ * with the device; 2: wait for the device before the first window) */
+fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) { io_err("Fail to open BAM file %s", path); return NULL; }
@@ -622,7 +626,7 @@ fastf_bam_t *fastf_bam_open(const char *path, int n_threads)
     { const char *sh = getenv("FASTF_BAM_SERIAL_HOP"); b->serial_hop = sh && sh[0] == '1'; }
     setvbuf(fp, NULL, _IONBF, 0);
     {   const char *gi = getenv("FASTF_GPU_INFLATE"), *dv = getenv("FASTF_DEVICE");
-        b->gpu_wanted = gi ? (gi[0] == '1' ? 1 : gi[0] == '2' ? 2 : 0) : 0;       /* 2: wait for the device before the first window (tests) */
+        b->gpu_wanted = gi ? (gi[0] == '1' ? 1 : gi[0] == '2' ? 2 : 0) : (gpu_inflate == 1 || gpu_inflate == 2 ? gpu_inflate : 0);
         b->gpu_device = dv ? atoi(dv) : 0;
         const char *sh2 = getenv("FASTF_GPU_INFLATE_SHARE"); b->gpu_share = sh2 ? atof(sh2) : 0.6; }
     const char *w = getenv("FASTF_BAM_WINDOW");

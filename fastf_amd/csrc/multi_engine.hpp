@@ -54,17 +54,25 @@ struct fastf_multi {
     std::vector<u32> ufeature, ucell, uumi, ncopy; std::vector<uint8_t> unonnull;
 };
 
+// librccl is loaded once per process and never unloaded: the library keeps threads, thread-local state and exit
+// handlers of its own, and unmapping its code under them is not safe.
 static int multi_load_rccl(fastf_multi* m) {
-    if (m->rccl.lib) return 0;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return set_err("cannot load librccl.so (%s); FASTF_EXCHANGE=peer uses device-to-device copies instead", dlerror());
-    RcclApi& r = m->rccl;
-    r.lib = h;
+    static std::mutex mu;
+    static RcclApi shared;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!shared.lib) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return set_err("cannot load librccl.so (%s); FASTF_EXCHANGE=peer uses device-to-device copies instead", dlerror());
+        RcclApi r;
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) return set_err("librccl.so lacks %s", name)
-    SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
+        SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+        r.lib = h;
+        shared = r;
+    }
+    m->rccl = shared;
     return 0;
 }
 #define NCCL_OK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return set_err("%s failed: %s", #call, (m)->rccl.GetErrorString(r_)); } while (0)
@@ -72,10 +80,13 @@ static int multi_load_rccl(fastf_multi* m) {
 static void multi_destroy(fastf_engine* e) {
     fastf_multi* m = e->multi;
     if (!m) return;
+    for (MultiDev& md : m->d) {                             // nothing of the exchange may still be queued when its communicator goes
+        (void)hipSetDevice(md.dev);
+        if (md.e) (void)hipStreamSynchronize(md.e->s_compute);
+    }
     for (auto& c : m->comms) if (c && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(c);
     for (MultiDev& md : m->d) {
         (void)hipSetDevice(md.dev);
-        if (md.e) (void)hipStreamSynchronize(md.e->s_compute);
         for (int i = 0; i < 2; ++i) {
             if (md.h_stage[i]) (void)hipHostFree(md.h_stage[i]);
             md.d_stage[i].release();
@@ -88,7 +99,6 @@ static void multi_destroy(fastf_engine* e) {
         for (DevBuf* b : all) b->release();
         if (md.e) fastf_engine_destroy(md.e);
     }
-    if (m->rccl.lib) dlclose(m->rccl.lib);
     delete m;
     e->multi = nullptr;
 }

@@ -1140,6 +1140,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         }
         if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
         const u64 nnz = e->h_small[SM_NNZ];
+        if (nnz > n) return set_err("internal error: %llu matrix rows out of %llu keys", (unsigned long long)nnz, (unsigned long long)n);
         if (nnz > e->h_coo_cap) {                                       // pinned: the rows come back at PCIe rate
             if (e->h_coo) (void)hipHostFree(e->h_coo);
             e->h_coo = nullptr; e->h_coo_cap = 0;
@@ -1191,6 +1192,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
         HIP_OK(hipStreamSynchronize(s));
         if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
         nrows = e->h_small[SM_NROWS_U];
+        if (nrows > n) return set_err("internal error: %llu -u rows out of %llu keys", (unsigned long long)nrows, (unsigned long long)n);
         ukeys.resize(nrows);
         e->h_ncopy.resize(nrows);
         if (nrows) {
