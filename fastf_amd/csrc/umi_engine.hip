@@ -356,14 +356,15 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     HIP_OK(hipMemcpy(e->img_genes.p, img.data(), bytes, hipMemcpyHostToDevice));
     e->lds_genes.image = (const u32*)e->img_genes.p; e->lds_genes.words = words; e->lds_genes.n_perm = (u32)best_n;
     e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes; e->lds_genes.direct = direct ? 1u : 0u;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(filter_pack_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess) return 0;
+    {
+        const void* fns[] = {(const void*)filter_pack_kernel<true, false>, (const void*)filter_pack_kernel<true, true>,
+                             (const void*)filter_pack_stream_kernel<false, false, false>, (const void*)filter_pack_stream_kernel<false, false, true>,
+                             (const void*)filter_pack_stream_kernel<false, true, false>, (const void*)filter_pack_stream_kernel<false, true, true>,
+                             (const void*)filter_pack_stream_kernel<true, false, false>, (const void*)filter_pack_stream_kernel<true, false, true>,
+                             (const void*)filter_pack_stream_kernel<true, true, false>, (const void*)filter_pack_stream_kernel<true, true, true>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 0;
+    }
     const size_t per_block = bytes + 1024;                           // + the kernel's static LDS (about 0.5 KB)
     e->genes_blocks_per_cu = (u32)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / per_block));
     e->use_lds_genes = true;
@@ -673,8 +674,16 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
                                                         (unsigned long long)((u64)grid * region), (unsigned long long)stride);
         if (e->d_segcount.ensure(grid * sizeof(u64)) || e->d_segprefix.ensure((grid + 1) * sizeof(u64))) return 1;
         StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
-        if (e->genes_blocks_per_cu >= 2) hipLaunchKernelGGL((filter_pack_stream_kernel<false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp);
-        else hipLaunchKernelGGL((filter_pack_stream_kernel<true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp);
+        // compile-time: roomy (one workgroup per CU: 128 VGPRs), width of the cell scratch, form of the gene image
+        const int variant = (e->genes_blocks_per_cu >= 2 ? 0 : 4) | (e->cell16 ? 2 : 0) | (e->lds_genes.direct ? 1 : 0);
+#define FPS(R, C, D) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp)
+        switch (variant) {
+        case 0: FPS(false, false, false); break; case 1: FPS(false, false, true); break;
+        case 2: FPS(false, true, false); break;  case 3: FPS(false, true, true); break;
+        case 4: FPS(true, false, false); break;  case 5: FPS(true, false, true); break;
+        case 6: FPS(true, true, false); break;   default: FPS(true, true, true); break;
+        }
+#undef FPS
         hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p, grid, (u64*)e->d_segprefix.p, key_counts);
         e->seg_n = grid; e->seg_stride = region;
     } else if (e->use_lds_genes) {

@@ -49,6 +49,47 @@ __device__ __forceinline__ int lane_id() {
 __device__ __forceinline__ u32 rank_below(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
+// Inputs that are read exactly once are loaded with the non-temporal hint: a plain 4 GiB streaming read reaches
+// 7.1 TB/s with it against 6.2 TB/s without (tools/hbm_probe2.hip).  FASTF_NT_* = 0 gives plain loads (A/B builds).
+#ifndef FASTF_NT_ALL
+#define FASTF_NT_ALL 1
+#endif
+#ifndef FASTF_NT_K1A
+#define FASTF_NT_K1A FASTF_NT_ALL
+#endif
+#ifndef FASTF_NT_K1B
+#define FASTF_NT_K1B FASTF_NT_ALL
+#endif
+#ifndef FASTF_NT_SORT
+#define FASTF_NT_SORT FASTF_NT_ALL
+#endif
+#ifndef FASTF_NT_K3
+#define FASTF_NT_K3 FASTF_NT_ALL
+#endif
+typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+template <bool NT, class T> __device__ __forceinline__ T ld_once(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT> __device__ __forceinline__ ulonglong2 ld_once2(const u64* p) {          // 16-byte aligned pair
+    if constexpr (NT) { const u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(p)); return make_ulonglong2(v.x, v.y); }
+    else return *reinterpret_cast<const ulonglong2*>(p);
+}
+// the same hint for stores (results the next kernel streams back in)
+#ifndef FASTF_NTS_K1A
+#define FASTF_NTS_K1A 0
+#endif
+#ifndef FASTF_NTS_K1B
+#define FASTF_NTS_K1B 0
+#endif
+#ifndef FASTF_NTS_SORT
+#define FASTF_NTS_SORT 0
+#endif
+#ifndef FASTF_NTS_K3
+#define FASTF_NTS_K3 0
+#endif
+template <bool NT, class T> __device__ __forceinline__ void st_once(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
 __device__ __forceinline__ u64 wave_sum64(u64 v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -250,6 +291,11 @@ __device__ __forceinline__ u32 get_cell(const void* __restrict__ in, bool c16, u
     return c16 ? (u32)reinterpret_cast<const unsigned short*>(in)[idx] : reinterpret_cast<const u32*>(in)[idx];
 }
 
+__device__ __forceinline__ u32 get_cell_once(const void* __restrict__ in, bool c16, u64 idx) {      // streaming K1b: read once
+    return c16 ? (u32)ld_once<FASTF_NT_K1B != 0>(reinterpret_cast<const unsigned short*>(in) + idx)
+               : ld_once<FASTF_NT_K1B != 0>(reinterpret_cast<const u32*>(in) + idx);
+}
+
 __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
     return (u32)((mix64((u64)cell) >> 32) % n_shards);
 }
@@ -409,7 +455,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
         if (whole) {
 #pragma unroll
             for (int j = 0; j < PAIRS; ++j) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(cb + base + 2ull * (j * WAVE + lane));
+                const ulonglong2 v = ld_once2<FASTF_NT_K1A != 0>(cb + base + 2ull * (j * WAVE + lane));
                 key[2 * j] = v.x; key[2 * j + 1] = v.y;
             }
         } else {
@@ -435,7 +481,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
             if (c16) {
 #pragma unroll
                 for (int j = 0; j < PAIRS; ++j)
-                    *reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(cell_out) + base + 2ull * (j * WAVE + lane)) = cell[2 * j] | (cell[2 * j + 1] << 16);
+                    st_once<FASTF_NTS_K1A != 0>(reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(cell_out) + base + 2ull * (j * WAVE + lane)), cell[2 * j] | (cell[2 * j + 1] << 16));
             } else {
 #pragma unroll
                 for (int j = 0; j < PAIRS; ++j)
@@ -719,12 +765,25 @@ struct StreamParams {
     u64* seg_count;                // [gridDim.x] out
 };
 
-template <bool ROOMY>
+// sum over the lanes 0..15 of one 16-lane row (DPP row shifts, no LDS traffic); the total is returned to every lane
+__device__ __forceinline__ u32 row16_sum_lane15(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);      // row_shr:8
+    return (u32)__builtin_amdgcn_readlane((int)x, 15);
+}
+
+// C16: the cell scratch holds u16 entries; DIRECT: the gene image is the dense u16 table.  Both are compile-time so that
+// the loop is straight-line code: with run-time flags every load sat in its own branch, with waits between them
+// (PMC on the configs[2] shape: 430 vector + 325 scalar instructions per 256 records, the vector ALU busy 60 % of the kernel).
+template <bool ROOMY, bool C16, bool DIRECT>
 __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
     __shared__ u64 s_tot[3];
     __shared__ u32 s_cursor, s_err;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the gene image
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const int tid = threadIdx.x, lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                // scalar: the unit's addresses are scalar base + lane
     const u32* s_bitmap = reinterpret_cast<const u32*>(smem);
     const unsigned short* s_rank = reinterpret_cast<const unsigned short*>(smem + (size_t)p.genes.words * 4);
     const unsigned short* s_perm = s_rank + ((p.genes.words + 1u) & ~1u);
@@ -738,41 +797,88 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
     if (tid == 0) { s_cursor = 0; s_err = 0; }
     __syncthreads();
 
+    constexpr bool NT = FASTF_NT_K1B != 0;
     u64* const region = p.keys + (u64)blockIdx.x * sp.region_stride;
     const u64 draw_off = p.draw_base ? *p.draw_base : 0;
     u32 w_hit = 0, w_samp = 0, w_valid = 0, errs = 0;                      // wave-uniform running counts
-    // the workgroup's 16 waves take the 16 units of one K1a tile per round: the same locality as the tile form
+    // the workgroup's 16 waves take the 16 units of one K1a tile per round: the same locality as the tile form.
+    // The two small inputs of a round — the tile's hit-rank base and its line of per-unit hit counts — are fetched one
+    // round ahead, so that the draws of a unit (a CONTIGUOUS range of the draw stream: ranks rank0 .. rank0 + own) are
+    // requested together with the unit's records instead of behind them.
+    u64 tb = 0; u32 hha = 0;
+    if (blockIdx.x < p.n_tiles) {
+        tb = p.tile_base[blockIdx.x];
+        hha = lane < 16 ? sp.half_hits[16ull * blockIdx.x + lane] : 0u;
+    }
     for (u32 t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
-        const u64 base = (u64)t * K1_TILE + (u64)w * K1S_UNIT;
+        const u64 base = (u64)t * K1_TILE + (u64)w * K1S_UNIT;             // scalar
+        // hit-rank base of this unit: the tile's base + the units in front of it inside the tile; own = this unit's hits
+        u64 rank0 = tb + draw_off + row16_sum_lane15(lane < w ? hha : 0u);  // w <= 15
+        const u32 own = (u32)__builtin_amdgcn_readlane((int)hha, w);
         // ---- loads ----
         u64 gxk[K1S_IPT]; u32 umi[K1S_IPT], meta[K1S_IPT], cell[K1S_IPT];
+        const u64* const gx_u = p.gx + base; const u32* const umi_u = p.umi + base; const u32* const meta_u = p.meta + base;
+        const unsigned short* const c16_u = reinterpret_cast<const unsigned short*>(p.cell) + base;
+        const u32* const c32_u = reinterpret_cast<const u32*>(p.cell) + base;
+        if (base + K1S_UNIT <= p.n) {                                      // scalar branch: the whole unit exists
 #pragma unroll
-        for (int j = 0; j < K1S_IPT; ++j) {
-            const u64 idx = base + (u64)j * WAVE + lane;
-            const bool in = idx < p.n;
-            cell[j] = in ? get_cell(p.cell, p.cell16, idx) : 0;
-            gxk[j]  = in ? p.gx[idx] : 0;
-            umi[j]  = in ? p.umi[idx] : 0;
-            meta[j] = in ? p.meta[idx] : 0;
+            for (int j = 0; j < K1S_IPT; ++j) {
+                const u32 o = (u32)j * WAVE + (u32)lane;
+                cell[j] = C16 ? (u32)ld_once<NT>(c16_u + o) : ld_once<NT>(c32_u + o);
+                gxk[j]  = ld_once<NT>(gx_u + o);
+                umi[j]  = ld_once<NT>(umi_u + o);
+                meta[j] = ld_once<NT>(meta_u + o);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K1S_IPT; ++j) {
+                const u32 o = (u32)j * WAVE + (u32)lane;
+                const bool in = base + o < p.n;
+                cell[j] = 0; gxk[j] = 0; umi[j] = 0; meta[j] = 0;
+                if (in) {
+                    cell[j] = C16 ? (u32)c16_u[o] : c32_u[o];
+                    gxk[j] = gx_u[o]; umi[j] = umi_u[o]; meta[j] = meta_u[o];
+                }
+            }
         }
-        // hit-rank base of this unit: one 64-byte line of half counts, summed over the units in front
-        const u32 hh = lane < w ? sp.half_hits[16ull * t + lane] : 0u;     // w <= 15
-        u64 rank0 = p.tile_base[t] + draw_off + wave_sum32(hh);
-        // ---- depth draw (E4/E5): ranks in record order, loads issued here and consumed after the gene lookup ----
+        // the unit's draws, lane l of dr[q] holding the draw of local hit rank 64 q + l
+        u32 dr[K1S_IPT];
+#pragma unroll
+        for (int q = 0; q < K1S_IPT; ++q) {
+            dr[q] = 0;
+            if ((u32)q * WAVE < own) {                                     // wave-uniform
+                const u64 r = rank0 + (u32)q * WAVE + lane;
+                if (r < p.n_draws) dr[q] = p.draws[r & p.draw_mask];
+            }
+        }
+        {   // next round's small inputs
+            const u32 tn = t + gridDim.x;
+            if (tn < p.n_tiles) {
+                tb = p.tile_base[tn];
+                hha = lane < 16 ? sp.half_hits[16ull * tn + lane] : 0u;
+            }
+        }
+        // ---- depth draw (E4/E5): ranks in record order; a record's draw comes from the lane that fetched its rank ----
         u32 draw[K1S_IPT];
+        u32 pre = 0;                                                       // hits of the unit in front of item j
 #pragma unroll
         for (int j = 0; j < K1S_IPT; ++j) {
             const u64 hm = __ballot(cell[j] != 0);
+            const u32 rl = pre + rank_below(hm);                           // local hit rank (meaningful on hit lanes)
+            // the hits of one item span at most two of the dr[] registers: q0 and q0 + 1 (q0 wave-uniform)
+            const u32 q0 = pre >> 6;
+            const u32 a = q0 == 0 ? dr[0] : q0 == 1 ? dr[1] : q0 == 2 ? dr[2] : dr[3];
+            const u32 b = q0 == 0 ? dr[1] : q0 == 1 ? dr[2] : dr[3];
+            const u32 va = (u32)__shfl((int)a, (int)(rl & 63u), WAVE), vb = (u32)__shfl((int)b, (int)(rl & 63u), WAVE);
             draw[j] = 0;
             if (cell[j] != 0) {
-                const u64 r = rank0 + rank_below(hm);
-                if (r < p.n_draws) draw[j] = p.draws[r & p.draw_mask];
+                if (rank0 + rl < p.n_draws) draw[j] = (rl >> 6) == q0 ? va : vb;
                 else { cell[j] = 0; errs |= (u32)ERR_DRAWS_SHORT; }
             }
             const u32 c = (u32)__popcll(hm);
-            rank0 += c; w_hit += c;
+            pre += c; w_hit += c;
         }
-        // ---- E8 ahead of E5/E7: the LDS lookup runs while the draw loads are in flight ----
+        // ---- E8: gene lookup in LDS ----
         u32 feat[K1S_IPT];
 #pragma unroll
         for (int j = 0; j < K1S_IPT; ++j) {
@@ -782,7 +888,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
                 if ((u32)(k >> 44) == p.genes.family) {
                     const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;                 // wraps to huge when below vmin
                     if (v < p.genes.range) {
-                        if (p.genes.direct) f = s_direct[(u32)v];
+                        if (DIRECT) f = s_direct[(u32)v];
                         else {
                             const u32 wd = s_bitmap[(u32)v >> 5], rk = s_rank[(u32)v >> 5], bit = (u32)v & 31u;
                             if ((wd >> bit) & 1u) f = s_perm[rk + __popc(wd & ((1u << bit) - 1u))];
@@ -814,7 +920,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
             else {
 #pragma unroll
                 for (int j = 0; j < K1S_IPT; ++j) {
-                    if ((em[j] >> lane) & 1) region[pos0 + rank_below(em[j])] = key[j];
+                    if ((em[j] >> lane) & 1) st_once<FASTF_NTS_K1B != 0>(region + pos0 + rank_below(em[j]), key[j]);
                     pos0 += (u32)__popcll(em[j]);
                 }
             }
@@ -953,13 +1059,13 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
 #pragma unroll
             for (int j = 0; j < SORT_IPT; ++j) {
                 const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-                k[j] = (j < (int)ipt && idx < n) ? keys[seg_phys(seg, idx, ts)] : 0;
+                k[j] = (j < (int)ipt && idx < n) ? ld_once<FASTF_NT_SORT != 0>(keys + seg_phys(seg, idx, ts)) : 0;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < SORT_IPT; ++j) {
                 const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
-                k[j] = (j < (int)ipt && idx < n) ? keys[idx] : 0;
+                k[j] = (j < (int)ipt && idx < n) ? ld_once<FASTF_NT_SORT != 0>(keys + idx) : 0;
             }
         }
 #pragma unroll
@@ -1065,13 +1171,13 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
 #pragma unroll
         for (int j = 0; j < SORT_IPT; ++j) {
             const u32 li = wbase + j * WAVE + lane;
-            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[seg_phys(seg, base + li, ts)] : ~0ULL;
+            key[j] = (j < ipt && (FULL || li < n_valid)) ? ld_once<FASTF_NT_SORT != 0>(in + seg_phys(seg, base + li, ts)) : ~0ULL;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < SORT_IPT; ++j) {
             const u32 li = wbase + j * WAVE + lane;
-            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[base + li] : ~0ULL;
+            key[j] = (j < ipt && (FULL || li < n_valid)) ? ld_once<FASTF_NT_SORT != 0>(in + base + li) : ~0ULL;
         }
     }
     __syncthreads();
@@ -1141,7 +1247,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         if (FULL || pidx < n_valid) {
             const u64 k = s_keys[pidx];
             const u32 d = digit_of<SHIFT>(k, rshift);
-            out[(u64)(u32)(s_delta[d] + pidx)] = k;
+            st_once<FASTF_NTS_SORT != 0>(out + (u64)(u32)(s_delta[d] + pidx), k);
         }
     }
     STAMP(5);
@@ -1271,7 +1377,7 @@ __global__ __launch_bounds__(K3_THREADS, 8) void reduce_kernel(const ReduceParam
 #pragma unroll
     for (int j = 0; j < K3_IPT; ++j) {
         const u64 idx = base + (u64)j * K3_THREADS + tid;
-        key[j] = idx < n ? p.keys[idx] : 0;
+        key[j] = idx < n ? ld_once<FASTF_NT_K3 != 0>(p.keys + idx) : 0;
         s_id[j * K3_THREADS + tid] = key[j];
     }
     __syncthreads();
@@ -1355,9 +1461,12 @@ __global__ __launch_bounds__(K3_THREADS, 8) void reduce_kernel(const ReduceParam
     for (u32 r = tid; r < n_rows; r += K3_THREADS) {
         const u32 c = s_pd[r + 1] - s_pd[r];
         const u64 id = s_id[r];
-        p.count[row_base + r] = c;
-        if (UMI_ROWS) p.ukeys[row_base + r] = id;
-        else { p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32); }
+        if (UMI_ROWS) { p.count[row_base + r] = c; p.ukeys[row_base + r] = id; }
+        else {
+            // (count stays a plain store: carry_fix_kernel adds to it with atomics)
+            p.count[row_base + r] = c;
+            st_once<FASTF_NTS_K3 != 0>(p.feature + row_base + r, (u32)id); st_once<FASTF_NTS_K3 != 0>(p.cell + row_base + r, (u32)(id >> 32));
+        }
     }
     __syncthreads();                               // the next tile restages the shared arrays
     }
