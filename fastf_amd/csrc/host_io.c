@@ -241,6 +241,7 @@ struct fastf_bam {
     void *pin_a, *pin_b; size_t pin_len;              /* what the device's init thread pins before it reports ready */
     uint8_t *gstatus; size_t gstatus_cap; double t_gpu; uint64_t n_gpu_windows;
     double gpu_share;                                 /* fraction of a window's blocks the device takes (hybrid inflate) */
+    double gpu_share_max;                             /* its upper bound (FASTF_GPU_INFLATE_MAX); the init thread pins the window buffers that far */
     unsigned char *gcomp; size_t gcomp_cap;           /* pinned copy of the window's compressed bytes (the file mapping cannot be pinned) */
     double t_read, t_inflate, t_hop, t_pack, t_wait;   /* FASTF_BAM_PROFILE=1 prints these at close; t_wait: consumer blocked on the filler */
 };
@@ -527,7 +528,7 @@ static int fill_next(fastf_bam_t *b)
                 double want = r_dev / (r_dev + r_host);
                 b->gpu_share = 0.5 * b->gpu_share + 0.5 * want;
                 if (b->gpu_share < 0.05) b->gpu_share = 0.05;
-                if (b->gpu_share > 0.60) b->gpu_share = 0.60;      /* what the init thread pinned of the window buffers */
+                if (b->gpu_share > b->gpu_share_max) b->gpu_share = b->gpu_share_max;   /* what the init thread pinned of the window buffers */
             }
         }
         b->t_inflate += now_s() - t0;
@@ -628,7 +629,12 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
     {   const char *gi = getenv("FASTF_GPU_INFLATE"), *dv = getenv("FASTF_DEVICE");
         b->gpu_wanted = gi ? (gi[0] == '1' ? 1 : gi[0] == '2' ? 2 : 0) : (gpu_inflate == 1 || gpu_inflate == 2 ? gpu_inflate : 0);
         b->gpu_device = dv ? atoi(dv) : 0;
-        const char *sh2 = getenv("FASTF_GPU_INFLATE_SHARE"); b->gpu_share = sh2 ? atof(sh2) : 0.6; }
+        const char *sh2 = getenv("FASTF_GPU_INFLATE_SHARE"), *sh3 = getenv("FASTF_GPU_INFLATE_MAX");
+        b->gpu_share_max = sh3 ? atof(sh3) : 0.60;
+        if (b->gpu_share_max < 0.05) b->gpu_share_max = 0.05;
+        if (b->gpu_share_max > 1.0) b->gpu_share_max = 1.0;
+        b->gpu_share = sh2 ? atof(sh2) : b->gpu_share_max;
+        if (b->gpu_share > b->gpu_share_max) b->gpu_share = b->gpu_share_max; }
     const char *w = getenv("FASTF_BAM_WINDOW");
     /* device inflate wants many blocks per launch (the chip holds 5 120 of them at once): 128 MiB windows, about 8 000
      * blocks, of which the device takes its share, unless told otherwise */
@@ -649,7 +655,7 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
         b->ucap = b->ncap = NX_RESERVE + b->ccap * 5;
         b->ubuf = (unsigned char *)malloc(b->ucap); b->nbuf = (unsigned char *)malloc(b->ncap);
         b->pin_a = b->ubuf; b->pin_b = b->nbuf;
-        b->pin_len = NX_RESERVE + (size_t)((double)b->ccap * 5 * 0.62);
+        b->pin_len = NX_RESERVE + (size_t)((double)b->ccap * 5 * (b->gpu_share_max + 0.02 > 1.0 ? 1.0 : b->gpu_share_max + 0.02));
     } else {
         b->ucap = 1 << 16; b->ubuf = (unsigned char *)malloc(b->ucap);
         b->ncap = NX_RESERVE + b->ccap * 4; b->nbuf = (unsigned char *)malloc(b->ncap);
