@@ -1400,33 +1400,39 @@ __global__ __launch_bounds__(K3_THREADS, 8) void reduce_kernel(const ReduceParam
                     // iff no earlier key of that little run equals it.  The run is (cell, feature, top UMI bits), i.e.
                     // 1/2^(sorted UMI bits) of a group plus its exact duplicates — a step or two in practice.
                     const u64 run = k >> p.low_skip;
-                    u64 q = prev, at = idx - 1;
-                    u32 steps = 0;
-                    bool open = true;                          // still inside the run, no equal key met yet
-                    constexpr u32 NEAR = 8;
-                    if (loc >= NEAR) {
-                        // the eight neighbours in front, read from LDS in one go (no load waits for the one before it):
-                        // most runs end within them
-                        u64 nb[NEAR];
+                    // most runs are a single key: only a key whose neighbour in front belongs to the same run (a few
+                    // percent of them) reads further back — the walk costs LDS bandwidth, not just latency
+                    if ((prev >> p.low_skip) == run) {
+                        if (prev == k) dist = false;
+                        else {
+                            u64 q = prev, at = idx - 1;
+                            u32 steps = 0;
+                            bool open = true;                      // still inside the run, no equal key met yet
+                            constexpr u32 NEAR = 4;
+                            if (loc >= NEAR + 1) {
+                                // the next neighbours in front, read from LDS in one go (no load waits for the one before it)
+                                u64 nb[NEAR];
 #pragma unroll
-                        for (u32 t = 0; t < NEAR; ++t) nb[t] = s_id[loc - 1 - t];
+                                for (u32 t = 0; t < NEAR; ++t) nb[t] = s_id[loc - 2 - t];
 #pragma unroll
-                        for (u32 t = 0; t < NEAR; ++t) {
-                            if (open) {
-                                if ((nb[t] >> p.low_skip) != run) open = false;
-                                else if (nb[t] == k) { dist = false; open = false; }
+                                for (u32 t = 0; t < NEAR; ++t) {
+                                    if (open) {
+                                        if ((nb[t] >> p.low_skip) != run) open = false;
+                                        else if (nb[t] == k) { dist = false; open = false; }
+                                    }
+                                }
+                                at = idx - 1 - NEAR; q = nb[NEAR - 1]; steps = NEAR;
                             }
-                        }
-                        at = idx - NEAR; q = nb[NEAR - 1]; steps = NEAR - 1;
-                    }
-                    if (open) {
-                        for (;; ++steps) {
-                            if ((q >> p.low_skip) != run) break;
-                            if (q == k) { dist = false; break; }
-                            if (at == 0) break;
-                            if (steps >= RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
-                            --at;
-                            q = at >= base ? s_id[(u32)(at - base)] : p.keys[at];
+                            if (open) {
+                                for (;; ++steps) {
+                                    if ((q >> p.low_skip) != run) break;
+                                    if (q == k) { dist = false; break; }
+                                    if (at == 0) break;
+                                    if (steps >= RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
+                                    --at;
+                                    q = at >= base ? s_id[(u32)(at - base)] : p.keys[at];
+                                }
+                            }
                         }
                     }
                 }
