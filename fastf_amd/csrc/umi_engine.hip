@@ -135,6 +135,7 @@ struct fastf_engine {
     DevBuf d_halfhits;                   // K1a: hits per 256-record unit (the streaming K1b's rank bases)
     DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
     u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
+    DevBuf d_scanblk;                    // chunk totals of a scan over more than 16 384 tiles
     DevBuf d_heads, d_rowbase;           // K3's tile counts / bases: not shared with K1, so K1 of the next batch may run beside K3 (other stream)
     // timing
     bool timing = false;
@@ -482,7 +483,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     if (e->h_coo) (void)hipHostFree(e->h_coo);
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase,
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -606,6 +607,20 @@ static u64* g_k1_stamps = nullptr;   // diagnostic builds only
 extern "C" void fastf_debug_set_k1_stamps(void* p) { g_k1_stamps = (u64*)p; }
 
 // K1a + scan: cell index per record, hit-rank base per tile, total hits
+// one workgroup scans the tile counts (see scan_tiles_kernel for the entries-per-thread choice)
+// slot: the K1 scan (0) and the K3 scan (1) may run side by side on two streams (pipelined sharded pass): each has its own chunk totals
+static void launch_scan_tiles(fastf_engine* e, int slot, hipStream_t s, u32* in, u64* out, u32 T, u64* total_out, u64* running, u64* base_out) {
+    constexpr u32 CHUNK = 16u * 1024u;
+    const u32 n_blk = (T + CHUNK - 1) / CHUNK;
+    if (n_blk <= 1 || n_blk > 64 || e->d_scanblk.ensure(2 * 64 * sizeof(u64))) {
+        hipLaunchKernelGGL(scan_tiles_kernel<16>, dim3(1), dim3(1024), 0, s, in, out, T, total_out, running, base_out, (u64*)nullptr);
+        return;
+    }
+    u64* const blk = (u64*)e->d_scanblk.p + 64 * slot;
+    hipLaunchKernelGGL(scan_tiles_kernel<16>, dim3(n_blk), dim3(1024), 0, s, in, out, T, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, blk);
+    hipLaunchKernelGGL(scan_fix_kernel<16>, dim3(n_blk), dim3(1024), 0, s, out, T, (const u64*)blk, n_blk, total_out, running, base_out);
+}
+
 static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s,
                               u64* d_running = nullptr, u64* d_base_out = nullptr) {
     if (reserve_workspace(e, n, 0)) return 1;
@@ -628,8 +643,7 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
                            e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p);
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_tilecnt.p,
-                       (u64*)e->d_tilebase.p, tiles, d_total_out, d_running, d_base_out);
+    launch_scan_tiles(e, 0, s, (u32*)e->d_tilecnt.p, (u64*)e->d_tilebase.p, tiles, d_total_out, d_running, d_base_out);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -826,8 +840,7 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
     t_begin(e, s);
     const u32 k3_grid = std::min<u32>(tiles, tile_grid(~0u - 8u));
     hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(k3_grid), dim3(K3_THREADS), 0, s, p);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, (u32*)e->d_heads.p,
-                       (u64*)e->d_rowbase.p, tiles, nrows, (u64*)nullptr, (u64*)nullptr);
+    launch_scan_tiles(e, 1, s, (u32*)e->d_heads.p, (u64*)e->d_rowbase.p, tiles, nrows, nullptr, nullptr);
     hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(k3_grid), dim3(K3_THREADS), 0, s, p);
     hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,
                        (const u64*)e->d_rowbase.p, count, d_n);

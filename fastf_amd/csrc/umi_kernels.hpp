@@ -222,19 +222,24 @@ __device__ __forceinline__ void table_probe_batch(const Table t, const u64 (&key
 // ------------------------------------------------------------------------------------
 // running / base_out (optional): a device-side running total across launches — *base_out = *running before this
 // launch's total is added (the streaming push path: hit-rank base of a chunk without a host round trip).
+// PER = entries per thread and round (a thread owns PER consecutive entries: 16; 64 in one round measured slower, each
+// of a thread's 48 memory instructions touches 64 different lines).  One workgroup scans 16 384 entries per round.  Longer
+// arrays (200 M records: 48 829 tiles, three rounds, 56 us on one CU) are cut into one chunk per workgroup — blk_tot !=
+// nullptr: workgroup b scans chunk b and leaves its total — and scan_fix_kernel adds the totals of the chunks in front.
+template <u32 PER>
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, u64* __restrict__ out, u32 T,
                                                           u64* __restrict__ total_out, u64* __restrict__ running = nullptr,
-                                                          u64* __restrict__ base_out = nullptr) {
+                                                          u64* __restrict__ base_out = nullptr, u64* __restrict__ blk_tot = nullptr) {
     __shared__ u32 s_w[16];
     __shared__ u64 s_carry;
     const int lane = lane_id(), w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    constexpr u32 PER = 16;                              // entries per thread and round: 48 k tiles (200 M records) in three rounds
-    for (u32 t0 = 0; t0 < T; t0 += PER * 1024) {
+    const u32 t_first = blk_tot ? blockIdx.x * PER * 1024u : 0u, t_end = blk_tot ? (t_first + PER * 1024u < T ? t_first + PER * 1024u : T) : T;
+    for (u32 t0 = t_first; t0 < t_end; t0 += PER * 1024) {
         const u32 t = t0 + PER * threadIdx.x;
         u32 v[PER];
-        if (t + PER <= T) {                              // (in is 16-byte aligned: hipMalloc; t is a multiple of 16)
+        if (t + PER <= T) {                              // (in is 16-byte aligned: hipMalloc; t is a multiple of PER)
 #pragma unroll
             for (u32 q = 0; q < PER / 4; ++q) {
                 const uint4 x = reinterpret_cast<const uint4*>(in + t)[q];
@@ -268,8 +273,24 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(u32* __restrict__ in, 
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();
     }
+    if (blk_tot) { if (threadIdx.x == 0) blk_tot[blockIdx.x] = s_carry; return; }
     if (threadIdx.x == 0 && total_out) *total_out = s_carry;
     if (threadIdx.x == 0 && running) { const u64 r = *running; *base_out = r; *running = r + s_carry; }
+}
+
+// second half of the chunked scan: chunk b's entries get the totals of the chunks in front; workgroup 0 hands out the total
+template <u32 PER>
+__global__ __launch_bounds__(1024) void scan_fix_kernel(u64* __restrict__ out, u32 T, const u64* __restrict__ blk_tot, u32 n_blk,
+                                                        u64* __restrict__ total_out, u64* __restrict__ running, u64* __restrict__ base_out) {
+    u64 off = 0, total = 0;
+    for (u32 i = 0; i < n_blk; ++i) { const u64 v = blk_tot[i]; if (i < blockIdx.x) off += v; total += v; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (total_out) *total_out = total;
+        if (running) { const u64 r = *running; *base_out = r; *running = r + total; }
+    }
+    if (blockIdx.x == 0 || off == 0) return;
+    const u32 t_first = blockIdx.x * PER * 1024u;
+    for (u32 k = threadIdx.x; k < PER * 1024u && t_first + k < T; k += 1024) out[t_first + k] += off;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1026,6 +1047,11 @@ __device__ __forceinline__ u32 num_tiles(u64 n, u32 ipt) { const u64 t = (u64)ip
 // rows of cnt[d][tile] are padded to a multiple of 4 tiles so a row scan can use 16-byte accesses
 __device__ __forceinline__ u32 row_stride(u32 T) { return (T + 3u) & ~3u; }
 
+// A sort whose keys outgrow the 256 MB Infinity Cache streams them (non-temporal loads: +14 % on tile_count at 38 M keys);
+// a smaller one finds the keys of the pass before still cached, and plain loads are faster there (10 M keys: scatter
+// 38 us plain, 43 us streamed).
+__device__ __forceinline__ bool sort_streams(u64 n_keys) { return n_keys >= (24ull << 20); }
+
 // XCD-contiguous tile of this workgroup.  The ranges are cut from the ACTUAL tile count T (the grid is sized for the
 // caller's upper bound on the key count and may be several times larger: cutting the ranges from gridDim would leave
 // most XCDs without a tile when the bound is loose).  Returns a value >= T for workgroups without a tile.
@@ -1061,11 +1087,17 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __r
                 const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
                 k[j] = (j < (int)ipt && idx < n) ? ld_once<FASTF_NT_SORT != 0>(keys + seg_phys(seg, idx, ts)) : 0;
             }
-        } else {
+        } else if (sort_streams(n)) {                        // block-uniform
 #pragma unroll
             for (int j = 0; j < SORT_IPT; ++j) {
                 const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
                 k[j] = (j < (int)ipt && idx < n) ? ld_once<FASTF_NT_SORT != 0>(keys + idx) : 0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SORT_IPT; ++j) {
+                const u64 idx = base + (u64)j * SORT_THREADS + threadIdx.x;
+                k[j] = (j < (int)ipt && idx < n) ? keys[idx] : 0;
             }
         }
 #pragma unroll
@@ -1144,7 +1176,7 @@ template <int SHIFT, bool FULL, bool SEG>
 __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
                                              u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
                                              const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, const int tid,
-                                             u64* stamps = nullptr) {
+                                             const bool streams, u64* stamps = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1173,11 +1205,17 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
             const u32 li = wbase + j * WAVE + lane;
             key[j] = (j < ipt && (FULL || li < n_valid)) ? ld_once<FASTF_NT_SORT != 0>(in + seg_phys(seg, base + li, ts)) : ~0ULL;
         }
-    } else {
+    } else if (streams) {                                      // block-uniform
 #pragma unroll
         for (int j = 0; j < SORT_IPT; ++j) {
             const u32 li = wbase + j * WAVE + lane;
             key[j] = (j < ipt && (FULL || li < n_valid)) ? ld_once<FASTF_NT_SORT != 0>(in + base + li) : ~0ULL;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SORT_IPT; ++j) {
+            const u32 li = wbase + j * WAVE + lane;
+            key[j] = (j < ipt && (FULL || li < n_valid)) ? in[base + li] : ~0ULL;
         }
     }
     __syncthreads();
@@ -1272,6 +1310,7 @@ __global__ __launch_bounds__(SORT_THREADS, 8) void scatter_kernel(const u64* __r
     // bin, so neighbouring tiles share the cache lines at their run boundaries: give each XCD a contiguous range of
     // tiles and those partial lines merge in that XCD's L2 instead of going to HBM twice.
     const u32 tile_keys = ipt * SORT_THREADS;
+    const bool streams = sort_streams(n);
     for (u32 r = blockIdx.x >> 3;; r += gridDim.x >> 3) {
 #ifdef FASTF_NO_XCD_SWIZZLE
         const u32 tile = (r << 3) | (blockIdx.x & 7u);
@@ -1286,8 +1325,8 @@ __global__ __launch_bounds__(SORT_THREADS, 8) void scatter_kernel(const u64* __r
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
         // (no barrier between tiles: whatever a tile reads last from LDS is rewritten only after two barriers of the next)
-        if (n_valid == tile_keys) scatter_tile<SHIFT, true, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, stamps);
-        else scatter_tile<SHIFT, false, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, stamps);
+        if (n_valid == tile_keys) scatter_tile<SHIFT, true, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps);
+        else scatter_tile<SHIFT, false, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps);
     }
 }
 
