@@ -1064,6 +1064,10 @@ __device__ __forceinline__ u32 xcd_tile(u32 T, u32 r) {
 
 // per-tile digit counts: cnt[d * T + tile].  Four LDS copies of the histogram (lane & 3) keep the
 // same-address atomic conflicts of skewed digits (e.g. the constant length bits) four times shorter.
+// At 38 M keys the kernel takes 63 us for 307 MB, which is what a plain cold read of that size takes on this chip
+// (tools/hbm_probe.hip: 74 us).  Tried without gain: 8 or 16 histogram copies, per-wave copies (slower), a persistent grid that
+// requests the next tile's keys before counting the current one (69 us), counting from one digit byte per key that the
+// scatter before leaves beside the keys (52 us, but the scatter pays 20 us for the byte stores).
 template <bool SEG>
 __global__ __launch_bounds__(SORT_THREADS) void tile_count_kernel(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
                                                                   u32 shift, u32* __restrict__ cnt, u32 ipt, const SegMap seg) {
@@ -1166,8 +1170,8 @@ __device__ __forceinline__ void match_digit(u32 d, u32& mlo, u32& mhi) {
 // shift at run time (digit grids that do not start on a byte boundary, see sort_low_bit() in umi_engine.hip)
 template <int SHIFT>
 __device__ __forceinline__ u32 digit_of(u64 key, u32 rshift) {
-    if (SHIFT >= 0) return (u32)(key >> SHIFT) & 255u;
-    return (u32)(key >> rshift) & 255u;
+    if constexpr (SHIFT >= 0) return (u32)(key >> SHIFT) & 255u;
+    else return (u32)(key >> rshift) & 255u;
 }
 
 // scatter: stable within the tile (wave-major, item, lane == memory order).  FULL tiles skip every
