@@ -178,6 +178,8 @@ def lib():
     L.fastf_bam_read_batch.restype = C.c_long
     L.fastf_bam_close.argtypes = [vp]
     L.fastf_bam_close.restype = None
+    L.fastf_bam_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.fastf_bam_stats.restype = None
     L.fastf_format_matrix.argtypes = [C.c_char_p, C.c_float, C.c_float, C.POINTER(u64 * 3), sz, sz,
                                       C.POINTER(Coo), C.POINTER(vp), C.POINTER(sz)]
     L.fastf_format_umi_rows.argtypes = [C.POINTER(UmiRows), C.POINTER(vp), C.POINTER(sz)]
