@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -122,7 +123,8 @@ struct fastf_engine {
     DevBuf d_small;              // key_counts[8] | counters[4] | nnz | nrows_u | n_tmp  (u64 each)
     u64* h_small = nullptr;      // pinned mirror
     DevBuf d_feature, d_cell, d_count, d_ukeys, d_ncopy;
-    u32* h_coo = nullptr; u64 h_coo_cap = 0, h_nnz = 0;      // pinned: feature | cell | count, h_coo_cap rows each
+    u32* h_coo = nullptr; u64 h_coo_cap = 0, h_nnz = 0;      // feature | cell | count, h_coo_cap rows each; pageable at first, pinned from its second use on
+    bool h_coo_pinned = false; u32 h_coo_uses = 0;
     std::vector<u32> h_ufeature, h_ucell, h_uumi, h_ncopy;
     std::vector<uint8_t> h_unonnull;
     u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;      // hits / keys: as of the last retired chunk
@@ -480,7 +482,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
         if (e->t_ev[i]) (void)hipEventDestroy(e->t_ev[i]);
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
-    if (e->h_coo) (void)hipHostFree(e->h_coo);
+    if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase, &e->d_scanblk,
@@ -956,7 +958,10 @@ static int grow_keys(fastf_engine* e, u64 need) {
     e->d_keys.release();
     e->d_keys.p = np; e->d_keys.bytes = ncap * sizeof(u64);
     e->key_cap = ncap;
-    return 0;
+    // what fastf_engine_finish needs for this many keys (sort buffer, row arrays, tile workspace) is allocated here, while
+    // the caller is still decoding, and not on the way out (a dozen hipMallocs: 10-15 ms of a 0.5 s end-to-end run)
+    if (e->d_tmp.ensure(ncap * sizeof(u64)) || e->d_feature.ensure(ncap * 4) || e->d_cell.ensure(ncap * 4) || e->d_count.ensure(ncap * 4)) return 1;
+    return reserve_workspace(e, 0, ncap);
 }
 
 // the draw source of the chunks being pushed: the engine-owned MT19937 stream, or an array the caller supplied
@@ -1119,7 +1124,11 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
     if (!e || !coo) return set_err("null argument");
     if (e->multi) return multi_finish(e, coo, counters);
     HIP_OK(hipSetDevice(e->device));
+    const bool prof = getenv("FASTF_PROFILE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (prof) fprintf(stderr, "[finish] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count()); };
     if (retire_all(e)) return 1;
+    lap("chunks retired");
     hipStream_t s = e->s_compute;
     u64* small = (u64*)e->d_small.p;
     const u64 n = e->keys_so_far;
@@ -1160,22 +1169,31 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
         }
+        lap("sorted and reduced");
         if (e->h_small[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3]));
         const u64 nnz = e->h_small[SM_NNZ];
         if (nnz > n) return set_err("internal error: %llu matrix rows out of %llu keys", (unsigned long long)nnz, (unsigned long long)n);
-        if (nnz > e->h_coo_cap) {                                       // pinned: the rows come back at PCIe rate
-            if (e->h_coo) (void)hipHostFree(e->h_coo);
-            e->h_coo = nullptr; e->h_coo_cap = 0;
+        // The row buffer is ordinary memory the first time it is used: pinning 23 MB takes 15 ms, the pageable copy of
+        // 2 M rows 2 ms, and a one-shot run (the CLI) never uses it twice.  An engine that finishes again (reset + push:
+        // benchmarks, sharded passes) pins it then and gets its rows at PCIe rate from there on.
+        if (nnz > e->h_coo_cap) {
+            if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
+            e->h_coo = nullptr; e->h_coo_cap = 0; e->h_coo_pinned = false; e->h_coo_uses = 0;
             const u64 cap = nnz + nnz / 8 + 1024;
-            HIP_OK(hipHostMalloc((void**)&e->h_coo, cap * 12, hipHostMallocDefault));
-            e->h_coo_cap = cap;
+            void* m = nullptr;
+            if (posix_memalign(&m, 4096, (size_t)cap * 12) != 0) return set_err("out of memory (%llu matrix rows)", (unsigned long long)nnz);
+            e->h_coo = (u32*)m; e->h_coo_cap = cap;
         }
+        if (!e->h_coo_pinned && e->h_coo && e->h_coo_uses++ >= 1 && hipHostRegister(e->h_coo, (size_t)e->h_coo_cap * 12, hipHostRegisterDefault) == hipSuccess)
+            e->h_coo_pinned = true;
+        lap("row buffer ready");
         if (nnz) {
             HIP_OK(hipMemcpyAsync(e->h_coo, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
             HIP_OK(hipMemcpyAsync(e->h_coo + e->h_coo_cap, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
             HIP_OK(hipMemcpyAsync(e->h_coo + 2 * e->h_coo_cap, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
         }
+        lap("rows on the host");
         e->h_nnz = nnz;
         e->n_sorted = n;
         e->finished = true;
