@@ -293,6 +293,11 @@ STREAM_CASES = {
     "nothing survives": dict(n=50_000, n_bar=100, n_gene=50, rate_depth=0.0),
     "no hits": dict(n=30_000, n_bar=100, n_gene=50, p_unlisted_cb=1.0),
     "sparse gene ids": dict(n=200_000, n_bar=500, n_gene=3000, gene_stride=8, rate_depth=0.7, umi_pool=128),
+    # the other instantiations of the streaming kernel: 32-bit cell scratch (more than 65 535 cells: the barcode table is the L2 one),
+    # gene images that leave room for one workgroup per CU only — the bitmap form and the dense table
+    "u32 cell scratch": dict(n=400_000, n_bar=70_000, n_gene=400, umi_pool=1024, rate_depth=0.6, p_unlisted_cb=0.1, data_seed=21),
+    "one workgroup per CU, bitmap image": dict(n=250_000, n_bar=1500, n_gene=30_000, gene_stride=8, umi_pool=2048, rate_depth=0.8, p_bad_xf=0.1),
+    "one workgroup per CU, dense table": dict(n=250_000, n_bar=1500, n_gene=60_000, gene_dist="zipf", umi_pool=2048, rate_cell=0.5),
 }
 
 
