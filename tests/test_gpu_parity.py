@@ -202,6 +202,28 @@ def test_multi_batch_push_equals_single():
         eng.close()
 
 
+def test_engine_reuse_cycles_grow_the_row_buffer():
+    """finish is idempotent; reset + push + finish cycles reuse the engine's buffers: the row buffer is ordinary memory on
+    its first use, pinned from the second, and reallocated (while pinned) when a later run has more rows"""
+    small = Case(n=20_000, n_bar=60, n_gene=40, umi_pool=64, data_seed=3)
+    big = Case(n=200_000, n_bar=60, n_gene=40, umi_pool=4096, data_seed=3)      # the same lists (they follow data_seed), ten times the records
+    lists = small.lists()
+    assert big.bt == small.bt and big.ft == small.ft
+    eng = F.Engine.from_lists(lists, rate_depth=small.rate_depth, seed=small.seed, batch_records=16_384)
+    try:
+        for case in (small, small, big, small, big):
+            eng.reset()
+            eng.reseed(case.seed, lists.mt_skip)           # (reset alone lets the draw stream go on, like the reference's global generator)
+            eng.push(*case.packed(lists))
+            res = eng.finish()
+            again = eng.finish()
+            for k in ("feature", "cell", "count"):
+                np.testing.assert_array_equal(res[k], again[k])
+            assert_matches_oracle(res, case.oracle(), eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
 def test_empty_input():
     case = Case(n=10, n_bar=4, n_gene=3)
     lists = case.lists()
