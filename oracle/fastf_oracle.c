@@ -7,6 +7,14 @@
  * party dependency (unpinned system library, 3.3x), so the aggregate is
  * restated from its documented semantics and cross-checked against the real
  * library in tests/test_oracle_pins.py::test_aggregate_matches_sqlite.
+ *
+ * Pinning status.  Pinned against the reference's own sources compiled in place (oracle/_ref, `make -C oracle ref`):
+ * the MT19937 stream and genrand_real1, SampleInt + the generator state after it, the first-wins / exact-match hash
+ * table (tests/test_oracle_pins.py).  PARITY UNPINNED for what restates bam2db_ds.c itself — the record loop, the 2-bit
+ * codec, the header text and the writers: that file needs htslib, which is neither in this image nor vendored, and the
+ * reference ships no golden vectors for the path.  Those parts rest on the line-by-line restatement, on the known
+ * answers recorded in SURVEY.md section 8c (tests/golden/survey_8c.json) and on real SQLite running the reference's two
+ * aggregate statements over the oracle's rows.
  */
 #define _GNU_SOURCE
 #include "fastf_oracle.h"
