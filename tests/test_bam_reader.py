@@ -217,3 +217,50 @@ def test_parallel_record_hop_survives_decoy_records(tmp_path, monkeypatch, windo
     got = read_all(bam, lists, cap=2500, threads=threads)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("window,threads", [(1 << 17, 4), (1 << 22, 8)])
+def test_odd_block_structure_and_giant_records(tmp_path, monkeypatch, window, threads):
+    """The same BAM stream re-blocked the hard way: blocks of 1 byte to 65 280 bytes, stored (level 0) blocks, empty
+    blocks (the EOF marker) in the middle of the file, and two records far larger than a BGZF block — one of them larger
+    than the space the reader reserves in front of a window for a record that straddles two windows."""
+    import gzip, zlib
+    case = Case(n=4000, n_bar=40, n_gene=25, umi_pool=32, p_no_cb=0.05, p_bad_xf=0.1)
+    lists = case.lists()
+
+    def extra(i):
+        if i == 1500:
+            return b"ZBBC" + struct.pack("<i", 300_000) + bytes(300_000)          # a record of 300 KB: five blocks
+        if i == 3000:
+            return b"ZCBs" + struct.pack("<i", 1_200_000) + bytes(2_400_000)      # 2.4 MB: longer than the carry-over reserve
+        return b""
+    plain = tmp_path / "plain.bam"
+    synth.write_bam(str(plain), case.flags, case.xf, case.cb, case.gx, case.ub, extra_aux=extra)
+    stream = gzip.decompress(plain.read_bytes())
+    rng = np.random.default_rng(8)
+    out, pos, k = bytearray(), 0, 0
+    while pos < len(stream):
+        n = int(rng.choice([1, 7, 300, 5000, 65280])) if k % 3 else int(rng.integers(1, 65281))
+        chunk = stream[pos:pos + n]
+        if k % 5 == 0:                                                          # stored block
+            co = zlib.compressobj(0, zlib.DEFLATED, -15)
+            data = co.compress(chunk) + co.flush()
+            if len(data) + 25 < 65536:
+                hdr = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, ord("B"), ord("C"), 2, len(data) + 25)
+                out += hdr + data + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+            else:
+                out += synth._bgzf_block(chunk)
+        else:
+            out += synth._bgzf_block(chunk)
+        if k % 11 == 0:
+            out += synth._BGZF_EOF                                              # an empty block in the middle
+        pos += len(chunk); k += 1
+    out += synth._BGZF_EOF
+    odd = tmp_path / "odd.bam"
+    odd.write_bytes(bytes(out))
+    monkeypatch.setenv("FASTF_BAM_WINDOW", str(window))
+    want = case.packed(lists)
+    for path in (plain, odd):
+        got = read_all(path, lists, cap=1234, threads=threads)
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
