@@ -1361,7 +1361,10 @@ struct ReduceParams {
 #ifndef FASTF_K3_IPT
 #define FASTF_K3_IPT 4
 #endif
-constexpr int K3_THREADS = 512, K3_IPT = FASTF_K3_IPT, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
+#ifndef FASTF_K3_THREADS
+#define FASTF_K3_THREADS 512
+#endif
+constexpr int K3_THREADS = FASTF_K3_THREADS, K3_IPT = FASTF_K3_IPT, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
 constexpr int K3_UNITS = K3_IPT * K3_WAVES;
 static_assert(K3_UNITS <= WAVE, "one wave scans the (item, wave) units");
 
@@ -1397,7 +1400,7 @@ __global__ __launch_bounds__(K3_THREADS) void head_count_kernel(const ReducePara
 }
 
 template <bool UMI_ROWS>
-__global__ __launch_bounds__(K3_THREADS, 8) void reduce_kernel(const ReduceParams p) {
+__global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce_kernel(const ReduceParams p) {
     // (item, wave) units in tile order: heads / distinct flags per unit, then their exclusive scans
     __shared__ u32 s_h[K3_IPT * K3_WAVES], s_d[K3_IPT * K3_WAVES];
     __shared__ u32 s_tot[2];
