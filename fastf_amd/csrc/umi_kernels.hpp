@@ -74,22 +74,8 @@ template <bool NT> __device__ __forceinline__ ulonglong2 ld_once2(const u64* p) 
     if constexpr (NT) { const u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(p)); return make_ulonglong2(v.x, v.y); }
     else return *reinterpret_cast<const ulonglong2*>(p);
 }
-// the same hint for stores (results the next kernel streams back in)
-#ifndef FASTF_NTS_K1A
-#define FASTF_NTS_K1A 0
-#endif
-#ifndef FASTF_NTS_K1B
-#define FASTF_NTS_K1B 0
-#endif
-#ifndef FASTF_NTS_SORT
-#define FASTF_NTS_SORT 0
-#endif
-#ifndef FASTF_NTS_K3
-#define FASTF_NTS_K3 0
-#endif
-template <bool NT, class T> __device__ __forceinline__ void st_once(T* p, T v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
+// (Non-temporal STORES were tried in K1a, K1b, the scatter and K3 and lost or changed nothing — scatter 0.127 -> 0.23 ms —
+// so results are written with plain stores: profiles/r2_notes/ab_nontemporal_stores.txt.)
 __device__ __forceinline__ u64 wave_sum64(u64 v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -502,7 +488,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
             if (c16) {
 #pragma unroll
                 for (int j = 0; j < PAIRS; ++j)
-                    st_once<FASTF_NTS_K1A != 0>(reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(cell_out) + base + 2ull * (j * WAVE + lane)), cell[2 * j] | (cell[2 * j + 1] << 16));
+                    *reinterpret_cast<u32*>(reinterpret_cast<unsigned short*>(cell_out) + base + 2ull * (j * WAVE + lane)) = cell[2 * j] | (cell[2 * j + 1] << 16);
             } else {
 #pragma unroll
                 for (int j = 0; j < PAIRS; ++j)
@@ -941,7 +927,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
             else {
 #pragma unroll
                 for (int j = 0; j < K1S_IPT; ++j) {
-                    if ((em[j] >> lane) & 1) st_once<FASTF_NTS_K1B != 0>(region + pos0 + rank_below(em[j]), key[j]);
+                    if ((em[j] >> lane) & 1) region[pos0 + rank_below(em[j])] = key[j];
                     pos0 += (u32)__popcll(em[j]);
                 }
             }
@@ -1289,7 +1275,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         if (FULL || pidx < n_valid) {
             const u64 k = s_keys[pidx];
             const u32 d = digit_of<SHIFT>(k, rshift);
-            st_once<FASTF_NTS_SORT != 0>(out + (u64)(u32)(s_delta[d] + pidx), k);
+            out[(u64)(u32)(s_delta[d] + pidx)] = k;
         }
     }
     STAMP(5);
@@ -1517,7 +1503,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
         else {
             // (count stays a plain store: carry_fix_kernel adds to it with atomics)
             p.count[row_base + r] = c;
-            st_once<FASTF_NTS_K3 != 0>(p.feature + row_base + r, (u32)id); st_once<FASTF_NTS_K3 != 0>(p.cell + row_base + r, (u32)(id >> 32));
+            p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32);
         }
     }
     __syncthreads();                               // the next tile restages the shared arrays
