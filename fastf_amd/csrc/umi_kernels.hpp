@@ -1499,12 +1499,9 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
     for (u32 r = tid; r < n_rows; r += K3_THREADS) {
         const u32 c = s_pd[r + 1] - s_pd[r];
         const u64 id = s_id[r];
-        if (UMI_ROWS) { p.count[row_base + r] = c; p.ukeys[row_base + r] = id; }
-        else {
-            // (count stays a plain store: carry_fix_kernel adds to it with atomics)
-            p.count[row_base + r] = c;
-            p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32);
-        }
+        p.count[row_base + r] = c;
+        if (UMI_ROWS) p.ukeys[row_base + r] = id;
+        else { p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32); }
     }
     __syncthreads();                               // the next tile restages the shared arrays
     }
