@@ -124,6 +124,20 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
         const char* x = getenv("FASTF_EXCHANGE");
         m->use_rccl = x ? (strcmp(x, "rccl") == 0) : !m->aliased;
         if (m->use_rccl && m->aliased) return set_err("FASTF_EXCHANGE=rccl needs distinct devices");
+        if (m->use_rccl) {
+            // communicators first: when RCCL cannot be loaded or initialised and nobody insisted on it, the exchange falls
+            // back to device-to-device copies (peer access is set up per device below)
+            std::vector<int> devs(G);
+            for (u32 g = 0; g < G; ++g) devs[g] = m->d[g].dev;
+            m->comms.assign(G, nullptr);
+            const bool ok = multi_load_rccl(m) == 0 && m->rccl.CommInitAll(m->comms.data(), (int)G, devs.data()) == ncclSuccess;
+            if (!ok) {
+                if (x) return set_err("FASTF_EXCHANGE=rccl: RCCL is not usable here (%s)", fastf_last_error());
+                fprintf(stderr, "Warning: RCCL is not usable here; the key exchange uses device-to-device copies\n");
+                m->comms.clear();
+                m->use_rccl = 0;
+            }
+        }
     }
     for (u32 g = 0; g < G; ++g) {
         MultiDev& md = m->d[g];
@@ -148,13 +162,6 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
                 }
             }
         }
-    }
-    if (m->use_rccl) {
-        if (multi_load_rccl(m)) return 1;
-        std::vector<int> devs(G);
-        for (u32 g = 0; g < G; ++g) devs[g] = m->d[g].dev;
-        m->comms.assign(G, nullptr);
-        NCCL_OK(m, m->rccl.CommInitAll(m->comms.data(), (int)G, devs.data()));
     }
     // the parent handle answers the layout queries from shard 0
     e->L = m->d[0].e->L; e->cell_bits = m->d[0].e->cell_bits; e->feat_bits = m->d[0].e->feat_bits;
