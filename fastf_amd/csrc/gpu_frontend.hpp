@@ -37,7 +37,7 @@ struct fastf_gpuinf {
     u64 n_blocks = 0, n_declined = 0;
 };
 
-extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) {
+extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) FASTF_TRY {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_err("no HIP device for the BGZF inflate"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) return nullptr;
@@ -48,9 +48,9 @@ extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) {
         ok = hipStreamCreateWithFlags(&g->s[i], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&g->ev_done[i]) == hipSuccess;
     if (!ok) { fastf_gpuinf_destroy(g); set_err("stream/event creation failed"); return nullptr; }
     return g;
-}
+} FASTF_CATCH_ZERO
 
-extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) {
+extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) FASTF_TRY {
     if (!g) return;
     (void)hipSetDevice(g->device);
     for (int i = 0; i < fastf_gpuinf::NS; ++i) {
@@ -62,12 +62,12 @@ extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) {
     }
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     delete g;
-}
+} FASTF_CATCH_VOID
 
-extern "C" void fastf_gpuinf_stats(const fastf_gpuinf_t* g, uint64_t* n_blocks, uint64_t* n_declined) {
+extern "C" void fastf_gpuinf_stats(const fastf_gpuinf_t* g, uint64_t* n_blocks, uint64_t* n_declined) FASTF_TRY {
     if (n_blocks) *n_blocks = g ? g->n_blocks : 0;
     if (n_declined) *n_declined = g ? g->n_declined : 0;
-}
+} FASTF_CATCH_VOID
 
 // blocks [0, n): compressed payload of block i at comp + blk[i].coff (clen bytes), inflated to out + blk[i].uoff (isize
 // bytes).  `comp` (readable 64 bytes past the last block) and `out` must be pinned host memory (fastf_pinned_alloc /
@@ -77,7 +77,7 @@ extern "C" void fastf_gpuinf_stats(const fastf_gpuinf_t* g, uint64_t* n_blocks, 
 // meanwhile.  wait() returns when everything has landed: status[i] != 0 means the device declined block i (the caller
 // inflates it on the host); *device_ms = time from the first copy to the last.
 extern "C" int fastf_gpuinf_submit(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
-                                   unsigned char* out) {
+                                   unsigned char* out) FASTF_TRY {
     if (!g) return set_err("null inflate handle");
     g->pending_n = 0;
     if (n == 0) return 0;
@@ -123,9 +123,9 @@ extern "C" int fastf_gpuinf_submit(fastf_gpuinf_t* g, const unsigned char* comp,
     }
     g->pending_n = n; g->pending_slices = n_slices;
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_gpuinf_wait(fastf_gpuinf_t* g, uint8_t* status, double* device_ms) {
+extern "C" int fastf_gpuinf_wait(fastf_gpuinf_t* g, uint8_t* status, double* device_ms) FASTF_TRY {
     if (!g) return set_err("null inflate handle");
     if (device_ms) *device_ms = 0;
     if (!g->pending_n) return 0;
@@ -142,10 +142,10 @@ extern "C" int fastf_gpuinf_wait(fastf_gpuinf_t* g, uint8_t* status, double* dev
     for (size_t i = 0; i < g->pending_n; ++i) g->n_declined += status[i] != 0;
     g->pending_n = 0;
     return 0;
-}
+} FASTF_CATCH_INT
 
 extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
-                                unsigned char* out, uint8_t* status) {
+                                unsigned char* out, uint8_t* status) FASTF_TRY {
     if (fastf_gpuinf_submit(g, comp, blk, n, out)) return 1;
     return fastf_gpuinf_wait(g, status, nullptr);
-}
+} FASTF_CATCH_INT

@@ -15,7 +15,7 @@
 //     least 62 line stores ago and the wave keeps at most four memory operations outstanding at that point
 //     (s_waitcnt vmcnt(4)): 7.4 KB of LDS per wave, twenty blocks in flight per CU.
 // The same source compiles for the host (GI_HOST: one lane) so that the decoder is fuzzed against zlib on the CPU
-// (tests/test_gpu_inflate_host.py, tools/gi_host_test.cpp); the device build is checked against zlib on real BGZF blocks.
+// (tests/test_gpu_inflate_host.py, tools/gi_host.cpp); the device build is checked against zlib on real BGZF blocks.
 #pragma once
 #include <stdint.h>
 #include <string.h>

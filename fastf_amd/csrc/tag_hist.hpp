@@ -85,7 +85,7 @@ struct fastf_taghist {
     std::vector<u32> h_pair_k1, h_tmp32;
 };
 
-extern "C" int fastf_taghist_create(int device, fastf_taghist_t** out) {
+extern "C" int fastf_taghist_create(int device, fastf_taghist_t** out) FASTF_TRY {
     if (!out) return set_err("null argument");
     *out = nullptr;
     static const u64 one = (1ull << 62) | (1ull << 57);        // any non-zero key: the workspace engine's lists are unused
@@ -99,9 +99,9 @@ extern "C" int fastf_taghist_create(int device, fastf_taghist_t** out) {
     if (h->d_small.ensure(8 * sizeof(u64))) { fastf_engine_destroy(ws); delete h; return 1; }
     *out = h;
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" void fastf_taghist_destroy(fastf_taghist_t* h) {
+extern "C" void fastf_taghist_destroy(fastf_taghist_t* h) FASTF_TRY {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
@@ -111,7 +111,7 @@ extern "C" void fastf_taghist_destroy(fastf_taghist_t* h) {
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     fastf_engine_destroy(h->ws);
     delete h;
-}
+} FASTF_CATCH_VOID
 
 static int th_grow(fastf_taghist* h, u64 need) {
     if (need <= h->cap) return 0;
@@ -130,7 +130,7 @@ static int th_grow(fastf_taghist* h, u64 need) {
     return 0;
 }
 
-extern "C" int fastf_taghist_push(fastf_taghist_t* h, const uint64_t* key1, const uint64_t* key2, size_t n) {
+extern "C" int fastf_taghist_push(fastf_taghist_t* h, const uint64_t* key1, const uint64_t* key2, size_t n) FASTF_TRY {
     if (!h) return set_err("null histogram");
     if (!key1) return set_err("null keys");
     if (h->mode_set && h->pair != (key2 != nullptr)) return set_err("single-tag and tag-pair pushes cannot be mixed");
@@ -168,7 +168,7 @@ extern "C" int fastf_taghist_push(fastf_taghist_t* h, const uint64_t* key1, cons
     }
     h->n += n;
     return 0;
-}
+} FASTF_CATCH_INT
 
 // LSD passes over the digits named in pass_mask only (the others are constant over all keys)
 static int th_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 n, u32 pass_mask, int* in_tmp, hipStream_t s) {
@@ -214,7 +214,7 @@ static int th_distinct(fastf_taghist* h, const u64* src, u64 fill_idx, u64 varyi
     return launch_reduce<true>(e, sorted, d_nn, n, nullptr, nullptr, d_c, d_u, d_m, 0, s);
 }
 
-extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* r) {
+extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* r) FASTF_TRY {
     if (!h || !r) return set_err("null argument");
     memset(r, 0, sizeof *r);
     r->n_records = h->n; r->n_valid = h->n_valid; r->n_key1_present = h->n_present1;
@@ -312,4 +312,4 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
     r->pair_k1 = h->h_pair_k1.data(); r->pair_key2 = (const uint64_t*)h->h_pair_key2.data(); r->pair_count = (const uint64_t*)h->h_pair_count.data();
     r->pair_first = (const uint64_t*)h->h_pair_first.data(); r->n_pairs = mp;
     return 0;
-}
+} FASTF_CATCH_INT

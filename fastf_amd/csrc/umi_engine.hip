@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -37,13 +39,40 @@ static int set_err(const char* fmt, ...) {
     memcpy(g_err, buf, sizeof g_err);
     return 1;
 }
+// Exception barrier of the C ABI.  The reference contract is "return 1 + a message on stderr" (bam2db_ds.h:60); a C
+// caller cannot catch, so a std::bad_alloc / std::length_error from a host-side container (row buffers sized from
+// device counters, per-device lists of the multi-device engine) that left an extern "C" function would end in
+// std::terminate and SIGABRT inside the caller's process.  Every extern "C" function of this translation unit with a
+// body of more than one statement is a function-try-block closed by one of these (tests/test_abi.py checks that none
+// is left out, and drives fastf_debug_raise_ through it).
+static int api_caught(const char* fn, const char* what) {
+    return set_err("%s: %s", fn, what ? what : "unknown C++ exception");
+}
+#define FASTF_TRY try
+#define FASTF_CATCH_(ret_stmt)                                                                       \
+    catch (const std::bad_alloc&) { (void)api_caught(__func__, "out of host memory (std::bad_alloc)"); ret_stmt; }   \
+    catch (const std::exception& x_) { (void)api_caught(__func__, x_.what()); ret_stmt; }             \
+    catch (...) { (void)api_caught(__func__, nullptr); ret_stmt; }
+#define FASTF_CATCH_INT  FASTF_CATCH_(return 1)
+#define FASTF_CATCH_ZERO FASTF_CATCH_(return 0)
+#define FASTF_CATCH_VOID FASTF_CATCH_(return)
+
+// test hook (tests/test_abi.py): raises inside the barrier the way a failing allocation would
+extern "C" int fastf_debug_raise_(int kind) FASTF_TRY {
+    if (kind == 0) { std::vector<u64> v; v.resize(~(size_t)0 / 2); return (int)v.size(); }   // std::length_error
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw 42;                                                                   // not a std::exception
+    if (kind == 3) { std::vector<std::vector<u64>> at(4); at.at(7).push_back(1); }             // std::out_of_range
+    return 0;
+} FASTF_CATCH_INT
+
 extern "C" const char* fastf_last_error(void) {
     static thread_local char snap[sizeof g_err];
     std::lock_guard<std::mutex> lk(g_err_mu);
     memcpy(snap, g_err, sizeof snap);
     return snap;
 }
-extern "C" const char* fastf_version(void) { return "fastf_amd 0.2 (gfx950)"; }
+extern "C" const char* fastf_version(void) { return "fastf_amd 0.3 (gfx950)"; }
 extern "C" void fastf_set_error_(const char* msg) { set_err("%s", msg); }
 
 #define HIP_OK(call)                                                                        \
@@ -306,13 +335,13 @@ static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
 
 // test hook (host only, no device needed): the LDS image of a barcode list and its parameters; returns the image size
 // in bytes (0: the list does not qualify), copies at most cap bytes
-extern "C" size_t fastf_debug_cell_image(const uint64_t* cell_keys, uint32_t n, void* image_out, size_t cap, uint32_t params[5]) {
+extern "C" size_t fastf_debug_cell_image(const uint64_t* cell_keys, uint32_t n, void* image_out, size_t cap, uint32_t params[5]) FASTF_TRY {
     CellImage ci;
     if (!make_cell_image((const u64*)cell_keys, n, ci)) return 0;
     if (image_out) memcpy(image_out, ci.img.data(), std::min(cap, (size_t)ci.bytes));
     if (params) { params[0] = ci.slot_bits; params[1] = ci.bucket_mask; params[2] = ci.family; params[3] = ci.bytes; params[4] = ci.seed; }
     return ci.bytes;
-}
+} FASTF_CATCH_ZERO
 
 static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
     if (n == 0 || n > 65535) return 0;
@@ -377,7 +406,7 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
 // ------------------------------------------------------------------------------------
 // create / destroy
 // ------------------------------------------------------------------------------------
-extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engine_t** out) {
+extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engine_t** out) FASTF_TRY {
     if (!cfg || !out) return set_err("null argument");
     *out = nullptr;
     int ndev = 0;
@@ -464,9 +493,9 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     if (rc) { fastf_engine_destroy(e); return 1; }
     *out = e;
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
+extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     if (!e) return;
     if (e->multi) { multi_destroy(e); delete e; return; }
     (void)hipSetDevice(e->device);
@@ -491,42 +520,42 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) {
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
     delete e;
-}
+} FASTF_CATCH_VOID
 
-extern "C" int fastf_engine_table_modes(const fastf_engine_t* e, int* cells_in_lds, int* genes_in_lds) {
+extern "C" int fastf_engine_table_modes(const fastf_engine_t* e, int* cells_in_lds, int* genes_in_lds) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (cells_in_lds) *cells_in_lds = e->use_lds_cells;
     if (genes_in_lds) *genes_in_lds = e->use_lds_genes ? (e->lds_genes.direct ? 2 : 1) : 0;
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_cell_scratch_bytes(const fastf_engine_t* e, uint32_t* bytes) {
+extern "C" int fastf_engine_cell_scratch_bytes(const fastf_engine_t* e, uint32_t* bytes) FASTF_TRY {
     if (!e || !bytes) return set_err("null argument");
     *bytes = (e->multi ? e->n_cells <= 65535u : e->cell16) ? 2u : 4u;
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_sort_passes(const fastf_engine_t* e, uint32_t flags, uint32_t* passes) {
+extern "C" int fastf_engine_sort_passes(const fastf_engine_t* e, uint32_t flags, uint32_t* passes) FASTF_TRY {
     if (!e || !passes) return set_err("null argument");
     *passes = sort_passes(e->L.total_bits, (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0);
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_skip_bits(const fastf_engine_t* e, uint32_t* bits) {
+extern "C" int fastf_engine_skip_bits(const fastf_engine_t* e, uint32_t* bits) FASTF_TRY {
     if (!e || !bits) return set_err("null argument");
     *bits = e->skip_bits;
     return 0;
-}
+} FASTF_CATCH_INT
 
 extern "C" int fastf_engine_key_bits(const fastf_engine_t* e, uint32_t* cell_bits, uint32_t* feature_bits,
-                                     uint32_t* umi_bits, uint32_t* total_bits) {
+                                     uint32_t* umi_bits, uint32_t* total_bits) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (cell_bits) *cell_bits = e->cell_bits;
     if (feature_bits) *feature_bits = e->feat_bits;
     if (umi_bits) *umi_bits = 1 + e->L.umi_bits + e->L.len_bits;
     if (total_bits) *total_bits = e->L.total_bits;
     return 0;
-}
+} FASTF_CATCH_INT
 
 // ------------------------------------------------------------------------------------
 // workspace
@@ -551,7 +580,14 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     const u64 t1 = max_tiles_for(max_records, K1_TILE), t3 = max_tiles_for(max_keys, K3_TILE);
     const u64 ts = max_tiles_for(max_keys, (u64)choose_sort_ipt(max_keys) * SORT_THREADS);
     if (max_records && e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
-    if (e->d_heads.ensure(t3 * sizeof(u32)) || e->d_rowbase.ensure(t3 * sizeof(u64))) return 1;
+    // K3's tile counts follow the same all-zero invariant as K1's (the scan clears what it reads): the scan covers the
+    // tiles of the caller's upper bound, the count kernel only writes the tiles of the actual key count
+    if (e->d_heads.bytes < t3 * sizeof(u32)) {
+        if (e->d_heads.ensure(t3 * sizeof(u32))) return 1;
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemset(e->d_heads.p, 0, e->d_heads.bytes));
+    }
+    if (e->d_rowbase.ensure(t3 * sizeof(u64))) return 1;
     if (e->d_tilecnt.bytes < t1 * sizeof(u32)) {                     // (re)allocated: establish the all-zero invariant
         if (e->d_tilecnt.ensure(t1 * sizeof(u32))) return 1;
         HIP_OK(hipDeviceSynchronize());
@@ -566,12 +602,12 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     return 0;
 }
 
-extern "C" int fastf_dev_reserve(fastf_engine_t* e, uint64_t max_records, uint64_t max_keys) {
+extern "C" int fastf_dev_reserve(fastf_engine_t* e, uint64_t max_records, uint64_t max_keys) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_reserve: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     return reserve_workspace(e, max_records, max_keys);
-}
+} FASTF_CATCH_INT
 
 // per-kernel timing helpers (only active in timing mode; adds event records to the stream)
 static void t_begin(fastf_engine* e, hipStream_t s) { if (e->timing) (void)hipEventRecord(e->t_ev[0], s); }
@@ -583,24 +619,24 @@ static void t_end(fastf_engine* e, hipStream_t s, double* acc, u64* cnt) {
     if (hipEventElapsedTime(&ms, e->t_ev[0], e->t_ev[1]) == hipSuccess) { *acc += ms; *cnt += 1; }
 }
 
-extern "C" int fastf_engine_set_timing(fastf_engine_t* e, int on) {
+extern "C" int fastf_engine_set_timing(fastf_engine_t* e, int on) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_engine_set_timing: device-level calls take a single-device engine");
     e->timing = on != 0;
     e->t_scatter_ms = e->t_k1_ms = e->t_k1b_ms = e->t_k3_ms = e->t_count_ms = 0;
     e->t_scatter_n = e->t_k1_n = e->t_k1b_n = e->t_k3_n = e->t_count_n = 0;
     return 0;
-}
+} FASTF_CATCH_INT
 // which: 0 = K1a probe_cells, 1 = K2 scatter, 2 = K3 (head_count + scan + reduce), 3 = K2 tile_count,
 //        4 = K1b filter_pack
-extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* total_ms, uint64_t* launches) {
+extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* total_ms, uint64_t* launches) FASTF_TRY {
     if (!e) return set_err("null engine");
     const double ms[5] = {e->t_k1_ms, e->t_scatter_ms, e->t_k3_ms, e->t_count_ms, e->t_k1b_ms};
     const u64 n[5] = {e->t_k1_n, e->t_scatter_n, e->t_k3_n, e->t_count_n, e->t_k1b_n};
     if (which < 0 || which > 4) return set_err("bad timer index");
     *total_ms = ms[which]; *launches = n[which];
     return 0;
-}
+} FASTF_CATCH_INT
 
 // ------------------------------------------------------------------------------------
 // device-level entry points
@@ -651,14 +687,14 @@ static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_tota
 }
 
 extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key, uint64_t n,
-                                    uint64_t* d_hits_out, void* stream) {
+                                    uint64_t* d_hits_out, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_count_hits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s)); return 0; }
     return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s);
-}
+} FASTF_CATCH_INT
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
@@ -718,7 +754,7 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
                                     const uint32_t* d_umi, const uint32_t* d_meta, uint64_t n,
                                     const uint32_t* d_draws, uint64_t n_draws, const uint64_t* d_draw_base,
                                     uint64_t* d_keys_out, uint64_t shard_stride, uint64_t* d_key_counts,
-                                    uint64_t* d_counters, uint32_t flags, void* stream) {
+                                    uint64_t* d_counters, uint32_t flags, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_probe_pack: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
@@ -728,9 +764,9 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
     return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
                         (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream, ~0ull, nullptr, seg);
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uint64_t* key_slots) {
+extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uint64_t* key_slots) FASTF_TRY {
     if (!e || !key_slots) return set_err("null argument");
     *key_slots = 0;
     if (!(e->n_shards == 1 && e->use_lds_genes) || getenv("FASTF_NO_STREAM_K1B")) return 0;
@@ -738,7 +774,7 @@ extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uin
     const u64 grid = std::min<u64>(std::max<u64>(tiles, 1), (u64)e->genes_blocks_per_cu * g_cu_count);
     *key_slots = grid * ((tiles + grid - 1) / grid) * K1_TILE;
     return 0;
-}
+} FASTF_CATCH_INT
 
 static u64* g_stamps = nullptr;   // diagnostic builds only (-DFASTF_STAMPS): per-tile phase timestamps of the last scatter
 extern "C" void fastf_debug_set_stamps(void* p) { g_stamps = (u64*)p; }
@@ -816,7 +852,7 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
 }
 
 extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_tmp, const uint64_t* d_n,
-                              uint64_t max_n, uint32_t key_bits, uint32_t flags, int* sorted_in_tmp, void* stream) {
+                              uint64_t max_n, uint32_t key_bits, uint32_t flags, int* sorted_in_tmp, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_sort: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
@@ -824,7 +860,7 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
                        (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0,
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream, (flags & FASTF_SORT_SEGMENTED) != 0);
-}
+} FASTF_CATCH_INT
 
 template <bool UMI_ROWS>
 static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u32* feature, u32* cell,
@@ -853,33 +889,33 @@ static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64
 
 extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
                                 uint32_t* d_feature, uint32_t* d_cell, uint32_t* d_count, uint64_t* d_nnz, uint32_t flags,
-                                void* stream) {
+                                void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_reduce: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, d_feature, d_cell, d_count, nullptr,
                                 (u64*)d_nnz, (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0, (hipStream_t)stream);
-}
+} FASTF_CATCH_INT
 
 extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
-                                  uint64_t* d_ukeys, uint32_t* d_ncopy, uint64_t* d_nrows, void* stream) {
+                                  uint64_t* d_ukeys, uint32_t* d_ncopy, uint64_t* d_nrows, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_umi_rows: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<true>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, nullptr, nullptr, d_ncopy,
                                (u64*)d_ukeys, (u64*)d_nrows, 0, (hipStream_t)stream);
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) {
+extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_error_bits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(bits, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64), hipMemcpyDeviceToHost));
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void* stream) {
+extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_clear_error_bits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
@@ -887,12 +923,12 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
     hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (u64*)e->d_small.p + SM_COUNTERS + 3, (u64)mask);
     HIP_OK(hipGetLastError());
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" const char* fastf_kernel_names(void) {
+extern "C" const char* fastf_kernel_names(void) FASTF_TRY {
     return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,filter_pack_stream_kernel,"
            "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
-}
+} FASTF_CATCH_ZERO
 
 // ------------------------------------------------------------------------------------
 // host-buffer streaming API
@@ -1087,40 +1123,40 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
     return 0;
 }
 
-extern "C" int fastf_engine_push(fastf_engine_t* e, const fastf_batch_t* batch) {
+extern "C" int fastf_engine_push(fastf_engine_t* e, const fastf_batch_t* batch) FASTF_TRY {
     return push_impl(e, batch, nullptr, 0, false);
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_push_draws(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws) {
+extern "C" int fastf_engine_push_draws(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws) FASTF_TRY {
     if (!draws && batch && batch->n) return set_err("null draws");
     return push_impl(e, batch, draws, n_draws, false);
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_push_pinned(fastf_engine_t* e, const fastf_batch_t* batch) {
+extern "C" int fastf_engine_push_pinned(fastf_engine_t* e, const fastf_batch_t* batch) FASTF_TRY {
     return push_impl(e, batch, nullptr, 0, true);
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_wait_input(fastf_engine_t* e) {
+extern "C" int fastf_engine_wait_input(fastf_engine_t* e) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return 0;                  // a multi-device push returns after its rounds have consumed the input
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize(e->s_copy));
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" void* fastf_pinned_alloc(size_t bytes) {
+extern "C" void* fastf_pinned_alloc(size_t bytes) FASTF_TRY {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
     return p;
-}
+} FASTF_CATCH_ZERO
 extern "C" void fastf_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
-extern "C" int fastf_pinned_register(void* p, size_t bytes) {
+extern "C" int fastf_pinned_register(void* p, size_t bytes) FASTF_TRY {
     HIP_OK(hipHostRegister(p, bytes, hipHostRegisterDefault));
     return 0;
-}
+} FASTF_CATCH_INT
 extern "C" void fastf_pinned_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
 
-extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) {
+extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) FASTF_TRY {
     if (!e || !coo) return set_err("null argument");
     if (e->multi) return multi_finish(e, coo, counters);
     HIP_OK(hipSetDevice(e->device));
@@ -1202,9 +1238,9 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
     coo->nnz = e->h_nnz;
     if (counters) { counters[0] = e->total_records; counters[1] = e->c_sampled; counters[2] = e->c_valid; }
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) {
+extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) FASTF_TRY {
     if (!e || !rows) return set_err("null argument");
     if (e->multi) return multi_umi_rows(e, rows);
     if (!e->finished) return set_err("call fastf_engine_finish first");
@@ -1256,9 +1292,9 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
     rows->feature = e->h_ufeature.data(); rows->cell = e->h_ucell.data(); rows->n_copy = e->h_ncopy.data();
     rows->umi = e->h_uumi.data(); rows->nonnull = e->h_unonnull.data(); rows->n = nrows;
     return 0;
-}
+} FASTF_CATCH_INT
 
-extern "C" int fastf_engine_reset(fastf_engine_t* e) {
+extern "C" int fastf_engine_reset(fastf_engine_t* e) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return multi_reset(e, false, 0, 0);
     HIP_OK(hipSetDevice(e->device));
@@ -1272,10 +1308,10 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) {
     e->draws_up = e->draws_valid = 0;
     e->mt_live = false;                  // the engine-owned stream goes on after the last draw a hit consumed
     return 0;
-}
+} FASTF_CATCH_INT
 
 // re-position the engine-owned draw stream (tests; bam2db() sets it through the config)
-extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t skip) {
+extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t skip) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return multi_reset(e, true, seed, skip);
     HIP_OK(hipSetDevice(e->device));
@@ -1283,7 +1319,7 @@ extern "C" int fastf_engine_reseed(fastf_engine_t* e, uint32_t seed, uint64_t sk
     e->mt_seed0 = seed; e->mt_skip0 = skip; e->mt_hits = 0;
     e->mt_live = false;
     return 0;
-}
+} FASTF_CATCH_INT
 
 // ------------------------------------------------------------------------------------
 // tag histogram (crb / extract): same translation unit, reuses K2 and K3u

@@ -93,3 +93,44 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode != 0 and "unknown option" in r.stderr
     r = subprocess.run([_lib.cli_path(), "bam2db", "-h"], capture_output=True, text=True)
     assert r.returncode == 0 and "--umicopies" in r.stdout
+
+
+def test_cpp_exceptions_do_not_cross_the_c_abi():
+    """bam2db_ds.h:60: failure = return 1 + a message.  An exception thrown by host-side C++ (a row buffer sized from a
+    device counter, a per-device list) must come back as that, not as std::terminate -> SIGABRT in the caller."""
+    L = C.CDLL(_lib.lib_path())
+    L.fastf_debug_raise_.restype = C.c_int
+    L.fastf_last_error.restype = C.c_char_p
+    expect = {0: "vector", 1: "out of host memory", 2: "unknown C++ exception", 3: "vector"}
+    for kind, text in expect.items():
+        assert L.fastf_debug_raise_(kind) == 1
+        msg = L.fastf_last_error().decode()
+        assert msg.startswith("fastf_debug_raise_: ") and text in msg, msg
+    assert L.fastf_debug_raise_(99) == 0
+
+
+def test_every_extern_c_body_in_the_cpp_unit_is_behind_the_barrier():
+    """static check: an extern "C" definition of the C++ translation unit either fits one line (getter / setter, no
+    allocation) or is a function-try-block closed by FASTF_CATCH_*"""
+    csrc = os.path.join(ROOT, "fastf_amd", "csrc")
+    n = 0
+    for name in ("umi_engine.hip", "multi_engine.hpp", "tag_hist.hpp", "gpu_frontend.hpp", "gpu_records.hpp"):
+        path = os.path.join(csrc, name)
+        if not os.path.exists(path):
+            continue
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            if not re.match(r'extern "C" .*\bfastf_\w+\(', line) or line.rstrip().endswith("}"):
+                continue
+            j = i
+            while not lines[j].rstrip().endswith("{"):
+                j += 1
+            if "fastf_last_error" in line:
+                continue
+            assert lines[j].rstrip().endswith("FASTF_TRY {"), "%s:%d has no exception barrier" % (name, i + 1)
+            k = j + 1
+            while not lines[k].startswith("}"):
+                k += 1
+            assert lines[k].startswith("} FASTF_CATCH_"), "%s:%d" % (name, k + 1)
+            n += 1
+    assert n >= 40

@@ -16,8 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def gi():
     so = os.path.join(ROOT, "build", "libgi_host.so")
-    os.makedirs(os.path.dirname(so), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "gi_host.cpp")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fastf_amd", "csrc"), so])
     L = C.CDLL(so)
     L.gi_host_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32]
 
