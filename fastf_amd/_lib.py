@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
     "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes", "fastf_engine_cell_scratch_bytes",
-    "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce",
+    "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce", "fastf_dev_rows_gather",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_error_bits",
     "fastf_dev_clear_error_bits", "fastf_kernel_names",
     # crb / extract
@@ -161,6 +161,7 @@ def lib():
     L.fastf_dev_probe_pack.argtypes = [vp, vp, vp, vp, vp, u64, vp, u64, vp, vp, u64, vp, vp, u32, vp]
     L.fastf_dev_sort.argtypes = [vp, vp, vp, vp, u64, u32, u32, C.POINTER(C.c_int), vp]
     L.fastf_dev_reduce.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, u32, vp]
+    L.fastf_dev_rows_gather.argtypes = [vp, vp, vp, vp, vp, vp]
     L.fastf_engine_skip_bits.argtypes = [vp, C.POINTER(u32)]
     L.fastf_engine_sort_passes.argtypes = [vp, u32, C.POINTER(u32)]
     L.fastf_engine_table_modes.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -162,12 +162,15 @@ struct fastf_engine {
     u32 skip_bits = 0;           // low key bits the matrix path leaves unsorted (dedup needs adjacency of equal keys only)
     bool fully_sorted = false;
     // workspace
-    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_tilecarry, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
+    DevBuf d_cellidx, d_tilecnt, d_tilebase, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
     DevBuf d_halfhits;                   // K1a: hits per 256-record unit (the streaming K1b's rank bases)
     DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
     u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
     DevBuf d_scanblk;                    // chunk totals of a scan over more than 16 384 tiles
-    DevBuf d_heads, d_rowbase;           // K3's tile counts / bases: not shared with K1, so K1 of the next batch may run beside K3 (other stream)
+    // K3: row regions (one slot per key: a workgroup's rows go to the slots of its own chunk), rows per chunk and their bases
+    DevBuf d_rg_feature, d_rg_cell, d_rg_count, d_rg_ukeys, d_spanrows, d_spanbase;
+    u32 rg_n = 0; bool rg_umi = false;   // chunks of the last reduce (0: none) and its kind
+    bool dedup_hash = false;             // matrix path: sort on (cell, feature) only, dedup through K3's hash set (else: run walk)
     // timing
     bool timing = false;
     hipEvent_t t_ev[2] = {nullptr, nullptr};
@@ -176,6 +179,7 @@ struct fastf_engine {
     double t_k1b_ms = 0; u64 t_k1b_n = 0;
     double t_k3_ms = 0; u64 t_k3_n = 0;
     double t_count_ms = 0; u64 t_count_n = 0;
+    double t_gather_ms = 0; u64 t_gather_n = 0;
 };
 
 // key_counts (one returning atomic per tile) and counters (three atomics per tile) sit on different 256-B segments
@@ -447,9 +451,13 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         // key bits from feat_shift - 8 upwards; the digit grid is anchored at the TOP of the key, so the number of 8-bit
         // passes is the minimum for that range whatever the key width (a byte-aligned grid spends a whole pass on the
         // one or two top bits of a 57/58-bit key).  Everything below the grid stays unsorted (K3 resolves those runs).
+        // FASTF_K3_DEDUP=hash: only (cell, feature) is sorted — every bit below feat_shift may stay unsorted — and K3 finds
+        // the distinct UMIs of a group through a hash set (one digit pass less on 57/58-bit keys); =walk: the run walk
         const char* sk = getenv("FASTF_SORT_SKIP_BITS");
+        const char* dd = getenv("FASTF_K3_DEDUP");
+        e->dedup_hash = dd ? strcmp(dd, "hash") == 0 : false;
         const u32 fs = e->L.feat_shift, kb = e->L.total_bits;
-        const u32 need_from = fs > 8 ? fs - 8 : 0;
+        const u32 need_from = e->dedup_hash ? fs : (fs > 8 ? fs - 8 : 0);
         const u32 passes = (kb - need_from + 7) / 8;
         e->skip_bits = sk ? (u32)atoi(sk) : (kb > 8 * passes ? kb - 8 * passes : 0);
         if (e->skip_bits >= fs) e->skip_bits = 0;
@@ -514,7 +522,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_tilecarry, &e->d_binbase, &e->d_cnt, &e->d_heads, &e->d_rowbase, &e->d_scanblk,
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -577,17 +585,9 @@ static u32 choose_sort_ipt(u64 n) {
 }
 
 static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
-    const u64 t1 = max_tiles_for(max_records, K1_TILE), t3 = max_tiles_for(max_keys, K3_TILE);
+    const u64 t1 = max_tiles_for(max_records, K1_TILE);
     const u64 ts = max_tiles_for(max_keys, (u64)choose_sort_ipt(max_keys) * SORT_THREADS);
     if (max_records && e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
-    // K3's tile counts follow the same all-zero invariant as K1's (the scan clears what it reads): the scan covers the
-    // tiles of the caller's upper bound, the count kernel only writes the tiles of the actual key count
-    if (e->d_heads.bytes < t3 * sizeof(u32)) {
-        if (e->d_heads.ensure(t3 * sizeof(u32))) return 1;
-        HIP_OK(hipDeviceSynchronize());
-        HIP_OK(hipMemset(e->d_heads.p, 0, e->d_heads.bytes));
-    }
-    if (e->d_rowbase.ensure(t3 * sizeof(u64))) return 1;
     if (e->d_tilecnt.bytes < t1 * sizeof(u32)) {                     // (re)allocated: establish the all-zero invariant
         if (e->d_tilecnt.ensure(t1 * sizeof(u32))) return 1;
         HIP_OK(hipDeviceSynchronize());
@@ -596,7 +596,6 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     if (e->d_tilebase.ensure(t1 * sizeof(u64))) return 1;
     if (e->d_halfhits.ensure(t1 * 16 * sizeof(u32))) return 1;
     if (e->d_tileseg.ensure((ts + 8) * sizeof(TileSeg))) return 1;
-    if (e->d_tilecarry.ensure(t3 * sizeof(u32))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
     return 0;
@@ -623,17 +622,17 @@ extern "C" int fastf_engine_set_timing(fastf_engine_t* e, int on) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_engine_set_timing: device-level calls take a single-device engine");
     e->timing = on != 0;
-    e->t_scatter_ms = e->t_k1_ms = e->t_k1b_ms = e->t_k3_ms = e->t_count_ms = 0;
-    e->t_scatter_n = e->t_k1_n = e->t_k1b_n = e->t_k3_n = e->t_count_n = 0;
+    e->t_scatter_ms = e->t_k1_ms = e->t_k1b_ms = e->t_k3_ms = e->t_count_ms = e->t_gather_ms = 0;
+    e->t_scatter_n = e->t_k1_n = e->t_k1b_n = e->t_k3_n = e->t_count_n = e->t_gather_n = 0;
     return 0;
 } FASTF_CATCH_INT
-// which: 0 = K1a probe_cells, 1 = K2 scatter, 2 = K3 (head_count + scan + reduce), 3 = K2 tile_count,
-//        4 = K1b filter_pack
+// which: 0 = K1a probe_cells, 1 = K2 scatter, 2 = K3 (reduce_windows + span_scan), 3 = K2 tile_count,
+//        4 = K1b filter_pack, 5 = rows_gather (concatenation of K3's row regions)
 extern "C" int fastf_engine_get_timing(fastf_engine_t* e, int which, double* total_ms, uint64_t* launches) FASTF_TRY {
     if (!e) return set_err("null engine");
-    const double ms[5] = {e->t_k1_ms, e->t_scatter_ms, e->t_k3_ms, e->t_count_ms, e->t_k1b_ms};
-    const u64 n[5] = {e->t_k1_n, e->t_scatter_n, e->t_k3_n, e->t_count_n, e->t_k1b_n};
-    if (which < 0 || which > 4) return set_err("bad timer index");
+    const double ms[6] = {e->t_k1_ms, e->t_scatter_ms, e->t_k3_ms, e->t_count_ms, e->t_k1b_ms, e->t_gather_ms};
+    const u64 n[6] = {e->t_k1_n, e->t_scatter_n, e->t_k3_n, e->t_count_n, e->t_k1b_n, e->t_gather_n};
+    if (which < 0 || which > 5) return set_err("bad timer index");
     *total_ms = ms[which]; *launches = n[which];
     return 0;
 } FASTF_CATCH_INT
@@ -862,29 +861,67 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream, (flags & FASTF_SORT_SEGMENTED) != 0);
 } FASTF_CATCH_INT
 
+// K3 grid: every workgroup owns one contiguous chunk of the keys, so the launch is one round of resident workgroups
+// (LDS: 25 KB per workgroup, 41 KB with the hash set of DEDUP 2; 64 VGPRs: eight waves per SIMD)
+static u32 k3_grid(u64 max_n, int dedup) {
+    static int per_cu[3] = {-1, -1, -1};
+    if (per_cu[dedup] < 0) {
+        const char* c = getenv("FASTF_K3_PER_CU");
+        per_cu[dedup] = c ? atoi(c) : (dedup == 2 ? 3 : 4);
+        if (per_cu[dedup] < 1) per_cu[dedup] = 1;
+    }
+    const u64 tiles = (max_n + K3_TILE - 1) / K3_TILE;
+    return (u32)std::min<u64>(std::max<u64>(tiles, 1), std::min<u64>((u64)per_cu[dedup] * g_cu_count, 4096));
+}
+
+// rows into the engine's row regions (one per workgroup chunk), chunk row counts -> bases, total -> *nrows
 template <bool UMI_ROWS>
-static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u32* feature, u32* cell,
-                         u32* count, u64* ukeys, u64* nrows, u32 low_skip, hipStream_t s) {
+static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u64* nrows, u32 low_skip, hipStream_t s) {
+    e->rg_n = 0;
     if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
-    if (reserve_workspace(e, 0, max_n)) return 1;
-    const u32 tiles = (u32)((max_n + K3_TILE - 1) / K3_TILE);
+    const int dedup = (UMI_ROWS || low_skip == 0) ? 0 : (e->dedup_hash ? 2 : 1);
+    const u32 G = k3_grid(max_n, dedup);
+    if (e->d_rg_count.ensure(max_n * 4)) return 1;
+    if (UMI_ROWS ? e->d_rg_ukeys.ensure(max_n * 8) : (e->d_rg_feature.ensure(max_n * 4) || e->d_rg_cell.ensure(max_n * 4))) return 1;
+    if (e->d_spanrows.ensure(4096 * sizeof(u32)) || e->d_spanbase.ensure(4097 * sizeof(u64))) return 1;
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
     p.low_skip = UMI_ROWS ? 0 : low_skip;
-    p.tile_heads = (u32*)e->d_heads.p; p.row_base = (const u64*)e->d_rowbase.p;
-    p.tile_carry = (u32*)e->d_tilecarry.p;
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
-    p.feature = feature; p.cell = cell; p.count = count; p.ukeys = ukeys;
+    p.feature = (u32*)e->d_rg_feature.p; p.cell = (u32*)e->d_rg_cell.p; p.count = (u32*)e->d_rg_count.p; p.ukeys = (u64*)e->d_rg_ukeys.p;
+    p.span_rows = (u32*)e->d_spanrows.p;
     t_begin(e, s);
-    const u32 k3_grid = std::min<u32>(tiles, tile_grid(~0u - 8u));
-    hipLaunchKernelGGL(head_count_kernel<UMI_ROWS>, dim3(k3_grid), dim3(K3_THREADS), 0, s, p);
-    launch_scan_tiles(e, 1, s, (u32*)e->d_heads.p, (u64*)e->d_rowbase.p, tiles, nrows, nullptr, nullptr);
-    hipLaunchKernelGGL(reduce_kernel<UMI_ROWS>, dim3(k3_grid), dim3(K3_THREADS), 0, s, p);
-    hipLaunchKernelGGL(carry_fix_kernel, dim3((tiles + 255) / 256), dim3(256), 0, s, (const u32*)e->d_tilecarry.p,
-                       (const u64*)e->d_rowbase.p, count, d_n);
+    if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else if (dedup == 1) hipLaunchKernelGGL((reduce_windows_kernel<false, 1>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((reduce_windows_kernel<false, 2>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
+    e->rg_n = G; e->rg_umi = UMI_ROWS;
     return 0;
+}
+
+// concatenation of the regions of the last launch_reduce_regions on this engine (same d_n); the destinations are device
+// arrays or pinned host memory
+template <bool UMI_ROWS>
+static int launch_rows_gather(fastf_engine* e, const u64* d_n, u32* feature, u32* cell, u32* count, u64* ukeys, hipStream_t s) {
+    if (!e->rg_n) return 0;                             // nothing was reduced (max_n == 0)
+    if (e->rg_umi != UMI_ROWS) return set_err("rows gather: the last reduce on this engine was of the other kind");
+    t_begin(e, s);
+    hipLaunchKernelGGL(rows_gather_kernel<UMI_ROWS>, dim3(e->rg_n), dim3(256), 0, s, (const u32*)e->d_rg_feature.p, (const u32*)e->d_rg_cell.p,
+                       (const u32*)e->d_rg_count.p, (const u64*)e->d_rg_ukeys.p, (const u32*)e->d_spanrows.p, (const u64*)e->d_spanbase.p,
+                       d_n, e->rg_n, feature, cell, count, ukeys);
+    HIP_OK(hipGetLastError());
+    if (!UMI_ROWS) t_end(e, s, &e->t_gather_ms, &e->t_gather_n);
+    return 0;
+}
+
+template <bool UMI_ROWS>
+static int launch_reduce(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u32* feature, u32* cell,
+                         u32* count, u64* ukeys, u64* nrows, u32 low_skip, hipStream_t s) {
+    if (launch_reduce_regions<UMI_ROWS>(e, sorted, d_n, max_n, nrows, low_skip, s)) return 1;
+    return launch_rows_gather<UMI_ROWS>(e, d_n, feature, cell, count, ukeys, s);
 }
 
 extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
@@ -893,8 +930,19 @@ extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, con
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_reduce: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
+    const u32 low = (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0;
+    if (flags & FASTF_REDUCE_SEGMENTED)
+        return launch_reduce_regions<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, (u64*)d_nnz, low, (hipStream_t)stream);
     return launch_reduce<false>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, d_feature, d_cell, d_count, nullptr,
-                                (u64*)d_nnz, (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0, (hipStream_t)stream);
+                                (u64*)d_nnz, low, (hipStream_t)stream);
+} FASTF_CATCH_INT
+
+extern "C" int fastf_dev_rows_gather(fastf_engine_t* e, const uint64_t* d_n, uint32_t* feature, uint32_t* cell, uint32_t* count,
+                                     void* stream) FASTF_TRY {
+    if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_rows_gather: device-level calls take a single-device engine");
+    HIP_OK(hipSetDevice(e->device));
+    return launch_rows_gather<false>(e, (const u64*)d_n, feature, cell, count, nullptr, (hipStream_t)stream);
 } FASTF_CATCH_INT
 
 extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, const uint64_t* d_n, uint64_t max_n,
@@ -927,7 +975,7 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 
 extern "C" const char* fastf_kernel_names(void) FASTF_TRY {
     return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,filter_pack_stream_kernel,"
-           "tile_count_kernel,row_scan_kernel,scatter_kernel,head_count_kernel,reduce_kernel";
+           "tile_count_kernel,row_scan_kernel,scatter_kernel,reduce_windows_kernel,span_scan_kernel,rows_gather_kernel";
 } FASTF_CATCH_ZERO
 
 // ------------------------------------------------------------------------------------

@@ -1322,112 +1322,157 @@ __global__ __launch_bounds__(SORT_THREADS, 8) void scatter_kernel(const u64* __r
 
 
 // ------------------------------------------------------------------------------------
-// K3 / K3u: segmented unique + reduce over the sorted keys.
+// K3 / K3u: segmented unique + reduce over the sorted keys — the keys are read ONCE.
 //   UMI_ROWS = false: one row per (cell, feature); count = distinct non-NULL umi keys
 //   UMI_ROWS = true : one row per distinct key;    count = copies of that key
-// K3a counts group heads per tile, scan_tiles_kernel turns that into row bases, K3b stages the
-// tile's rows in LDS (identity + prefix count of distinct flags at each head: a row's count is the
-// difference of two neighbouring prefixes) and writes them with coalesced plain stores; the few
-// groups that straddle tiles are patched by carry_fix_kernel.  No atomics, no memset on the row
-// arrays (mixing plain stores and device-scope atomics on the same lines cost 60 us here).
+// Each workgroup owns a contiguous chunk of the key array and walks it in windows of K3_TILE keys.  A window always
+// starts at the head of a group and is CUT at a head: the group that is still open at the end of a window is not
+// processed, the next window starts at its head (those few keys are read again: they are the tail of a tile this
+// workgroup has just touched).  A chunk starts at the first head at or after its nominal start and ends at the first
+// head at or after its nominal end, so groups never straddle windows or chunks: no carries, no fix-up pass, and the row
+// count of a chunk is known to the workgroup alone.  Rows therefore go to a REGION per workgroup (the slots of its own
+// keys: a chunk has at most as many rows as keys) with coalesced plain stores, span_rows[] keeps the counts,
+// span_scan_kernel turns them into row bases + the total, and rows_gather_kernel concatenates the regions wherever the
+// rows are wanted — into device arrays, or straight into pinned host memory, where it IS the device-to-host copy.
+// Traffic: 8 bytes per key in, 12 (16 for -u) bytes per row out: SURVEY 8d's K3 bytes.
+// A group longer than a window (only one head in it) is carried as an "open row" across windows in the modes that can
+// (DEDUP 0/1); the hash mode flags ERR_RUN_TOO_LONG and the caller finishes the sort (same contract as the run cap).
+//   DEDUP 0: keys fully sorted              -> a key is new iff it differs from its neighbour in front
+//   DEDUP 1: sorted on bits >= low_skip     -> equal keys sit in one unsorted run: walk back over the run (cap RUN_CAP)
+//   DEDUP 2: sorted on (cell, feature) only -> exact dedup through a window-local hash set in LDS (the table holds
+//            positions into the staged keys, a hit compares the full 64-bit keys): one digit pass less for the sort
 // ------------------------------------------------------------------------------------
 struct ReduceParams {
     const u64* keys; const u64* n_ptr;
     KeyLayout L; u32 feat_mask;
     u32 low_skip;                          // the keys are sorted on bits >= low_skip only (0 = fully sorted)
-    u32* tile_heads;                       // K3a out
-    u32* tile_carry;                       // K3b out: distinct flags in front of the tile's first head
     u64* err;                              // error bits (ERR_RUN_TOO_LONG)
-    const u64* row_base;                   // K3b in (scan of tile_heads)
-    u32* feature; u32* cell; u32* count;   // UMI_ROWS: feature/cell unused
+    u32* feature; u32* cell; u32* count;   // row REGIONS (capacity: one slot per key); UMI_ROWS: feature/cell unused
     u64* ukeys;                            // UMI_ROWS only
+    u32* span_rows;                        // rows per workgroup chunk [gridDim.x]
 };
 
-// 4 keys per thread (2048-key tiles, 24 KB of LDS: six workgroups per CU): 324 us vs 352 us for 8 on the configs[2] shape
+// 4 keys per thread (2048-key windows): 324 us vs 352 us for 8 on the configs[2] shape (two-pass form of round 2)
 #ifndef FASTF_K3_IPT
 #define FASTF_K3_IPT 4
 #endif
 #ifndef FASTF_K3_THREADS
 #define FASTF_K3_THREADS 512
 #endif
+#ifndef FASTF_K3_TAB
+#define FASTF_K3_TAB 4096                  // hash-set slots of DEDUP 2 (u32 each): at most K3_TILE keys go in
+#endif
 constexpr int K3_THREADS = FASTF_K3_THREADS, K3_IPT = FASTF_K3_IPT, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
 constexpr int K3_UNITS = K3_IPT * K3_WAVES;
+constexpr u32 K3_TAB = FASTF_K3_TAB;
 static_assert(K3_UNITS <= WAVE, "one wave scans the (item, wave) units");
+static_assert((K3_TAB & (K3_TAB - 1)) == 0 && K3_TAB >= (u32)K3_TILE, "hash set: power of two, room for a whole window");
 
-// both K3 kernels run on a capped grid and walk their tiles (tile += gridDim): the launch is sized for the caller's
-// upper bound on the key count, and workgroups without a tile are not free
-template <bool UMI_ROWS>
-__global__ __launch_bounds__(K3_THREADS) void head_count_kernel(const ReduceParams p) {
-    __shared__ u32 s_w[K3_WAVES];
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const u64 n = *p.n_ptr;
-    const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
-    for (u64 tile = blockIdx.x; tile * K3_TILE < n; tile += gridDim.x) {
-        const u64 base = tile * K3_TILE;
-        u32 heads = 0;
-#pragma unroll
-        for (int j = 0; j < K3_IPT; ++j) {
-            const u64 idx = base + (u64)j * K3_THREADS + tid;
-            if (idx < n) {
-                const u64 k = p.keys[idx];
-                heads += idx == 0 || (k >> gshift) != (p.keys[idx - 1] >> gshift);
-            }
-        }
-        heads = wave_sum32(heads);
-        if (lane == 0) s_w[w] = heads;
-        __syncthreads();
-        if (tid == 0) {
-            u32 t = 0;
-            for (int i = 0; i < K3_WAVES; ++i) t += s_w[i];
-            p.tile_heads[tile] = t;
-        }
-        __syncthreads();
-    }
+// nominal chunk of workgroup b of G: whole tiles, spread evenly; [start, end) in keys
+__host__ __device__ __forceinline__ u64 k3_chunk_start(u64 n, u32 b, u32 G) {
+    const u64 T = (n + K3_TILE - 1) / K3_TILE;
+    const u64 s = (T * b / G) * K3_TILE;
+    return s < n ? s : n;
 }
 
-template <bool UMI_ROWS>
-__global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce_kernel(const ReduceParams p) {
-    // (item, wave) units in tile order: heads / distinct flags per unit, then their exclusive scans
-    __shared__ u32 s_h[K3_IPT * K3_WAVES], s_d[K3_IPT * K3_WAVES];
+__device__ __forceinline__ u32 wave_min32(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)v, o, WAVE); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ u32 wave_max32(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)v, o, WAVE); v = t > v ? t : v; }
+    return v;
+}
+
+template <bool UMI_ROWS, int DEDUP>
+__global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce_windows_kernel(const ReduceParams p) {
+    static_assert(!UMI_ROWS || DEDUP == 0, "-u rows come from fully sorted keys");
+    // (item, wave) units in window order: heads / distinct flags per unit, then their exclusive scans
+    __shared__ u32 s_h[K3_UNITS], s_d[K3_UNITS];
+    __shared__ u64 s_hb[K3_UNITS];         // head ballots of the units (the cut is found from these)
     __shared__ u32 s_tot[2];
-    // rows of this tile, by local row: distinct-prefix at the head, and the row's identity
-    __shared__ u32 s_pd[K3_TILE + 1];
-    __shared__ u64 s_id[K3_TILE];          // UMI_ROWS: the key; else (cell << 32) | feature
+    __shared__ u32 s_pd[K3_TILE + 1];      // by local row: distinct-prefix at the head
+    __shared__ u64 s_id[K3_TILE];          // the window's keys, later the row identities (UMI_ROWS: the key; else (cell << 32) | feature)
+    __shared__ u32 s_tab[DEDUP == 2 ? K3_TAB : 1];
+    __shared__ u32 s_first;                // chunk start search
 
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const u64 n = *p.n_ptr;
     const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
     const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
-    for (u32 tile = blockIdx.x; (u64)tile * K3_TILE < n; tile += gridDim.x) {
-    const u64 base = (u64)tile * K3_TILE;
+    const u32 G = gridDim.x, b = blockIdx.x;
+    const u64 nom_start = k3_chunk_start(n, b, G), nom_end = k3_chunk_start(n, b + 1, G);
+    u32 rows_so_far = 0;                   // (uniform) rows of this chunk written so far
+    if (DEDUP == 2) { for (u32 i = tid; i < K3_TAB; i += K3_THREADS) s_tab[i] = 0; }
 
-    u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
-    bool too_long = false;
-    // the tile's keys go through LDS (the array that holds the row identities later): the neighbour of a key and, on the
-    // group-only path, the walk back over a run of unsorted keys are LDS reads; only what lies in front of the tile is
-    // fetched from memory
-#pragma unroll
-    for (int j = 0; j < K3_IPT; ++j) {
-        const u64 idx = base + (u64)j * K3_THREADS + tid;
-        key[j] = idx < n ? ld_once<FASTF_NT_K3 != 0>(p.keys + idx) : 0;
-        s_id[j * K3_THREADS + tid] = key[j];
+    // ---- chunk start: the first head at or after the nominal start (a group that began earlier belongs to the chunk before) ----
+    u64 cursor = nom_start;
+    if (b > 0 && nom_start < nom_end) {
+        for (;;) {
+            if (tid == 0) s_first = ~0u;
+            __syncthreads();
+            const u64 idx = cursor + tid;
+            bool head = false;
+            if (idx < nom_end) head = idx == 0 || (p.keys[idx] >> gshift) != (p.keys[idx - 1] >> gshift);
+            const u64 m = __ballot(head);
+            if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            const u32 f = s_first;
+            __syncthreads();
+            if (f != ~0u) { cursor += f; break; }
+            cursor += K3_THREADS;
+            if (cursor >= nom_end) break;
+        }
     }
-    __syncthreads();
+    if (cursor >= nom_end) { if (tid == 0) p.span_rows[b] = 0; return; }   // no group starts in this chunk (or it is empty)
+
+    const u64 region = nom_start;          // rows of this chunk go to the slots of its own keys
+    bool open_valid = false;               // (uniform) a group longer than a window is being carried
+    u64 open_id = 0; u32 open_cnt = 0;
+    bool done = false;
+    while (!done) {
+        const u64 base = cursor;
+        const u32 W = (u32)(n - base < (u64)K3_TILE ? n - base : (u64)K3_TILE);
+        u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
+        u32 slot[K3_IPT];
+        bool too_long = false;
 #pragma unroll
-    for (int j = 0; j < K3_IPT; ++j) {
-        const u32 loc = (u32)j * K3_THREADS + tid;
-        const u64 idx = base + loc;
-        const bool valid = idx < n;
-        const u64 k = key[j];
-        const u64 prev = (valid && idx > 0) ? (loc > 0 ? s_id[loc - 1] : p.keys[idx - 1]) : ~k;
-        const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
-        bool dist;
-        if (UMI_ROWS) dist = valid;
-        else {
-            dist = valid && ((k >> nn_shift) & 1);
-            if (dist && idx > 0) {
-                if (p.low_skip == 0) dist = k != prev;
-                else {
+        for (int j = 0; j < K3_IPT; ++j) {
+            const u32 loc = (u32)j * K3_THREADS + tid;
+            key[j] = loc < W ? ld_once<FASTF_NT_K3 != 0>(p.keys + base + loc) : 0;
+            s_id[loc] = key[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < K3_IPT; ++j) {
+            const u32 loc = (u32)j * K3_THREADS + tid;
+            const u64 idx = base + loc;
+            const bool valid = loc < W;
+            const u64 k = key[j];
+            const u64 prev = (valid && idx > 0) ? (loc > 0 ? s_id[loc - 1] : p.keys[idx - 1]) : ~k;
+            const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
+            bool dist;
+            slot[j] = ~0u;
+            if (UMI_ROWS) dist = valid;
+            else {
+                dist = valid && ((k >> nn_shift) & 1);
+                if (DEDUP == 0) { if (dist && idx > 0) dist = k != prev; }
+                else if (DEDUP == 2) {
+                    if (dist) {
+                        // window-local hash set: the first key to take a slot is the one that counts
+                        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
+                        for (;;) {
+                            u32 v = s_tab[h];
+                            if (v == 0) {
+                                if (__hip_atomic_compare_exchange_strong(&s_tab[h], &v, loc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = h; break; }
+                            }
+                            if (s_id[v - 1] == k) { dist = false; break; }
+                            h = (h + 1) & (K3_TAB - 1);
+                        }
+                    }
+                } else if (dist && idx > 0) {
                     // keys that agree on the sorted bits are neighbours but in arbitrary order: this key is a new UMI
                     // iff no earlier key of that little run equals it.  The run is (cell, feature, top UMI bits), i.e.
                     // 1/2^(sorted UMI bits) of a group plus its exact duplicates — a step or two in practice.
@@ -1456,65 +1501,167 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
                                 at = idx - 1 - NEAR; q = nb[NEAR - 1]; steps = NEAR;
                             }
                             if (open) {
+                                // inside the window the walk reads LDS; a run that began in front of it goes on in memory
+                                // (two loops, not one load through a selected pointer: an LDS/global pointer select becomes a
+                                // flat access and trips the gfx950 backend)
+                                bool in_lds = true;
                                 for (;; ++steps) {
-                                    if ((q >> p.low_skip) != run) break;
-                                    if (q == k) { dist = false; break; }
-                                    if (at == 0) break;
-                                    if (steps >= RUN_CAP) { too_long = true; break; }   // not this path's kind of data: sort fully instead
+                                    if ((q >> p.low_skip) != run) { in_lds = false; break; }
+                                    if (q == k) { dist = false; in_lds = false; break; }
+                                    if (at == 0) { in_lds = false; break; }
+                                    if (steps >= RUN_CAP) { too_long = true; in_lds = false; break; }   // not this path's kind of data: sort fully instead
+                                    if (at == base) break;
                                     --at;
-                                    q = at >= base ? s_id[(u32)(at - base)] : p.keys[at];
+                                    q = s_id[(u32)(at - base)];
+                                }
+                                if (in_lds) {
+                                    for (;; ++steps) {
+                                        --at;
+                                        q = __builtin_nontemporal_load(p.keys + at);
+                                        if ((q >> p.low_skip) != run) break;
+                                        if (q == k) { dist = false; break; }
+                                        if (at == 0) break;
+                                        if (steps >= RUN_CAP) { too_long = true; break; }
+                                    }
                                 }
                             }
                         }
                     }
                 }
             }
+            hm[j] = __ballot(head); dm[j] = __ballot(dist);
+            if (lane == 0) s_hb[j * K3_WAVES + w] = hm[j];
         }
-        hm[j] = __ballot(head); dm[j] = __ballot(dist);
-        if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }
-    }
-    if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
-    __syncthreads();
-    if (w == 0) {
-        const u32 h = lane < K3_UNITS ? s_h[lane] : 0u, d = lane < K3_UNITS ? s_d[lane] : 0u;
-        const u32 hi = wave_incl_scan32(h, lane), di = wave_incl_scan32(d, lane);
-        if (lane < K3_UNITS) { s_h[lane] = hi - h; s_d[lane] = di - d; }
-        if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = di; }   // sentinel: all distinct flags of the tile
-    }
-    __syncthreads();
-    const u32 n_rows = s_tot[0];
+        __syncthreads();
+        // ---- the cut (every wave works it out for itself from the 32 head ballots) ----
+        //   stop: the first head at or beyond the chunk's nominal end — it and everything after it belong to the next chunk
+        //   else, at the end of the data, the whole window; else the last head of the window (its group is left to the
+        //   next window); else (one group fills the window) the whole window, the group stays open
+        const u32 lim = nom_end > base ? (u32)(nom_end - base < (u64)K3_TILE ? nom_end - base : (u64)K3_TILE) : 0u;
+        u32 c_stop = ~0u, c_last = 0;
+        if (lane < K3_UNITS) {
+            const u64 hb = s_hb[lane];
+            const u32 ub = (u32)(lane / K3_WAVES) * K3_THREADS + (u32)(lane % K3_WAVES) * WAVE;    // first position of the unit
+            u64 at_or_after = hb;
+            if (lim > ub) at_or_after = lim - ub >= 64 ? 0ull : hb & ~((1ull << (lim - ub)) - 1);
+            if (at_or_after) c_stop = ub + (u32)__builtin_ctzll(at_or_after);
+            const u64 not_first = ub == 0 ? hb & ~1ull : hb;
+            if (not_first) c_last = ub + 63u - (u32)__builtin_clzll(not_first);
+        }
+        c_stop = wave_min32(c_stop); c_last = wave_max32(c_last);
+        u32 cut; bool closed;
+        if (c_stop != ~0u) { cut = c_stop; closed = true; done = true; }
+        else if (base + W == n) { cut = W; closed = true; done = true; }
+        else if (c_last > 0) { cut = c_last; closed = true; }
+        else { cut = W; closed = false; if (DEDUP == 2) too_long = true; }
+        if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
+        // keys at or beyond the cut are not this window's
 #pragma unroll
-    for (int j = 0; j < K3_IPT; ++j) {
-        if ((hm[j] >> lane) & 1) {
-            const u32 r = s_h[j * K3_WAVES + w] + rank_below(hm[j]);
-            s_pd[r] = s_d[j * K3_WAVES + w] + rank_below(dm[j]);
-            s_id[r] = UMI_ROWS ? key[j]
-                               : (((u64)(u32)(key[j] >> p.L.cell_shift)) << 32) | ((u32)(key[j] >> p.L.feat_shift) & p.feat_mask);
+        for (int j = 0; j < K3_IPT; ++j) {
+            const u32 ub = (u32)j * K3_THREADS + (u32)w * WAVE;
+            const u64 below = cut <= ub ? 0ull : (cut - ub >= 64 ? ~0ull : (1ull << (cut - ub)) - 1);
+            hm[j] &= below; dm[j] &= below;
+            if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }
         }
+        __syncthreads();
+        if (w == 0) {
+            const u32 h = lane < K3_UNITS ? s_h[lane] : 0u, d = lane < K3_UNITS ? s_d[lane] : 0u;
+            const u32 hi = wave_incl_scan32(h, lane), di = wave_incl_scan32(d, lane);
+            if (lane < K3_UNITS) { s_h[lane] = hi - h; s_d[lane] = di - d; }
+            if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = di; }   // sentinel: all distinct flags of the window
+        }
+        __syncthreads();
+        const u32 n_rows = s_tot[0], d_all = s_tot[1];
+#pragma unroll
+        for (int j = 0; j < K3_IPT; ++j) {
+            if (DEDUP == 2 && slot[j] != ~0u) s_tab[slot[j]] = 0;        // the set is empty again for the next window
+            if ((hm[j] >> lane) & 1) {
+                const u32 r = s_h[j * K3_WAVES + w] + rank_below(hm[j]);
+                s_pd[r] = s_d[j * K3_WAVES + w] + rank_below(dm[j]);
+                s_id[r] = UMI_ROWS ? key[j]
+                                   : (((u64)(u32)(key[j] >> p.L.cell_shift)) << 32) | ((u32)(key[j] >> p.L.feat_shift) & p.feat_mask);
+            }
+        }
+        __syncthreads();
+        // distinct flags in front of the window's first head belong to the open row (none unless a group is being carried)
+        const u32 lead = n_rows ? s_pd[0] : d_all;
+        if (open_valid) open_cnt += lead;
+        u32 first_row = 0, last_row = n_rows;              // rows [first_row, last_row) of the window are written now
+        if (open_valid && (n_rows > 0 || done)) {
+            // the carried group has ended: its row goes out in front of the window's own
+            if (tid == 0) {
+                const u64 at = region + rows_so_far;
+                p.count[at] = open_cnt;
+                if (UMI_ROWS) p.ukeys[at] = open_id;
+                else { p.feature[at] = (u32)open_id; p.cell[at] = (u32)(open_id >> 32); }
+            }
+            rows_so_far += 1; open_valid = false;
+        }
+        if (!closed && n_rows > 0) {                       // one group fills the window and goes on: carry it
+            last_row = n_rows - 1;
+            open_valid = true; open_id = s_id[last_row]; open_cnt = s_pd[n_rows] - s_pd[last_row];
+        }
+        const u64 row_base = region + rows_so_far;
+        for (u32 r = first_row + tid; r < last_row; r += K3_THREADS) {
+            const u32 c = s_pd[r + 1] - s_pd[r];
+            const u64 id = s_id[r];
+            p.count[row_base + r] = c;
+            if (UMI_ROWS) p.ukeys[row_base + r] = id;
+            else { p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32); }
+        }
+        rows_so_far += last_row - first_row;
+        cursor = base + cut;
+        __syncthreads();                               // the next window restages the shared arrays
     }
-    __syncthreads();
-    // distinct flags in front of the first head belong to a group that started in an earlier tile
-    if (tid == 0) p.tile_carry[tile] = n_rows ? s_pd[0] : s_tot[1];
-    const u64 row_base = p.row_base[tile];
-    for (u32 r = tid; r < n_rows; r += K3_THREADS) {
-        const u32 c = s_pd[r + 1] - s_pd[r];
-        const u64 id = s_id[r];
-        p.count[row_base + r] = c;
-        if (UMI_ROWS) p.ukeys[row_base + r] = id;
-        else { p.feature[row_base + r] = (u32)id; p.cell[row_base + r] = (u32)(id >> 32); }
+    if (open_valid) {                                  // (cannot happen: the last window closes the group — kept as a guard)
+        if (tid == 0) {
+            const u64 at = region + rows_so_far;
+            p.count[at] = open_cnt;
+            if (UMI_ROWS) p.ukeys[at] = open_id;
+            else { p.feature[at] = (u32)open_id; p.cell[at] = (u32)(open_id >> 32); }
+        }
+        rows_so_far += 1;
     }
-    __syncthreads();                               // the next tile restages the shared arrays
-    }
+    if (tid == 0) p.span_rows[b] = rows_so_far;
 }
 
-// groups that straddle tiles: add the carried distinct counts to the row whose head is in an earlier tile
-__global__ __launch_bounds__(256) void carry_fix_kernel(const u32* __restrict__ tile_carry, const u64* __restrict__ row_base,
-                                                        u32* __restrict__ count, const u64* __restrict__ n_ptr) {
+// row bases of the chunks (exclusive scan of span_rows, G <= 4096) and the total
+__global__ __launch_bounds__(1024) void span_scan_kernel(const u32* __restrict__ span_rows, u32 G, u64* __restrict__ span_base,
+                                                         u64* __restrict__ total_out) {
+    __shared__ u32 s_w[16];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    u32 v[4]; u32 sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) { const u32 i = threadIdx.x * 4 + k; v[k] = i < G ? span_rows[i] : 0u; sum += v[k]; }
+    const u32 inc = wave_incl_scan32(sum, lane);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    u64 off = 0;
+    for (int i = 0; i < w; ++i) off += s_w[i];
+    u64 e = off + inc - sum;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) { const u32 i = threadIdx.x * 4 + k; if (i < G) span_base[i] = e; e += v[k]; }
+    if (threadIdx.x == 1023) { span_base[G] = e; if (total_out) *total_out = e; }
+}
+
+// concatenation of the chunks' row regions: one workgroup per chunk.  The destinations may be device arrays or pinned
+// host memory (then this kernel is the device-to-host copy of the rows).
+template <bool UMI_ROWS>
+__global__ __launch_bounds__(256) void rows_gather_kernel(const u32* __restrict__ rg_feature, const u32* __restrict__ rg_cell,
+                                                          const u32* __restrict__ rg_count, const u64* __restrict__ rg_ukeys,
+                                                          const u32* __restrict__ span_rows, const u64* __restrict__ span_base,
+                                                          const u64* __restrict__ n_ptr, u32 G,
+                                                          u32* __restrict__ feature, u32* __restrict__ cell, u32* __restrict__ count,
+                                                          u64* __restrict__ ukeys) {
     const u64 n = *n_ptr;
-    const u32 T = (u32)((n + K3_TILE - 1) / K3_TILE);
-    for (u32 t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
-        const u32 c = tile_carry[t];
-        if (c && t > 0) atomicAdd(&count[row_base[t] - 1], c);
+    for (u32 b = blockIdx.x; b < G; b += gridDim.x) {
+        const u32 rows = span_rows[b];
+        const u64 src = k3_chunk_start(n, b, G), dst = span_base[b];
+        for (u32 r = threadIdx.x; r < rows; r += 256) {
+            count[dst + r] = rg_count[src + r];
+            if (UMI_ROWS) ukeys[dst + r] = rg_ukeys[src + r];
+            else { feature[dst + r] = rg_feature[src + r]; cell[dst + r] = rg_cell[src + r]; }
+        }
     }
 }
 

@@ -306,9 +306,14 @@ class Engine:
                                      (2 if skip_low else 0) | (4 if segmented else 0), C.byref(in_tmp), stream))
         return bool(in_tmp.value)
 
-    def dev_reduce(self, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz, stream=0, skip_low=False):
+    def dev_reduce(self, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz, stream=0, skip_low=False, segmented=False):
+        """segmented: the rows stay in the engine's row regions (only *d_nnz is written); dev_rows_gather concatenates them"""
         check(self._L.fastf_dev_reduce(self._h, d_sorted, d_n, max_n, d_feature, d_cell, d_count, d_nnz,
-                                       2 if skip_low else 0, stream))
+                                       (2 if skip_low else 0) | (8 if segmented else 0), stream))
+
+    def dev_rows_gather(self, d_n, feature, cell, count, stream=0):
+        """concatenate the row regions of the last dev_reduce into feature/cell/count (device or pinned host pointers)"""
+        check(self._L.fastf_dev_rows_gather(self._h, d_n, feature, cell, count, stream))
 
     @property
     def table_modes(self) -> str:

@@ -294,9 +294,17 @@ int fastf_dev_sort(fastf_engine_t *e, uint64_t *d_keys, uint64_t *d_tmp,
 
 /* K3: segmented unique/reduce of sorted keys → COO (SoA, capacity max_n rows);
  * *d_nnz (u64) receives the row count. */
+#define FASTF_REDUCE_SEGMENTED 8u   /* leave the rows in the engine's row regions (one per workgroup chunk, each in
+                                       order, the regions in order) and only report *d_nnz: d_feature/d_cell/d_count are
+                                       not touched; fastf_dev_rows_gather concatenates the regions later */
 int fastf_dev_reduce(fastf_engine_t *e, const uint64_t *d_sorted, const uint64_t *d_n,
                      uint64_t max_n, uint32_t *d_feature, uint32_t *d_cell,
                      uint32_t *d_count, uint64_t *d_nnz, uint32_t flags, void *stream);
+/* Concatenates the row regions of the last fastf_dev_reduce on this engine (same d_n) into feature/cell/count: device
+ * arrays, or PINNED HOST memory (hipHostMalloc / fastf_pinned_alloc) — then this kernel is the device-to-host copy of
+ * the matrix rows.  A fastf_dev_reduce without FASTF_REDUCE_SEGMENTED runs it itself. */
+int fastf_dev_rows_gather(fastf_engine_t *e, const uint64_t *d_n, uint32_t *feature, uint32_t *cell,
+                          uint32_t *count, void *stream);
 
 /* K3u: run-length rows for -u (capacity max_n rows). */
 int fastf_dev_umi_rows(fastf_engine_t *e, const uint64_t *d_sorted, const uint64_t *d_n,

@@ -142,3 +142,108 @@ def test_group_only_sort_plus_run_aware_reduce(env, n, n_groups, low_values, see
     np.add.at(want, np.searchsorted(ug, uk >> np.uint64(fs)), 1)
     np.testing.assert_array_equal(d_k.cpu().numpy()[:nnz].astype(np.int64), want)
     np.testing.assert_array_equal(d_c.cpu().numpy()[:nnz].astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64))
+
+
+def _want_rows(keys, fs=27, cs=36):
+    ug = np.unique(keys >> np.uint64(fs))
+    uk = np.unique(keys[(keys >> np.uint64(26)) & np.uint64(1) == 1])
+    want = np.zeros(len(ug), dtype=np.int64)
+    np.add.at(want, np.searchsorted(ug, uk >> np.uint64(fs)), 1)
+    return (ug & np.uint64((1 << 9) - 1)).astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64), want
+
+
+def _group_keys(rng, n, sizes_of_groups, null_frac=0.1, umi_values=1 << 24):
+    """keys of the fixture engine's layout [cell 10][feature 9][nonnull 1][umi 24][len 2] with the given group sizes"""
+    fs, cs = 27, 36
+    ids = rng.choice(1000 * 500, size=len(sizes_of_groups), replace=False)
+    cell = (ids // 500 + 1).astype(np.uint64); feat = (ids % 500 + 1).astype(np.uint64)
+    g = np.repeat(np.arange(len(sizes_of_groups)), sizes_of_groups)[:n]
+    m = len(g)
+    nonnull = (rng.random(m) > null_frac).astype(np.uint64)
+    umi = rng.integers(0, umi_values, size=m, dtype=np.uint64) * nonnull
+    return (cell[g] << np.uint64(cs)) | (feat[g] << np.uint64(fs)) | (nonnull << np.uint64(26)) | (umi << np.uint64(2)) | (np.uint64(3) * nonnull)
+
+
+@pytest.mark.parametrize("sizes,seed", [([1] * 70_000, 1), ([5000, 1, 1, 7000, 2048, 2047, 2049, 3, 4096, 1], 2),
+                                        ([300_000], 3), ([2048] * 40, 4), ([1, 2047] * 60, 5)])
+def test_reduce_windows_groups_longer_than_a_window_and_regions(env, sizes, seed):
+    """K3 reads the keys once: windows cut at group heads, a group longer than a window carried as an open row, the rows
+    left in per-workgroup regions and concatenated by the gather — into device arrays and straight into pinned host
+    memory; the device-side key count is smaller than the caller's bound"""
+    torch, F, eng = env
+    rng = np.random.default_rng(seed)
+    keys = np.sort(_group_keys(rng, 10**9, sizes, umi_values=64))
+    n = len(keys)
+    max_n = n + 12_345                                    # launch sized for an upper bound, n read on the device
+    d_keys = _t(torch, np.concatenate([keys, np.full(max_n - n, np.uint64((1 << 46) - 1), np.uint64)]))
+    d_n = torch.tensor([n], dtype=torch.int64, device="cuda")
+    d_f = torch.empty(max_n, dtype=torch.int32, device="cuda"); d_c = torch.empty_like(d_f); d_k = torch.empty_like(d_f)
+    d_nnz = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    f, c, k = _want_rows(keys)
+    # (1) segmented: only the count comes back, then the gather into device arrays
+    eng.dev_reduce(d_keys.data_ptr(), d_n.data_ptr(), max_n, 0, 0, 0, d_nnz.data_ptr(), stream=s, segmented=True)
+    torch.cuda.synchronize()
+    assert int(d_nnz.item()) == len(f)
+    eng.dev_rows_gather(d_n.data_ptr(), d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_f.cpu().numpy()[:len(f)].astype(np.int64), f)
+    np.testing.assert_array_equal(d_c.cpu().numpy()[:len(f)].astype(np.int64), c)
+    np.testing.assert_array_equal(d_k.cpu().numpy()[:len(f)].astype(np.int64), k)
+    # (2) the same regions straight into pinned host memory
+    h = [torch.empty(len(f) + 1, dtype=torch.int32).pin_memory() for _ in range(3)]
+    for t in h:
+        t.fill_(-7)
+    eng.dev_rows_gather(d_n.data_ptr(), h[0].data_ptr(), h[1].data_ptr(), h[2].data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(h[0].numpy()[:len(f)].astype(np.int64), f)
+    np.testing.assert_array_equal(h[1].numpy()[:len(f)].astype(np.int64), c)
+    np.testing.assert_array_equal(h[2].numpy()[:len(f)].astype(np.int64), k)
+    assert h[0][len(f)] == -7 and h[2][len(f)] == -7       # nothing written past the last row
+    assert eng.dev_error_bits() == 0
+
+
+@pytest.mark.parametrize("sizes,too_long,seed", [([3] * 50_000, False, 1), ([2047, 1, 2047, 5, 900] * 30, False, 2),
+                                                 ([100, 2048, 100], True, 3), ([40_000], True, 4),
+                                                 (list(range(1, 600)), False, 5)])
+def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypatch):
+    """FASTF_K3_DEDUP=hash: the sort orders (cell, feature) only; K3 finds the distinct UMIs of a group through its
+    window-local hash set.  A group that does not fit a window raises ERR_RUN_TOO_LONG (sort fully, reduce again)."""
+    import torch
+    import fastf_amd as F
+    monkeypatch.setenv("FASTF_K3_DEDUP", "hash")
+    cells = np.arange(1, 1001, dtype=np.uint64) | (np.uint64(1) << np.uint64(62))
+    feats = np.arange(1, 501, dtype=np.uint64) | (np.uint64(2) << np.uint64(62))
+    eng = F.Engine(cells, feats, umi_max_bases=12)
+    try:
+        assert eng.skip_bits >= 22 and eng.sort_passes(True) == 3       # 46-bit keys: 19 group bits + the NULL flag in 3 passes
+        rng = np.random.default_rng(seed)
+        keys = _group_keys(rng, 10**9, sizes, umi_values=200)            # heavy duplication inside the groups
+        keys = keys[rng.permutation(len(keys))]
+        n = len(keys)
+        d_keys = _t(torch, keys); d_tmp = torch.empty_like(d_keys)
+        d_n = torch.tensor([n], dtype=torch.int64, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), n, stream=s, skip_low=True)
+        src = d_tmp if in_tmp else d_keys
+        d_f = torch.empty(n, dtype=torch.int32, device="cuda"); d_c = torch.empty_like(d_f); d_k = torch.empty_like(d_f)
+        d_nnz = torch.zeros(1, dtype=torch.int64, device="cuda")
+        eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s, skip_low=True)
+        torch.cuda.synchronize()
+        flagged = bool(eng.dev_error_bits() & 16)
+        assert flagged == too_long
+        if flagged:
+            eng.dev_clear_error_bits(16, s)
+            other = d_keys if in_tmp else d_tmp
+            in_other = eng.dev_sort(src.data_ptr(), other.data_ptr(), d_n.data_ptr(), n, stream=s)
+            src = other if in_other else src
+            eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s)
+            torch.cuda.synchronize()
+            assert eng.dev_error_bits() == 0
+        f, c, k = _want_rows(keys)
+        assert int(d_nnz.item()) == len(f)
+        np.testing.assert_array_equal(d_f.cpu().numpy()[:len(f)].astype(np.int64), f)
+        np.testing.assert_array_equal(d_c.cpu().numpy()[:len(f)].astype(np.int64), c)
+        np.testing.assert_array_equal(d_k.cpu().numpy()[:len(f)].astype(np.int64), k)
+    finally:
+        eng.close()
