@@ -53,7 +53,8 @@ def kernel_table(eng, N, H, K, Z):
     c = eng.cell_scratch_bytes
     names = {0: ("probe_cells (K1a)", (8 + c) * N), 4: ("filter_pack (K1b)", (16 + c) * N + 4 * H + 8 * K),
              3: ("tile_count (K2, per pass)", 8 * K), 1: ("scatter (K2, per pass)", 16 * K),
-             2: ("head_count+scan+reduce+carry (K3)", 16 * K + 12 * Z)}
+             2: ("reduce_windows+span_scan (K3)", 8 * K + 12 * Z),
+             5: ("rows_gather (not part of the step: concatenates K3's row regions where the rows are wanted)", 24 * Z)}
     out = {}
     for which, (nm, b) in names.items():
         ms, n = eng.get_timing(which)
@@ -162,6 +163,7 @@ def main():
     eng.set_timing(True)
     for _ in range(3):
         step()
+        sp.st.rows_gather(sp.d_n, sp.feature, sp.cell, sp.count)      # concatenation of K3's row regions (timed as its own line)
     torch.cuda.synchronize()
     H_local = hits // G
     ktab = kernel_table(eng, n_local, H_local, K_local, Z_local)
@@ -176,7 +178,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     kernels_of = {"probe_cells": ["probe_cells_lds_kernel", "probe_cells_filtered_kernel", "probe_cells_kernel"],
                   "filter_pack": ["filter_pack_stream_kernel", "filter_pack_kernel"], "tile_count": ["tile_count_kernel"],
-                  "scatter": ["scatter_kernel"], "head_count+scan+reduce+carry": ["head_count_kernel", "reduce_kernel", "carry_fix_kernel"]}
+                  "scatter": ["scatter_kernel"], "reduce_windows+span_scan": ["reduce_windows_kernel", "span_scan_kernel"]}
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -184,7 +186,7 @@ def main():
                 names = kernels_of.get(dom.split(" ")[0], [])
                 got = [tj["kernels"][k]["hbm_bytes_per_launch"] for k in names if k in tj.get("kernels", {})]
                 if got:
-                    traffic = sum(got) if dom.startswith("head_count") else got[0]
+                    traffic = sum(got) if dom.startswith("reduce_windows") else got[0]
         except Exception:
             traffic = None
 

@@ -1045,6 +1045,7 @@ static int grow_keys(fastf_engine* e, u64 need) {
     // what fastf_engine_finish needs for this many keys (sort buffer, row arrays, tile workspace) is allocated here, while
     // the caller is still decoding, and not on the way out (a dozen hipMallocs: 10-15 ms of a 0.5 s end-to-end run)
     if (e->d_tmp.ensure(ncap * sizeof(u64)) || e->d_feature.ensure(ncap * 4) || e->d_cell.ensure(ncap * 4) || e->d_count.ensure(ncap * 4)) return 1;
+    if (e->d_rg_feature.ensure(ncap * 4) || e->d_rg_cell.ensure(ncap * 4) || e->d_rg_count.ensure(ncap * 4)) return 1;   // K3's row regions
     return reserve_workspace(e, 0, ncap);
 }
 
@@ -1227,9 +1228,8 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
                 return 1;
             e->fully_sorted = e->skip_bits == 0;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
-            if (launch_reduce<false>(e, sorted, small + SM_KEYCOUNT, n, (u32*)e->d_feature.p, (u32*)e->d_cell.p,
-                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, e->skip_bits, s))
-                return 1;
+            // the rows stay in K3's regions until the host buffer is known to be large enough (the gather below)
+            if (launch_reduce_regions<false>(e, sorted, small + SM_KEYCOUNT, n, small + SM_NNZ, e->skip_bits, s)) return 1;
         } else {
             HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
         }
@@ -1247,9 +1247,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
             e->fully_sorted = true;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
-            if (launch_reduce<false>(e, sorted, small + SM_KEYCOUNT, n, (u32*)e->d_feature.p, (u32*)e->d_cell.p,
-                                     (u32*)e->d_count.p, nullptr, small + SM_NNZ, 0, s))
-                return 1;
+            if (launch_reduce_regions<false>(e, sorted, small + SM_KEYCOUNT, n, small + SM_NNZ, 0, s)) return 1;
             HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
             HIP_OK(hipStreamSynchronize(s));
         }
@@ -1272,9 +1270,15 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             e->h_coo_pinned = true;
         lap("row buffer ready");
         if (nnz) {
-            HIP_OK(hipMemcpyAsync(e->h_coo, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
-            HIP_OK(hipMemcpyAsync(e->h_coo + e->h_coo_cap, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
-            HIP_OK(hipMemcpyAsync(e->h_coo + 2 * e->h_coo_cap, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
+            if (e->h_coo_pinned) {
+                // pinned row buffer: the gather of K3's row regions writes it directly — that kernel is the D2H copy
+                if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, e->h_coo, e->h_coo + e->h_coo_cap, e->h_coo + 2 * e->h_coo_cap, nullptr, s)) return 1;
+            } else {
+                if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, (u32*)e->d_feature.p, (u32*)e->d_cell.p, (u32*)e->d_count.p, nullptr, s)) return 1;
+                HIP_OK(hipMemcpyAsync(e->h_coo, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(e->h_coo + e->h_coo_cap, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(e->h_coo + 2 * e->h_coo_cap, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
+            }
             HIP_OK(hipStreamSynchronize(s));
         }
         lap("rows on the host");

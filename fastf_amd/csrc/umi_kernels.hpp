@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
                                     if (q == k) { dist = false; in_lds = false; break; }
                                     if (at == 0) { in_lds = false; break; }
                                     if (steps >= RUN_CAP) { too_long = true; in_lds = false; break; }   // not this path's kind of data: sort fully instead
-                                    if (at == base) break;
+                                    if (at <= base) break;                 // the next key lies in front of the window
                                     --at;
                                     q = s_id[(u32)(at - base)];
                                 }

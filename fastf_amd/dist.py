@@ -88,9 +88,14 @@ class HipStages:
         in_tmp = self.eng.dev_sort(keys.data_ptr(), tmp.data_ptr(), d_n.data_ptr(), max_n, stream=self._s(),
                                    skip_low=self.skip_low, segmented=fresh and getattr(self, "segmented", False))
         src = tmp if in_tmp else keys
+        # K3 leaves the rows in the engine's row regions (one per workgroup chunk) and reports the count; rows_gather
+        # concatenates them into feature/cell/count when somebody wants them (ShardedPass.local_coo)
         self.eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, feature.data_ptr(), cell.data_ptr(),
-                            count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=self.skip_low)
+                            count.data_ptr(), nnz.data_ptr(), self._s(), skip_low=self.skip_low, segmented=True)
         return src
+
+    def rows_gather(self, d_n, feature, cell, count):
+        self.eng.dev_rows_gather(d_n.data_ptr(), feature.data_ptr(), cell.data_ptr(), count.data_ptr(), self._s())
 
 
 class ShardedPass:
@@ -248,19 +253,16 @@ class ShardedPass:
             self._recv_free[b] = ev
         self._keys_buf = keys
         self._verified = False
+        self._gathered = not hasattr(st, "rows_gather")   # stages that reduce straight into feature/cell/count
 
     def _exchange_keys(self, send, recv):
         """the one exchange of the pass: shard buffer g of this rank → rank g; what arrives lands in self.recv"""
         G = self.G
-        if self._nccl:
-            outs, o = [], 0
-            for c in recv:
-                outs.append(self.recv[o:o + c]); o += c
-            ins = [self.keys_out[g, :send[g]] for g in range(G)]
-            dist.all_to_all(outs, ins, group=self.group)
-        else:                                           # gloo: contiguous send buffer
-            flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
-            self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
+        # one all_to_all_single with split sizes on both backends (zero-length splits are legal there; the list form of
+        # all_to_all with empty tensors is not something to meet for the first time on an 8-GPU node): the shard
+        # buffers' valid prefixes are packed into one contiguous send buffer first (8 bytes per key, once)
+        flat = torch.cat([self.keys_out[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
+        self._all_to_all_single(self.recv[:self.n_recv], flat, recv, send)
 
     # ---- collectives: direct on RCCL (and on CPU tensors over gloo), staged through the host otherwise ----
     def _all_gather(self, out, inp):
@@ -300,9 +302,17 @@ class ShardedPass:
             other = self.tmp if src.data_ptr() != self.tmp.data_ptr() else self._keys_buf
             self.sorted = st.sort_reduce(src, other, self.d_n, self.n_recv, self.feature, self.cell,
                                          self.count, self.nnz, fresh=False)
+            self._gathered = not hasattr(st, "rows_gather")
+
+    def gather_rows(self):
+        """rows of the last pass into self.feature / .cell / .count (device), if the reduce left them segmented"""
+        self.ensure_exact()
+        if not getattr(self, "_gathered", True):
+            self.st.rows_gather(self.d_n, self.feature, self.cell, self.count)
+            self._gathered = True
 
     def local_coo(self):
-        self.ensure_exact()
+        self.gather_rows()
         z = int(self.nnz.item())
         return (self.feature[:z].cpu().numpy().astype(np.int64), self.cell[:z].cpu().numpy().astype(np.int64),
                 self.count[:z].cpu().numpy().astype(np.int64))
