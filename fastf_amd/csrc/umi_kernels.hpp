@@ -1386,6 +1386,9 @@ __device__ __forceinline__ u32 wave_max32(u32 v) {
     return v;
 }
 
+// workgroup barrier that waits for this wave's LDS traffic only (not for its global loads and stores)
+__device__ __forceinline__ void k3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool UMI_ROWS, int DEDUP>
 __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce_windows_kernel(const ReduceParams p) {
     static_assert(!UMI_ROWS || DEDUP == 0, "-u rows come from fully sorted keys");
@@ -1398,7 +1401,10 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
     __shared__ u32 s_tab[DEDUP == 2 ? K3_TAB : 1];
     __shared__ u32 s_first;                // chunk start search
 
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    // everything that is the same for the whole wave is kept in scalar registers (readfirstlane): the wave index, what
+    // comes back from LDS broadcasts and cross-lane reductions, the open row — left to itself the compiler keeps those
+    // in vector registers and the kernel spills at its 64-VGPR budget
+    const int tid = threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u64 n = *p.n_ptr;
     const u32 gshift = UMI_ROWS ? 0u : p.L.feat_shift;
     const u32 nn_shift = p.L.umi_bits + p.L.len_bits;
@@ -1419,7 +1425,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
             const u64 m = __ballot(head);
             if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __syncthreads();
-            const u32 f = s_first;
+            const u32 f = __builtin_amdgcn_readfirstlane(s_first);
             __syncthreads();
             if (f != ~0u) { cursor += f; break; }
             cursor += K3_THREADS;
@@ -1432,6 +1438,21 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
     bool open_valid = false;               // (uniform) a group longer than a window is being carried
     u64 open_id = 0; u32 open_cnt = 0;
     bool done = false;
+    // The loop is a chain of phases separated by barriers; what crosses a barrier is in LDS only, so the barriers wait for
+    // LDS traffic alone (k3_barrier) and global loads and stores stay in flight across them: the keys of the NEXT window are
+    // requested as soon as the cut of this one is known and arrive while its rows are scanned, staged and written, and the
+    // row stores are never waited for.  (With __syncthreads each window paid three memory round trips one after the other:
+    // its keys, the key in front of it, its stores.)
+    u64 nkey[K3_IPT];                      // keys of the window about to be processed
+    {
+        const u32 W0 = (u32)(n - cursor < (u64)K3_TILE ? n - cursor : (u64)K3_TILE);
+#pragma unroll
+        for (int j = 0; j < K3_IPT; ++j) {
+            const u32 loc = (u32)j * K3_THREADS + tid;
+            nkey[j] = loc < W0 ? ld_once<FASTF_NT_K3 != 0>(p.keys + cursor + loc) : 0;
+        }
+    }
+    u64 prev0 = cursor > 0 ? p.keys[cursor - 1] : 0;       // (uniform) the key in front of the window
     while (!done) {
         const u64 base = cursor;
         const u32 W = (u32)(n - base < (u64)K3_TILE ? n - base : (u64)K3_TILE);
@@ -1440,18 +1461,17 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
         bool too_long = false;
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
-            const u32 loc = (u32)j * K3_THREADS + tid;
-            key[j] = loc < W ? ld_once<FASTF_NT_K3 != 0>(p.keys + base + loc) : 0;
-            s_id[loc] = key[j];
+            key[j] = nkey[j];
+            s_id[(u32)j * K3_THREADS + tid] = key[j];
         }
-        __syncthreads();
+        k3_barrier();
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
             const u32 loc = (u32)j * K3_THREADS + tid;
             const u64 idx = base + loc;
             const bool valid = loc < W;
             const u64 k = key[j];
-            const u64 prev = (valid && idx > 0) ? (loc > 0 ? s_id[loc - 1] : p.keys[idx - 1]) : ~k;
+            const u64 prev = (valid && idx > 0) ? (loc > 0 ? s_id[loc - 1] : prev0) : ~k;
             const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
             bool dist;
             slot[j] = ~0u;
@@ -1532,7 +1552,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
             hm[j] = __ballot(head); dm[j] = __ballot(dist);
             if (lane == 0) s_hb[j * K3_WAVES + w] = hm[j];
         }
-        __syncthreads();
+        k3_barrier();
         // ---- the cut (every wave works it out for itself from the 32 head ballots) ----
         //   stop: the first head at or beyond the chunk's nominal end — it and everything after it belong to the next chunk
         //   else, at the end of the data, the whole window; else the last head of the window (its group is left to the
@@ -1548,13 +1568,29 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
             const u64 not_first = ub == 0 ? hb & ~1ull : hb;
             if (not_first) c_last = ub + 63u - (u32)__builtin_clzll(not_first);
         }
-        c_stop = wave_min32(c_stop); c_last = wave_max32(c_last);
+        c_stop = __builtin_amdgcn_readfirstlane(wave_min32(c_stop)); c_last = __builtin_amdgcn_readfirstlane(wave_max32(c_last));
         u32 cut; bool closed;
         if (c_stop != ~0u) { cut = c_stop; closed = true; done = true; }
         else if (base + W == n) { cut = W; closed = true; done = true; }
         else if (c_last > 0) { cut = c_last; closed = true; }
+#ifdef FASTF_K3_HASH_NOFLAG   /* timing experiment only: counts of groups longer than a window are wrong */
+        else { cut = W; closed = false; }
+#else
         else { cut = W; closed = false; if (DEDUP == 2) too_long = true; }
+#endif
         if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
+        // the next window starts at the cut: request its keys now, and keep the key in front of it (s_id is restaged below)
+        if (!done) {
+            const u64 nb = base + cut;
+            const u32 Wn = (u32)(n - nb < (u64)K3_TILE ? n - nb : (u64)K3_TILE);
+#pragma unroll
+            for (int j = 0; j < K3_IPT; ++j) {
+                const u32 loc = (u32)j * K3_THREADS + tid;
+                nkey[j] = loc < Wn ? ld_once<FASTF_NT_K3 != 0>(p.keys + nb + loc) : 0;
+            }
+            const u64 pk = s_id[cut - 1];                  // cut >= 1 whenever the loop goes on
+            prev0 = ((u64)__builtin_amdgcn_readfirstlane((u32)(pk >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)pk);
+        }
         // keys at or beyond the cut are not this window's
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
@@ -1563,15 +1599,15 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
             hm[j] &= below; dm[j] &= below;
             if (lane == 0) { s_h[j * K3_WAVES + w] = (u32)__popcll(hm[j]); s_d[j * K3_WAVES + w] = (u32)__popcll(dm[j]); }
         }
-        __syncthreads();
+        k3_barrier();
         if (w == 0) {
             const u32 h = lane < K3_UNITS ? s_h[lane] : 0u, d = lane < K3_UNITS ? s_d[lane] : 0u;
             const u32 hi = wave_incl_scan32(h, lane), di = wave_incl_scan32(d, lane);
             if (lane < K3_UNITS) { s_h[lane] = hi - h; s_d[lane] = di - d; }
             if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = di; }   // sentinel: all distinct flags of the window
         }
-        __syncthreads();
-        const u32 n_rows = s_tot[0], d_all = s_tot[1];
+        k3_barrier();
+        const u32 n_rows = __builtin_amdgcn_readfirstlane(s_tot[0]), d_all = __builtin_amdgcn_readfirstlane(s_tot[1]);
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
             if (DEDUP == 2 && slot[j] != ~0u) s_tab[slot[j]] = 0;        // the set is empty again for the next window
@@ -1582,9 +1618,9 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
                                    : (((u64)(u32)(key[j] >> p.L.cell_shift)) << 32) | ((u32)(key[j] >> p.L.feat_shift) & p.feat_mask);
             }
         }
-        __syncthreads();
+        k3_barrier();
         // distinct flags in front of the window's first head belong to the open row (none unless a group is being carried)
-        const u32 lead = n_rows ? s_pd[0] : d_all;
+        const u32 lead = n_rows ? __builtin_amdgcn_readfirstlane(s_pd[0]) : d_all;
         if (open_valid) open_cnt += lead;
         u32 first_row = 0, last_row = n_rows;              // rows [first_row, last_row) of the window are written now
         if (open_valid && (n_rows > 0 || done)) {
@@ -1599,7 +1635,10 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
         }
         if (!closed && n_rows > 0) {                       // one group fills the window and goes on: carry it
             last_row = n_rows - 1;
-            open_valid = true; open_id = s_id[last_row]; open_cnt = s_pd[n_rows] - s_pd[last_row];
+            const u64 oid = s_id[last_row];
+            open_valid = true;
+            open_id = ((u64)__builtin_amdgcn_readfirstlane((u32)(oid >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)oid);
+            open_cnt = __builtin_amdgcn_readfirstlane(s_pd[n_rows] - s_pd[last_row]);
         }
         const u64 row_base = region + rows_so_far;
         for (u32 r = first_row + tid; r < last_row; r += K3_THREADS) {
@@ -1611,7 +1650,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
         }
         rows_so_far += last_row - first_row;
         cursor = base + cut;
-        __syncthreads();                               // the next window restages the shared arrays
+        k3_barrier();                                  // the next window restages the shared arrays
     }
     if (open_valid) {                                  // (cannot happen: the last window closes the group — kept as a guard)
         if (tid == 0) {
