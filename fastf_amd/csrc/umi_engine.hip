@@ -867,7 +867,7 @@ static u32 k3_grid(u64 max_n, int dedup) {
     static int per_cu[3] = {-1, -1, -1};
     if (per_cu[dedup] < 0) {
         const char* c = getenv("FASTF_K3_PER_CU");
-        per_cu[dedup] = c ? atoi(c) : (dedup == 2 ? 3 : 4);
+        per_cu[dedup] = c ? atoi(c) : (dedup == 0 ? 4 : 3);
         if (per_cu[dedup] < 1) per_cu[dedup] = 1;
     }
     const u64 tiles = (max_n + K3_TILE - 1) / K3_TILE;

@@ -1386,11 +1386,21 @@ __device__ __forceinline__ u32 wave_max32(u32 v) {
     return v;
 }
 
+// a wave-uniform 64-bit value into scalar registers (readfirstlane returns int: the halves are widened unsigned)
+__device__ __forceinline__ u64 uniform64(u64 v) {
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
 // workgroup barrier that waits for this wave's LDS traffic only (not for its global loads and stores)
 __device__ __forceinline__ void k3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// register budget: 64 VGPRs (eight waves per SIMD, four workgroups per CU) hold the plain compare; the run walk and the hash
+// probe keep more alive next to the prefetched keys and get 80 (six waves per SIMD, three workgroups per CU) — at 64 they
+// spill, and the spilled registers are the prefetched keys: every window then pays a scratch round trip
+#ifndef FASTF_K3_MINW_DEDUP
+#define FASTF_K3_MINW_DEDUP 6
+#endif
 template <bool UMI_ROWS, int DEDUP>
-__global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce_windows_kernel(const ReduceParams p) {
+__global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) void reduce_windows_kernel(const ReduceParams p) {
     static_assert(!UMI_ROWS || DEDUP == 0, "-u rows come from fully sorted keys");
     // (item, wave) units in window order: heads / distinct flags per unit, then their exclusive scans
     __shared__ u32 s_h[K3_UNITS], s_d[K3_UNITS];
@@ -1589,7 +1599,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
                 nkey[j] = loc < Wn ? ld_once<FASTF_NT_K3 != 0>(p.keys + nb + loc) : 0;
             }
             const u64 pk = s_id[cut - 1];                  // cut >= 1 whenever the loop goes on
-            prev0 = ((u64)__builtin_amdgcn_readfirstlane((u32)(pk >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)pk);
+            prev0 = uniform64(pk);
         }
         // keys at or beyond the cut are not this window's
 #pragma unroll
@@ -1621,6 +1631,9 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
         k3_barrier();
         // distinct flags in front of the window's first head belong to the open row (none unless a group is being carried)
         const u32 lead = n_rows ? __builtin_amdgcn_readfirstlane(s_pd[0]) : d_all;
+#ifdef FASTF_K3_DEBUG
+        if (tid == 0) printf("b %u base %llu W %u lim %u cstop %u clast %u cut %u closed %d done %d n_rows %u d_all %u lead %u open %d cnt %u prev0 %llx key0 %llx\n", b, (unsigned long long)base, W, lim, c_stop, c_last, cut, (int)closed, (int)done, n_rows, d_all, lead, (int)open_valid, open_cnt, (unsigned long long)prev0, (unsigned long long)key[0]);
+#endif
         if (open_valid) open_cnt += lead;
         u32 first_row = 0, last_row = n_rows;              // rows [first_row, last_row) of the window are written now
         if (open_valid && (n_rows > 0 || done)) {
@@ -1637,7 +1650,7 @@ __global__ __launch_bounds__(K3_THREADS, K3_THREADS >= 1024 ? 4 : 8) void reduce
             last_row = n_rows - 1;
             const u64 oid = s_id[last_row];
             open_valid = true;
-            open_id = ((u64)__builtin_amdgcn_readfirstlane((u32)(oid >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)oid);
+            open_id = uniform64(oid);
             open_cnt = __builtin_amdgcn_readfirstlane(s_pd[n_rows] - s_pd[last_row]);
         }
         const u64 row_base = region + rows_so_far;
