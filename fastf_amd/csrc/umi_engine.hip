@@ -168,7 +168,7 @@ struct fastf_engine {
     u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
     DevBuf d_scanblk;                    // chunk totals of a scan over more than 16 384 tiles
     // K3: row regions (one slot per key: a workgroup's rows go to the slots of its own chunk), rows per chunk and their bases
-    DevBuf d_rg_feature, d_rg_cell, d_rg_count, d_rg_ukeys, d_spanrows, d_spanbase;
+    DevBuf d_rg_feature, d_rg_cell, d_rg_count, d_rg_ukeys, d_spanrows, d_spanbase, d_giant;
     u32 rg_n = 0; bool rg_umi = false;   // chunks of the last reduce (0: none) and its kind
     bool dedup_hash = false;             // matrix path: sort on (cell, feature) only, dedup through K3's hash set (else: run walk)
     // timing
@@ -455,7 +455,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         // the distinct UMIs of a group through a hash set (one digit pass less on 57/58-bit keys); =walk: the run walk
         const char* sk = getenv("FASTF_SORT_SKIP_BITS");
         const char* dd = getenv("FASTF_K3_DEDUP");
-        e->dedup_hash = dd ? strcmp(dd, "hash") == 0 : false;
+        e->dedup_hash = dd ? strcmp(dd, "hash") == 0 : true;
         const u32 fs = e->L.feat_shift, kb = e->L.total_bits;
         const u32 need_from = e->dedup_hash ? fs : (fs > 8 ? fs - 8 : 0);
         const u32 passes = (kb - need_from + 7) / 8;
@@ -522,7 +522,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
-                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_scanblk,
+                     &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
@@ -884,18 +884,27 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     if (e->d_rg_count.ensure(max_n * 4)) return 1;
     if (UMI_ROWS ? e->d_rg_ukeys.ensure(max_n * 8) : (e->d_rg_feature.ensure(max_n * 4) || e->d_rg_cell.ensure(max_n * 4))) return 1;
     if (e->d_spanrows.ensure(4096 * sizeof(u32)) || e->d_spanbase.ensure(4097 * sizeof(u64))) return 1;
+    if (dedup == 2 && !e->d_giant.p) {                  // work items of groups longer than a window + their counter (live, frozen)
+        if (e->d_giant.ensure((size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64) + 64)) return 1;
+        HIP_OK(hipMemsetAsync((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64), 0, 64, s));
+    }
+    u32* const giant_n = dedup == 2 ? (u32*)((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64)) : nullptr;
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
     p.low_skip = UMI_ROWS ? 0 : low_skip;
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
     p.feature = (u32*)e->d_rg_feature.p; p.cell = (u32*)e->d_rg_cell.p; p.count = (u32*)e->d_rg_count.p; p.ukeys = (u64*)e->d_rg_ukeys.p;
     p.span_rows = (u32*)e->d_spanrows.p;
+    p.giant_list = (u64*)e->d_giant.p; p.giant_n = giant_n;
     t_begin(e, s);
     if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 1) hipLaunchKernelGGL((reduce_windows_kernel<false, 1>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else hipLaunchKernelGGL((reduce_windows_kernel<false, 2>), dim3(G), dim3(K3_THREADS), 0, s, p);
-    hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows);
+    hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows, giant_n);
+    if (dedup == 2)
+        hipLaunchKernelGGL(giant_groups_kernel, dim3(g_cu_count), dim3(512), 0, s, sorted, (const u64*)e->d_giant.p, (const u32*)(giant_n + 1), e->L,
+                           (u32*)e->d_rg_count.p, (u64*)e->d_small.p + SM_COUNTERS + 3);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
     e->rg_n = G; e->rg_umi = UMI_ROWS;
@@ -975,7 +984,7 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 
 extern "C" const char* fastf_kernel_names(void) FASTF_TRY {
     return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,filter_pack_stream_kernel,"
-           "tile_count_kernel,row_scan_kernel,scatter_kernel,reduce_windows_kernel,span_scan_kernel,rows_gather_kernel";
+           "tile_count_kernel,row_scan_kernel,scatter_kernel,reduce_windows_kernel,span_scan_kernel,giant_groups_kernel,rows_gather_kernel";
 } FASTF_CATCH_ZERO
 
 // ------------------------------------------------------------------------------------

@@ -1350,7 +1350,14 @@ struct ReduceParams {
     u32* feature; u32* cell; u32* count;   // row REGIONS (capacity: one slot per key); UMI_ROWS: feature/cell unused
     u64* ukeys;                            // UMI_ROWS only
     u32* span_rows;                        // rows per workgroup chunk [gridDim.x]
+    // DEDUP 2: groups longer than a window are counted by giant_groups_kernel: one work item per (group, hash partition)
+    u64* giant_list; u32* giant_n;         // items {start, len, row slot, partition | partitions << 32} (GIANT_ITEM_WORDS u64 each)
 };
+
+// a (cell, feature) group longer than a window (DEDUP 2) is cut into hash partitions of about GIANT_PART keys: each partition
+// is one work item of giant_groups_kernel, which counts its distinct keys in an LDS hash set of full keys; longer than
+// GIANT_MAX (or more than GIANT_LIST_CAP items in one launch) raises ERR_RUN_TOO_LONG: sort fully instead
+constexpr u32 GIANT_MAX = 1u << 16, GIANT_PART = 1536, GIANT_LIST_CAP = 4096, GIANT_ITEM_WORDS = 4, GIANT_TAB = 4096;
 
 // 4 keys per thread (2048-key windows): 324 us vs 352 us for 8 on the configs[2] shape (two-pass form of round 2)
 #ifndef FASTF_K3_IPT
@@ -1586,11 +1593,12 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
 #ifdef FASTF_K3_HASH_NOFLAG   /* timing experiment only: counts of groups longer than a window are wrong */
         else { cut = W; closed = false; }
 #else
-        else { cut = W; closed = false; if (DEDUP == 2) too_long = true; }
+        else { cut = W; closed = false; }
 #endif
         if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
         // the next window starts at the cut: request its keys now, and keep the key in front of it (s_id is restaged below)
-        if (!done) {
+        const u64 g0 = DEDUP == 2 ? uniform64(s_id[0]) >> gshift : 0;      // the group at the head of the window
+        if (!done && !(DEDUP == 2 && !closed)) {
             const u64 nb = base + cut;
             const u32 Wn = (u32)(n - nb < (u64)K3_TILE ? n - nb : (u64)K3_TILE);
 #pragma unroll
@@ -1646,6 +1654,56 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
             }
             rows_so_far += 1; open_valid = false;
         }
+        if (DEDUP == 2 && !closed) {
+            // One group fills the window (and the window starts at its head: this mode never carries a group).  Its row goes
+            // out with a count of zero, the next head is looked for, and giant_groups_kernel counts the group's distinct
+            // keys — one work item per hash partition, added up with atomics on that row's count.
+            u64 pos = base + W;
+            u32 found = ~0u;
+            for (;;) {
+                if (tid == 0) s_first = ~0u;
+                __syncthreads();
+                const u64 idx = pos + tid;
+                const bool h = idx < n && (p.keys[idx] >> gshift) != g0;
+                const u64 m = __ballot(h);
+                if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __syncthreads();
+                found = __builtin_amdgcn_readfirstlane(s_first);
+                __syncthreads();
+                if (found != ~0u || pos + K3_THREADS >= n) break;
+                pos += K3_THREADS;
+            }
+            const u64 next = found != ~0u ? pos + found : n;
+            const u64 len = next - base;
+            const u32 parts = (u32)((len + GIANT_PART - 1) / GIANT_PART);
+            const u64 row = region + rows_so_far;
+            if (tid == 0) { const u64 id = s_id[0]; p.count[row] = 0; p.feature[row] = (u32)id; p.cell[row] = (u32)(id >> 32); }
+            if (len > GIANT_MAX) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
+            else {
+                if (tid == 0) s_first = atomicAdd(p.giant_n, parts);
+                __syncthreads();
+                const u32 at = __builtin_amdgcn_readfirstlane(s_first);
+                if (at + parts > GIANT_LIST_CAP) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
+                else if ((u32)tid < parts) {
+                    u64* it = p.giant_list + (u64)(at + tid) * GIANT_ITEM_WORDS;
+                    it[0] = base; it[1] = len; it[2] = row; it[3] = (u64)tid | ((u64)parts << 32);
+                }
+            }
+            rows_so_far += 1; first_row = last_row = 0;
+            cursor = next;
+            if (cursor >= nom_end || cursor >= n) done = true;
+            else {
+                const u32 Wn = (u32)(n - cursor < (u64)K3_TILE ? n - cursor : (u64)K3_TILE);
+#pragma unroll
+                for (int j = 0; j < K3_IPT; ++j) {
+                    const u32 loc = (u32)j * K3_THREADS + tid;
+                    nkey[j] = loc < Wn ? ld_once<FASTF_NT_K3 != 0>(p.keys + cursor + loc) : 0;
+                }
+                prev0 = uniform64(p.keys[cursor - 1]);
+            }
+            k3_barrier();
+            continue;
+        }
         if (!closed && n_rows > 0) {                       // one group fills the window and goes on: carry it
             last_row = n_rows - 1;
             const u64 oid = s_id[last_row];
@@ -1677,9 +1735,56 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
     if (tid == 0) p.span_rows[b] = rows_so_far;
 }
 
-// row bases of the chunks (exclusive scan of span_rows, G <= 4096) and the total
+// distinct non-NULL keys of one hash partition of a group longer than a window (work items left by DEDUP 2)
+__global__ __launch_bounds__(512) void giant_groups_kernel(const u64* __restrict__ keys, const u64* __restrict__ list, const u32* __restrict__ n_items,
+                                                           KeyLayout L, u32* __restrict__ count, u64* __restrict__ err) {
+    __shared__ u64 s_set[GIANT_TAB];
+    __shared__ u32 s_cnt;
+    const u32 items = *n_items < GIANT_LIST_CAP ? *n_items : GIANT_LIST_CAP;
+    const u32 nn_shift = L.umi_bits + L.len_bits;
+    for (u32 g = blockIdx.x; g < items; g += gridDim.x) {
+        const u64* it = list + (u64)g * GIANT_ITEM_WORDS;
+        const u64 start = it[0], len = it[1], row = it[2];
+        const u32 part = (u32)it[3], parts = (u32)(it[3] >> 32);
+        for (u32 i = threadIdx.x; i < GIANT_TAB; i += 512) s_set[i] = 0;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        u32 mine = 0; bool full = false;
+        for (u64 i0 = 0; i0 < len; i0 += 4 * 512) {
+            u64 k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const u64 i = i0 + (u64)u * 512 + threadIdx.x; k[u] = i < len ? keys[start + i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!((k[u] >> nn_shift) & 1)) continue;                  // NULL umi (and the padding zeros): not counted
+                const u64 hh = k[u] * 0x9E3779B97F4A7C15ull;
+                if ((u32)(((hh >> 32) * parts) >> 32) != part) continue;   // another partition's key
+                u32 h = (u32)(hh >> 7) & (GIANT_TAB - 1);
+                for (u32 step = 0;; ++step) {
+                    u64 v = s_set[h];
+                    if (v == 0) {
+                        if (__hip_atomic_compare_exchange_strong(&s_set[h], &v, k[u], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { ++mine; break; }
+                    }
+                    if (v == k[u]) break;
+                    if (step >= GIANT_TAB) { full = true; break; }        // (a partition far larger than its share: cannot hold it)
+                    h = (h + 1) & (GIANT_TAB - 1);
+                }
+            }
+        }
+        mine = wave_sum32(mine);
+        if (lane_id() == 0 && mine) atomicAdd(&s_cnt, mine);
+        if (full) atomicOr(err, ERR_RUN_TOO_LONG);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(&count[row], s_cnt);
+        __syncthreads();
+    }
+}
+
+// row bases of the chunks (exclusive scan of span_rows, G <= 4096) and the total; the work-item counter of the giant
+// groups is handed over (frozen for giant_groups_kernel) and cleared for the next launch
 __global__ __launch_bounds__(1024) void span_scan_kernel(const u32* __restrict__ span_rows, u32 G, u64* __restrict__ span_base,
-                                                         u64* __restrict__ total_out) {
+                                                         u64* __restrict__ total_out, u32* __restrict__ giant_n = nullptr) {
+    if (giant_n && threadIdx.x == 0) { giant_n[1] = giant_n[0]; giant_n[0] = 0; }
     __shared__ u32 s_w[16];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     u32 v[4]; u32 sum = 0;

@@ -90,15 +90,31 @@ def test_dev_reduce_matches_numpy(env, n, n_groups, seed):
     assert eng.dev_error_bits() == 0
 
 
+@pytest.mark.parametrize("mode", ["hash", "walk"])
 @pytest.mark.parametrize("n,n_groups,low_values,seed", [(200_000, 50_000, 1 << 16, 1), (120_000, 3, 1 << 16, 2),
-                                                        (60_000, 1, 5000, 3), (300_000, 200_000, 4, 4)])
-def test_group_only_sort_plus_run_aware_reduce(env, n, n_groups, low_values, seed):
-    """FASTF_SORT_SKIP_LOW: only the high digits are sorted; equal keys are neighbours of their run but unordered.
-    The reduce kernel must still count distinct non-NULL keys per (cell, feature) exactly — including long runs
-    (one group, thousands of distinct low parts sharing the sorted prefix) and heavy duplication."""
-    torch, F, eng = env
+                                                        (60_000, 1, 5000, 3), (300_000, 200_000, 4, 4), (150_000, 2, 1 << 20, 5)])
+def test_group_only_sort_plus_dedup_in_reduce(mode, n, n_groups, low_values, seed, monkeypatch):
+    """FASTF_SORT_SKIP_LOW: only the high digits are sorted; equal keys are neighbours of their group (hash mode) or of
+    their run (walk mode) but unordered.  The reduce kernel must still count distinct non-NULL keys per (cell, feature)
+    exactly — including groups far longer than a window (hash: counted by giant_groups_kernel up to 65 536 keys) and long
+    runs (walk: thousands of distinct low parts sharing the sorted prefix), and heavy duplication.  What neither can
+    hold raises ERR_RUN_TOO_LONG: sort fully, reduce again."""
+    import torch
+    import fastf_amd as F
+    monkeypatch.setenv("FASTF_K3_DEDUP", mode)
+    cells = np.arange(1, 1001, dtype=np.uint64) | (np.uint64(1) << np.uint64(62))
+    feats = np.arange(1, 501, dtype=np.uint64) | (np.uint64(2) << np.uint64(62))
+    eng = F.Engine(cells, feats, umi_max_bases=12)
+    try:
+        _group_only_case(torch, eng, mode, n, n_groups, low_values, seed)
+    finally:
+        eng.close()
+
+
+def _group_only_case(torch, eng, mode, n, n_groups, low_values, seed):
     skip = eng.skip_bits
     assert 0 < skip < 27 and eng.sort_passes(True) == (46 - skip + 7) // 8      # 46-bit keys: the digit grid ends at the top bit
+    assert eng.sort_passes(True) == (3 if mode == "hash" else 4)
     rng = np.random.default_rng(seed)
     fs, cs = 27, 36
     cell = rng.integers(1, 1001, size=n_groups, dtype=np.uint64)
@@ -123,9 +139,12 @@ def test_group_only_sort_plus_run_aware_reduce(env, n, n_groups, low_values, see
     eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(),
                    stream=s, skip_low=True)
     torch.cuda.synchronize()
-    long_runs = low_values >= 1000 and n_groups <= 3          # thousands of distinct low parts per run
+    if mode == "walk":
+        expect = low_values >= 1000 and n_groups <= 3        # thousands of distinct low parts per run
+    else:
+        expect = n // n_groups > 65_536                       # a group beyond what the partition kernel takes
     flagged = bool(eng.dev_error_bits() & 16)
-    assert flagged == long_runs
+    assert flagged == expect
     if flagged:                                               # the documented contract: sort fully, reduce again
         eng.dev_clear_error_bits(16, s)
         other = d_keys if in_tmp else d_tmp
@@ -204,11 +223,13 @@ def test_reduce_windows_groups_longer_than_a_window_and_regions(env, sizes, seed
 
 
 @pytest.mark.parametrize("sizes,too_long,seed", [([3] * 50_000, False, 1), ([2047, 1, 2047, 5, 900] * 30, False, 2),
-                                                 ([100, 2048, 100], True, 3), ([40_000], True, 4),
+                                                 ([100, 2048, 100], False, 3), ([40_000], False, 4), ([65_536, 9, 65_537, 1], True, 6),
+                                                 ([5000, 1, 1, 7000, 2048, 2047, 2049, 3, 4096, 1, 30_000, 2], False, 7),
                                                  (list(range(1, 600)), False, 5)])
 def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypatch):
     """FASTF_K3_DEDUP=hash: the sort orders (cell, feature) only; K3 finds the distinct UMIs of a group through its
-    window-local hash set.  A group that does not fit a window raises ERR_RUN_TOO_LONG (sort fully, reduce again)."""
+    window-local hash set; a group that does not fit a window is counted by giant_groups_kernel, hash partition by hash
+    partition; beyond 65 536 keys it raises ERR_RUN_TOO_LONG (sort fully, reduce again)."""
     import torch
     import fastf_amd as F
     monkeypatch.setenv("FASTF_K3_DEDUP", "hash")
@@ -218,7 +239,7 @@ def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypat
     try:
         assert eng.skip_bits >= 22 and eng.sort_passes(True) == 3       # 46-bit keys: 19 group bits + the NULL flag in 3 passes
         rng = np.random.default_rng(seed)
-        keys = _group_keys(rng, 10**9, sizes, umi_values=200)            # heavy duplication inside the groups
+        keys = _group_keys(rng, 10**9, sizes, umi_values=200 if seed != 7 else 1 << 24)   # heavy duplication / nearly all distinct
         keys = keys[rng.permutation(len(keys))]
         n = len(keys)
         d_keys = _t(torch, keys); d_tmp = torch.empty_like(d_keys)
