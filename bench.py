@@ -16,8 +16,12 @@ The one JSON line carries
   value            records/s of the timed steps, inputs resident in HBM when the clock starts
   roofline         the kernel that takes most of the step: algorithmic bytes / its HIP-event time
   whole_path       SURVEY 8d's B and B_read over the step time (nominal and executed radix passes)
-  device_path      N=1: pinned host SoA -> hipMemcpyAsync -> kernels -> COO on the host (PCIe-inclusive)
-  e2e              N=1: the real CLI on generated BAM files, process start to the .gz files closed
+  device_path      N=1: pinned host SoA -> hipMemcpyAsync -> kernels -> COO on the host (PCIe-inclusive): SURVEY 8d's
+                   device-path scope; its rate is repeated at the top level as device_path_records_per_s
+  e2e              N=1: the real CLI on generated BAM files, process start to process EXIT (outputs-closed beside it);
+                   the Cell-Ranger-shaped rate is repeated at the top level as e2e_records_per_s_to_process_exit
+  (`value` itself is the resident-input rate the bench contract asks for; the two rates above are what a caller of
+  bam2db() sees and are never folded into it)
   cpu_baseline     N=1: the CPU oracle on a bounded sample of the same records, 1 core (+ parity check)
 """
 import argparse
@@ -249,6 +253,10 @@ def main():
             out["cpu_baseline"] = None
         if not args.no_e2e:
             out["e2e"] = e2e_leg(job, [int(x) for x in args.e2e_records.split(",")])
+        # the three scopes side by side: kernels on resident inputs (= value), host SoA -> COO on the host, BAM -> .gz
+        out["scopes"] = {"kernels_only_records_per_s": out["value"],
+                         "device_path_records_per_s": (out.get("device_path") or {}).get("value"),
+                         "e2e_records_per_s_to_process_exit": {k: v.get("value") for k, v in (out.get("e2e") or {}).items() if isinstance(v, dict)}}
     elif rank == 0:
         out["cpu_baseline"] = None
 
@@ -339,7 +347,8 @@ def cpu_leg(job, dev, local, n_seg):
 
 
 def e2e_leg(job, sizes):
-    """the real CLI (fastF bam2db -c .5 -r .5) on generated BAM files: process start -> the three .gz files closed"""
+    """the real CLI (fastF bam2db -c .5 -r .5) on generated BAM files, timed from process start to process EXIT (the time
+    to "the three .gz files closed" beside it)"""
     threads = int(os.environ.get("FASTF_HOST_THREADS", "16"))
     gen = os.path.join(ROOT, "build", "gen_bam")
     os.makedirs(os.path.dirname(gen), exist_ok=True)
@@ -379,9 +388,11 @@ def e2e_leg(job, sizes):
                     # BAM, the pinned slab and the GPU context of the exiting process) is reported next to it, not in it
                     done = (closed[-1] - w0) if closed else wall
                     md5 = subprocess.run("zcat %s/matrix.mtx.gz | md5sum" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()[0]
-                    if best is None or done < best["seconds"]:
-                        best = {"value": n / done, "unit": "records/s", "seconds": done, "seconds_until_process_exit": wall,
-                                "records_per_s_until_process_exit": n / wall, "matrix_md5": md5,
+                    # the clock a user lives with: process start -> process exit.  "outputs closed" (SURVEY 8d's end-to-end
+                    # scope) is kept beside it
+                    if best is None or wall < best["seconds"]:
+                        best = {"value": n / wall, "unit": "records/s", "seconds": wall, "scope": "process start -> process exit",
+                                "seconds_to_outputs_closed": done, "records_per_s_to_outputs_closed": n / done, "matrix_md5": md5,
                                 "stages": prof[-1] if prof else "", "reader": " | ".join(rdr)}
                 out[label][variant] = best
             v = [out[label][k] for k in ("host_inflate", "hybrid_inflate") if "value" in out[label][k]]

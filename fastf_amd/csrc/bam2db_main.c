@@ -56,6 +56,28 @@ static void *decoder_main(void *vp)
     return NULL;
 }
 
+/* release thread: once the last record has been pushed, the reader (pinned window buffers, the pinned staging of the
+ * compressed bytes, the BAM mapping, ~1 GB of touched pages) and the pinned slab are of no use any more.  Unpinning and
+ * unmapping them takes 0.1-0.15 s that the exiting process used to pay after its outputs were closed; here it runs
+ * beside the sort, the reduce and the writers. */
+typedef struct {
+    pthread_t dec_thread; fastf_bam_t *bam; unsigned char *slab; int slab_pinned;
+    uint64_t no_xf, no_gx; double t_release;
+} rel_ctx;
+
+static void *release_main(void *vp)
+{
+    rel_ctx *r = (rel_ctx *)vp;
+    const double t0 = now_s();
+    pthread_join(r->dec_thread, NULL);                  /* it has delivered its end-of-file batch and is on its way out */
+    fastf_bam_stats(r->bam, NULL, &r->no_xf, &r->no_gx);
+    fastf_bam_close(r->bam);                            /* prints the reader's profile lines first */
+    if (r->slab_pinned) fastf_pinned_unregister(r->slab);
+    free(r->slab);
+    r->t_release = now_s() - t0;
+    return NULL;
+}
+
 static uint32_t bits_for(uint64_t v) { uint32_t b = 0; while (b < 64 && (v >> b)) b++; return b ? b : 1; }
 
 int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, char *features_file,
@@ -64,13 +86,14 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     (void)db_file;                      /* no SQLite in this engine */
     int rc = 1;
     const int prof = getenv("FASTF_PROFILE") != NULL;
-    double t0 = now_s(), t_lists = 0, t_engine = 0, t_decode = 0, t_push = 0, t_finish = 0, t_write = 0, tt;
+    double t0 = now_s(), t_lists = 0, t_engine = 0, t_decode = 0, t_push = 0, t_finish = 0, t_write = 0, t_wait_release = 0, tt;
     fastf_lists_t lists; memset(&lists, 0, sizeof lists);
     fastf_bam_t *bam = NULL;
     fastf_engine_t *eng = NULL;
     dec_ctx dec; pthread_t dec_thread; int dec_started = 0; double t_wait = 0;
     unsigned char *slab = NULL; int slab_pinned = 0;
-    memset(&dec, 0, sizeof dec);
+    rel_ctx rel; pthread_t rel_thread; int rel_started = 0;
+    memset(&dec, 0, sizeof dec); memset(&rel, 0, sizeof rel);
 
     /* bam2db needs a device anyway: unless told otherwise (FASTF_GPU_INFLATE=0) the BGZF inflate of big windows is
      * shared between the host threads and the device (host_io.c: hybrid inflate, every block CRC-checked on the host) */
@@ -163,6 +186,9 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         pthread_mutex_unlock(&dec.mu);
     }
     t_decode = dec.t_decode;
+    /* every record is on the device (each push waited for its copies): the reader and the slab go now, beside what follows */
+    rel.dec_thread = dec_thread; rel.bam = bam; rel.slab = slab; rel.slab_pinned = slab_pinned;
+    if (pthread_create(&rel_thread, NULL, release_main, &rel) == 0) { rel_started = 1; dec_started = 0; bam = NULL; slab = NULL; slab_pinned = 0; }
     fastf_coo_t coo; uint64_t counters[3];
     tt = now_s();
     if (fastf_engine_finish(eng, &coo, counters)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
@@ -170,11 +196,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     printf("In %s, total fastQ reads: %zu\n", bam_file, (size_t)counters[0]);
     printf("In %s, sampled fastQ reads: %zu\n", bam_file, (size_t)counters[1]);
     printf("In %s, sampled and valid fastQ reads: %zu\n", bam_file, (size_t)counters[2]);
-    uint64_t no_xf = 0, no_gx = 0;
-    fastf_bam_stats(bam, NULL, &no_xf, &no_gx);
-    if (no_xf || no_gx)
-        fprintf(stderr, "Note: %llu records with a CB but no xf tag and %llu with a valid xf but no GX tag were skipped "
-                        "(the reference dereferences NULL on them).\n", (unsigned long long)no_xf, (unsigned long long)no_gx);
+    if (!rel_started) fastf_bam_stats(bam, NULL, &rel.no_xf, &rel.no_gx);
 
     fastf_umi_rows_t urows; memset(&urows, 0, sizeof urows);
     if (_umi_copies_flag && fastf_engine_umi_rows(eng, &urows)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
@@ -187,12 +209,18 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     t_write = now_s() - tt;
     rc = 0;
     if (prof) { struct timespec rt; clock_gettime(CLOCK_REALTIME, &rt); fprintf(stderr, "[bam2db] outputs closed at %.6f (unix time)\n", rt.tv_sec + rt.tv_nsec * 1e-9); }
+    if (rel_started) { tt = now_s(); pthread_join(rel_thread, NULL); rel_started = 0; t_wait_release = now_s() - tt; }
+    if (rel.no_xf || rel.no_gx)
+        fprintf(stderr, "Note: %llu records with a CB but no xf tag and %llu with a valid xf but no GX tag were skipped "
+                        "(the reference dereferences NULL on them).\n", (unsigned long long)rel.no_xf, (unsigned long long)rel.no_gx);
     if (prof)
         fprintf(stderr, "[bam2db] lists %.3f s, engine create %.3f s, BAM decode+pack %.3f s (decoder thread; main waited %.3f s), "
-                        "push (stage+H2D+K1 enqueue) %.3f s, finish (sort+reduce+D2H) %.3f s, write %.3f s, total so far %.3f s\n",
-                t_lists, t_engine, t_decode, t_wait, t_push, t_finish, t_write, now_s() - t0);
+                        "push (stage+H2D+K1 enqueue) %.3f s, finish (sort+reduce+D2H) %.3f s, write %.3f s, reader+slab release %.3f s "
+                        "(beside finish and write; waited %.3f s for it), total so far %.3f s\n",
+                t_lists, t_engine, t_decode, t_wait, t_push, t_finish, t_write, rel.t_release, t_wait_release, now_s() - t0);
 done:
     tt = now_s();
+    if (rel_started) pthread_join(rel_thread, NULL);    /* (an error after the end of the input) */
     if (dec_started) {
         pthread_mutex_lock(&dec.mu); dec.stop = 1; dec.filled[0] = dec.filled[1] = 0;
         pthread_cond_broadcast(&dec.cv); pthread_mutex_unlock(&dec.mu);
@@ -201,8 +229,8 @@ done:
     if (fastf_process_is_exiting_) {
         /* the fastF CLI leaves through _exit() right after this call: device memory, pinned pages and the BAM mapping
          * go back with the process, and unmapping them one by one first costs 0.1-0.2 s */
-        fastf_bam_print_profile(bam);
-        if (prof) fprintf(stderr, "[bam2db] teardown skipped (process exits), %.3f s\n", now_s() - tt);
+        if (bam) fastf_bam_print_profile(bam);
+        if (prof) fprintf(stderr, "[bam2db] engine teardown skipped (process exits), %.3f s\n", now_s() - tt);
         return rc;
     }
     if (eng) fastf_engine_destroy(eng);

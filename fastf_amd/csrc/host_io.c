@@ -217,6 +217,7 @@ struct fastf_bam {
     int file_eof;
     unsigned char *cbuf; size_t ccap, clen;      /* compressed window (whole blocks + a partial tail) */
     unsigned char *map; size_t map_len, map_pos; unsigned char *cbuf_own;   /* the file mapped read-only: windows are views, nothing is copied */
+    size_t map_released;                          /* bytes at the front of the mapping already unmapped (windows behind the reader) */
     unsigned char *ubuf; size_t ucap, ulen, upos;/* inflated window; [upos, ulen) not yet consumed     */
     bgzf_blk *blk; size_t nblk, blkcap;
     /* prefetch: a filler thread reads + inflates the NEXT window into nbuf[NX_RESERVE ...) while the caller
@@ -533,7 +534,12 @@ static int fill_next(fastf_bam_t *b)
         }
         b->t_inflate += now_s() - t0;
         b->nlen = NX_RESERVE + utotal;
-        if (b->map) b->map_pos += pos;                        /* the partial block stays where it is */
+        if (b->map) {
+            b->map_pos += pos;                                /* the partial block stays where it is */
+            /* what lies behind the reader goes back now, window by window, not in one piece when the process ends */
+            const size_t upto = b->map_pos & ~(size_t)4095;
+            if (upto > b->map_released && munmap(b->map + b->map_released, upto - b->map_released) == 0) b->map_released = upto;
+        }
         else { memmove(b->cbuf, b->cbuf + pos, b->clen - pos); b->clen -= pos; }   /* keep the partial block for the next round */
         return 0;
     }
@@ -717,7 +723,7 @@ void fastf_bam_close(fastf_bam_t *b)
     free(b->gstatus);
     fastf_pinned_free(b->gcomp);
     if (b->fp) fclose(b->fp);
-    if (b->map) munmap(b->map, b->map_len);
+    if (b->map && b->map_len > b->map_released) munmap(b->map + b->map_released, b->map_len - b->map_released);
     free(b->cbuf_own); free(b->ubuf); free(b->nbuf); free(b->blk); free(b->rec); free(b->wrec); free(b->spec); free(b);
 }
 
