@@ -120,7 +120,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
     /* one slab for both decoder slots: pinned once the HIP runtime is up (below), so that the engine copies the
      * packed records to the device straight from where the decoder wrote them */
-    if (posix_memalign((void **)&slab, 4096, 2 * cap * 24) != 0) { slab = NULL; fprintf(stderr, "out of memory\n"); goto done; }
+    if (!(slab = (unsigned char *)fastf_big_alloc(2 * cap * 24))) { fprintf(stderr, "out of memory\n"); goto done; }
     for (int k = 0; k < 2; k++) {
         unsigned char *base = slab + (size_t)k * cap * 24;
         dec.slot[k].cb = (uint64_t *)base; dec.slot[k].gx = (uint64_t *)(base + cap * 8);

@@ -100,4 +100,7 @@ void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *fea
 #ifdef __cplusplus
 }
 #endif
+/* 2 MiB-aligned allocation that asks for transparent huge pages (big short-lived buffers); release with free() */
+void *fastf_big_alloc(size_t bytes);
+
 #endif

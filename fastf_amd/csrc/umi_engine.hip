@@ -1271,8 +1271,8 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
             e->h_coo = nullptr; e->h_coo_cap = 0; e->h_coo_pinned = false; e->h_coo_uses = 0;
             const u64 cap = nnz + nnz / 8 + 1024;
-            void* m = nullptr;
-            if (posix_memalign(&m, 4096, (size_t)cap * 12) != 0) return set_err("out of memory (%llu matrix rows)", (unsigned long long)nnz);
+            void* m = fastf_big_alloc((size_t)cap * 12);               // 2 MiB aligned, transparent huge pages (host_io.c)
+            if (!m) return set_err("out of memory (%llu matrix rows)", (unsigned long long)nnz);
             e->h_coo = (u32*)m; e->h_coo_cap = cap;
         }
         if (!e->h_coo_pinned && e->h_coo && e->h_coo_uses++ >= 1 && hipHostRegister(e->h_coo, (size_t)e->h_coo_cap * 12, hipHostRegisterDefault) == hipSuccess)
