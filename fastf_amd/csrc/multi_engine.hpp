@@ -4,11 +4,18 @@
 // The path shards by cell: GROUP BY cell_index, feature_index (bam2db_ds.c:480-483) never joins rows of
 // different cells, so every key goes to the device that owns its cell (murmur(cell_index) mod G, shard_of()).
 //
-//   push     chunks of the record stream are dealt round-robin to the devices.  Per round of G chunks:
-//              1. H2D + K1a on every device            (hit count of each chunk -> one u64 back to the host)
-//              2. the host turns the G counts into hit-rank bases in STREAM order (a draw is consumed per CB hit in
-//                 record order, bam2db_ds.c:385), generates exactly each chunk's draws and sends them
-//              3. K1b on every device: keys land in G per-destination buffers on the device that filtered them
+//   push     chunks of the record stream are dealt round-robin to the devices — chunk i of the STREAM goes to device
+//            i mod G, across push calls (a caller that pushes one batch at a time still feeds every device).  A chunk is
+//              1. staged (pageable input only), copied (s_copy) and counted: K1a + scan on s_compute, the hit count and the
+//                 device's key counts come back into a pinned snapshot, an event marks it               [enqueue_chunk]
+//              2. retired, in stream order, once its count is in: the host adds the counts up into hit-rank bases (a
+//                 draw is consumed per CB hit in record order, bam2db_ds.c:385), generates exactly the chunk's draws, sends
+//                 them and queues K1b: keys land in G per-destination buffers on the device that filtered them [retire_chunk]
+//            Nothing waits for a round: the host blocks only on the count of the OLDEST chunk in flight, and only when the
+//            device it lives on is needed again (or at finish), so the copy of chunk i+G overlaps K1b of chunk i and the
+//            other devices' work.  Stage slots are double-buffered per device; a slot is refilled behind the K1b that read
+//            it (event per device and slot).  The per-destination buffers grow ahead of need from upper bounds, on the
+//            stream, and the old buffer is kept until the streams are known to be idle — no hipMalloc/hipFree stall.
 //   finish   ONE exchange: buffer h of device g -> device h (RCCL send/recv in one group over xGMI, or peer copies
 //            when devices alias — the one-GPU rehearsal — or FASTF_EXCHANGE=peer), then K2 + K3 locally on every
 //            device, rows back, and a merge of the G row lists by cell (each cell lives on exactly one device).
@@ -21,12 +28,18 @@ struct MultiDev {
     int dev = 0;
     void* h_stage[2] = {nullptr, nullptr};     // pinned chunk staging (pageable input only)
     DevBuf d_stage[2];
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_sent = nullptr;
-    u32* h_draws = nullptr; DevBuf d_draws;    // the draws of the chunk in flight
-    u64* h_info = nullptr;                     // pinned mirror of the sub-engine's d_small
+    // per stage slot: copy done / K1a counted and the snapshot is on the host / K1b done (the slot may be refilled)
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cnt[2] = {nullptr, nullptr}, ev_k1b[2] = {nullptr, nullptr}, ev_sent = nullptr;
+    bool k1b_queued[2] = {false, false};
+    u32* h_draws[2] = {nullptr, nullptr}; DevBuf d_draws[2];     // the draws of the chunk in that slot
+    u64* h_cnt[2] = {nullptr, nullptr};        // pinned snapshot of the sub-engine's d_small behind that slot's K1a
+    int next_slot = 0;
+    u64* h_info = nullptr;                     // pinned mirror of the sub-engine's d_small (finish)
     DevBuf d_shard; u64 stride = 0;            // keys by destination: [G][stride]
+    std::vector<void*> old_shards;             // replaced while work was queued: freed when the streams are idle
     u64 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // keys per destination, exact as of the last read-back
-    u64 chunk_n = 0, chunk_hits = 0;
+    u64 keys_exact = 0, recs_since = 0;        // most keys in one destination as of the last snapshot; records counted since
+    u64 records = 0;                           // records this device has been given (tests: every device takes part)
     // receive side
     DevBuf d_recv, d_tmp, d_f, d_c, d_k, d_ukeys, d_ncopy;
     u64 n_recv = 0; int sorted_in_tmp = 0; bool fully_sorted = false;
@@ -45,7 +58,9 @@ struct RcclApi {
 struct fastf_multi {
     u32 G = 0;
     std::vector<MultiDev> d;
-    u64 cap = 0, round = 0;
+    u64 cap = 0, chunks = 0;                                     // chunks dealt so far: chunk i lives on device i mod G
+    struct InFlight { u32 dev; int slot; u64 n; };
+    std::vector<InFlight> fifo;                                  // counted, not yet retired (stream order)
     fastf_mt_t mt{}; u32 mt_seed0 = 0; u64 mt_skip0 = 0;
     u64 hits = 0, total_records = 0, c_sampled = 0, c_valid = 0;
     bool finished = false, aliased = false;
@@ -65,7 +80,8 @@ static int multi_load_rccl(fastf_multi* m) {
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return set_err("cannot load librccl.so (%s); FASTF_EXCHANGE=peer uses device-to-device copies instead", dlerror());
         RcclApi r;
-#define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) return set_err("librccl.so lacks %s", name)
+        // (a library without one of these is of no use and has run nothing yet: it may be unloaded again)
+#define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) { dlclose(h); return set_err("librccl.so lacks %s", name); }
         SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
         SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
@@ -76,7 +92,11 @@ static int multi_load_rccl(fastf_multi* m) {
     return 0;
 }
 #define NCCL_OK(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return set_err("%s failed: %s", #call, (m)->rccl.GetErrorString(r_)); } while (0)
+// inside ncclGroupStart .. ncclGroupEnd: the group is closed before the error is reported
+#define NCCL_OK_IN_GROUP(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (void)(m)->rccl.GroupEnd(); return set_err("%s failed: %s", #call, (m)->rccl.GetErrorString(r_)); } } while (0)
 
+static void multi_free_old_shards(MultiDev& md);
+static int multi_retire_all(fastf_multi* m);
 static void multi_destroy(fastf_engine* e) {
     fastf_multi* m = e->multi;
     if (!m) return;
@@ -87,15 +107,20 @@ static void multi_destroy(fastf_engine* e) {
     for (auto& c : m->comms) if (c && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(c);
     for (MultiDev& md : m->d) {
         (void)hipSetDevice(md.dev);
+        if (md.e) (void)hipStreamSynchronize(md.e->s_copy);
         for (int i = 0; i < 2; ++i) {
             if (md.h_stage[i]) (void)hipHostFree(md.h_stage[i]);
-            md.d_stage[i].release();
+            md.d_stage[i].release(); md.d_draws[i].release();
             if (md.ev_in[i]) (void)hipEventDestroy(md.ev_in[i]);
+            if (md.ev_cnt[i]) (void)hipEventDestroy(md.ev_cnt[i]);
+            if (md.ev_k1b[i]) (void)hipEventDestroy(md.ev_k1b[i]);
+            if (md.h_draws[i]) (void)hipHostFree(md.h_draws[i]);
+            if (md.h_cnt[i]) (void)hipHostFree(md.h_cnt[i]);
         }
         if (md.ev_sent) (void)hipEventDestroy(md.ev_sent);
-        if (md.h_draws) (void)hipHostFree(md.h_draws);
         if (md.h_info) (void)hipHostFree(md.h_info);
-        DevBuf* all[] = {&md.d_draws, &md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy};
+        multi_free_old_shards(md);
+        DevBuf* all[] = {&md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy};
         for (DevBuf* b : all) b->release();
         if (md.e) fastf_engine_destroy(md.e);
     }
@@ -130,10 +155,18 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
             std::vector<int> devs(G);
             for (u32 g = 0; g < G; ++g) devs[g] = m->d[g].dev;
             m->comms.assign(G, nullptr);
-            const bool ok = multi_load_rccl(m) == 0 && m->rccl.CommInitAll(m->comms.data(), (int)G, devs.data()) == ncclSuccess;
+            bool ok = multi_load_rccl(m) == 0;                       // (sets the error text itself)
+            if (ok) {
+                const ncclResult_t ir = m->rccl.CommInitAll(m->comms.data(), (int)G, devs.data());
+                if (ir != ncclSuccess) {
+                    ok = false;
+                    set_err("ncclCommInitAll over %u devices failed: %s", G, m->rccl.GetErrorString(ir));
+                    for (auto& c : m->comms) if (c) { (void)m->rccl.CommDestroy(c); c = nullptr; }     // what it had created
+                }
+            }
             if (!ok) {
-                if (x) return set_err("FASTF_EXCHANGE=rccl: RCCL is not usable here (%s)", fastf_last_error());
-                fprintf(stderr, "Warning: RCCL is not usable here; the key exchange uses device-to-device copies\n");
+                if (x) { const std::string why = fastf_last_error(); return set_err("FASTF_EXCHANGE=rccl: RCCL is not usable here (%s)", why.c_str()); }
+                fprintf(stderr, "Warning: RCCL is not usable here (%s); the key exchange uses device-to-device copies\n", fastf_last_error());
                 m->comms.clear();
                 m->use_rccl = 0;
             }
@@ -147,9 +180,11 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
         if (fastf_engine_create(&sub, &md.e)) return 1;
         HIP_OK(hipSetDevice(md.dev));
         HIP_OK(hipHostMalloc((void**)&md.h_info, SM_WORDS * sizeof(u64), hipHostMallocDefault));
-        HIP_OK(hipHostMalloc((void**)&md.h_draws, m->cap * 4, hipHostMallocDefault));
-        HIP_OK(hipEventCreateWithFlags(&md.ev_in[0], hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&md.ev_in[1], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            HIP_OK(hipEventCreateWithFlags(&md.ev_in[i], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&md.ev_cnt[i], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&md.ev_k1b[i], hipEventDisableTiming));
+        }
         HIP_OK(hipEventCreateWithFlags(&md.ev_sent, hipEventDisableTiming));
         if (!m->use_rccl) {                             // peer copies: let the devices reach each other's memory
             for (u32 q = 0; q < G; ++q) {
@@ -170,94 +205,129 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
     return 0;
 }
 
-// per-destination key buffers of one device: make room for `need` keys per destination
+// per-destination key buffers of one device: make room for `need` keys per destination.  The new buffer is filled by
+// copies queued on the compute stream (whole old regions: the exact counts are not known here) and the old one is kept
+// until the streams are idle — growing never waits for the device.
 static int multi_grow_shards(fastf_multi* m, MultiDev& md, u64 need) {
     if (need <= md.stride && md.d_shard.p) return 0;
-    HIP_OK(hipStreamSynchronize(md.e->s_compute));
     const u64 ns = std::max<u64>(need, std::max<u64>(md.stride * 2, 1u << 20));
     void* np = nullptr;
     HIP_OK(hipMalloc(&np, (size_t)m->G * ns * sizeof(u64)));
-    for (u32 h = 0; h < m->G && md.d_shard.p; ++h)
-        if (md.cnt[h]) HIP_OK(hipMemcpy((u64*)np + (u64)h * ns, (u64*)md.d_shard.p + (u64)h * md.stride, md.cnt[h] * sizeof(u64), hipMemcpyDeviceToDevice));
-    md.d_shard.release();
+    if (md.d_shard.p) {
+        for (u32 h = 0; h < m->G; ++h)
+            HIP_OK(hipMemcpyAsync((u64*)np + (u64)h * ns, (u64*)md.d_shard.p + (u64)h * md.stride, md.stride * sizeof(u64), hipMemcpyDeviceToDevice, md.e->s_compute));
+        md.old_shards.push_back(md.d_shard.p);
+    }
     md.d_shard.p = np; md.d_shard.bytes = (size_t)m->G * ns * sizeof(u64);
     md.stride = ns;
     return 0;
 }
+static void multi_free_old_shards(MultiDev& md) {          // caller: the device's streams are idle
+    for (void* q : md.old_shards) (void)hipFree(q);
+    md.old_shards.clear();
+}
 
-// one round: up to G chunks, chunk j on device j
-static int multi_round(fastf_engine* e, const fastf_batch_t* b, const size_t* off, const size_t* len, u32 k, bool pinned) {
-    fastf_multi* m = e->multi;
-    const int slot = (int)(m->round & 1);
+// the oldest chunk in flight: its hit count -> hit-rank base, its draws, K1b
+static int multi_retire_chunk(fastf_multi* m) {
+    const fastf_multi::InFlight c = m->fifo.front();
+    m->fifo.erase(m->fifo.begin());
+    MultiDev& md = m->d[c.dev];
+    fastf_engine* se = md.e;
     const u64 cap = m->cap;
     const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
-    // 1. staging, H2D, K1a, hit count back
-    for (u32 j = 0; j < k; ++j) {
-        MultiDev& md = m->d[j];
-        fastf_engine* se = md.e;
-        const size_t n = len[j];
-        HIP_OK(hipSetDevice(md.dev));
-        if (md.d_stage[slot].ensure(stage_bytes(cap))) return 1;
-        const void *s_cb = b->cb_key + off[j], *s_gx = b->gx_key + off[j], *s_umi = b->umi + off[j], *s_meta = b->meta + off[j];
-        if (!pinned) {
-            if (!md.h_stage[slot]) HIP_OK(hipHostMalloc(&md.h_stage[slot], stage_bytes(cap), hipHostMallocDefault));
-            char* hs = (char*)md.h_stage[slot];
-            memcpy(hs, s_cb, n * 8); memcpy(hs + o_gx, s_gx, n * 8); memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4);
-            s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
-        }
-        char* ds = (char*)md.d_stage[slot].p;
-        HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyHostToDevice, se->s_copy));
-        HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyHostToDevice, se->s_copy));
-        HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyHostToDevice, se->s_copy));
-        HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyHostToDevice, se->s_copy));
-        HIP_OK(hipEventRecord(md.ev_in[slot], se->s_copy));
-        HIP_OK(hipStreamWaitEvent(se->s_compute, md.ev_in[slot], 0));
-        u64* small = (u64*)se->d_small.p;
-        if (launch_probe_cells(se, (const u64*)ds, n, small + SM_N, se->s_compute)) return 1;
-        HIP_OK(hipMemcpyAsync(md.h_info, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, se->s_compute));
-        md.chunk_n = n;
+    HIP_OK(hipSetDevice(md.dev));
+    HIP_OK(hipEventSynchronize(md.ev_cnt[c.slot]));
+    const u64* snap = md.h_cnt[c.slot];
+    const u64 hits = snap[SM_N];
+    if (hits > c.n) return set_err("internal: more hits than records");
+    // the snapshot was taken behind this chunk's K1a, i.e. behind K1b of every earlier chunk of this device: exact counts
+    u64 most = 0;
+    for (u32 h = 0; h < m->G; ++h) { md.cnt[h] = snap[SM_KEYCOUNT + h]; most = std::max(most, md.cnt[h]); }
+    md.keys_exact = most; md.recs_since = c.n;             // (later chunks of this device are not in flight: see enqueue)
+    if (multi_grow_shards(m, md, md.keys_exact + md.recs_since)) return 1;
+    // exactly this chunk's draws, in stream order (the chunks are retired in stream order)
+    fastf_mt_fill(&m->mt, md.h_draws[c.slot], hits);
+    m->hits += hits;
+    if (hits) HIP_OK(hipMemcpyAsync(md.d_draws[c.slot].p, md.h_draws[c.slot], hits * 4, hipMemcpyHostToDevice, se->s_compute));
+    u64* small = (u64*)se->d_small.p;
+    char* ds = (char*)md.d_stage[c.slot].p;
+    if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), c.n,
+                     (const u32*)md.d_draws[c.slot].p, hits, nullptr, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
+                     small + SM_COUNTERS, true, se->s_compute))
+        return 1;
+    HIP_OK(hipEventRecord(md.ev_k1b[c.slot], se->s_compute));
+    md.k1b_queued[c.slot] = true;
+    return 0;
+}
+
+// one chunk (n <= cap records at offset off of the caller's batch) onto its device: stage, copy, count
+static int multi_enqueue_chunk(fastf_multi* m, const fastf_batch_t* b, size_t off, size_t n, bool pinned) {
+    const u32 dev = (u32)(m->chunks % m->G);
+    MultiDev& md = m->d[dev];
+    fastf_engine* se = md.e;
+    const u64 cap = m->cap;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
+    // K1a of this chunk overwrites the device's K1 scratch (cell indices, tile bases): K1b of the chunk this device took
+    // before must be queued first, i.e. that chunk — and, for the stream order of the draws, every older one — retired
+    for (;;) {
+        bool pending = false;
+        for (const auto& c : m->fifo) pending = pending || c.dev == dev;
+        if (!pending) break;
+        if (multi_retire_chunk(m)) return 1;
     }
-    // 2. + 3. hit-rank bases in stream order, draws, K1b
-    for (u32 j = 0; j < k; ++j) {
-        MultiDev& md = m->d[j];
-        fastf_engine* se = md.e;
-        HIP_OK(hipSetDevice(md.dev));
-        HIP_OK(hipStreamSynchronize(se->s_compute));
-        const u64 hits = md.h_info[SM_N];
-        for (u32 h = 0; h < m->G; ++h) md.cnt[h] = md.h_info[SM_KEYCOUNT + h];       // exact: K1b of the round before is behind us
-        if (hits > md.chunk_n) return set_err("internal: more hits than records");
-        if (md.d_draws.ensure(std::max<u64>(cap, 1) * 4)) return 1;
-        fastf_mt_fill(&m->mt, md.h_draws, hits);
-        m->hits += hits;
-        if (hits) HIP_OK(hipMemcpyAsync(md.d_draws.p, md.h_draws, hits * 4, hipMemcpyHostToDevice, se->s_compute));
-        u64 most = 0;
-        for (u32 h = 0; h < m->G; ++h) most = std::max(most, md.cnt[h]);
-        if (multi_grow_shards(m, md, most + md.chunk_n)) return 1;
-        u64* small = (u64*)se->d_small.p;
-        char* ds = (char*)md.d_stage[slot].p;
-        if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), md.chunk_n,
-                         (const u32*)md.d_draws.p, hits, nullptr, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
-                         small + SM_COUNTERS, true, se->s_compute))
-            return 1;
-        m->total_records += md.chunk_n;
+    HIP_OK(hipSetDevice(md.dev));
+    const int slot = md.next_slot; md.next_slot ^= 1;
+    if (md.d_stage[slot].ensure(stage_bytes(cap)) || md.d_draws[slot].ensure(std::max<u64>(cap, 1) * 4)) return 1;
+    if (!md.h_draws[slot]) HIP_OK(hipHostMalloc((void**)&md.h_draws[slot], std::max<u64>(cap, 1) * 4, hipHostMallocDefault));
+    if (!md.h_cnt[slot]) HIP_OK(hipHostMalloc((void**)&md.h_cnt[slot], SM_WORDS * sizeof(u64), hipHostMallocDefault));
+    // the slot is refilled behind the K1b that read it (two chunks of this device ago)
+    if (md.k1b_queued[slot]) HIP_OK(hipStreamWaitEvent(se->s_copy, md.ev_k1b[slot], 0));
+    const void *s_cb = b->cb_key + off, *s_gx = b->gx_key + off, *s_umi = b->umi + off, *s_meta = b->meta + off;
+    if (!pinned) {
+        if (!md.h_stage[slot]) HIP_OK(hipHostMalloc(&md.h_stage[slot], stage_bytes(cap), hipHostMallocDefault));
+        else HIP_OK(hipEventSynchronize(md.ev_in[slot]));   // the copy that last read this staging buffer has left it
+        char* hs = (char*)md.h_stage[slot];
+        memcpy(hs, s_cb, n * 8); memcpy(hs + o_gx, s_gx, n * 8); memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4);
+        s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
     }
-    m->round++;
+    char* ds = (char*)md.d_stage[slot].p;
+    HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyHostToDevice, se->s_copy));
+    HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyHostToDevice, se->s_copy));
+    HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyHostToDevice, se->s_copy));
+    HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyHostToDevice, se->s_copy));
+    HIP_OK(hipEventRecord(md.ev_in[slot], se->s_copy));
+    HIP_OK(hipStreamWaitEvent(se->s_compute, md.ev_in[slot], 0));
+    u64* small = (u64*)se->d_small.p;
+    if (launch_probe_cells(se, (const u64*)ds, n, small + SM_N, se->s_compute)) return 1;
+    HIP_OK(hipMemcpyAsync(md.h_cnt[slot], small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, se->s_compute));
+    HIP_OK(hipEventRecord(md.ev_cnt[slot], se->s_compute));
+    m->fifo.push_back({dev, slot, (u64)n});
+    m->chunks++;
+    md.records += n;
+    m->total_records += n;
     m->finished = false;
+    return 0;
+}
+
+static int multi_retire_all(fastf_multi* m) {
+    while (!m->fifo.empty()) if (multi_retire_chunk(m)) return 1;
     return 0;
 }
 
 static int multi_push(fastf_engine* e, const fastf_batch_t* b, bool pinned) {
     fastf_multi* m = e->multi;
-    size_t off = 0;
-    while (off < b->n) {
-        size_t offs[8], lens[8]; u32 k = 0;
-        while (k < m->G && off < b->n) {
-            const size_t n = std::min<size_t>(b->n - off, m->cap);
-            offs[k] = off; lens[k] = n; off += n; ++k;
-        }
-        if (multi_round(e, b, offs, lens, k, pinned)) return 1;
-        if (pinned) {                                    // the caller's arrays may not change before the copies have left them
-            // (kept simple: the next round waits for the hit counts of this one anyway)
+    for (size_t off = 0; off < b->n;) {
+        const size_t n = std::min<size_t>(b->n - off, m->cap);
+        if (multi_enqueue_chunk(m, b, off, n, pinned)) return 1;
+        off += n;
+    }
+    if (pinned) {
+        // the caller's arrays may change once this returns (fastf_engine_wait_input has nothing left to wait for): the
+        // copies out of them must have left — the K1 work behind them stays queued
+        for (u32 g = 0; g < m->G; ++g) {
+            MultiDev& md = m->d[g];
+            HIP_OK(hipSetDevice(md.dev));
+            HIP_OK(hipStreamSynchronize(md.e->s_copy));
         }
     }
     return 0;
@@ -280,6 +350,7 @@ static void multi_merge_by_cell(u32 G, const std::vector<const u32*>& cell, cons
 
 static int multi_exchange(fastf_multi* m) {
     const u32 G = m->G;
+    if (multi_retire_all(m)) return 1;
     // exact key counts
     for (u32 g = 0; g < G; ++g) {
         MultiDev& md = m->d[g];
@@ -288,6 +359,7 @@ static int multi_exchange(fastf_multi* m) {
         HIP_OK(hipStreamSynchronize(md.e->s_compute));
         for (u32 h = 0; h < G; ++h) md.cnt[h] = md.h_info[SM_KEYCOUNT + h];
         if (md.h_info[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(md.h_info[SM_COUNTERS + 3]));
+        multi_free_old_shards(md);                                          // the compute stream has just been waited for
     }
     m->c_sampled = m->c_valid = 0;
     for (u32 g = 0; g < G; ++g) { m->c_sampled += m->d[g].h_info[SM_COUNTERS + 1]; m->c_valid += m->d[g].h_info[SM_COUNTERS + 2]; }
@@ -306,8 +378,8 @@ static int multi_exchange(fastf_multi* m) {
         for (u32 g = 0; g < G; ++g) {
             MultiDev& mg = m->d[g];
             for (u32 h = 0; h < G; ++h) {
-                if (mg.cnt[h]) NCCL_OK(m, m->rccl.Send((const u64*)mg.d_shard.p + (u64)h * mg.stride, mg.cnt[h], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
-                if (m->d[h].cnt[g]) NCCL_OK(m, m->rccl.Recv((u64*)mg.d_recv.p + at[g][h], m->d[h].cnt[g], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+                if (mg.cnt[h]) NCCL_OK_IN_GROUP(m, m->rccl.Send((const u64*)mg.d_shard.p + (u64)h * mg.stride, mg.cnt[h], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+                if (m->d[h].cnt[g]) NCCL_OK_IN_GROUP(m, m->rccl.Recv((u64*)mg.d_recv.p + at[g][h], m->d[h].cnt[g], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
             }
         }
         NCCL_OK(m, m->rccl.GroupEnd());
@@ -481,13 +553,27 @@ static int multi_umi_rows(fastf_engine* e, fastf_umi_rows_t* rows) {
 
 static int multi_reset(fastf_engine* e, bool reseed, u32 seed, u64 skip) {
     fastf_multi* m = e->multi;
-    if (reseed) { m->mt_seed0 = seed; m->mt_skip0 = skip; fastf_mt_seed(&m->mt, seed); fastf_mt_skip(&m->mt, skip); return 0; }
-    for (MultiDev& md : m->d) {
-        if (fastf_engine_reset(md.e)) return 1;
-        for (u64& c : md.cnt) c = 0;
-        md.n_recv = 0;
+    if (reseed) {
+        if (multi_retire_all(m)) return 1;                   // chunks in flight take their draws from the stream as it was
+        m->mt_seed0 = seed; m->mt_skip0 = skip; fastf_mt_seed(&m->mt, seed); fastf_mt_skip(&m->mt, skip);
+        return 0;
     }
+    if (multi_retire_all(m)) return 1;                        // (what is in flight is finished, then forgotten)
+    for (MultiDev& md : m->d) {
+        if (fastf_engine_reset(md.e)) return 1;              // synchronises the device
+        multi_free_old_shards(md);
+        for (u64& c : md.cnt) c = 0;
+        md.n_recv = 0; md.keys_exact = md.recs_since = md.records = 0;
+    }
+    m->chunks = 0;
     m->hits = m->total_records = m->c_sampled = m->c_valid = 0;
     m->finished = false;
+    return 0;
+}
+
+static int multi_device_records(const fastf_engine* e, uint64_t* records, u32 n) {
+    if (!e->multi) { if (n < 1) return set_err("room for one count needed"); records[0] = e->total_records; return 0; }
+    if (n < e->multi->G) return set_err("room for %u counts needed", e->multi->G);
+    for (u32 g = 0; g < e->multi->G; ++g) records[g] = e->multi->d[g].records;
     return 0;
 }

@@ -194,6 +194,7 @@ static int multi_push(fastf_engine* e, const fastf_batch_t* b, bool pinned);
 static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3]);
 static int multi_umi_rows(fastf_engine* e, fastf_umi_rows_t* rows);
 static int multi_reset(fastf_engine* e, bool reseed, u32 seed, u64 skip);
+static int multi_device_records(const fastf_engine* e, uint64_t* records, u32 n);
 static size_t scatter_smem_bytes(u32 ipt = SORT_IPT) {        // LDS follows the tile size: smaller tiles → more workgroups per CU
     return (size_t)ipt * SORT_THREADS * 8 + (size_t)SORT_WAVES * RADIX * 4 + RADIX * 4 * 2 + 64;     // 64: s_wtot[8] + slack
 }
@@ -1353,6 +1354,12 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
     rows->feature = e->h_ufeature.data(); rows->cell = e->h_ucell.data(); rows->n_copy = e->h_ncopy.data();
     rows->umi = e->h_uumi.data(); rows->nonnull = e->h_unonnull.data(); rows->n = nrows;
     return 0;
+} FASTF_CATCH_INT
+
+// records each device of a multi-device engine has been given since the last reset (a single-device engine: its total)
+extern "C" int fastf_engine_device_records(const fastf_engine_t* e, uint64_t* records, uint32_t n) FASTF_TRY {
+    if (!e || !records) return set_err("null argument");
+    return multi_device_records(e, records, n);
 } FASTF_CATCH_INT
 
 extern "C" int fastf_engine_reset(fastf_engine_t* e) FASTF_TRY {

@@ -273,6 +273,12 @@ class Engine:
     def set_timing(self, on: bool):
         check(self._L.fastf_engine_set_timing(self._h, 1 if on else 0))
 
+    def device_records(self, n_devices=1):
+        """records each device of a multi-device engine has been given since the last reset"""
+        out = (C.c_uint64 * max(1, n_devices))()
+        check(self._L.fastf_engine_device_records(self._h, out, max(1, n_devices)))
+        return [int(x) for x in out]
+
     def get_timing(self, which: int):
         ms, n = C.c_double(), C.c_uint64()
         check(self._L.fastf_engine_get_timing(self._h, which, C.byref(ms), C.byref(n)))

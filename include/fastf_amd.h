@@ -208,6 +208,9 @@ void  fastf_pinned_unregister(void *p);
  * reset/destroy.  counters = {total, sampled, sampled_valid} (bam2db_ds.c:342-344). */
 int  fastf_engine_finish(fastf_engine_t *e, fastf_coo_t *coo, uint64_t counters[3]);
 int  fastf_engine_umi_rows(fastf_engine_t *e, fastf_umi_rows_t *rows);
+/* records each device of a multi-device engine (n_devices > 1) has been given since the last reset, records[n_devices];
+ * a single-device engine reports its total in records[0] */
+int  fastf_engine_device_records(const fastf_engine_t *e, uint64_t *records, uint32_t n);
 int  fastf_engine_reset(fastf_engine_t *e);
 /* key layout chosen at create time */
 int  fastf_engine_key_bits(const fastf_engine_t *e, uint32_t *cell_bits, uint32_t *feature_bits,

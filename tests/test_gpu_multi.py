@@ -107,3 +107,37 @@ def test_cli_with_fastf_devices(tmp_path):
     rd = lambda n: gzip.decompress((out / n).read_bytes())
     assert rd("matrix.mtx.gz") == ora["matrix"]
     assert rd("umi.tsv.gz") == ora["umi"]
+
+
+@pytest.mark.parametrize("G,pinned", [(4, False), (3, True)])
+def test_every_device_takes_part_when_pushes_are_small(G, pinned):
+    """bam2db() pushes one batch of at most batch_records records per call: chunk i of the STREAM goes to device i mod G
+    across calls (a cursor that restarted with every push left every chunk on device 0), ragged pushes included, and the
+    asynchronous pipeline (a chunk is retired only when its device is needed again) gives the oracle's matrix"""
+    case = Case(n=210_000, n_bar=700, n_gene=300, rate_cell=0.7, rate_depth=0.5, umi_pool=256, cell_dist="lognormal",
+                p_no_cb=0.03, p_unlisted_cb=0.1, p_bad_xf=0.1, p_n_umi=0.01)
+    lists = case.lists()
+    cbk, gxk, umi, meta = case.packed(lists)
+    cap = 9_000
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12, batch_records=cap, devices=[0] * G)
+    try:
+        rng = np.random.default_rng(5)
+        off, n_push = 0, 0
+        if pinned:
+            pb = F.PinnedBatch(case.n)
+            pb.fill(0, cbk, gxk, umi, meta)
+        while off < case.n:
+            n = int(min(case.n - off, rng.integers(1, cap + 1)))                 # never more than one chunk per call
+            if pinned:
+                eng.push_pinned(pb, off, off + n)
+            else:
+                eng.push(cbk[off:off + n], gxk[off:off + n], umi[off:off + n], meta[off:off + n])
+            off += n; n_push += 1
+        per_dev = eng.device_records(G)
+        assert sum(per_dev) == case.n and all(r > 0 for r in per_dev)
+        assert max(per_dev) - min(per_dev) <= case.n // 3, per_dev                # dealt, not piled up
+        assert_matches_oracle(eng.finish(), case.oracle(), eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+        if pinned:
+            pb.close()
