@@ -164,6 +164,7 @@ struct fastf_engine {
     // workspace
     DevBuf d_cellidx, d_tilecnt, d_tilebase, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
     DevBuf d_halfhits;                   // K1a: hits per 256-record unit (the streaming K1b's rank bases)
+    DevBuf d_segkeys;                    // several shards: the streaming K1b's unsharded output (workgroup regions) in front of shard_partition_kernel
     DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
     u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
     DevBuf d_scanblk;                    // chunk totals of a scan over more than 16 384 tiles
@@ -524,7 +525,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
-                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg};
+                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -717,13 +718,20 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.stamps = g_k1_stamps;
     p.n_tiles = tiles;
     p.genes = e->lds_genes;
+    // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
+    // deals the keys to the per-destination buffers (same interface as the tile form: keys[G][stride], key_counts[G] += ...)
+    const bool no_stream = getenv("FASTF_NO_STREAM_K1B") != nullptr;
+    const bool stream_shards = !segmented && e->n_shards > 1 && e->n_shards <= (u32)MAX_SHARDS && e->use_lds_genes && !no_stream;
     t_begin(e, s);
-    if (segmented) {
+    if (segmented || stream_shards) {
         // streaming form: every wave on its own, keys into one private region per workgroup (see filter_pack_stream_kernel)
         const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
         const u64 region = (u64)((tiles + grid - 1) / grid) * K1_TILE;
-        if ((u64)grid * region > stride) return set_err("segmented key output needs %llu slots, the buffer has %llu (fastf_dev_probe_capacity)",
-                                                        (unsigned long long)((u64)grid * region), (unsigned long long)stride);
+        if (stream_shards) {
+            if (e->d_segkeys.ensure((size_t)grid * region * sizeof(u64))) return 1;
+            p.keys = (u64*)e->d_segkeys.p;
+        } else if ((u64)grid * region > stride) return set_err("segmented key output needs %llu slots, the buffer has %llu (fastf_dev_probe_capacity)",
+                                                               (unsigned long long)((u64)grid * region), (unsigned long long)stride);
         if (e->d_segcount.ensure(grid * sizeof(u64)) || e->d_segprefix.ensure((grid + 1) * sizeof(u64))) return 1;
         StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
         // compile-time: roomy (one workgroup per CU: 128 VGPRs), width of the cell scratch, form of the gene image
@@ -736,8 +744,13 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
         case 6: FPS(true, true, false); break;   default: FPS(true, true, true); break;
         }
 #undef FPS
-        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p, grid, (u64*)e->d_segprefix.p, key_counts);
-        e->seg_n = grid; e->seg_stride = region;
+        if (stream_shards) {
+            hipLaunchKernelGGL(shard_partition_kernel, dim3(grid), dim3(SP_THREADS), 0, s, (const u64*)e->d_segkeys.p, (const u64*)e->d_segcount.p,
+                               region, e->L.cell_shift, e->n_shards, keys, stride, key_counts, counters + 3);
+        } else {
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p, grid, (u64*)e->d_segprefix.p, key_counts);
+            e->seg_n = grid; e->seg_stride = region;
+        }
     } else if (e->use_lds_genes) {
         const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
         if (e->genes_blocks_per_cu >= 2) hipLaunchKernelGGL((filter_pack_kernel<true, false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p);

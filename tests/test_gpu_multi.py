@@ -109,11 +109,13 @@ def test_cli_with_fastf_devices(tmp_path):
     assert rd("umi.tsv.gz") == ora["umi"]
 
 
-@pytest.mark.parametrize("G,pinned", [(4, False), (3, True)])
-def test_every_device_takes_part_when_pushes_are_small(G, pinned):
+@pytest.mark.parametrize("G,pinned,tile_form", [(4, False, False), (3, True, False), (2, False, True)])
+def test_every_device_takes_part_when_pushes_are_small(G, pinned, tile_form, monkeypatch):
     """bam2db() pushes one batch of at most batch_records records per call: chunk i of the STREAM goes to device i mod G
     across calls (a cursor that restarted with every push left every chunk on device 0), ragged pushes included, and the
     asynchronous pipeline (a chunk is retired only when its device is needed again) gives the oracle's matrix"""
+    if tile_form:
+        monkeypatch.setenv("FASTF_NO_STREAM_K1B", "1")      # K1b in its tile form (what sharded passes ran before the partition kernel)
     case = Case(n=210_000, n_bar=700, n_gene=300, rate_cell=0.7, rate_depth=0.5, umi_pool=256, cell_dist="lognormal",
                 p_no_cb=0.03, p_unlisted_cb=0.1, p_bad_xf=0.1, p_n_umi=0.01)
     lists = case.lists()
