@@ -11,6 +11,7 @@
 // The window is cut into slices that run H2D -> kernel -> D2H on alternating streams, so the three stages of
 // neighbouring slices overlap.
 #include "gpu_inflate.hpp"
+#include "gpu_records.hpp"
 
 struct GiBlock { u64 coff; u32 clen, isize; u64 uoff; };          // offsets into the slice's compressed / inflated bytes
 
@@ -35,6 +36,14 @@ struct fastf_gpuinf {
     hipEvent_t ev0 = nullptr, ev_done[NS] = {nullptr, nullptr, nullptr};
     size_t first[NS + 1] = {0, 0, 0, 0}; size_t pending_n = 0; int pending_slices = 0;
     u64 n_blocks = 0, n_declined = 0;
+    // keep mode (fastf_gpuinf_submit_keep): the inflated bytes stay on the device, in one window buffer per parity that
+    // mirrors the host window's offsets; CRC-32 per block on the device; fastf_gpurec_parse hops and packs from there
+    DevBuf d_win[2]; GrCrcBlock* h_crc[NS] = {nullptr, nullptr, nullptr}; DevBuf d_crc[NS]; DevBuf d_crctab;
+    int keep_parity = -1;
+    hipStream_t s_parse = nullptr;
+    DevBuf d_seg, d_offs, d_result, d_soa[2]; u64 soa_cap[2] = {0, 0};
+    u64* h_result = nullptr;
+    u64 n_parsed_windows = 0, n_parse_fallbacks = 0;
 };
 
 extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) FASTF_TRY {
@@ -58,8 +67,13 @@ extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) FASTF_TRY {
         if (g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
         if (g->h_blk[i]) (void)hipHostFree(g->h_blk[i]);
         if (g->h_status[i]) (void)hipHostFree(g->h_status[i]);
-        g->d_comp[i].release(); g->d_out[i].release(); g->d_blk[i].release(); g->d_status[i].release();
+        if (g->h_crc[i]) (void)hipHostFree(g->h_crc[i]);
+        g->d_comp[i].release(); g->d_out[i].release(); g->d_blk[i].release(); g->d_status[i].release(); g->d_crc[i].release();
     }
+    if (g->s_parse) { (void)hipStreamSynchronize(g->s_parse); (void)hipStreamDestroy(g->s_parse); }
+    if (g->h_result) (void)hipHostFree(g->h_result);
+    g->d_win[0].release(); g->d_win[1].release(); g->d_crctab.release(); g->d_seg.release(); g->d_offs.release(); g->d_result.release();
+    g->d_soa[0].release(); g->d_soa[1].release();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     delete g;
 } FASTF_CATCH_VOID
@@ -76,12 +90,46 @@ extern "C" void fastf_gpuinf_stats(const fastf_gpuinf_t* g, uint64_t* n_blocks, 
 // another and the D2H of a third overlap — and returns; the caller is free to inflate other blocks on the host
 // meanwhile.  wait() returns when everything has landed: status[i] != 0 means the device declined block i (the caller
 // inflates it on the host); *device_ms = time from the first copy to the last.
+static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
+                              unsigned char* out, int keep_parity, const uint32_t* crc);
 extern "C" int fastf_gpuinf_submit(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
                                    unsigned char* out) FASTF_TRY {
+    return gpuinf_submit_impl(g, comp, blk, n, out, -1, nullptr);
+} FASTF_CATCH_INT
+// keep mode: the inflated bytes of blocks [0, n) stay on the device, in the window buffer of `parity` (block i at its host
+// offset blk[i].uoff), and every block's CRC-32 is compared with crc[i] (its trailer) on the device: status bit 1.
+// Nothing is copied back; fastf_gpurec_parse / fastf_gpurec_fetch read the window buffer afterwards.
+extern "C" int fastf_gpuinf_submit_keep(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
+                                        int parity, const uint32_t* crc) FASTF_TRY {
+    if (parity < 0 || parity > 1 || !crc) return set_err("bad keep-mode arguments");
+    return gpuinf_submit_impl(g, comp, blk, n, nullptr, parity, crc);
+} FASTF_CATCH_INT
+
+static void gr_crc_tables(uint32_t* t) {                     // [0, 256): byte table; [256, 288): x^(2^i) mod P
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = c & 1 ? (c >> 1) ^ gr::CRC_POLY : c >> 1; t[i] = c; }
+    uint32_t p = 1u << 30;                                   // x^1
+    t[256] = p;
+    for (int i = 1; i < 32; ++i) t[256 + i] = p = gr::crc_multmodp(p, p);
+}
+
+static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
+                              unsigned char* out, int keep_parity, const uint32_t* crc) {
     if (!g) return set_err("null inflate handle");
     g->pending_n = 0;
+    g->keep_parity = keep_parity;
     if (n == 0) return 0;
     HIP_OK(hipSetDevice(g->device));
+    const bool keep = keep_parity >= 0;
+    if (keep) {
+        u64 wend = 0;
+        for (size_t i = 0; i < n; ++i) wend = std::max<u64>(wend, blk[i].uoff + blk[i].isize);
+        if (g->d_win[keep_parity].ensure((size_t)wend + 4096)) return 1;
+        if (!g->d_crctab.p) {
+            uint32_t t[288]; gr_crc_tables(t);
+            if (g->d_crctab.ensure(sizeof t)) return 1;
+            HIP_OK(hipMemcpy(g->d_crctab.p, t, sizeof t, hipMemcpyHostToDevice));
+        }
+    }
     constexpr int NS = fastf_gpuinf::NS;
     // A block takes one wave several milliseconds (the decode is a chain of dependent table look-ups), so throughput is
     // the number of blocks in flight over that latency: slices of at least 4096 blocks, at most NS of them.
@@ -104,26 +152,37 @@ extern "C" int fastf_gpuinf_submit(fastf_gpuinf_t* g, const unsigned char* comp,
             const size_t cap = nb + nb / 4 + 64;
             HIP_OK(hipHostMalloc((void**)&g->h_blk[q], cap * sizeof(GiBlock), hipHostMallocDefault));
             HIP_OK(hipHostMalloc((void**)&g->h_status[q], cap, hipHostMallocDefault));
+            if (g->h_crc[q]) (void)hipHostFree(g->h_crc[q]);
+            g->h_crc[q] = nullptr;
+            HIP_OK(hipHostMalloc((void**)&g->h_crc[q], cap * sizeof(GrCrcBlock), hipHostMallocDefault));
             g->h_blk_cap[q] = cap;
         }
         for (size_t i = a; i < b; ++i) g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0};
-        if (g->d_comp[q].ensure(cbytes) || g->d_out[q].ensure(std::max<size_t>(ubytes, 64)) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
+        if (g->d_comp[q].ensure(cbytes) || (!keep && g->d_out[q].ensure(std::max<size_t>(ubytes, 64))) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
             g->d_status[q].ensure(nb))
             return 1;
+        uint8_t* const d_dst = keep ? (uint8_t*)g->d_win[keep_parity].p + u0 : (uint8_t*)g->d_out[q].p;     // block i lands at d_dst + (uoff - u0)
         hipStream_t s = g->s[q];
         if (q) HIP_OK(hipStreamWaitEvent(s, g->ev0, 0));
         HIP_OK(hipMemcpyAsync(g->d_comp[q].p, comp + c0, cbytes, hipMemcpyHostToDevice, s));
         HIP_OK(hipMemcpyAsync(g->d_blk[q].p, g->h_blk[q], nb * sizeof(GiBlock), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((u32)nb), dim3(64), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
-                           (const uint8_t*)g->d_comp[q].p, (uint8_t*)g->d_out[q].p, (uint8_t*)g->d_status[q].p);
+                           (const uint8_t*)g->d_comp[q].p, d_dst, (uint8_t*)g->d_status[q].p);
         HIP_OK(hipGetLastError());
-        if (ubytes) HIP_OK(hipMemcpyAsync(out + u0, g->d_out[q].p, ubytes, hipMemcpyDeviceToHost, s));
+        if (keep) {
+            for (size_t i = a; i < b; ++i) g->h_crc[q][i - a] = GrCrcBlock{blk[i].uoff - u0, blk[i].isize, crc[i]};
+            if (g->d_crc[q].ensure(nb * sizeof(GrCrcBlock))) return 1;
+            HIP_OK(hipMemcpyAsync(g->d_crc[q].p, g->h_crc[q], nb * sizeof(GrCrcBlock), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(gr_crc_kernel, dim3((u32)nb), dim3(64), 0, s, (const GrCrcBlock*)g->d_crc[q].p, (u32)nb, (const uint8_t*)d_dst,
+                               (const uint32_t*)g->d_crctab.p, (uint8_t*)g->d_status[q].p);
+            HIP_OK(hipGetLastError());
+        } else if (ubytes) HIP_OK(hipMemcpyAsync(out + u0, g->d_out[q].p, ubytes, hipMemcpyDeviceToHost, s));
         HIP_OK(hipMemcpyAsync(g->h_status[q], g->d_status[q].p, nb, hipMemcpyDeviceToHost, s));
         HIP_OK(hipEventRecord(g->ev_done[q], s));
     }
     g->pending_n = n; g->pending_slices = n_slices;
     return 0;
-} FASTF_CATCH_INT
+}
 
 extern "C" int fastf_gpuinf_wait(fastf_gpuinf_t* g, uint8_t* status, double* device_ms) FASTF_TRY {
     if (!g) return set_err("null inflate handle");
@@ -149,3 +208,80 @@ extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, co
     if (fastf_gpuinf_submit(g, comp, blk, n, out)) return 1;
     return fastf_gpuinf_wait(g, status, nullptr);
 } FASTF_CATCH_INT
+
+// ---- second stage: record hop + tag extraction + key packing on the window buffer of `parity` (keep mode) ----
+// The window buffer mirrors the host window's offsets.  `tail` (tail_len bytes, a record boundary at its first byte: what
+// the host carried over from the window before) is placed in front of offset `data_off` (= the host window's reserve), the
+// records that START in [data_off - tail_len, end) and are complete there are hopped and packed.
+//   out->status     0 ok; 1 = the chains of the segments did not line up (a record longer than a segment, a wrong guess):
+//                   nothing was packed, the caller fetches the bytes and parses on the host
+//   out->n          records packed, as SoA in device memory (out->batch: valid until the second next parse of this parity)
+//   out->handover   offset behind the last complete record: the host goes on from there (fastf_gpurec_fetch brings the
+//                   bytes [handover, end) over)
+static void gr_dict_from_view(gr::Dict& d, const fastf_keydict_view_t& v) {
+    memset(&d, 0, sizeof d);
+    d.n_prefix = v.n_prefix;
+    for (uint32_t i = 0; i < v.n_prefix && i < (uint32_t)gr::MAX_PREFIX; ++i) {
+        d.plen[i] = v.prefix_len[i]; d.pid[i] = v.prefix_id[i];
+        memcpy(d.ptext[i], v.prefix[i], gr::MAX_PREFIX_LEN);
+    }
+}
+extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned char* tail, size_t tail_len, uint64_t data_off,
+                                  uint64_t end, uint32_t n_ref, const fastf_keydict_view_t* cells, const fastf_keydict_view_t* feats,
+                                  fastf_gpurec_result_t* out) FASTF_TRY {
+    if (!g || !out || !cells || !feats || parity < 0 || parity > 1) return set_err("bad fastf_gpurec_parse arguments");
+    if (tail_len > data_off || end < data_off || !g->d_win[parity].p || g->d_win[parity].bytes < end) return set_err("fastf_gpurec_parse: window not on the device");
+    HIP_OK(hipSetDevice(g->device));
+    if (!g->s_parse) HIP_OK(hipStreamCreateWithFlags(&g->s_parse, hipStreamNonBlocking));
+    if (!g->h_result) HIP_OK(hipHostMalloc((void**)&g->h_result, 8 * sizeof(u64), hipHostMallocDefault));
+    hipStream_t s = g->s_parse;
+    uint8_t* win = (uint8_t*)g->d_win[parity].p;
+    const u64 start = data_off - tail_len;
+    memset(out, 0, sizeof *out);
+    out->handover = start;
+    if (end - start < 36) return 0;                                    // not even a fixed part: all of it is the host's
+    if (tail_len) HIP_OK(hipMemcpyAsync(win + start, tail, tail_len, hipMemcpyHostToDevice, s));
+    const u32 n_seg = (u32)((end - start + GR_SEG - 1) / GR_SEG);
+    const u64 cap = (end - start) / 36 + 1;
+    if (g->d_seg.ensure((size_t)n_seg * sizeof(GrSeg)) || g->d_offs.ensure((size_t)n_seg * GR_SEG_RECS * sizeof(u32)) || g->d_result.ensure(8 * sizeof(u64))) return 1;
+    if (g->soa_cap[parity] < cap) {
+        if (g->d_soa[parity].ensure((size_t)cap * 24)) return 1;
+        g->soa_cap[parity] = cap;
+    }
+    const u64 sc = g->soa_cap[parity];
+    u64* cb = (u64*)g->d_soa[parity].p; u64* gx = cb + sc; u32* umi = (u32*)(gx + sc); u32* meta = umi + sc;
+    gr::Dict dc, df;
+    gr_dict_from_view(dc, *cells); gr_dict_from_view(df, *feats);
+    hipLaunchKernelGGL(gr_hop_kernel, dim3(n_seg), dim3(64), 0, s, (const uint8_t*)win, start, end, n_ref, (GrSeg*)g->d_seg.p, (u32*)g->d_offs.p);
+    hipLaunchKernelGGL(gr_stitch_kernel, dim3(1), dim3(1024), 0, s, (GrSeg*)g->d_seg.p, n_seg, end, (u64*)g->d_result.p);
+    HIP_OK(hipMemcpyAsync(g->h_result, g->d_result.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    g->n_parsed_windows++;
+    if (g->h_result[0]) { out->status = 1; g->n_parse_fallbacks++; return 0; }
+    const u64 n_rec = g->h_result[1];
+    if (n_rec > sc) return set_err("internal: %llu records in a window sized for %llu", (unsigned long long)n_rec, (unsigned long long)sc);
+    if (n_rec) {
+        hipLaunchKernelGGL(gr_pack_kernel, dim3(n_seg), dim3(64), 0, s, (const uint8_t*)win, start, (const GrSeg*)g->d_seg.p, (const u32*)g->d_offs.p,
+                           dc, df, cb, gx, umi, meta, sc, (u64*)g->d_result.p);
+        HIP_OK(hipMemcpyAsync(g->h_result, g->d_result.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    out->n = n_rec; out->handover = g->h_result[2]; out->no_xf = g->h_result[3]; out->no_gx = g->h_result[4];
+    out->batch.cb_key = (const uint64_t*)cb; out->batch.gx_key = (const uint64_t*)gx; out->batch.umi = umi; out->batch.meta = meta; out->batch.n = (size_t)n_rec;
+    return 0;
+} FASTF_CATCH_INT
+
+// bytes [from, to) of the window buffer of `parity` into dst (dst[0] = byte `from`); dst pinned or not
+extern "C" int fastf_gpurec_fetch(fastf_gpuinf_t* g, int parity, unsigned char* dst, uint64_t from, uint64_t to) FASTF_TRY {
+    if (!g || parity < 0 || parity > 1 || to < from || !g->d_win[parity].p || g->d_win[parity].bytes < to) return set_err("bad fastf_gpurec_fetch arguments");
+    if (to == from) return 0;
+    HIP_OK(hipSetDevice(g->device));
+    HIP_OK(hipMemcpy(dst, (const uint8_t*)g->d_win[parity].p + from, (size_t)(to - from), hipMemcpyDeviceToHost));
+    return 0;
+} FASTF_CATCH_INT
+
+extern "C" void fastf_gpurec_stats(const fastf_gpuinf_t* g, uint64_t* windows, uint64_t* fallbacks) FASTF_TRY {
+    if (windows) *windows = g ? g->n_parsed_windows : 0;
+    if (fallbacks) *fallbacks = g ? g->n_parse_fallbacks : 0;
+} FASTF_CATCH_VOID

@@ -51,6 +51,26 @@ int  fastf_gpuinf_wait(fastf_gpuinf_t *g, uint8_t *status, double *device_ms);
 int  fastf_gpuinf_run(fastf_gpuinf_t *g, const unsigned char *comp, const fastf_gpuinf_blk_t *blk, size_t n,
                       unsigned char *out, uint8_t *status);
 void fastf_gpuinf_stats(const fastf_gpuinf_t *g, uint64_t *n_blocks, uint64_t *n_declined);
+/* keep mode + second stage (gpu_records.hpp): the inflated bytes stay on the device (window buffer per parity, block i at its
+ * host offset), CRC-32 per block on the device (status bit 1), then record hop + tag extraction + key packing there */
+int  fastf_gpuinf_submit_keep(fastf_gpuinf_t *g, const unsigned char *comp, const fastf_gpuinf_blk_t *blk, size_t n,
+                              int parity, const uint32_t *crc);
+/* what a key dictionary needs on the device: its ID-form prefixes.  fastf_keydict_export returns 1 (and leaves the view
+ * unusable) when the dictionary holds escape strings, more than 8 prefixes or a prefix longer than 32 bytes */
+typedef struct {
+    uint32_t n_prefix; uint32_t prefix_len[8]; uint64_t prefix_id[8]; unsigned char prefix[8][32];
+} fastf_keydict_view_t;
+int  fastf_keydict_export(const fastf_keydict_t *d, fastf_keydict_view_t *v);
+typedef struct {
+    int status;                    /* 0 ok; 1: the segment chains did not line up — parse this window on the host */
+    uint64_t n, handover, no_xf, no_gx;
+    fastf_batch_t batch;           /* DEVICE pointers: n packed records */
+} fastf_gpurec_result_t;
+int  fastf_gpurec_parse(fastf_gpuinf_t *g, int parity, const unsigned char *tail, size_t tail_len, uint64_t data_off,
+                        uint64_t end, uint32_t n_ref, const fastf_keydict_view_t *cells, const fastf_keydict_view_t *feats,
+                        fastf_gpurec_result_t *out);
+int  fastf_gpurec_fetch(fastf_gpuinf_t *g, int parity, unsigned char *dst, uint64_t from, uint64_t to);
+void fastf_gpurec_stats(const fastf_gpuinf_t *g, uint64_t *windows, uint64_t *fallbacks);
 void *fastf_pinned_alloc(size_t bytes);
 void fastf_pinned_free(void *p);
 int  fastf_pinned_register(void *p, size_t bytes);

@@ -10,6 +10,7 @@
  *                         strcmp-verified chained table (hashtable.c:70-115)
  */
 #include "fastf_amd.h"
+#include "host_io.h"
 
 #include <pthread.h>
 #include <stdio.h>
@@ -405,6 +406,22 @@ uint64_t fastf_keydict_add(fastf_keydict_t *d, const char *s, size_t len)
     uint64_t ord = d->escapes.n;
     rev_put(&d->escape_by_ord, &d->escape_cap, ord, map_put(&d->escapes, s, len, ord));
     return (3ull << 62) | ord;
+}
+
+/* the ID-form prefixes for the device-side packer (gpu_records.hpp pack_key); 1 = this dictionary needs the host packer */
+int fastf_keydict_export(const fastf_keydict_t *d, fastf_keydict_view_t *v)
+{
+    memset(v, 0, sizeof *v);
+    if (!d || d->escapes.n || d->prefixes.n > 8) return 1;
+    for (size_t i = 0; i < d->prefixes.cap; i++) {
+        const kd_ent *e = &d->prefixes.e[i];
+        if (!e->s) continue;
+        if (e->len > 32) return 1;
+        const uint32_t q = v->n_prefix++;
+        v->prefix_len[q] = e->len; v->prefix_id[q] = e->val;
+        memcpy(v->prefix[q], e->s, e->len);
+    }
+    return 0;
 }
 
 uint64_t fastf_keydict_pack(const fastf_keydict_t *d, const char *s, size_t len)
