@@ -26,7 +26,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 /* decoder thread: BAM → packed SoA batches, double-buffered, while the caller pushes the previous batch
  * (and, for the first batch, while the HIP runtime and the engine come up) */
-typedef struct { uint64_t *cb, *gx; uint32_t *umi, *meta; long n; } dec_slot;
+typedef struct { uint64_t *cb, *gx; uint32_t *umi, *meta; long n; int on_device; fastf_batch_t dev; } dec_slot;   /* on_device: the batch lies packed in device memory (dev) */
 typedef struct {
     fastf_bam_t *bam; const fastf_lists_t *lists; size_t cap;
     dec_slot slot[2]; int filled[2];
@@ -44,8 +44,8 @@ static void *decoder_main(void *vp)
         pthread_mutex_unlock(&d->mu);
         if (stop) break;
         double t = now_s();
-        long n = fastf_bam_read_batch(d->bam, d->lists->cell_dict, d->lists->feat_dict, d->slot[k].cb, d->slot[k].gx,
-                                      d->slot[k].umi, d->slot[k].meta, d->cap);
+        long n = fastf_bam_read_batch_dev(d->bam, d->lists->cell_dict, d->lists->feat_dict, d->slot[k].cb, d->slot[k].gx,
+                                          d->slot[k].umi, d->slot[k].meta, d->cap, &d->slot[k].on_device, &d->slot[k].dev);
         d->t_decode += now_s() - t;
         pthread_mutex_lock(&d->mu);
         d->slot[k].n = n; d->filled[k] = 1;
@@ -126,6 +126,11 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         dec.slot[k].cb = (uint64_t *)base; dec.slot[k].gx = (uint64_t *)(base + cap * 8);
         dec.slot[k].umi = (uint32_t *)(base + cap * 16); dec.slot[k].meta = (uint32_t *)(base + cap * 20);
     }
+    /* the windows the device inflates are hopped and packed there as well (one device; lists the device packer can hold) */
+    {   const char *dvs = getenv("FASTF_DEVICES");
+        const int several = dvs && *dvs && (strchr(dvs, ',') || atoi(dvs) >= 2);
+        if (!several) (void)fastf_bam_enable_device_parse(bam, lists.cell_dict, lists.feat_dict);
+    }
     printf("Start to convert bam file to UMI keys on the device...\n");
     if (pthread_create(&dec_thread, NULL, decoder_main, &dec) != 0) { fprintf(stderr, "cannot start decoder thread\n"); goto done; }
     dec_started = 1;
@@ -174,9 +179,11 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         if (n < 0) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
         if (n == 0) break;
         fastf_batch_t batch = { dec.slot[k].cb, dec.slot[k].gx, dec.slot[k].umi, dec.slot[k].meta, (size_t)n };
+        const int on_dev = dec.slot[k].on_device;
+        if (on_dev) batch = dec.slot[k].dev;                  /* packed on the device: a device-to-device copy into the engine's staging */
         tt = now_s();
         /* pinned slots: queue the copies, and hand the slot back to the decoder once they have left it */
-        if (slab_pinned ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
+        if ((slab_pinned || on_dev) ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
             fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
         }
         t_push += now_s() - tt;

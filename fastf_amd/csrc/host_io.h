@@ -81,6 +81,13 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate); 
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                           uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap);
+/* device-side parse of the windows the device inflates (gpu_records.hpp): 0 = on, 1 = this reader keeps the host parser */
+int  fastf_bam_enable_device_parse(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats);
+/* as fastf_bam_read_batch; a batch either fills the host arrays (*on_device = 0) or lies packed in device memory already
+ * (*on_device = 1, dev: valid until the second next call) */
+long fastf_bam_read_batch_dev(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
+                              uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap,
+                              int *on_device, fastf_batch_t *dev);
 /* Tag reader of the histogram paths (crb / extract): per record the key of tag1 (and tag2, or NULL) — type 0 string
  * (interned in dict), type 1 integer; 0 = absent.  Returns the count, 0 at EOF, -1 on error; *n_undefined is
  * incremented for string-mode tags that are not of type Z (NULL dereference in the reference, extract.c:102-103,189). */

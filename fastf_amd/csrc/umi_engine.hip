@@ -1125,10 +1125,11 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
         s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
     }
     hipStream_t sc = e->s_copy, sk = e->s_compute;
-    HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyHostToDevice, sc));
-    HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyHostToDevice, sc));
+    // (hipMemcpyDefault: a "pinned" batch may also be DEVICE memory — the records the device-side BAM front end packed)
+    HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyDefault, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyDefault, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyDefault, sc));
+    HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyDefault, sc));
     if (upload_draws(e, sl, src, hits_ub + n)) return 1;               // generated while the record copies are in flight
     if (!src.ext) e->draws_valid = e->draws_up;
     HIP_OK(hipEventRecord(sl.ev_copy, sc));

@@ -197,7 +197,9 @@ int  fastf_engine_push_draws(fastf_engine_t *e, const fastf_batch_t *batch,
  * returns once the copies are queued; the arrays must stay untouched until fastf_engine_wait_input() or
  * fastf_engine_finish() has returned.  This is the path SURVEY 8d calls "device-path": pinned SoA batches ->
  * hipMemcpyAsync on the copy stream -> kernels.  No push waits for the result of an earlier one: the hit-rank base
- * of a chunk (bam2db_ds.c:385 consumes one draw per CB hit) is carried on the device. */
+ * of a chunk (bam2db_ds.c:385 consumes one draw per CB hit) is carried on the device.
+ * The arrays may also be DEVICE memory of the engine's device (single-device engines): records packed on the device by
+ * the BAM front end (fastf_bam_read_batch_dev) are pushed this way. */
 int  fastf_engine_push_pinned(fastf_engine_t *e, const fastf_batch_t *batch);
 int  fastf_engine_wait_input(fastf_engine_t *e);   /* every host-to-device copy queued so far has completed */
 void *fastf_pinned_alloc(size_t bytes);            /* hipHostMalloc; NULL on failure */
