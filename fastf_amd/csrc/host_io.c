@@ -687,6 +687,9 @@ static int bam_need(fastf_bam_t *b, size_t need)
         int r = bam_fill(b);
         if (r < 0) return -1;
         if (r == 1) return (b->ulen == b->upos) ? 1 : -1;
+        /* the new window brought device-packed records: they are handed out before anything else happens to the window
+         * (the callers look at dev_i / dev_batch right after this returns and come back for the rest) */
+        if (b->dev_i < b->dev_batch.n) return 0;
     }
     return 0;
 }
