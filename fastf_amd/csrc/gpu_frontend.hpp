@@ -257,7 +257,22 @@ extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned 
     HIP_OK(hipMemcpyAsync(g->h_result, g->d_result.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     g->n_parsed_windows++;
-    if (g->h_result[0]) { out->status = 1; g->n_parse_fallbacks++; return 0; }
+    if (g->h_result[0]) {
+        out->status = 1; g->n_parse_fallbacks++;
+        const char* pv = getenv("FASTF_BAM_PROFILE");
+        if (pv && pv[0] == '2') {                                      // where the chains parted
+            std::vector<GrSeg> hs(n_seg);
+            if (hipMemcpy(hs.data(), g->d_seg.p, (size_t)n_seg * sizeof(GrSeg), hipMemcpyDeviceToHost) == hipSuccess)
+                for (u32 i = 0; i < n_seg; ++i)
+                    if (hs[i].first == GR_NONE || (i > 0 && hs[i - 1].exit_off != hs[i].first)) {
+                        fprintf(stderr, "[bam] device parse: window [%llu, %llu), %u segments: segment %u begins at %lld (lo %llu), the chain before it ends at %llu\n",
+                                (unsigned long long)start, (unsigned long long)end, n_seg, i, hs[i].first == GR_NONE ? -1ll : (long long)hs[i].first,
+                                (unsigned long long)(start + (u64)i * GR_SEG), i ? (unsigned long long)hs[i - 1].exit_off : 0ull);
+                        break;
+                    }
+        }
+        return 0;
+    }
     const u64 n_rec = g->h_result[1];
     if (n_rec > sc) return set_err("internal: %llu records in a window sized for %llu", (unsigned long long)n_rec, (unsigned long long)sc);
     if (n_rec) {
