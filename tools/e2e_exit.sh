@@ -28,7 +28,7 @@ wall = time.perf_counter() - t0
 closed = [float(l.split(" at ")[1].split()[0]) - w0 for l in p.stderr.splitlines() if "outputs closed at" in l]
 print("== %s: exit %.3f s, outputs closed %.3f s, rc %d" % (" ".join(sys.argv[2:]) or "(default)", wall, closed[-1] if closed else -1, p.returncode))
 for l in p.stderr.splitlines():
-    if l.startswith("[bam2db] lists") or l.startswith("[bam] close") or "teardown" in l: print("   ", l[:420])
+    if l.startswith("[bam2db] lists") or l.startswith("[bam]") or "teardown" in l: print("   ", l[:460])
 PY
 done; done
 rm -rf /dev/shm/gb
