@@ -97,7 +97,11 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
 
     /* bam2db needs a device anyway: unless told otherwise (FASTF_GPU_INFLATE=0) the BGZF inflate of big windows is
      * shared between the host threads and the device (host_io.c: hybrid inflate, every block CRC-checked on the host) */
-    bam = fastf_bam_open2(bam_file, 0, 1);
+    {   /* | 4: the device-side parse will be asked for (below, once the lists are known) unless it is switched off */
+        const char *gp = getenv("FASTF_GPU_PARSE"), *dvs = getenv("FASTF_DEVICES");
+        const int several = dvs && *dvs && (strchr(dvs, ',') || atoi(dvs) >= 2);
+        bam = fastf_bam_open2(bam_file, 0, 1 | ((gp && gp[0] == '0') || several ? 0 : 4));
+    }
     if (!bam) { fprintf(stderr, "Fail to open BAM file %s (%s)\n", bam_file, fastf_last_error()); goto done; }
     fprintf(stderr, "Opened BAM file %s successfully\n", bam_file);
 

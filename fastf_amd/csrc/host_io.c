@@ -248,6 +248,8 @@ struct fastf_bam {
      * device's window buffer of that parity, CRC-checked there — and when the window becomes current its records are hopped
      * and packed on the device; the host goes on from the hand-over offset */
     int parse_ok;                                     /* fastf_bam_enable_device_parse accepted the dictionaries */
+    int parse_expected;                               /* fastf_bam_open2(.., gpu_inflate | 4): the caller is going to ask for it */
+    double gpu_share_cap_keep;                        /* upper bound of the device's share in keep mode (no pinned window front limits it) */
     fastf_keydict_view_t view_cells, view_feats;
     int nparity, uparity;                             /* device window buffer of nbuf / ubuf */
     size_t nkeep_end, ukeep_end;                      /* keep mode: end of the device's share in nbuf / ubuf (0: not a keep window) */
@@ -374,8 +376,10 @@ static void *gpu_init_main(void *vp)
     if (g) {
         b->gcomp = (unsigned char *)fastf_pinned_alloc(b->ccap + 4096);
         b->gcomp_cap = b->gcomp ? b->ccap + 4096 : 0;
-        if (b->pin_a) (void)pin_ensure(b, b->pin_a, b->pin_len, b->pin_len);
-        if (b->pin_b) (void)pin_ensure(b, b->pin_b, b->pin_len, b->pin_len);
+        /* (a reader that expects the device-side parse keeps the device's share on the device: nothing to pin; should the
+         * parse stay off after all, fill_next pins what a copy-back window needs when it needs it) */
+        if (b->pin_a && !b->parse_expected) (void)pin_ensure(b, b->pin_a, b->pin_len, b->pin_len);
+        if (b->pin_b && !b->parse_expected) (void)pin_ensure(b, b->pin_b, b->pin_len, b->pin_len);
     }
     __atomic_store_n(&b->gpu_ready, g, __ATOMIC_RELEASE);
     return NULL;
@@ -576,7 +580,8 @@ static int fill_next(fastf_bam_t *b)
                 double want = r_dev / (r_dev + r_host);
                 b->gpu_share = 0.5 * b->gpu_share + 0.5 * want;
                 if (b->gpu_share < 0.05) b->gpu_share = 0.05;
-                if (b->gpu_share > b->gpu_share_max) b->gpu_share = b->gpu_share_max;   /* what the init thread pinned of the window buffers */
+                const double cap = keep ? b->gpu_share_cap_keep : b->gpu_share_max;     /* copy-back mode: what the init thread pinned of the window buffers */
+                if (b->gpu_share > cap) b->gpu_share = cap;
             }
         }
         b->t_inflate += now_s() - t0;
@@ -708,10 +713,15 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
     { const char *sh = getenv("FASTF_BAM_SERIAL_HOP"); b->serial_hop = sh && sh[0] == '1'; }
     setvbuf(fp, NULL, _IONBF, 0);
     {   const char *gi = getenv("FASTF_GPU_INFLATE"), *dv = getenv("FASTF_DEVICE");
-        b->gpu_wanted = gi ? (gi[0] == '1' ? 1 : gi[0] == '2' ? 2 : 0) : (gpu_inflate == 1 || gpu_inflate == 2 ? gpu_inflate : 0);
+        const int want = gpu_inflate < 0 ? 0 : (gpu_inflate & 3);
+        b->parse_expected = gpu_inflate > 0 && (gpu_inflate & 4) != 0;
+        b->gpu_wanted = gi ? (gi[0] == '1' ? 1 : gi[0] == '2' ? 2 : 0) : (want == 1 || want == 2 ? want : 0);
         b->gpu_device = dv ? atoi(dv) : 0;
         const char *sh2 = getenv("FASTF_GPU_INFLATE_SHARE"), *sh3 = getenv("FASTF_GPU_INFLATE_MAX");
         b->gpu_share_max = sh3 ? atof(sh3) : 0.60;
+        b->gpu_share_cap_keep = sh3 ? atof(sh3) : 0.95;
+        if (b->gpu_share_cap_keep < 0.05) b->gpu_share_cap_keep = 0.05;
+        if (b->gpu_share_cap_keep > 1.0) b->gpu_share_cap_keep = 1.0;
         if (b->gpu_share_max < 0.05) b->gpu_share_max = 0.05;
         if (b->gpu_share_max > 1.0) b->gpu_share_max = 1.0;
         b->gpu_share = sh2 ? atof(sh2) : b->gpu_share_max;

@@ -77,7 +77,9 @@ int  fastf_pinned_register(void *p, size_t bytes);
 void fastf_pinned_unregister(void *p);
 void fastf_bam_print_profile(const fastf_bam_t *b);   /* FASTF_BAM_PROFILE=1: stage times of the reader on stderr */
 fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
-fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate);   /* gpu_inflate: default when FASTF_GPU_INFLATE is unset */
+/* gpu_inflate: what to do when FASTF_GPU_INFLATE is unset — 0/-1 host threads only, 1 inflate shared with the device, 2 wait for
+ * the device; | 4: the caller will call fastf_bam_enable_device_parse (nothing is pinned for copy-back windows up front) */
+fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate);
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                           uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap);
