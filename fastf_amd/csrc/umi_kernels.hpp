@@ -1450,6 +1450,12 @@ __device__ __forceinline__ void k3_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 #ifndef FASTF_K3_MINW_DEDUP
 #define FASTF_K3_MINW_DEDUP 6
 #endif
+#ifndef FASTF_K3_PD32
+typedef unsigned short k3_pd_t;
+#else
+typedef u32 k3_pd_t;
+#endif
+static_assert(K3_TILE <= 65535 || sizeof(k3_pd_t) == 4, "distinct prefixes of a window must fit k3_pd_t");
 template <bool UMI_ROWS, int DEDUP>
 __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) void reduce_windows_kernel(const ReduceParams p) {
     static_assert(!UMI_ROWS || DEDUP == 0, "-u rows come from fully sorted keys");
@@ -1457,7 +1463,7 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
     __shared__ u32 s_h[K3_UNITS], s_d[K3_UNITS];
     __shared__ u64 s_hb[K3_UNITS];         // head ballots of the units (the cut is found from these)
     __shared__ u32 s_tot[2];
-    __shared__ u32 s_pd[K3_TILE + 1];      // by local row: distinct-prefix at the head
+    __shared__ k3_pd_t s_pd[K3_TILE + 2];  // by local row: distinct-prefix at the head (at most K3_TILE: 16 bits do)
     __shared__ u64 s_id[K3_TILE];          // the window's keys, later the row identities (UMI_ROWS: the key; else (cell << 32) | feature)
     __shared__ u32 s_tab[DEDUP == 2 ? K3_TAB : 1];
     __shared__ u32 s_first;                // chunk start search
@@ -1541,7 +1547,10 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                 dist = valid && ((k >> nn_shift) & 1);
                 if (DEDUP == 0) { if (dist && idx > 0) dist = k != prev; }
                 else if (DEDUP == 2) {
-                    if (dist) {
+                    // a group of one key (a head whose neighbour behind is a head too) needs no set: about a tenth of the keys
+                    const u64 hnow = __ballot(head);
+                    const bool single = head && lane < WAVE - 1 && ((hnow >> (lane + 1)) & 1);
+                    if (dist && !single) {
                         // window-local hash set: the first key to take a slot is the one that counts
                         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
                         for (;;) {
@@ -1666,7 +1675,7 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
             const u32 h = lane < K3_UNITS ? s_h[lane] : 0u, d = lane < K3_UNITS ? s_d[lane] : 0u;
             const u32 hi = wave_incl_scan32(h, lane), di = wave_incl_scan32(d, lane);
             if (lane < K3_UNITS) { s_h[lane] = hi - h; s_d[lane] = di - d; }
-            if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = di; }   // sentinel: all distinct flags of the window
+            if (lane == WAVE - 1) { s_tot[0] = hi; s_tot[1] = di; s_pd[hi] = (k3_pd_t)di; }   // sentinel: all distinct flags of the window
         }
         k3_barrier();
         const u32 n_rows = __builtin_amdgcn_readfirstlane(s_tot[0]), d_all = __builtin_amdgcn_readfirstlane(s_tot[1]);
@@ -1675,14 +1684,14 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
             if (DEDUP == 2 && slot[j] != ~0u) s_tab[slot[j]] = 0;        // the set is empty again for the next window
             if ((hm[j] >> lane) & 1) {
                 const u32 r = s_h[j * K3_WAVES + w] + rank_below(hm[j]);
-                s_pd[r] = s_d[j * K3_WAVES + w] + rank_below(dm[j]);
+                s_pd[r] = (k3_pd_t)(s_d[j * K3_WAVES + w] + rank_below(dm[j]));
                 s_id[r] = UMI_ROWS ? key[j]
                                    : (((u64)(u32)(key[j] >> p.L.cell_shift)) << 32) | ((u32)(key[j] >> p.L.feat_shift) & p.feat_mask);
             }
         }
         k3_barrier();
         // distinct flags in front of the window's first head belong to the open row (none unless a group is being carried)
-        const u32 lead = n_rows ? __builtin_amdgcn_readfirstlane(s_pd[0]) : d_all;
+        const u32 lead = n_rows ? (u32)__builtin_amdgcn_readfirstlane((int)s_pd[0]) : d_all;
 #ifdef FASTF_K3_DEBUG
         if (tid == 0) printf("b %u base %llu W %u lim %u cstop %u clast %u cut %u closed %d done %d n_rows %u d_all %u lead %u open %d cnt %u prev0 %llx key0 %llx\n", b, (unsigned long long)base, W, lim, c_stop, c_last, cut, (int)closed, (int)done, n_rows, d_all, lead, (int)open_valid, open_cnt, (unsigned long long)prev0, (unsigned long long)key[0]);
 #endif
@@ -1753,11 +1762,11 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
             const u64 oid = s_id[last_row];
             open_valid = true;
             open_id = uniform64(oid);
-            open_cnt = __builtin_amdgcn_readfirstlane(s_pd[n_rows] - s_pd[last_row]);
+            open_cnt = (u32)__builtin_amdgcn_readfirstlane((int)((u32)s_pd[n_rows] - (u32)s_pd[last_row]));
         }
         const u64 row_base = region + rows_so_far;
         for (u32 r = first_row + tid; r < last_row; r += K3_THREADS) {
-            const u32 c = s_pd[r + 1] - s_pd[r];
+            const u32 c = (u32)s_pd[r + 1] - (u32)s_pd[r];
             const u64 id = s_id[r];
             p.count[row_base + r] = c;
             if (UMI_ROWS) p.ukeys[row_base + r] = id;
