@@ -876,12 +876,12 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
 } FASTF_CATCH_INT
 
 // K3 grid: every workgroup owns one contiguous chunk of the keys, so the launch is one round of resident workgroups
-// (LDS: 25 KB per workgroup, 41 KB with the hash set of DEDUP 2; 64 VGPRs: eight waves per SIMD)
+// (LDS: 21 KB per workgroup, 37 KB with the hash set of DEDUP 2; 64 VGPRs: eight waves per SIMD, four workgroups per CU)
 static u32 k3_grid(u64 max_n, int dedup) {
     static int per_cu[3] = {-1, -1, -1};
     if (per_cu[dedup] < 0) {
         const char* c = getenv("FASTF_K3_PER_CU");
-        per_cu[dedup] = c ? atoi(c) : (dedup == 0 ? 4 : 3);
+        per_cu[dedup] = c ? atoi(c) : 4;
         if (per_cu[dedup] < 1) per_cu[dedup] = 1;
     }
     const u64 tiles = (max_n + K3_TILE - 1) / K3_TILE;

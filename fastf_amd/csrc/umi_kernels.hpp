@@ -1444,11 +1444,11 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
 // workgroup barrier that waits for this wave's LDS traffic only (not for its global loads and stores)
 __device__ __forceinline__ void k3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// register budget: 64 VGPRs (eight waves per SIMD, four workgroups per CU) hold the plain compare; the run walk and the hash
-// probe keep more alive next to the prefetched keys and get 80 (six waves per SIMD, three workgroups per CU) — at 64 they
-// spill, and the spilled registers are the prefetched keys: every window then pays a scratch round trip
+// register budget: 64 VGPRs (eight waves per SIMD, four workgroups per CU).  The hash probe needs 80 to stay out of scratch
+// (three spilled registers at 64), but the fourth workgroup per CU is worth more than that: 0.261 ms against 0.280 on the
+// configs[2] shape (profiles/r3_notes/ab_k3_hash_occupancy.txt).  FASTF_K3_MINW_DEDUP=6 gives the 80-register build.
 #ifndef FASTF_K3_MINW_DEDUP
-#define FASTF_K3_MINW_DEDUP 6
+#define FASTF_K3_MINW_DEDUP 8
 #endif
 #ifndef FASTF_K3_PD32
 typedef unsigned short k3_pd_t;
