@@ -1525,11 +1525,9 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
         const u32 W = (u32)(n - base < (u64)K3_TILE ? n - base : (u64)K3_TILE);
         u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
         u32 slot[K3_IPT];
-        bool hneed[K3_IPT], dflag[K3_IPT];             // DEDUP 2: the key goes through the hash set / counts as distinct
         bool too_long = false;
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
-            hneed[j] = false; dflag[j] = false;
             key[j] = nkey[j];
             s_id[(u32)j * K3_THREADS + tid] = key[j];
         }
@@ -1549,11 +1547,21 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                 dist = valid && ((k >> nn_shift) & 1);
                 if (DEDUP == 0) { if (dist && idx > 0) dist = k != prev; }
                 else if (DEDUP == 2) {
-                    // (the hash set is worked below, the four keys of a thread side by side)
                     // a group of one key (a head whose neighbour behind is a head too) needs no set: about a tenth of the keys
                     const u64 hnow = __ballot(head);
-                    if (head && lane < WAVE - 1 && ((hnow >> (lane + 1)) & 1)) hneed[j] = false;
-                    else hneed[j] = dist;
+                    const bool single = head && lane < WAVE - 1 && ((hnow >> (lane + 1)) & 1);
+                    if (dist && !single) {
+                        // window-local hash set: the first key to take a slot is the one that counts
+                        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
+                        for (;;) {
+                            u32 v = s_tab[h];
+                            if (v == 0) {
+                                if (__hip_atomic_compare_exchange_strong(&s_tab[h], &v, loc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = h; break; }
+                            }
+                            if (s_id[v - 1] == k) { dist = false; break; }
+                            h = (h + 1) & (K3_TAB - 1);
+                        }
+                    }
                 } else if (dist && idx > 0) {
                     // keys that agree on the sorted bits are neighbours but in arbitrary order: this key is a new UMI
                     // iff no earlier key of that little run equals it.  The run is (cell, feature, top UMI bits), i.e.
@@ -1611,47 +1619,8 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                     }
                 }
             }
-            hm[j] = __ballot(head);
-            if (DEDUP == 2) dflag[j] = dist; else dm[j] = __ballot(dist);
+            hm[j] = __ballot(head); dm[j] = __ballot(dist);
             if (lane == 0) s_hb[j * K3_WAVES + w] = hm[j];
-        }
-        if (DEDUP == 2) {
-            // window-local hash set: the first key to take a slot is the one that counts.  The probes of a thread's four keys
-            // go out together — slot reads, then the claims of the empty slots, then the occupants' keys — so that their LDS
-            // round trips overlap; what is left (a slot held by another key) walks on one by one.
-            u32 h[K3_IPT], v[K3_IPT];
-#pragma unroll
-            for (int j = 0; j < K3_IPT; ++j) {
-                h[j] = (u32)((key[j] * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
-                v[j] = hneed[j] ? s_tab[h[j]] : 1u;
-            }
-#pragma unroll
-            for (int j = 0; j < K3_IPT; ++j) {
-                if (hneed[j] && v[j] == 0 &&
-                    __hip_atomic_compare_exchange_strong(&s_tab[h[j]], &v[j], (u32)j * K3_THREADS + tid + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    slot[j] = h[j]; hneed[j] = false;                  // taken: this key counts
-                }
-            }
-            u64 occ[K3_IPT];
-#pragma unroll
-            for (int j = 0; j < K3_IPT; ++j) occ[j] = hneed[j] ? s_id[v[j] - 1] : 0;
-#pragma unroll
-            for (int j = 0; j < K3_IPT; ++j) {
-                if (!hneed[j]) continue;
-                const u64 k = key[j];
-                if (occ[j] == k) { dflag[j] = false; continue; }
-                u32 hh = (h[j] + 1) & (K3_TAB - 1);
-                for (;;) {
-                    u32 vv = s_tab[hh];
-                    if (vv == 0) {
-                        if (__hip_atomic_compare_exchange_strong(&s_tab[hh], &vv, (u32)j * K3_THREADS + tid + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = hh; break; }
-                    }
-                    if (s_id[vv - 1] == k) { dflag[j] = false; break; }
-                    hh = (hh + 1) & (K3_TAB - 1);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < K3_IPT; ++j) dm[j] = __ballot(dflag[j]);
         }
         k3_barrier();
         // ---- the cut (every wave works it out for itself from the 32 head ballots) ----
