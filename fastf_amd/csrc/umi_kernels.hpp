@@ -1549,7 +1549,10 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                 else if (DEDUP == 2) {
                     // a group of one key (a head whose neighbour behind is a head too) needs no set: about a tenth of the keys
                     const u64 hnow = __ballot(head);
-                    const bool single = head && lane < WAVE - 1 && ((hnow >> (lane + 1)) & 1);
+                    bool single = head && lane < WAVE - 1 && ((hnow >> (lane + 1)) & 1);
+#ifdef FASTF_K3_NOHASH   /* elimination experiment only (wrong counts): what the window structure costs without the set (0.138 ms) */
+                    single = true;
+#endif
                     if (dist && !single) {
                         // window-local hash set: the first key to take a slot is the one that counts
                         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
