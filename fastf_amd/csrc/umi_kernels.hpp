@@ -1557,10 +1557,10 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                         // window-local hash set: the first key to take a slot is the one that counts
                         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
                         for (;;) {
-                            u32 v = s_tab[h];
-                            if (v == 0) {
-                                if (__hip_atomic_compare_exchange_strong(&s_tab[h], &v, loc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = h; break; }
-                            }
+                            // claim first, look afterwards: a first occurrence (two keys out of three) is done after ONE LDS
+                            // round trip; the compare-and-swap of a taken slot hands back its occupant
+                            u32 v = 0;
+                            if (__hip_atomic_compare_exchange_strong(&s_tab[h], &v, loc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = h; break; }
                             if (s_id[v - 1] == k) { dist = false; break; }
                             h = (h + 1) & (K3_TAB - 1);
                         }

@@ -226,6 +226,7 @@ def test_reduce_windows_groups_longer_than_a_window_and_regions(env, sizes, seed
 @pytest.mark.parametrize("sizes,too_long,seed", [([3] * 50_000, False, 1), ([2047, 1, 2047, 5, 900] * 30, False, 2),
                                                  ([100, 2048, 100], False, 3), ([40_000], False, 4), ([65_536, 9, 65_537, 1], True, 6),
                                                  ([5000, 1, 1, 7000, 2048, 2047, 2049, 3, 4096, 1, 30_000, 2], False, 7),
+                                                 ([2100] * 2100, True, 8),      # more work items than giant_groups_kernel's list holds
                                                  (list(range(1, 600)), False, 5)])
 def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypatch):
     """FASTF_K3_DEDUP=hash: the sort orders (cell, feature) only; K3 finds the distinct UMIs of a group through its
