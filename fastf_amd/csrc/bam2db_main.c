@@ -198,6 +198,8 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     }
     t_decode = dec.t_decode;
     /* every record is on the device (each push waited for its copies): the reader and the slab go now, beside what follows */
+    {   extern int fastf_reader_leaves_device_side_;
+        fastf_reader_leaves_device_side_ = fastf_process_is_exiting_; }
     rel.dec_thread = dec_thread; rel.bam = bam; rel.slab = slab; rel.slab_pinned = slab_pinned;
     if (pthread_create(&rel_thread, NULL, release_main, &rel) == 0) { rel_started = 1; dec_started = 0; bam = NULL; slab = NULL; slab_pinned = 0; }
     fastf_coo_t coo; uint64_t counters[3];
