@@ -164,8 +164,6 @@ struct fastf_engine {
     // workspace
     DevBuf d_cellidx, d_tilecnt, d_tilebase, d_binbase, d_cnt;   // d_binbase: per-pass bin totals
     DevBuf d_halfhits;                   // K1a: hits per 256-record unit (the streaming K1b's rank bases)
-    DevBuf d_hitmask;                    // compact scratch (LDS K1a -> streaming K1b): a hit bit per record; the indices of the hits lie dense per 512-record chunk in d_cellidx
-    bool scratch_compact = false;        // which form the last K1a left in d_cellidx
     DevBuf d_segkeys;                    // several shards: the streaming K1b's unsharded output (workgroup regions) in front of shard_partition_kernel
     DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
     u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
@@ -527,7 +525,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
-                     &e->d_halfhits, &e->d_hitmask, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys};
+                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -599,7 +597,6 @@ static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
     }
     if (e->d_tilebase.ensure(t1 * sizeof(u64))) return 1;
     if (e->d_halfhits.ensure(t1 * 16 * sizeof(u32))) return 1;
-    if (e->d_hitmask.ensure(t1 * (K1_TILE / 64) * sizeof(u64))) return 1;
     if (e->d_tileseg.ensure((ts + 8) * sizeof(TileSeg))) return 1;
     if (e->d_binbase.ensure(RADIX * sizeof(u32))) return 1;
     if (e->d_cnt.ensure((ts + 4) * RADIX * sizeof(u32))) return 1;     // rows padded to a multiple of 4 tiles
@@ -663,28 +660,19 @@ static void launch_scan_tiles(fastf_engine* e, int slot, hipStream_t s, u32* in,
     hipLaunchKernelGGL(scan_fix_kernel<16>, dim3(n_blk), dim3(1024), 0, s, out, T, (const u64*)blk, n_blk, total_out, running, base_out);
 }
 
-// which scratch form the K1b that follows wants: the streaming form behind the LDS K1a takes the compact one
-static bool stream_k1b_possible(const fastf_engine* e) { return e->use_lds_genes && e->n_shards <= (u32)MAX_SHARDS && !getenv("FASTF_NO_STREAM_K1B"); }
-static bool compact_scratch_wanted(const fastf_engine* e, bool k1b_streams) {
-    return k1b_streams && e->use_lds_cells && !getenv("FASTF_NO_COMPACT_SCRATCH");
-}
-
 static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s,
-                              u64* d_running = nullptr, u64* d_base_out = nullptr, bool compact = false) {
+                              u64* d_running = nullptr, u64* d_base_out = nullptr) {
     if (reserve_workspace(e, n, 0)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
-    compact = compact && e->use_lds_cells;
-    e->scratch_compact = compact;
-    u64* const hmask = compact ? (u64*)e->d_hitmask.p : nullptr;
     t_begin(e, s);
     if (e->use_lds_cells) {                          // tile counts are all-zero here: scan_tiles_kernel clears what it reads
         const u32 grid = std::min<u32>(e->cells_blocks_per_cu * g_cu_count, (tiles + 1) / 2);
         if (e->cells_blocks_per_cu >= 2)
             hipLaunchKernelGGL(probe_cells_lds_kernel<true>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles, hmask);
+                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
         else
             hipLaunchKernelGGL(probe_cells_lds_kernel<false>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles, hmask);
+                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else if (e->cell_filter.bits) {
         const u32 grid = std::min<u32>(tiles, 4 * g_cu_count);
         hipLaunchKernelGGL(probe_cells_filtered_kernel, dim3(grid), dim3(K1_THREADS), (e->cell_filter.mask + 1u) / 8u, s, cb, n,
@@ -706,9 +694,7 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
     HIP_OK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s)); return 0; }
-    // (the K1b of a device-level pass streams whenever it can: the scratch is left in the form it reads; a fastf_dev_probe_pack
-    // that turns out to want the other form runs K1a again)
-    return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s, nullptr, nullptr, compact_scratch_wanted(e, stream_k1b_possible(e)));
+    return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s);
 } FASTF_CATCH_INT
 
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
@@ -719,17 +705,10 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     if (n == 0) return 0;
     // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order).
     // d_running: the scan leaves the running hit total of the earlier chunks at draw_base and adds this chunk's hits.
-    const bool no_stream = getenv("FASTF_NO_STREAM_K1B") != nullptr;
-    const bool stream_shards = !segmented && e->n_shards > 1 && e->n_shards <= (u32)MAX_SHARDS && e->use_lds_genes && !no_stream;
-    const bool compact = compact_scratch_wanted(e, segmented || stream_shards);
-    if (!reuse_hits) {
-        if (launch_probe_cells(e, cb, n, nullptr, s, d_running, d_running ? const_cast<u64*>(draw_base) : nullptr, compact)) return 1;
-    } else if (e->scratch_compact != compact) {
-        if (launch_probe_cells(e, cb, n, nullptr, s, nullptr, nullptr, compact)) return 1;      // the hits were counted for the other K1b form
-    }
+    if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s, d_running, d_running ? const_cast<u64*>(draw_base) : nullptr)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     PackParams p{};
-    p.cell = e->d_cellidx.p; p.cell16 = e->cell16; p.hit_mask = compact ? (const u64*)e->d_hitmask.p : nullptr; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
+    p.cell = e->d_cellidx.p; p.cell16 = e->cell16; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
     p.tile_base = (const u64*)e->d_tilebase.p;
     p.draws = draws; p.n_draws = n_draws; p.draw_base = draw_base; p.draw_mask = draw_mask;
     p.feats = e->feats;
@@ -741,6 +720,8 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.genes = e->lds_genes;
     // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
     // deals the keys to the per-destination buffers (same interface as the tile form: keys[G][stride], key_counts[G] += ...)
+    const bool no_stream = getenv("FASTF_NO_STREAM_K1B") != nullptr;
+    const bool stream_shards = !segmented && e->n_shards > 1 && e->n_shards <= (u32)MAX_SHARDS && e->use_lds_genes && !no_stream;
     t_begin(e, s);
     if (segmented || stream_shards) {
         // streaming form: every wave on its own, keys into one private region per workgroup (see filter_pack_stream_kernel)
@@ -755,8 +736,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
         StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
         // compile-time: roomy (one workgroup per CU: 128 VGPRs), width of the cell scratch, form of the gene image
         const int variant = (e->genes_blocks_per_cu >= 2 ? 0 : 4) | (e->cell16 ? 2 : 0) | (e->lds_genes.direct ? 1 : 0);
-#define FPS(R, C, D) do { if (compact) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp); \
-                          else hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp); } while (0)
+#define FPS(R, C, D) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp)
         switch (variant) {
         case 0: FPS(false, false, false); break; case 1: FPS(false, false, true); break;
         case 2: FPS(false, true, false); break;  case 3: FPS(false, true, true); break;

@@ -437,23 +437,10 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
 // stores) — and adds its hit count to tile_hits[] (all-zero on entry) with one atomic: no barrier after the image is
 // in LDS.
 // TWO_PER_CU: the image leaves room for two workgroups per CU, which takes 64 VGPRs at most
-// hit_mask != nullptr: COMPACT scratch for the streaming K1b — instead of one cell index per record (2N bytes written here, 2N
-// read there, more than half of them zeros) the chunk leaves a hit bit per record (8 x u64 per 512-record chunk, bit b of word
-// q = record 64 q + b) and the cell indices of its HITS only, packed in record order at the front of the chunk's slots.
-// spread the low 32 bits of x over the even bit positions
-__device__ __forceinline__ u64 spread_bits32(u64 x) {
-    x &= 0xFFFFFFFFull;
-    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x << 2)) & 0x3333333333333333ull;
-    x = (x | (x << 1)) & 0x5555555555555555ull;
-    return x;
-}
 template <bool TWO_PER_CU>
 __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
                                                                void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
-                                                               u32* __restrict__ half_hits, u32 n_tiles, u64* __restrict__ hit_mask = nullptr) {
+                                                               u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 S = c.slot_bits, smask = (1u << S) - 1u, lo_mask = (1u << (32u - S)) - 1u;
     const u32* s_slot = reinterpret_cast<const u32*>(smem);
@@ -497,29 +484,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
             hits += (u32)__popcll(__ballot(v != 0));
             if (j == K1_IPT / 2 - 1) hits_lo = hits;
         }
-        if (hit_mask) {
-            // lane l of pair row jj holds records 128 jj + 2 l and + 1: their ranks among the chunk's hits, in record order
-            u32 before = 0;
-#pragma unroll
-            for (int jj = 0; jj < PAIRS; ++jj) {
-                const u64 m0 = __ballot(cell[2 * jj] != 0), m1 = __ballot(cell[2 * jj + 1] != 0);
-                const u32 r0 = before + rank_below(m0) + rank_below(m1), r1 = r0 + (cell[2 * jj] != 0 ? 1u : 0u);
-                if (c16) {
-                    unsigned short* o = reinterpret_cast<unsigned short*>(cell_out) + base;
-                    if (cell[2 * jj]) o[r0] = (unsigned short)cell[2 * jj];
-                    if (cell[2 * jj + 1]) o[r1] = (unsigned short)cell[2 * jj + 1];
-                } else {
-                    u32* o = reinterpret_cast<u32*>(cell_out) + base;
-                    if (cell[2 * jj]) o[r0] = cell[2 * jj];
-                    if (cell[2 * jj + 1]) o[r1] = cell[2 * jj + 1];
-                }
-                before += (u32)__popcll(m0) + (u32)__popcll(m1);
-                if (lane == 0) {                                      // records 128 jj .. +63 and +64 .. +127
-                    hit_mask[8ull * chunk + 2 * jj] = spread_bits32(m0) | (spread_bits32(m1) << 1);
-                    hit_mask[8ull * chunk + 2 * jj + 1] = spread_bits32(m0 >> 32) | (spread_bits32(m1 >> 32) << 1);
-                }
-            }
-        } else if (whole) {
+        if (whole) {
             if (c16) {
 #pragma unroll
                 for (int j = 0; j < PAIRS; ++j)
@@ -559,7 +524,6 @@ static_assert(K1B_THREADS * K1B_IPT == K1_TILE, "K1b walks K1a's tiles");
 
 struct PackParams {
     const void* cell; bool cell16;  // K1a's scratch: u16 or u32 entries
-    const u64* hit_mask;            // compact scratch (streaming K1b behind the LDS K1a): a hit bit per record + the hits' indices, dense per 512-record chunk
     const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
     const u32* draws; u64 n_draws; // draw of hit rank r: draws[r & draw_mask], valid while r < n_draws
@@ -820,7 +784,7 @@ __device__ __forceinline__ u32 row16_sum_lane15(u32 x) {
 // C16: the cell scratch holds u16 entries; DIRECT: the gene image is the dense u16 table.  Both are compile-time so that
 // the loop is straight-line code: with run-time flags every load sat in its own branch, with waits between them
 // (PMC on the configs[2] shape: 430 vector + 325 scalar instructions per 256 records, the vector ALU busy 60 % of the kernel).
-template <bool ROOMY, bool C16, bool DIRECT, bool COMPACT = false>
+template <bool ROOMY, bool C16, bool DIRECT>
 __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
     __shared__ u64 s_tot[3];
     __shared__ u32 s_cursor, s_err;
@@ -863,29 +827,11 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
         const u64* const gx_u = p.gx + base; const u32* const umi_u = p.umi + base; const u32* const meta_u = p.meta + base;
         const unsigned short* const c16_u = reinterpret_cast<const unsigned short*>(p.cell) + base;
         const u32* const c32_u = reinterpret_cast<const u32*>(p.cell) + base;
-        // compact scratch: the unit's four hit words (scalar loads) and the dense run of its hits' indices — the unit is half of
-        // a K1a chunk, its hits sit behind those of the half in front
-        u64 hmk[K1S_IPT];
-        if (COMPACT) {
-            const u64 chunk = (u64)t * (K1_TILE / 512) + ((u32)w >> 1);
-            const u32 dense0 = (w & 1) ? (u32)__builtin_amdgcn_readlane((int)hha, w - 1) : 0u;     // (w odd: the half in front)
-            const u64* mk = p.hit_mask + 8 * chunk + 4 * (w & 1);
-            u32 pre_c = 0;
-#pragma unroll
-            for (int j = 0; j < K1S_IPT; ++j) {
-                hmk[j] = mk[j];
-                const u32 r = dense0 + pre_c + rank_below(hmk[j]);
-                cell[j] = 0;
-                if ((hmk[j] >> lane) & 1) cell[j] = C16 ? (u32)ld_once<NT>(reinterpret_cast<const unsigned short*>(p.cell) + chunk * 512 + r)
-                                                       : ld_once<NT>(reinterpret_cast<const u32*>(p.cell) + chunk * 512 + r);
-                pre_c += (u32)__popcll(hmk[j]);
-            }
-        }
         if (base + K1S_UNIT <= p.n) {                                      // scalar branch: the whole unit exists
 #pragma unroll
             for (int j = 0; j < K1S_IPT; ++j) {
                 const u32 o = (u32)j * WAVE + (u32)lane;
-                if (!COMPACT) cell[j] = C16 ? (u32)ld_once<NT>(c16_u + o) : ld_once<NT>(c32_u + o);
+                cell[j] = C16 ? (u32)ld_once<NT>(c16_u + o) : ld_once<NT>(c32_u + o);
                 gxk[j]  = ld_once<NT>(gx_u + o);
                 umi[j]  = ld_once<NT>(umi_u + o);
                 meta[j] = ld_once<NT>(meta_u + o);
@@ -895,10 +841,9 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
             for (int j = 0; j < K1S_IPT; ++j) {
                 const u32 o = (u32)j * WAVE + (u32)lane;
                 const bool in = base + o < p.n;
-                if (!COMPACT) cell[j] = 0;
-                gxk[j] = 0; umi[j] = 0; meta[j] = 0;
+                cell[j] = 0; gxk[j] = 0; umi[j] = 0; meta[j] = 0;
                 if (in) {
-                    if (!COMPACT) cell[j] = C16 ? (u32)c16_u[o] : c32_u[o];
+                    cell[j] = C16 ? (u32)c16_u[o] : c32_u[o];
                     gxk[j] = gx_u[o]; umi[j] = umi_u[o]; meta[j] = meta_u[o];
                 }
             }
@@ -925,7 +870,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
         u32 pre = 0;                                                       // hits of the unit in front of item j
 #pragma unroll
         for (int j = 0; j < K1S_IPT; ++j) {
-            const u64 hm = COMPACT ? hmk[j] : __ballot(cell[j] != 0);
+            const u64 hm = __ballot(cell[j] != 0);
             const u32 rl = pre + rank_below(hm);                           // local hit rank (meaningful on hit lanes)
             // the hits of one item span at most two of the dr[] registers: q0 and q0 + 1 (q0 wave-uniform)
             const u32 q0 = pre >> 6;

@@ -337,13 +337,9 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
     t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
     d = [t(x) for x in (cbk, gxk, umi, meta)]
     draws = t(F.mt_draws(case.seed, lists.mt_skip, case.n))
-    for force_tile_form, dense_scratch in ((False, False), (False, True), (True, False)):
-        # streaming K1b behind the compact cell scratch (hit bits + the hits' indices; the default behind the LDS K1a), the
-        # same with one index per record (FASTF_NO_COMPACT_SCRATCH), then the tile form
+    for force_tile_form in (False, True):
         if force_tile_form:
             os.environ["FASTF_NO_STREAM_K1B"] = "1"
-        if dense_scratch:
-            os.environ["FASTF_NO_COMPACT_SCRATCH"] = "1"
         try:
             eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12)
             sp = ShardedPass(HipStages(eng, dev), case.n, dev)
@@ -361,4 +357,3 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
             eng.close()
         finally:
             os.environ.pop("FASTF_NO_STREAM_K1B", None)
-            os.environ.pop("FASTF_NO_COMPACT_SCRATCH", None)
