@@ -1553,7 +1553,10 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
 #ifdef FASTF_K3_NOHASH   /* elimination experiment only (wrong counts): what the window structure costs without the set (0.138 ms) */
                     single = true;
 #endif
-                    if (dist && !single) {
+                    // a key equal to its neighbour in front is a copy of it (coordinate-sorted BAMs keep the reads of one molecule
+                    // together, and the sort is stable): no set needed either
+                    if (dist && !head && k == prev) dist = false;
+                    else if (dist && !single) {
                         // window-local hash set: the first key to take a slot is the one that counts
                         u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
                         for (;;) {
