@@ -290,7 +290,7 @@ def device_path_leg(job, dev, local, N_total, want):
             t0 = time.perf_counter()
             eng.push_pinned(pb)
             t1 = time.perf_counter()
-            res = eng.finish()
+            res = eng.finish(copy=False)            # the C ABI's own arrays (the ctypes wrapper's copy of 12 bytes per row is not the path)
             t2 = time.perf_counter()
             runs.append((t2 - t0, t1 - t0, t2 - t1))
     finally:

@@ -215,14 +215,19 @@ class Engine:
     def wait_input(self):
         check(self._L.fastf_engine_wait_input(self._h))
 
-    def finish(self):
+    def finish(self, copy=True):
+        """copy=False: the arrays are VIEWS of the engine's row buffer (valid until the next reset / finish / close): what a C
+        caller of fastf_engine_finish gets, without the 12 bytes per row this wrapper would copy"""
         coo = Coo()
         cnt = (C.c_uint64 * 3)()
         check(self._L.fastf_engine_finish(self._h, C.byref(coo), C.byref(cnt)))
         n = coo.nnz
 
         def arr(p):
-            return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)
+            if not n:
+                return np.zeros(0, dtype=np.uint32)
+            a = np.ctypeslib.as_array(p, shape=(n,))
+            return a.copy() if copy else a
         return dict(feature=arr(coo.feature), cell=arr(coo.cell), count=arr(coo.count), nnz=n,
                     total=int(cnt[0]), sampled=int(cnt[1]), valid=int(cnt[2]))
 
