@@ -357,3 +357,20 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
             eng.close()
         finally:
             os.environ.pop("FASTF_NO_STREAM_K1B", None)
+
+
+def test_finish_without_copy_returns_views_of_the_engines_rows():
+    """Engine.finish(copy=False): what a C caller of fastf_engine_finish gets — arrays that live in the engine's row buffer"""
+    case = Case(n=60_000, n_bar=300, n_gene=100, umi_pool=64, rate_depth=0.7)
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed)
+    try:
+        eng.push(*case.packed(lists))
+        a = eng.finish(copy=False)
+        b = eng.finish()                                   # idempotent, copied
+        assert not a["count"].flags["OWNDATA"] and b["count"].flags["OWNDATA"]
+        for k in ("feature", "cell", "count"):
+            np.testing.assert_array_equal(a[k], b[k])
+        assert_matches_oracle(b, case.oracle())
+    finally:
+        eng.close()
