@@ -1561,14 +1561,20 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                     if (dist && !head && k == prev) dist = false;
                     else if (dist && !single) {
                         // window-local hash set: the first key to take a slot is the one that counts
-                        u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & (K3_TAB - 1);
+                        const u64 hk = k * 0x9E3779B97F4A7C15ull;
+                        u32 h = (u32)(hk >> 40) & (K3_TAB - 1);
+#ifdef FASTF_K3_LINEAR_PROBE
+                        const u32 step = 1;
+#else
+                        const u32 step = ((u32)(hk >> 24) & 0xFFu) | 1u;        // double hashing: an odd stride walks the whole table, no clusters
+#endif
                         for (;;) {
                             // claim first, look afterwards: a first occurrence (two keys out of three) is done after ONE LDS
                             // round trip; the compare-and-swap of a taken slot hands back its occupant
                             u32 v = 0;
                             if (__hip_atomic_compare_exchange_strong(&s_tab[h], &v, loc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = h; break; }
                             if (s_id[v - 1] == k) { dist = false; break; }
-                            h = (h + 1) & (K3_TAB - 1);
+                            h = (h + step) & (K3_TAB - 1);
                         }
                     }
                 } else if (dist && idx > 0) {
