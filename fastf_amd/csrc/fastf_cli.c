@@ -11,6 +11,19 @@ extern int fastf_process_is_exiting_;
 struct cmd_struct { const char *cmd; int (*fn)(int, const char **); };
 static const struct cmd_struct commands[] = { {"crb", cmd_crb}, {"bam2db", cmd_bam2db}, {"extract", cmd_extract} };
 
+/* One command uses one GPU unless FASTF_DEVICES asks for more: hide the others from the HIP runtime before it loads,
+ * so that its start-up (which opens every visible device) costs the same on an 8-GPU host as on a 1-GPU one.
+ * Any visibility setting of the caller's wins; FASTF_ALL_DEVICES=1 switches this off. */
+static void narrow_visible_devices(void)
+{
+    if (getenv("FASTF_DEVICES") || getenv("FASTF_ALL_DEVICES") || getenv("ROCR_VISIBLE_DEVICES") ||
+        getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES") || getenv("GPU_DEVICE_ORDINAL")) return;
+    const char *dev = getenv("FASTF_DEVICE");
+    if (dev && (dev[0] < '0' || dev[0] > '9' || strlen(dev) > 3)) return;
+    setenv("ROCR_VISIBLE_DEVICES", dev ? dev : "0", 1);
+    setenv("FASTF_DEVICE", "0", 1);
+}
+
 int main(int argc, const char **argv)
 {
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
@@ -23,6 +36,7 @@ int main(int argc, const char **argv)
     }
     for (size_t i = 0; i < sizeof commands / sizeof commands[0]; i++)
         if (!strcmp(commands[i].cmd, argv[1])) {
+            narrow_visible_devices();
             fastf_process_is_exiting_ = getenv("FASTF_FULL_TEARDOWN") == NULL;   /* this process ends with the command */
             int rc = commands[i].fn(argc - 1, argv + 1);
             /* every output is closed by now; skip the ~0.2 s the HIP runtime spends unloading at exit */

@@ -343,3 +343,17 @@ def test_adversarial_share_of_config5():
         np.testing.assert_array_equal(res["count"].astype(np.int64), cnt)
     finally:
         eng.close()
+
+
+def test_adversarial_config5_whole_on_one_gpu():
+    """BASELINE configs[4] WHOLE on one GPU (tools/config5_whole.py): 1 B records, all 100 k barcodes (the L2 cell table),
+    keep-all, Zipf-skewed UMI reuse; records generated on the device and pushed as device-resident batches, 1 B keys through
+    K2/K3, every row of the 270 M-row matrix compared with torch.unique over the packed codes.  The maximum-size case:
+    24 GB of records, 8 GB of keys, indices beyond 2^29 everywhere."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "config5_whole", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "config5_whole.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.run(1_000_000_000, 25_000_000, log=lambda s: print(s))
+    assert out["rows"] > 200_000_000
