@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",
     "fastf_engine_push_pinned", "fastf_engine_wait_input",
     "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
-    "fastf_engine_finish", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
+    "fastf_engine_finish", "fastf_engine_lend_rows", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes", "fastf_engine_cell_scratch_bytes",
     "fastf_dev_count_hits", "fastf_dev_probe_pack", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce", "fastf_dev_rows_gather", "fastf_engine_device_records",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_error_bits",
@@ -151,6 +151,7 @@ def lib():
     L.fastf_engine_push.argtypes = [vp, C.POINTER(Batch)]
     L.fastf_engine_push_draws.argtypes = [vp, C.POINTER(Batch), vp, sz]
     L.fastf_engine_finish.argtypes = [vp, C.POINTER(Coo), C.POINTER(u64 * 3)]
+    L.fastf_engine_lend_rows.argtypes = [vp, vp, sz]
     L.fastf_engine_umi_rows.argtypes = [vp, C.POINTER(UmiRows)]
     L.fastf_engine_reset.argtypes = [vp]
     L.fastf_engine_device_records.argtypes = [vp, C.POINTER(u64), u32]

@@ -61,7 +61,7 @@ static void *decoder_main(void *vp)
  * unmapping them takes 0.1-0.15 s that the exiting process used to pay after its outputs were closed; here it runs
  * beside the sort, the reduce and the writers. */
 typedef struct {
-    pthread_t dec_thread; fastf_bam_t *bam; unsigned char *slab; int slab_pinned;
+    pthread_t dec_thread; fastf_bam_t *bam; unsigned char *slab; size_t slot_bytes; int slab_pinned, keep_first;
     uint64_t no_xf, no_gx; double t_release;
 } rel_ctx;
 
@@ -72,8 +72,9 @@ static void *release_main(void *vp)
     pthread_join(r->dec_thread, NULL);                  /* it has delivered its end-of-file batch and is on its way out */
     fastf_bam_stats(r->bam, NULL, &r->no_xf, &r->no_gx);
     fastf_bam_close(r->bam);                            /* prints the reader's profile lines first */
-    if (r->slab_pinned) fastf_pinned_unregister(r->slab);
-    free(r->slab);
+    /* keep_first: the first slot is on loan to the engine as its row buffer until the outputs are written (bam2db() below) */
+    if (r->slab_pinned) { fastf_pinned_unregister(r->slab + r->slot_bytes); if (!r->keep_first) fastf_pinned_unregister(r->slab); }
+    if (!r->keep_first) free(r->slab);
     r->t_release = now_s() - t0;
     return NULL;
 }
@@ -91,7 +92,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     fastf_bam_t *bam = NULL;
     fastf_engine_t *eng = NULL;
     dec_ctx dec; pthread_t dec_thread; int dec_started = 0; double t_wait = 0;
-    unsigned char *slab = NULL; int slab_pinned = 0;
+    unsigned char *slab = NULL; int slab_pinned = 0; size_t cap_bytes = 0;     /* cap_bytes: one decoder slot */
     rel_ctx rel; pthread_t rel_thread; int rel_started = 0;
     memset(&dec, 0, sizeof dec); memset(&rel, 0, sizeof rel);
 
@@ -125,6 +126,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     /* one slab for both decoder slots: pinned once the HIP runtime is up (below), so that the engine copies the
      * packed records to the device straight from where the decoder wrote them */
     if (!(slab = (unsigned char *)fastf_big_alloc(2 * cap * 24))) { fprintf(stderr, "out of memory\n"); goto done; }
+    cap_bytes = cap * 24;
     for (int k = 0; k < 2; k++) {
         unsigned char *base = slab + (size_t)k * cap * 24;
         dec.slot[k].cb = (uint64_t *)base; dec.slot[k].gx = (uint64_t *)(base + cap * 8);
@@ -169,7 +171,12 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
     {   const char *zc = getenv("FASTF_ZERO_COPY");                 /* "0": stage every batch through the engine's own pinned buffers */
-        if (!(zc && zc[0] == '0') && fastf_pinned_register(slab, 2 * cap * 24) == 0) slab_pinned = 1;
+        /* one registration per decoder slot: the second goes back as soon as the last record is on the device, the first
+         * stays as the row buffer of fastf_engine_finish (below) */
+        if (!(zc && zc[0] == '0') && fastf_pinned_register(slab, cap * 24) == 0) {
+            if (fastf_pinned_register(slab + cap * 24, cap * 24) == 0) slab_pinned = 3;       /* bit 0: first slot, bit 1: second */
+            else fastf_pinned_unregister(slab);
+        }
     }
     t_engine = now_s() - tt;
 
@@ -200,8 +207,17 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     /* every record is on the device (each push waited for its copies): the reader and the slab go now, beside what follows */
     {   extern int fastf_reader_leaves_device_side_;
         fastf_reader_leaves_device_side_ = fastf_process_is_exiting_; }
-    rel.dec_thread = dec_thread; rel.bam = bam; rel.slab = slab; rel.slab_pinned = slab_pinned;
-    if (pthread_create(&rel_thread, NULL, release_main, &rel) == 0) { rel_started = 1; dec_started = 0; bam = NULL; slab = NULL; slab_pinned = 0; }
+    /* the matrix rows go into the first decoder slot — pinned already, its pages touched, idle from here on: finish() then
+     * has no row buffer to allocate and fault in (0.03-0.05 s beside the release thread's unmapping) and the device writes
+     * the rows at PCIe rate.  A matrix that does not fit takes the engine's own buffer. */
+    const char *lr = getenv("FASTF_LEND_ROWS");                                  /* "0": the engine's own row buffer (A/B) */
+    const int lend = slab_pinned && !(lr && lr[0] == '0') && fastf_engine_lend_rows(eng, slab, cap * 24) == 0;
+    rel.dec_thread = dec_thread; rel.bam = bam; rel.slab = slab; rel.slot_bytes = cap * 24; rel.slab_pinned = slab_pinned; rel.keep_first = lend;
+    if (pthread_create(&rel_thread, NULL, release_main, &rel) == 0) {
+        rel_started = 1; dec_started = 0; bam = NULL;
+        if (lend) slab_pinned = 1;                          /* the second slot is the release thread's now */
+        else { slab = NULL; slab_pinned = 0; }
+    }
     fastf_coo_t coo; uint64_t counters[3];
     tt = now_s();
     if (fastf_engine_finish(eng, &coo, counters)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
@@ -247,7 +263,8 @@ done:
         return rc;
     }
     if (eng) fastf_engine_destroy(eng);
-    if (slab_pinned) fastf_pinned_unregister(slab);
+    if (slab_pinned & 1) fastf_pinned_unregister(slab);
+    if (slab_pinned & 2) fastf_pinned_unregister(slab + cap_bytes);
     free(slab);
     if (bam) fastf_bam_close(bam);
     fastf_lists_free(&lists);

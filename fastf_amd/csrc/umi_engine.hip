@@ -154,6 +154,8 @@ struct fastf_engine {
     DevBuf d_feature, d_cell, d_count, d_ukeys, d_ncopy;
     u32* h_coo = nullptr; u64 h_coo_cap = 0, h_nnz = 0;      // feature | cell | count, h_coo_cap rows each; pageable at first, pinned from its second use on
     bool h_coo_pinned = false; u32 h_coo_uses = 0;
+    u32* lent_rows = nullptr; u64 lent_cap = 0;              // fastf_engine_lend_rows: pinned memory of the caller's, lent_cap rows per array
+    u32* rows_at = nullptr; u64 rows_stride = 0;             // where the rows of the last finish lie (h_coo or the loan)
     std::vector<u32> h_ufeature, h_ucell, h_uumi, h_ncopy;
     std::vector<uint8_t> h_unonnull;
     u64 total_records = 0, hits_so_far = 0, keys_so_far = 0;      // hits / keys: as of the last retired chunk
@@ -1282,26 +1284,35 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         // The row buffer is ordinary memory the first time it is used: pinning 23 MB takes 15 ms, the pageable copy of
         // 2 M rows 2 ms, and a one-shot run (the CLI) never uses it twice.  An engine that finishes again (reset + push:
         // benchmarks, sharded passes) pins it then and gets its rows at PCIe rate from there on.
-        if (nnz > e->h_coo_cap) {
-            if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
-            e->h_coo = nullptr; e->h_coo_cap = 0; e->h_coo_pinned = false; e->h_coo_uses = 0;
-            const u64 cap = nnz + nnz / 8 + 1024;
-            void* m = fastf_big_alloc((size_t)cap * 12);               // 2 MiB aligned, transparent huge pages (host_io.c)
-            if (!m) return set_err("out of memory (%llu matrix rows)", (unsigned long long)nnz);
-            e->h_coo = (u32*)m; e->h_coo_cap = cap;
+        const bool on_loan = e->lent_rows && nnz <= e->lent_cap;
+        if (on_loan) {
+            // pinned memory the caller lent (bam2db(): the decoder's slab, idle by now): no allocation, no first-touch page
+            // faults, and the gather kernel writes it directly
+            e->rows_at = e->lent_rows; e->rows_stride = e->lent_cap;
+        } else {
+            if (nnz > e->h_coo_cap) {
+                if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
+                e->h_coo = nullptr; e->h_coo_cap = 0; e->h_coo_pinned = false; e->h_coo_uses = 0;
+                const u64 cap = nnz + nnz / 8 + 1024;
+                void* m = fastf_big_alloc((size_t)cap * 12);               // 2 MiB aligned, transparent huge pages (host_io.c)
+                if (!m) return set_err("out of memory (%llu matrix rows)", (unsigned long long)nnz);
+                e->h_coo = (u32*)m; e->h_coo_cap = cap;
+            }
+            if (!e->h_coo_pinned && e->h_coo && e->h_coo_uses++ >= 1 && hipHostRegister(e->h_coo, (size_t)e->h_coo_cap * 12, hipHostRegisterDefault) == hipSuccess)
+                e->h_coo_pinned = true;
+            e->rows_at = e->h_coo; e->rows_stride = e->h_coo_cap;
         }
-        if (!e->h_coo_pinned && e->h_coo && e->h_coo_uses++ >= 1 && hipHostRegister(e->h_coo, (size_t)e->h_coo_cap * 12, hipHostRegisterDefault) == hipSuccess)
-            e->h_coo_pinned = true;
         lap("row buffer ready");
         if (nnz) {
-            if (e->h_coo_pinned) {
+            u32 *h_f = e->rows_at, *h_c = e->rows_at + e->rows_stride, *h_k = e->rows_at + 2 * e->rows_stride;
+            if (on_loan || e->h_coo_pinned) {
                 // pinned row buffer: the gather of K3's row regions writes it directly — that kernel is the D2H copy
-                if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, e->h_coo, e->h_coo + e->h_coo_cap, e->h_coo + 2 * e->h_coo_cap, nullptr, s)) return 1;
+                if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, h_f, h_c, h_k, nullptr, s)) return 1;
             } else {
                 if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, (u32*)e->d_feature.p, (u32*)e->d_cell.p, (u32*)e->d_count.p, nullptr, s)) return 1;
-                HIP_OK(hipMemcpyAsync(e->h_coo, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
-                HIP_OK(hipMemcpyAsync(e->h_coo + e->h_coo_cap, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
-                HIP_OK(hipMemcpyAsync(e->h_coo + 2 * e->h_coo_cap, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(h_f, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(h_c, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(h_k, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
             }
             HIP_OK(hipStreamSynchronize(s));
         }
@@ -1310,7 +1321,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
         e->n_sorted = n;
         e->finished = true;
     }
-    coo->feature = e->h_coo; coo->cell = e->h_coo ? e->h_coo + e->h_coo_cap : nullptr; coo->count = e->h_coo ? e->h_coo + 2 * e->h_coo_cap : nullptr;
+    coo->feature = e->rows_at; coo->cell = e->rows_at ? e->rows_at + e->rows_stride : nullptr; coo->count = e->rows_at ? e->rows_at + 2 * e->rows_stride : nullptr;
     coo->nnz = e->h_nnz;
     if (counters) { counters[0] = e->total_records; counters[1] = e->c_sampled; counters[2] = e->c_valid; }
     return 0;
@@ -1387,8 +1398,20 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) FASTF_TRY {
     e->inflight_records = 0;
     e->total_records = e->hits_so_far = e->keys_so_far = e->c_sampled = e->c_valid = 0;
     e->finished = false; e->h_nnz = 0;
+    e->lent_rows = nullptr; e->lent_cap = 0; e->rows_at = nullptr; e->rows_stride = 0;     // a loan lasts for one finish
     e->draws_up = e->draws_valid = 0;
     e->mt_live = false;                  // the engine-owned stream goes on after the last draw a hit consumed
+    return 0;
+} FASTF_CATCH_INT
+
+// Pinned host memory of the caller's for the rows of the next fastf_engine_finish: three arrays of bytes / 12 rows each.
+// finish() uses it when the matrix fits (and its own row buffer otherwise); the coo pointers then point into it.
+extern "C" int fastf_engine_lend_rows(fastf_engine_t* e, void* pinned, size_t bytes) FASTF_TRY {
+    if (!e) return set_err("null engine");
+    if (e->multi) return 0;                                  // the multi-device merge writes its own buffer
+    if (e->finished) return set_err("fastf_engine_lend_rows: the rows of this pass are out already (reset first)");
+    if (!pinned || bytes < 12 || ((uintptr_t)pinned & 3u)) { e->lent_rows = nullptr; e->lent_cap = 0; return pinned ? set_err("fastf_engine_lend_rows: needs 4-byte aligned memory of at least 12 bytes") : 0; }
+    e->lent_rows = (u32*)pinned; e->lent_cap = bytes / 12;
     return 0;
 } FASTF_CATCH_INT
 

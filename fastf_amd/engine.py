@@ -215,6 +215,10 @@ class Engine:
     def wait_input(self):
         check(self._L.fastf_engine_wait_input(self._h))
 
+    def lend_rows(self, ptr, nbytes):
+        """pinned host memory (address, bytes) the next finish() may place the rows in; 0 / None withdraws the loan"""
+        check(self._L.fastf_engine_lend_rows(self._h, ptr or None, nbytes))
+
     def finish(self, copy=True):
         """copy=False: the arrays are VIEWS of the engine's row buffer (valid until the next reset / finish / close): what a C
         caller of fastf_engine_finish gets, without the 12 bytes per row this wrapper would copy"""

@@ -209,6 +209,12 @@ void  fastf_pinned_unregister(void *p);
 /* Sort + segmented unique/reduce over everything pushed; results stay valid until
  * reset/destroy.  counters = {total, sampled, sampled_valid} (bam2db_ds.c:342-344). */
 int  fastf_engine_finish(fastf_engine_t *e, fastf_coo_t *coo, uint64_t counters[3]);
+/* Optional, before fastf_engine_finish: PINNED host memory of the caller's (fastf_pinned_alloc / fastf_pinned_register)
+ * for the matrix rows — three arrays of bytes / 12 entries.  When the matrix fits, finish() writes the rows there from
+ * the device (no row buffer of its own to allocate and fault in) and the coo pointers point into it; the caller keeps
+ * the memory alive and untouched until it is done with the rows.  NULL withdraws the loan; fastf_engine_reset ends it.
+ * bam2db() lends one half of its decoder slab, idle once the last record is on the device. */
+int  fastf_engine_lend_rows(fastf_engine_t *e, void *pinned, size_t bytes);
 int  fastf_engine_umi_rows(fastf_engine_t *e, fastf_umi_rows_t *rows);
 /* records each device of a multi-device engine (n_devices > 1) has been given since the last reset, records[n_devices];
  * a single-device engine reports its total in records[0] */

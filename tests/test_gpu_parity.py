@@ -374,3 +374,45 @@ def test_finish_without_copy_returns_views_of_the_engines_rows():
         assert_matches_oracle(b, case.oracle())
     finally:
         eng.close()
+
+
+def test_rows_on_loan_in_the_callers_pinned_memory():
+    """fastf_engine_lend_rows: finish() writes the rows into pinned memory of the caller's when the matrix fits (bam2db()
+    lends a decoder slot), into its own buffer when it does not; a reset ends the loan."""
+    case = Case(n=80_000, n_bar=400, n_gene=120, umi_pool=64, rate_depth=0.8, p_n_umi=0.01)
+    lists = case.lists()
+    packed = case.packed(lists)
+    ora = case.oracle()
+    pb = F.PinnedBatch(40_000)                             # 960 000 bytes of pinned memory: 80 000 rows
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed)
+    try:
+        lo, hi = pb._p, pb._p + pb.n * 24
+        eng.push(*packed)
+        eng.lend_rows(pb._p, pb.n * 24)
+        a = eng.finish(copy=False)
+        assert 0 < a["nnz"] <= pb.n * 2
+        for k in ("feature", "cell", "count"):
+            assert lo <= a[k].ctypes.data < hi, k          # the rows lie in the loan
+        assert_matches_oracle(eng.finish(), ora)
+        # a loan that is too small for the matrix is left alone
+        eng.reset(); eng.reseed(case.seed, lists.mt_skip)
+        eng.push(*packed)
+        pb.cb_key[:] = 0x5A5A5A5A5A5A5A5A
+        eng.lend_rows(pb._p, 12 * (a["nnz"] - 1))
+        b = eng.finish(copy=False)
+        assert not (lo <= b["count"].ctypes.data < hi)
+        assert np.all(pb.cb_key == 0x5A5A5A5A5A5A5A5A)
+        assert_matches_oracle(eng.finish(), ora)
+        # the loan ended with the reset: the next pass uses the engine's buffer again
+        eng.reset(); eng.reseed(case.seed, lists.mt_skip)
+        eng.lend_rows(pb._p, pb.n * 24)
+        eng.reset(); eng.reseed(case.seed, lists.mt_skip)
+        eng.push(*packed)
+        c = eng.finish(copy=False)
+        assert not (lo <= c["count"].ctypes.data < hi)
+        with pytest.raises(F.FastfError):
+            eng.lend_rows(pb._p, pb.n * 24)                # the rows of this pass are out already
+        assert_matches_oracle(eng.finish(), ora)
+    finally:
+        eng.close()
+        pb.close()
