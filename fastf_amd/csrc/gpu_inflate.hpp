@@ -27,6 +27,7 @@ constexpr int GI_LANES = 1;
 #define GI_COHERENT_LOAD8(p) (*(p))
 #define GI_WAVE_SYNC() do { } while (0)
 #define GI_UNIFORM(x) (x)
+#define GI_UNIFORM64(x) (x)
 #else
 #define GI_FN __device__ __forceinline__
 constexpr int GI_LANES = 64;
@@ -43,8 +44,10 @@ __device__ __forceinline__ uint8_t gi_coherent_load8(const uint8_t* p) {
 // on the scalar unit instead of 64 identical vector lanes
 #ifdef GI_NO_UNIFORM
 #define GI_UNIFORM(x) (x)
+#define GI_UNIFORM64(x) (x)
 #else
 #define GI_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define GI_UNIFORM64(x) (((uint64_t)GI_UNIFORM((uint32_t)((uint64_t)(x) >> 32)) << 32) | (uint64_t)GI_UNIFORM((uint32_t)(x)))
 #endif
 // lanes of one wave exchange data through LDS without a workgroup barrier: keep the compiler from moving LDS accesses
 // across the hand-over (the hardware runs a wave's LDS instructions in order)
@@ -321,6 +324,11 @@ GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* ou
             }
             // the symbols: at most two refills per symbol (>= 33 bits after each: code <= 15 + extra <= 13 bits)
             for (;;) {
+#ifdef GI_SCALAR_STATE
+                // the reader's state is wave-uniform by construction; say so once per symbol, so that the bit arithmetic and
+                // the branches on it are scalar instructions instead of 64 identical lanes under an execution mask
+                b.buf = GI_UNIFORM64(b.buf); b.cnt = GI_UNIFORM(b.cnt); b.pos = GI_UNIFORM(b.pos); o.op = GI_UNIFORM(o.op);
+#endif
                 refill(b);
                 const int sym = decode(b, w.lit_tab, LIT_TB, w.lit_sorted, w.lit_count);
                 if (sym < 256) {
