@@ -112,6 +112,62 @@ static void gr_crc_tables(uint32_t* t) {                     // [0, 256): byte t
     for (int i = 1; i < 32; ++i) t[256 + i] = p = gr::crc_multmodp(p, p);
 }
 
+// pinned descriptor / status / CRC arrays of slice q for nb blocks
+static int gpuinf_slice_host(fastf_gpuinf_t* g, int q, size_t nb) {
+    if (nb <= g->h_blk_cap[q]) return 0;
+    if (g->h_blk[q]) (void)hipHostFree(g->h_blk[q]);
+    if (g->h_status[q]) (void)hipHostFree(g->h_status[q]);
+    if (g->h_crc[q]) (void)hipHostFree(g->h_crc[q]);
+    g->h_blk[q] = nullptr; g->h_status[q] = nullptr; g->h_crc[q] = nullptr; g->h_blk_cap[q] = 0;
+    const size_t cap = nb + nb / 4 + 64;
+    HIP_OK(hipHostMalloc((void**)&g->h_blk[q], cap * sizeof(GiBlock), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&g->h_status[q], cap, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&g->h_crc[q], cap * sizeof(GrCrcBlock), hipHostMallocDefault));
+    g->h_blk_cap[q] = cap;
+    return 0;
+}
+static int gpuinf_crc_table(fastf_gpuinf_t* g) {
+    if (g->d_crctab.p) return 0;
+    uint32_t t[288]; gr_crc_tables(t);
+    if (g->d_crctab.ensure(sizeof t)) return 1;
+    HIP_OK(hipMemcpy(g->d_crctab.p, t, sizeof t, hipMemcpyHostToDevice));
+    return 0;
+}
+static int gpurec_parse_buffers(fastf_gpuinf_t* g, int parity, u64 bytes) {       // for a parse over `bytes` of window
+    if (!g->s_parse) HIP_OK(hipStreamCreateWithFlags(&g->s_parse, hipStreamNonBlocking));
+    if (!g->h_result) HIP_OK(hipHostMalloc((void**)&g->h_result, 8 * sizeof(u64), hipHostMallocDefault));
+    const u32 n_seg = (u32)((bytes + GR_SEG - 1) / GR_SEG);
+    const u64 cap = bytes / 36 + 1;
+    if (g->d_seg.ensure((size_t)n_seg * sizeof(GrSeg)) || g->d_offs.ensure((size_t)n_seg * GR_SEG_RECS * sizeof(u32)) || g->d_result.ensure(8 * sizeof(u64))) return 1;
+    if (g->soa_cap[parity] < cap) {
+        if (g->d_soa[parity].ensure((size_t)cap * 24)) return 1;
+        g->soa_cap[parity] = cap;
+    }
+    return 0;
+}
+
+// Everything a keep-mode window of up to `window_bytes` inflated / `comp_bytes` compressed bytes in `n_blocks` blocks needs,
+// allocated ahead of the first window (the reader's init thread calls this while the host threads inflate alone): the two
+// window buffers, the slices' staging and descriptor arrays, the CRC table, the parse buffers.  Without it the first shared
+// window pays ~15 ms of allocations and every growth of the device's share another (hipFree waits for the device).
+extern "C" int fastf_gpuinf_reserve(fastf_gpuinf_t* g, size_t window_bytes, size_t comp_bytes, size_t n_blocks) FASTF_TRY {
+    if (!g) return set_err("null inflate handle");
+    HIP_OK(hipSetDevice(g->device));
+    if (gpuinf_crc_table(g)) return 1;
+    for (int parity = 0; parity < 2; ++parity) {
+        if (g->d_win[parity].ensure(window_bytes + 4096)) return 1;
+        if (gpurec_parse_buffers(g, parity, window_bytes)) return 1;
+    }
+    for (int q = 0; q < fastf_gpuinf::NS; ++q) {
+        if (gpuinf_slice_host(g, q, n_blocks)) return 1;
+        const size_t cap = g->h_blk_cap[q];
+        if (g->d_comp[q].ensure(comp_bytes + 128) || g->d_blk[q].ensure(cap * sizeof(GiBlock)) || g->d_status[q].ensure(cap) ||
+            g->d_crc[q].ensure(cap * sizeof(GrCrcBlock)))
+            return 1;
+    }
+    return 0;
+} FASTF_CATCH_INT
+
 static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
                               unsigned char* out, int keep_parity, const uint32_t* crc) {
     if (!g) return set_err("null inflate handle");
@@ -123,12 +179,9 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
     if (keep) {
         u64 wend = 0;
         for (size_t i = 0; i < n; ++i) wend = std::max<u64>(wend, blk[i].uoff + blk[i].isize);
-        if (g->d_win[keep_parity].ensure((size_t)wend + 4096)) return 1;
-        if (!g->d_crctab.p) {
-            uint32_t t[288]; gr_crc_tables(t);
-            if (g->d_crctab.ensure(sizeof t)) return 1;
-            HIP_OK(hipMemcpy(g->d_crctab.p, t, sizeof t, hipMemcpyHostToDevice));
-        }
+        // (room for a growing share: a buffer that is replaced costs a hipFree, which waits for the whole device)
+        if (g->d_win[keep_parity].bytes < (size_t)wend + 4096 && g->d_win[keep_parity].ensure((size_t)wend + (size_t)wend / 4 + 4096)) return 1;
+        if (gpuinf_crc_table(g)) return 1;
     }
     constexpr int NS = fastf_gpuinf::NS;
     // A block takes one wave several milliseconds (the decode is a chain of dependent table look-ups), so throughput is
@@ -145,18 +198,7 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
         const u64 u0 = blk[a].uoff; u64 u1 = u0;
         for (size_t i = a; i < b; ++i) u1 = std::max<u64>(u1, blk[i].uoff + blk[i].isize);
         const size_t cbytes = (size_t)(c1 - c0) + 64, ubytes = (size_t)(u1 - u0);
-        if (nb > g->h_blk_cap[q]) {
-            if (g->h_blk[q]) (void)hipHostFree(g->h_blk[q]);
-            if (g->h_status[q]) (void)hipHostFree(g->h_status[q]);
-            g->h_blk[q] = nullptr; g->h_status[q] = nullptr; g->h_blk_cap[q] = 0;
-            const size_t cap = nb + nb / 4 + 64;
-            HIP_OK(hipHostMalloc((void**)&g->h_blk[q], cap * sizeof(GiBlock), hipHostMallocDefault));
-            HIP_OK(hipHostMalloc((void**)&g->h_status[q], cap, hipHostMallocDefault));
-            if (g->h_crc[q]) (void)hipHostFree(g->h_crc[q]);
-            g->h_crc[q] = nullptr;
-            HIP_OK(hipHostMalloc((void**)&g->h_crc[q], cap * sizeof(GrCrcBlock), hipHostMallocDefault));
-            g->h_blk_cap[q] = cap;
-        }
+        if (gpuinf_slice_host(g, q, nb)) return 1;
         for (size_t i = a; i < b; ++i) g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0};
         if (g->d_comp[q].ensure(cbytes) || (!keep && g->d_out[q].ensure(std::max<size_t>(ubytes, 64))) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
             g->d_status[q].ensure(nb))
@@ -232,22 +274,15 @@ extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned 
     if (!g || !out || !cells || !feats || parity < 0 || parity > 1) return set_err("bad fastf_gpurec_parse arguments");
     if (tail_len > data_off || end < data_off || !g->d_win[parity].p || g->d_win[parity].bytes < end) return set_err("fastf_gpurec_parse: window not on the device");
     HIP_OK(hipSetDevice(g->device));
-    if (!g->s_parse) HIP_OK(hipStreamCreateWithFlags(&g->s_parse, hipStreamNonBlocking));
-    if (!g->h_result) HIP_OK(hipHostMalloc((void**)&g->h_result, 8 * sizeof(u64), hipHostMallocDefault));
-    hipStream_t s = g->s_parse;
-    uint8_t* win = (uint8_t*)g->d_win[parity].p;
     const u64 start = data_off - tail_len;
     memset(out, 0, sizeof *out);
     out->handover = start;
     if (end - start < 36) return 0;                                    // not even a fixed part: all of it is the host's
+    if (gpurec_parse_buffers(g, parity, end - start)) return 1;
+    hipStream_t s = g->s_parse;
+    uint8_t* win = (uint8_t*)g->d_win[parity].p;
     if (tail_len) HIP_OK(hipMemcpyAsync(win + start, tail, tail_len, hipMemcpyHostToDevice, s));
     const u32 n_seg = (u32)((end - start + GR_SEG - 1) / GR_SEG);
-    const u64 cap = (end - start) / 36 + 1;
-    if (g->d_seg.ensure((size_t)n_seg * sizeof(GrSeg)) || g->d_offs.ensure((size_t)n_seg * GR_SEG_RECS * sizeof(u32)) || g->d_result.ensure(8 * sizeof(u64))) return 1;
-    if (g->soa_cap[parity] < cap) {
-        if (g->d_soa[parity].ensure((size_t)cap * 24)) return 1;
-        g->soa_cap[parity] = cap;
-    }
     const u64 sc = g->soa_cap[parity];
     u64* cb = (u64*)g->d_soa[parity].p; u64* gx = cb + sc; u32* umi = (u32*)(gx + sc); u32* meta = umi + sc;
     gr::Dict dc, df;

@@ -243,6 +243,15 @@ GR_FN bool rec_plausible(const uint8_t* buf, uint64_t o, uint64_t end, uint32_t 
     return true;
 }
 
+// a chain of plausible records that stops at q because the WINDOW ends there: less than a fixed part is left, or the
+// record at q announces a sane size that reaches beyond `end` (the device's share of a window ends in the middle of a
+// record as a rule; that record is the host's).  Only used to GUESS chain starts, like rec_plausible.
+GR_FN bool chain_meets_window_end(const uint8_t* buf, uint64_t q, uint64_t end) {
+    if (end - q < 36) return true;
+    const uint32_t bs = rd32(buf + q);
+    return bs >= 32 && bs <= (64u << 20) && (uint64_t)bs + 4 > end - q;
+}
+
 // ---- CRC-32 (IEEE 802.3, reflected, as zlib): slices of a block are hashed side by side and combined ----
 constexpr uint32_t CRC_POLY = 0xEDB88320u;
 // a(x) * b(x) mod P(x) in the reflected representation (zlib crc32.c multmodp)
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(64) void gr_hop_kernel(const uint8_t* __restrict__ 
             if (o < hi) {
                 uint64_t q = o; int k = 0;
                 while (k < GR_PLAUSIBLE && gr::rec_plausible(buf, q, end, n_ref)) { q = gr::rec_end(buf, q, end); k++; }
-                ok = k == GR_PLAUSIBLE || (k > 0 && q >= end - 36);     // fewer only at the very end of the window
+                ok = k == GR_PLAUSIBLE || (k > 0 && gr::chain_meets_window_end(buf, q, end));   // fewer only at the very end of the window
             }
             const uint64_t m = __ballot(ok);
             if (m) first = o0 + (uint64_t)__builtin_ctzll(m);

@@ -50,6 +50,8 @@ int  fastf_gpuinf_submit(fastf_gpuinf_t *g, const unsigned char *comp, const fas
 int  fastf_gpuinf_wait(fastf_gpuinf_t *g, uint8_t *status, double *device_ms);
 int  fastf_gpuinf_run(fastf_gpuinf_t *g, const unsigned char *comp, const fastf_gpuinf_blk_t *blk, size_t n,
                       unsigned char *out, uint8_t *status);
+/* allocate ahead what keep-mode windows of this size need (window buffers, slice staging, parse buffers) */
+int  fastf_gpuinf_reserve(fastf_gpuinf_t *g, size_t window_bytes, size_t comp_bytes, size_t n_blocks);
 void fastf_gpuinf_stats(const fastf_gpuinf_t *g, uint64_t *n_blocks, uint64_t *n_declined);
 /* keep mode + second stage (gpu_records.hpp): the inflated bytes stay on the device (window buffer per parity, block i at its
  * host offset), CRC-32 per block on the device (status bit 1), then record hop + tag extraction + key packing there */

@@ -10,6 +10,7 @@ void fastf_set_error_(const char *m) { fprintf(stderr, "err: %s\n", m); }
 const char *fastf_last_error(void) { return ""; }
 /* the HIP side of the library is not part of this build: no device, nothing pinned */
 fastf_gpuinf_t *fastf_gpuinf_create(int d) { (void)d; return NULL; }
+int fastf_gpuinf_reserve(fastf_gpuinf_t *g, size_t w, size_t c, size_t n) { (void)g; (void)w; (void)c; (void)n; return 1; }
 void fastf_gpuinf_destroy(fastf_gpuinf_t *g) { (void)g; }
 int fastf_gpuinf_submit(fastf_gpuinf_t *g, const unsigned char *c, const fastf_gpuinf_blk_t *b, size_t n, unsigned char *o) { (void)g; (void)c; (void)b; (void)n; (void)o; return 1; }
 int fastf_gpuinf_submit_keep(fastf_gpuinf_t *g, const unsigned char *c, const fastf_gpuinf_blk_t *b, size_t n, int p, const uint32_t *crc) { (void)g; (void)c; (void)b; (void)n; (void)p; (void)crc; return 1; }
