@@ -32,25 +32,69 @@ typedef struct {
     dec_slot slot[2]; int filled[2];
     pthread_mutex_t mu; pthread_cond_t cv;
     int stop; double t_decode;
+    int engine_up;                       /* set by the pusher once it can take batches */
+    int trace; double t_origin;          /* FASTF_PROFILE=2: one line per batch, times since bam2db() was entered */
 } dec_ctx;
+
+/* hand slot k to the pusher */
+static void dec_deliver(dec_ctx *d, int k, long n, double t_start)
+{
+    if (d->trace) fprintf(stderr, "[trace] %.3f decoder: slot %d filled, %ld records%s, %.3f s\n", now_s() - d->t_origin, k, n,
+                          d->slot[k].on_device ? " (packed on the device)" : "", now_s() - t_start);
+    pthread_mutex_lock(&d->mu);
+    d->slot[k].n = n; d->filled[k] = 1;
+    pthread_cond_broadcast(&d->cv);
+    pthread_mutex_unlock(&d->mu);
+}
+/* wait until the pusher has given slot k back; 0 when told to stop */
+static int dec_wait_free(dec_ctx *d, int k)
+{
+    pthread_mutex_lock(&d->mu);
+    while (d->filled[k] && !d->stop) pthread_cond_wait(&d->cv, &d->mu);
+    const int stop = d->stop;
+    pthread_mutex_unlock(&d->mu);
+    if (!stop && d->trace) fprintf(stderr, "[trace] %.3f decoder: slot %d free\n", now_s() - d->t_origin, k);
+    return !stop;
+}
 
 static void *decoder_main(void *vp)
 {
     dec_ctx *d = (dec_ctx *)vp;
+    /* The reader hands out one window's records per call.  Until the engine is up nobody takes a slot, so the slot being
+     * filled goes on taking windows (two slots of `cap` records, not two windows, are what the host can decode ahead while
+     * the HIP runtime starts).  That ends with the first batch the device packed: its arrays stay valid for one more window
+     * of that parity only, so from then on every call is handed over at once — by then the engine is up or about to be. */
+    int accumulate = 1;
     for (int k = 0;; k ^= 1) {
-        pthread_mutex_lock(&d->mu);
-        while (d->filled[k] && !d->stop) pthread_cond_wait(&d->cv, &d->mu);
-        int stop = d->stop;
-        pthread_mutex_unlock(&d->mu);
-        if (stop) break;
+        if (!dec_wait_free(d, k)) break;
         double t = now_s();
-        long n = fastf_bam_read_batch_dev(d->bam, d->lists->cell_dict, d->lists->feat_dict, d->slot[k].cb, d->slot[k].gx,
-                                          d->slot[k].umi, d->slot[k].meta, d->cap, &d->slot[k].on_device, &d->slot[k].dev);
+        dec_slot *sl = &d->slot[k];
+        size_t fill = 0;
+        long n;
+        int on_dev = 0;
+        fastf_batch_t dev; memset(&dev, 0, sizeof dev);
+        for (;;) {
+            n = fastf_bam_read_batch_dev(d->bam, d->lists->cell_dict, d->lists->feat_dict, sl->cb + fill, sl->gx + fill,
+                                         sl->umi + fill, sl->meta + fill, d->cap - fill, &on_dev, &dev);
+            if (n <= 0 || on_dev) break;
+            fill += (size_t)n;
+            if (!accumulate || __atomic_load_n(&d->engine_up, __ATOMIC_ACQUIRE) || d->cap - fill < ((size_t)1 << 16)) break;
+        }
         d->t_decode += now_s() - t;
-        pthread_mutex_lock(&d->mu);
-        d->slot[k].n = n; d->filled[k] = 1;
-        pthread_cond_broadcast(&d->cv);
-        pthread_mutex_unlock(&d->mu);
+        if (on_dev) accumulate = 0;
+        if (fill) {
+            sl->on_device = 0;
+            dec_deliver(d, k, (long)fill, t);
+            if (n > 0 && !on_dev) continue;
+            /* the call that ended the filling brought something else: the end of the input, an error, or a batch that lies on
+             * the device — it goes into the next slot, behind the records above */
+            k ^= 1;
+            if (!dec_wait_free(d, k)) break;
+            sl = &d->slot[k];
+            t = now_s();
+        }
+        sl->on_device = on_dev; sl->dev = dev;
+        dec_deliver(d, k, n, t);
         if (n <= 0) break;
     }
     return NULL;
@@ -86,6 +130,9 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
 {
     (void)db_file;                      /* no SQLite in this engine */
     int rc = 1;
+    {   extern int fastf_worker_nice_;
+        const char *wn = getenv("FASTF_WORKER_NICE");
+        fastf_worker_nice_ = wn ? atoi(wn) : 0; }
     const int prof = getenv("FASTF_PROFILE") != NULL;
     double t0 = now_s(), t_lists = 0, t_engine = 0, t_decode = 0, t_push = 0, t_finish = 0, t_write = 0, t_wait_release = 0, tt;
     fastf_lists_t lists; memset(&lists, 0, sizeof lists);
@@ -122,6 +169,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     const size_t cap = bs ? (size_t)strtoull(bs, NULL, 0) : ((size_t)4 << 20);
     memset(&dec, 0, sizeof dec);
     dec.bam = bam; dec.lists = &lists; dec.cap = cap;
+    {   const char *pf = getenv("FASTF_PROFILE"); dec.trace = pf && pf[0] == '2'; dec.t_origin = t0; }
     pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
     /* one slab for both decoder slots: pinned once the HIP runtime is up (below), so that the engine copies the
      * packed records to the device straight from where the decoder wrote them */
@@ -179,6 +227,8 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         }
     }
     t_engine = now_s() - tt;
+    __atomic_store_n(&dec.engine_up, 1, __ATOMIC_RELEASE);
+    if (dec.trace) fprintf(stderr, "[trace] %.3f main: engine up\n", now_s() - t0);
 
     for (int k = 0;; k ^= 1) {
         tt = now_s();
@@ -198,6 +248,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
             fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
         }
         t_push += now_s() - tt;
+        if (dec.trace) fprintf(stderr, "[trace] %.3f main: slot %d pushed (%ld records) in %.3f s\n", now_s() - t0, k, n, now_s() - tt);
         pthread_mutex_lock(&dec.mu);
         dec.filled[k] = 0;
         pthread_cond_broadcast(&dec.cv);
