@@ -118,7 +118,7 @@ static void *release_main(void *vp)
     fastf_bam_close(r->bam);                            /* prints the reader's profile lines first */
     /* keep_first: the first slot is on loan to the engine as its row buffer until the outputs are written (bam2db() below) */
     if (r->slab_pinned) { fastf_pinned_unregister(r->slab + r->slot_bytes); if (!r->keep_first) fastf_pinned_unregister(r->slab); }
-    if (!r->keep_first) free(r->slab);
+    if (!r->keep_first) fastf_big_free(r->slab, 2 * r->slot_bytes);
     r->t_release = now_s() - t0;
     return NULL;
 }
@@ -316,7 +316,7 @@ done:
     if (eng) fastf_engine_destroy(eng);
     if (slab_pinned & 1) fastf_pinned_unregister(slab);
     if (slab_pinned & 2) fastf_pinned_unregister(slab + cap_bytes);
-    free(slab);
+    fastf_big_free(slab, 2 * cap_bytes);
     if (bam) fastf_bam_close(bam);
     fastf_lists_free(&lists);
     if (prof) fprintf(stderr, "[bam2db] teardown (engine, pinned slab, BAM mapping, lists) %.3f s\n", now_s() - tt);

@@ -1,5 +1,5 @@
 // exit_probe.hip — what a process pays between its last useful instruction and its exit, by what it still holds:
-//   exit_probe <device MiB> <pinned-registered MiB> <file to mmap or -> <free first: 0|1>
+//   exit_probe <device MiB> <pinned-registered MiB> <file to mmap or -> <free first: 0|1, 2 = hipDeviceReset before the exit>
 // prints the time of the explicit frees (if asked); the caller times the whole process (tools/exit_probe.sh).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,7 +27,10 @@ int main(int argc, char** argv) {
     }
     (void)hipStreamSynchronize(s);
     const double t1 = now();
-    if (free_first) {
+    if (free_first == 2) {                                 // the runtime torn down explicitly: how much of the exit is that?
+        (void)hipDeviceReset();
+        printf("setup %.3f s; hipDeviceReset %.3f s\n", t1 - t0, now() - t1);
+    } else if (free_first) {
         if (m) munmap(m, mlen);
         const double a = now();
         if (h) { (void)hipHostUnregister(h); free(h); }

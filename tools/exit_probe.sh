@@ -5,7 +5,7 @@ f=${1:--}
 python3 - "$f" <<'PY'
 import subprocess, sys, time
 f = sys.argv[1]
-cases = [("0", "0", "-", "0"), ("4096", "0", "-", "0"), ("4096", "0", "-", "1"), ("0", "1024", "-", "0"), ("0", "1024", "-", "1"),
+cases = [("0", "0", "-", "0"), ("0", "0", "-", "2"), ("4096", "256", "-", "0"), ("4096", "256", "-", "2"), ("4096", "0", "-", "0"), ("4096", "0", "-", "1"), ("0", "1024", "-", "0"), ("0", "1024", "-", "1"),
          ("0", "0", f, "0"), ("0", "0", f, "1"), ("4096", "1024", f, "0"), ("4096", "1024", f, "1")]
 for rep in range(2):
     for c in cases:
