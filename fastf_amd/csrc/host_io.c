@@ -305,9 +305,10 @@ static void *zap_main(void *vp)
 void fastf_big_free(void *p, size_t bytes)
 {
     if (!p) return;
-    if (bytes >= ((size_t)4 << 20)) {
+    if (bytes >= ((size_t)4 << 20) && ((uintptr_t)p & 4095) == 0) {
         /* (the read lock lets several threads return pages at once: four of them for the big buffers) */
-        zap_job j = { (char *)p, bytes, 0 };
+        /* whole pages inside the buffer only: madvise rounds a length UP, and the page behind a heap chunk is not ours */
+        zap_job j = { (char *)p, bytes & ~(size_t)4095, 0 };
         pthread_t th[3]; int n = 0;
         if (bytes >= ((size_t)128 << 20)) for (; n < 3; n++) if (pthread_create(&th[n], NULL, zap_main, &j) != 0) break;
         zap_main(&j);
