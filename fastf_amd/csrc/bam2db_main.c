@@ -27,9 +27,14 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 /* decoder thread: BAM → packed SoA batches, double-buffered, while the caller pushes the previous batch
  * (and, for the first batch, while the HIP runtime and the engine come up) */
 typedef struct { uint64_t *cb, *gx; uint32_t *umi, *meta; long n; int on_device; fastf_batch_t dev; } dec_slot;   /* on_device: the batch lies packed in device memory (dev) */
+#define DEC_SLOTS 6                      /* ring of decoder slots; only those the decoder reaches are ever touched or pinned */
 typedef struct {
     fastf_bam_t *bam; const fastf_lists_t *lists; size_t cap;
-    dec_slot slot[2]; int filled[2];
+    dec_slot slot[DEC_SLOTS]; int filled[DEC_SLOTS]; int n_slots;
+    /* pinning (the pin thread): begun[k] = the decoder has started on slot k for the first time; pinned[k] = 1 registered
+     * with the HIP runtime, -1 registration failed or switched off (that slot is pushed through the engine's staging) */
+    int begun[DEC_SLOTS], pinned[DEC_SLOTS], pin_stop;
+    unsigned char *slab; size_t slot_bytes;
     pthread_mutex_t mu; pthread_cond_t cv;
     int stop; double t_decode;
     int engine_up;                       /* set by the pusher once it can take batches */
@@ -46,27 +51,56 @@ static void dec_deliver(dec_ctx *d, int k, long n, double t_start)
     pthread_cond_broadcast(&d->cv);
     pthread_mutex_unlock(&d->mu);
 }
-/* wait until the pusher has given slot k back; 0 when told to stop */
-static int dec_wait_free(dec_ctx *d, int k)
+/* wait until the pusher has given slot k back and at most `ahead` other slots are still waiting for it; 0 when told to stop */
+static int dec_wait_free(dec_ctx *d, int k, int ahead)
 {
     pthread_mutex_lock(&d->mu);
-    while (d->filled[k] && !d->stop) pthread_cond_wait(&d->cv, &d->mu);
+    for (;;) {
+        int out = 0;
+        for (int i = 0; i < d->n_slots; i++) out += d->filled[i];
+        if ((!d->filled[k] && out <= ahead) || d->stop) break;
+        pthread_cond_wait(&d->cv, &d->mu);
+    }
     const int stop = d->stop;
+    if (!stop && !d->begun[k]) { d->begun[k] = 1; pthread_cond_broadcast(&d->cv); }     /* the pin thread may take it now */
     pthread_mutex_unlock(&d->mu);
     if (!stop && d->trace) fprintf(stderr, "[trace] %.3f decoder: slot %d free\n", now_s() - d->t_origin, k);
     return !stop;
+}
+
+/* pin thread: registers the slots with the HIP runtime in the order the decoder reaches them (23 ms per 100 MB slot —
+ * beside the engine's start-up and the pushes, not in front of the first push) */
+static void *pin_main(void *vp)
+{
+    dec_ctx *d = (dec_ctx *)vp;
+    for (int k = 0; k < d->n_slots; k++) {
+        pthread_mutex_lock(&d->mu);
+        while (!d->begun[k] && !d->pin_stop) pthread_cond_wait(&d->cv, &d->mu);
+        const int stop = d->pin_stop;
+        pthread_mutex_unlock(&d->mu);
+        if (stop) break;
+        const int ok = fastf_pinned_register(d->slab + (size_t)k * d->slot_bytes, d->slot_bytes) == 0;
+        if (d->trace) fprintf(stderr, "[trace] %.3f pin thread: slot %d %s\n", now_s() - d->t_origin, k, ok ? "registered" : "not registered");
+        pthread_mutex_lock(&d->mu);
+        d->pinned[k] = ok ? 1 : -1;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+    }
+    return NULL;
 }
 
 static void *decoder_main(void *vp)
 {
     dec_ctx *d = (dec_ctx *)vp;
     /* The reader hands out one window's records per call.  Until the engine is up nobody takes a slot, so the slot being
-     * filled goes on taking windows (two slots of `cap` records, not two windows, are what the host can decode ahead while
-     * the HIP runtime starts).  That ends with the first batch the device packed: its arrays stay valid for one more window
-     * of that parity only, so from then on every call is handed over at once — by then the engine is up or about to be. */
+     * filled goes on taking windows, and the decoder walks on through the ring (DEC_SLOTS slots of `cap` records are what
+     * the host can decode ahead while the HIP runtime starts: a skinny BAM runs at 80 M records/s on the host alone).
+     * That ends with the first batch the device packed: its arrays stay valid for one more window of that parity only, so
+     * from then on every call is handed over at once and the decoder stays one slot ahead of the pusher, no more — by then
+     * the engine is up or about to be. */
     int accumulate = 1;
-    for (int k = 0;; k ^= 1) {
-        if (!dec_wait_free(d, k)) break;
+    for (int k = 0;; k = (k + 1) % d->n_slots) {
+        if (!dec_wait_free(d, k, accumulate ? d->n_slots : 1)) break;
         double t = now_s();
         dec_slot *sl = &d->slot[k];
         size_t fill = 0;
@@ -88,8 +122,8 @@ static void *decoder_main(void *vp)
             if (n > 0 && !on_dev) continue;
             /* the call that ended the filling brought something else: the end of the input, an error, or a batch that lies on
              * the device — it goes into the next slot, behind the records above */
-            k ^= 1;
-            if (!dec_wait_free(d, k)) break;
+            k = (k + 1) % d->n_slots;
+            if (!dec_wait_free(d, k, accumulate ? d->n_slots : 1)) break;
             sl = &d->slot[k];
             t = now_s();
         }
@@ -105,9 +139,22 @@ static void *decoder_main(void *vp)
  * unmapping them takes 0.1-0.15 s that the exiting process used to pay after its outputs were closed; here it runs
  * beside the sort, the reduce and the writers. */
 typedef struct {
-    pthread_t dec_thread; fastf_bam_t *bam; unsigned char *slab; size_t slot_bytes; int slab_pinned, keep_first;
+    pthread_t dec_thread, pin_thread; int pin_started; dec_ctx *dec; fastf_bam_t *bam; int keep_first;
     uint64_t no_xf, no_gx; double t_release;
 } rel_ctx;
+
+/* the pin thread has stopped: unregister what it registered (but the first slot if it is on loan), free the slab (if not) */
+static void slab_release(dec_ctx *d, int keep_first)
+{
+    for (int k = keep_first ? 1 : 0; k < d->n_slots; k++)
+        if (d->pinned[k] == 1) { fastf_pinned_unregister(d->slab + (size_t)k * d->slot_bytes); d->pinned[k] = 0; }
+    if (!keep_first) { fastf_big_free(d->slab, (size_t)d->n_slots * d->slot_bytes); d->slab = NULL; }
+}
+static void pin_thread_stop(dec_ctx *d, pthread_t th)
+{
+    pthread_mutex_lock(&d->mu); d->pin_stop = 1; pthread_cond_broadcast(&d->cv); pthread_mutex_unlock(&d->mu);
+    pthread_join(th, NULL);
+}
 
 static void *release_main(void *vp)
 {
@@ -117,8 +164,8 @@ static void *release_main(void *vp)
     fastf_bam_stats(r->bam, NULL, &r->no_xf, &r->no_gx);
     fastf_bam_close(r->bam);                            /* prints the reader's profile lines first */
     /* keep_first: the first slot is on loan to the engine as its row buffer until the outputs are written (bam2db() below) */
-    if (r->slab_pinned) { fastf_pinned_unregister(r->slab + r->slot_bytes); if (!r->keep_first) fastf_pinned_unregister(r->slab); }
-    if (!r->keep_first) fastf_big_free(r->slab, 2 * r->slot_bytes);
+    if (r->pin_started) pin_thread_stop(r->dec, r->pin_thread);
+    slab_release(r->dec, r->keep_first);
     r->t_release = now_s() - t0;
     return NULL;
 }
@@ -138,8 +185,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     fastf_lists_t lists; memset(&lists, 0, sizeof lists);
     fastf_bam_t *bam = NULL;
     fastf_engine_t *eng = NULL;
-    dec_ctx dec; pthread_t dec_thread; int dec_started = 0; double t_wait = 0;
-    unsigned char *slab = NULL; int slab_pinned = 0; size_t cap_bytes = 0;     /* cap_bytes: one decoder slot */
+    dec_ctx dec; pthread_t dec_thread, pin_thread; int dec_started = 0, pin_started = 0; double t_wait = 0;
     rel_ctx rel; pthread_t rel_thread; int rel_started = 0;
     memset(&dec, 0, sizeof dec); memset(&rel, 0, sizeof rel);
 
@@ -171,12 +217,12 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     dec.bam = bam; dec.lists = &lists; dec.cap = cap;
     {   const char *pf = getenv("FASTF_PROFILE"); dec.trace = pf && pf[0] == '2'; dec.t_origin = t0; }
     pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
-    /* one slab for both decoder slots: pinned once the HIP runtime is up (below), so that the engine copies the
-     * packed records to the device straight from where the decoder wrote them */
-    if (!(slab = (unsigned char *)fastf_big_alloc(2 * cap * 24))) { fprintf(stderr, "out of memory\n"); goto done; }
-    cap_bytes = cap * 24;
-    for (int k = 0; k < 2; k++) {
-        unsigned char *base = slab + (size_t)k * cap * 24;
+    /* one slab for the ring of decoder slots (untouched pages cost nothing): each slot is pinned when the decoder reaches
+     * it, so that the engine copies the packed records to the device straight from where the decoder wrote them */
+    dec.n_slots = DEC_SLOTS; dec.slot_bytes = cap * 24;
+    if (!(dec.slab = (unsigned char *)fastf_big_alloc((size_t)dec.n_slots * dec.slot_bytes))) { fprintf(stderr, "out of memory\n"); goto done; }
+    for (int k = 0; k < dec.n_slots; k++) {
+        unsigned char *base = dec.slab + (size_t)k * dec.slot_bytes;
         dec.slot[k].cb = (uint64_t *)base; dec.slot[k].gx = (uint64_t *)(base + cap * 8);
         dec.slot[k].umi = (uint32_t *)(base + cap * 16); dec.slot[k].meta = (uint32_t *)(base + cap * 20);
     }
@@ -188,6 +234,10 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     printf("Start to convert bam file to UMI keys on the device...\n");
     if (pthread_create(&dec_thread, NULL, decoder_main, &dec) != 0) { fprintf(stderr, "cannot start decoder thread\n"); goto done; }
     dec_started = 1;
+    {   const char *zc = getenv("FASTF_ZERO_COPY");                 /* "0": stage every batch through the engine's own pinned buffers */
+        if (!(zc && zc[0] == '0') && pthread_create(&pin_thread, NULL, pin_main, &dec) == 0) pin_started = 1;
+        else for (int k = 0; k < dec.n_slots; k++) dec.pinned[k] = -1;
+    }
 
     fastf_engine_config_t cfg; memset(&cfg, 0, sizeof cfg);
     cfg.cell_keys = lists.cell_key; cfg.n_cells = (uint32_t)lists.n_cells;
@@ -218,22 +268,17 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     cfg.batch_records = cap;
     tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
-    {   const char *zc = getenv("FASTF_ZERO_COPY");                 /* "0": stage every batch through the engine's own pinned buffers */
-        /* one registration per decoder slot: the second goes back as soon as the last record is on the device, the first
-         * stays as the row buffer of fastf_engine_finish (below) */
-        if (!(zc && zc[0] == '0') && fastf_pinned_register(slab, cap * 24) == 0) {
-            if (fastf_pinned_register(slab + cap * 24, cap * 24) == 0) slab_pinned = 3;       /* bit 0: first slot, bit 1: second */
-            else fastf_pinned_unregister(slab);
-        }
-    }
     t_engine = now_s() - tt;
     __atomic_store_n(&dec.engine_up, 1, __ATOMIC_RELEASE);
     if (dec.trace) fprintf(stderr, "[trace] %.3f main: engine up\n", now_s() - t0);
 
-    for (int k = 0;; k ^= 1) {
+    for (int k = 0;; k = (k + 1) % dec.n_slots) {
         tt = now_s();
         pthread_mutex_lock(&dec.mu);
         while (!dec.filled[k]) pthread_cond_wait(&dec.cv, &dec.mu);
+        /* records in the slab wait for their slot's registration (the pin thread is at most a few slots behind) */
+        while (dec.slot[k].n > 0 && !dec.slot[k].on_device && dec.pinned[k] == 0) pthread_cond_wait(&dec.cv, &dec.mu);
+        const int slot_pinned = dec.pinned[k] == 1;
         pthread_mutex_unlock(&dec.mu);
         t_wait += now_s() - tt;
         const long n = dec.slot[k].n;
@@ -244,7 +289,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         if (on_dev) batch = dec.slot[k].dev;                  /* packed on the device: a device-to-device copy into the engine's staging */
         tt = now_s();
         /* pinned slots: queue the copies, and hand the slot back to the decoder once they have left it */
-        if ((slab_pinned || on_dev) ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
+        if ((slot_pinned || on_dev) ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
             fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
         }
         t_push += now_s() - tt;
@@ -262,12 +307,14 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
      * has no row buffer to allocate and fault in (0.03-0.05 s beside the release thread's unmapping) and the device writes
      * the rows at PCIe rate.  A matrix that does not fit takes the engine's own buffer. */
     const char *lr = getenv("FASTF_LEND_ROWS");                                  /* "0": the engine's own row buffer (A/B) */
-    const int lend = slab_pinned && !(lr && lr[0] == '0') && fastf_engine_lend_rows(eng, slab, cap * 24) == 0;
-    rel.dec_thread = dec_thread; rel.bam = bam; rel.slab = slab; rel.slot_bytes = cap * 24; rel.slab_pinned = slab_pinned; rel.keep_first = lend;
+    pthread_mutex_lock(&dec.mu);
+    const int first_pinned = dec.pinned[0] == 1;
+    pthread_mutex_unlock(&dec.mu);
+    const int lend = first_pinned && !(lr && lr[0] == '0') && fastf_engine_lend_rows(eng, dec.slab, dec.slot_bytes) == 0;
+    rel.dec_thread = dec_thread; rel.pin_thread = pin_thread; rel.pin_started = pin_started; rel.dec = &dec; rel.bam = bam; rel.keep_first = lend;
     if (pthread_create(&rel_thread, NULL, release_main, &rel) == 0) {
-        rel_started = 1; dec_started = 0; bam = NULL;
-        if (lend) slab_pinned = 1;                          /* the second slot is the release thread's now */
-        else { slab = NULL; slab_pinned = 0; }
+        /* the release thread stops the pin thread and gives the slab back, but for the first slot if that is on loan */
+        rel_started = 1; dec_started = 0; pin_started = 0; bam = NULL;
     }
     fastf_coo_t coo; uint64_t counters[3];
     tt = now_s();
@@ -302,10 +349,11 @@ done:
     tt = now_s();
     if (rel_started) pthread_join(rel_thread, NULL);    /* (an error after the end of the input) */
     if (dec_started) {
-        pthread_mutex_lock(&dec.mu); dec.stop = 1; dec.filled[0] = dec.filled[1] = 0;
+        pthread_mutex_lock(&dec.mu); dec.stop = 1; memset(dec.filled, 0, sizeof dec.filled);
         pthread_cond_broadcast(&dec.cv); pthread_mutex_unlock(&dec.mu);
         pthread_join(dec_thread, NULL);
     }
+    if (pin_started) { pin_thread_stop(&dec, pin_thread); pin_started = 0; }
     if (fastf_process_is_exiting_) {
         /* the fastF CLI leaves through _exit() right after this call: device memory, pinned pages and the BAM mapping
          * go back with the process, and unmapping them one by one first costs 0.1-0.2 s */
@@ -314,9 +362,7 @@ done:
         return rc;
     }
     if (eng) fastf_engine_destroy(eng);
-    if (slab_pinned & 1) fastf_pinned_unregister(slab);
-    if (slab_pinned & 2) fastf_pinned_unregister(slab + cap_bytes);
-    fastf_big_free(slab, 2 * cap_bytes);
+    if (dec.slab) slab_release(&dec, 0);                /* (whatever the release thread left: the lent slot, or all of it) */
     if (bam) fastf_bam_close(bam);
     fastf_lists_free(&lists);
     if (prof) fprintf(stderr, "[bam2db] teardown (engine, pinned slab, BAM mapping, lists) %.3f s\n", now_s() - tt);

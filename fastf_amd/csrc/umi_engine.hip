@@ -417,8 +417,13 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
 extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engine_t** out) FASTF_TRY {
     if (!cfg || !out) return set_err("null argument");
     *out = nullptr;
+    const char* pf_ = getenv("FASTF_PROFILE");
+    const bool lap_on = pf_ && pf_[0] == '2';
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (lap_on) fprintf(stderr, "[engine create] %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count()); };
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
+    lap("device count");
     if (he != hipSuccess || ndev == 0)
         return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
     if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 16) return set_err("umi_max_bases must be 1..16");
@@ -432,6 +437,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     if (cfg->n_shards < 1 || cfg->n_shards > 8 || cfg->shard_rank >= cfg->n_shards) return set_err("bad shard config");
     HIP_OK(hipSetDevice(cfg->device));
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) g_cu_count = (u32)pr.multiProcessorCount; }
+    lap("device set, properties");
 
     fastf_engine* e = new fastf_engine();
     e->device = cfg->device;
@@ -480,6 +486,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
             hipEventCreate(&e->t_ev[0]) != hipSuccess || hipEventCreate(&e->t_ev[1]) != hipSuccess) {
             rc = set_err("stream/event creation failed"); break;
         }
+        lap("streams and events");
         if ((rc = build_table((const u64*)cfg->cell_keys, cfg->n_cells, e->tab_cells, e->cells, "cell"))) break;
         if ((rc = build_table((const u64*)cfg->feature_keys, cfg->n_features, e->tab_feats, e->feats, "feature"))) break;
         {
@@ -491,14 +498,17 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
                 if ((rc = build_gene_lds(e, (const u64*)cfg->feature_keys, cfg->n_features))) break;
             }
         }
+        lap("tables built and uploaded");
         if ((rc = e->d_small.ensure(SM_WORDS * sizeof(u64)))) break;
         if (hipHostMalloc((void**)&e->h_small, SM_WORDS * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
             rc = set_err("hipHostMalloc failed"); break;
         }
         if (hipMemset(e->d_small.p, 0, SM_WORDS * sizeof(u64)) != hipSuccess) { rc = set_err("memset failed"); break; }
+        lap("counters allocated and cleared");
         if (set_scatter_lds_limit()) {
             rc = set_err("cannot raise dynamic LDS limit to %zu bytes", scatter_smem_bytes()); break;
         }
+        lap("kernel attributes (code object loaded)");
         e->batch_cap = cfg->batch_records ? cfg->batch_records : (4ull << 20);
         e->key_cap = cfg->key_capacity;
     } while (0);

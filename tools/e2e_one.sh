@@ -11,5 +11,5 @@ bt,ft,_,_=synth.make_lists(50000,36601,seed=77); open('/dev/shm/gb/bar.tsv','wb'
 gcc -O2 -o $R/build/gen_bam $R/tools/gen_bam.c -lz -lpthread
 $R/build/gen_bam /dev/shm/gb/in.bam /dev/shm/gb/bar.tsv /dev/shm/gb/feat.tsv $N 7 12 $SL 16
 shift 2 || true
-env FASTF_PROFILE=${FASTF_PROFILE:-1} FASTF_BAM_PROFILE=2 FASTF_HOST_THREADS=16 "$@" $R/fastf_amd/bin/fastF bam2db -b /dev/shm/gb/in.bam -a /dev/shm/gb/bar.tsv -f /dev/shm/gb/feat.tsv -o /dev/shm/gb/out -c 0.5 -r 0.5 2>&1 >/dev/null | grep "^\[bam\|^\[finish\|^\[trace\|^\[write"
+env FASTF_PROFILE=${FASTF_PROFILE:-1} FASTF_BAM_PROFILE=2 FASTF_HOST_THREADS=16 "$@" $R/fastf_amd/bin/fastF bam2db -b /dev/shm/gb/in.bam -a /dev/shm/gb/bar.tsv -f /dev/shm/gb/feat.tsv -o /dev/shm/gb/out -c 0.5 -r 0.5 2>&1 >/dev/null | grep "^\[bam\|^\[finish\|^\[trace\|^\[write\|^\[engine"
 rm -rf /dev/shm/gb
