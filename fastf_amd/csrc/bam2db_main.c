@@ -149,6 +149,7 @@ static void slab_release(dec_ctx *d, int keep_first)
     for (int k = keep_first ? 1 : 0; k < d->n_slots; k++)
         if (d->pinned[k] == 1) { fastf_pinned_unregister(d->slab + (size_t)k * d->slot_bytes); d->pinned[k] = 0; }
     if (!keep_first) { fastf_big_free(d->slab, (size_t)d->n_slots * d->slot_bytes); d->slab = NULL; }
+    else fastf_big_drop(d->slab + d->slot_bytes, (size_t)(d->n_slots - 1) * d->slot_bytes);      /* the other slots' pages, at least */
 }
 static void pin_thread_stop(dec_ctx *d, pthread_t th)
 {
