@@ -682,10 +682,11 @@ static int fill_next(fastf_bam_t *b)
                   fprintf(stderr, "[bam] %.3f window %llu: %zu blocks, %zu on the device in %.1f ms, %zu on the host in %.1f ms, staged+queued in %.1f ms, whole window %.1f ms (%.1f ms of page mapping and block walk before), share %.2f\n",
                           now_s() - b->t_open, (unsigned long long)b->n_gpu_windows, b->nblk, n_dev, dev_ms, b->nblk - n_dev, t_host * 1e3, (t_sub - t0) * 1e3, (now_s() - t0) * 1e3, (t0 - t_entry) * 1e3, b->gpu_share); }
             if (b->gpu_wanted != 2 && dev_ms > 0 && t_host > 0 && n_dev < b->nblk) {
-                /* next window: shares in proportion to the two rates (blocks per second), moved half way */
+                /* next window: shares in proportion to the two rates (blocks per second) */
                 const double r_dev = (double)n_dev / (dev_ms * 1e-3), r_host = (double)(b->nblk - n_dev) / t_host;
                 double want = r_dev / (r_dev + r_host);
-                b->gpu_share = 0.5 * b->gpu_share + 0.5 * want;
+                /* (a run has a dozen shared windows: three quarters of the way per window, not half) */
+                b->gpu_share = 0.25 * b->gpu_share + 0.75 * want;
                 if (b->gpu_share < 0.05) b->gpu_share = 0.05;
                 const double cap = keep ? b->gpu_share_cap_keep : b->gpu_share_max;     /* copy-back mode: what the init thread pinned of the window buffers */
                 if (b->gpu_share > cap) b->gpu_share = cap;
@@ -842,7 +843,10 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
         if (b->gpu_share_max < 0.05) b->gpu_share_max = 0.05;
         if (b->gpu_share_max > 1.0) b->gpu_share_max = 1.0;
         b->gpu_share = sh2 ? atof(sh2) : b->gpu_share_max;
-        if (b->gpu_share > b->gpu_share_max) b->gpu_share = b->gpu_share_max; }
+        if (b->gpu_share > b->gpu_share_max) b->gpu_share = b->gpu_share_max;
+        /* keep mode (the device parses its share too): the host threads also hop and pack beside their inflate, and the
+         * shares settle at 0.65-0.72 on the files measured — start there */
+        if (b->parse_expected && !sh2 && !sh3) b->gpu_share = 0.68; }
     const char *w = getenv("FASTF_BAM_WINDOW");
     /* device inflate wants many blocks per launch (the chip holds 5 120 of them at once): 128 MiB windows, about 8 000
      * blocks, of which the device takes its share, unless told otherwise */
