@@ -59,6 +59,30 @@ def test_cli_outputs_equal_oracle_bytes(tmp_path, name, kw, args, gz):
     assert not (tmp_path / "unused.db").exists()
 
 
+@pytest.mark.parametrize("env_extra", [
+    dict(FASTF_BATCH_RECORDS="70000", FASTF_BAM_WINDOW="262144"),                           # the slot ring wraps, many windows per slot
+    dict(FASTF_BATCH_RECORDS="70000", FASTF_BAM_WINDOW="262144", FASTF_GPU_INFLATE="2"),    # every window on the device: device-packed batches between host ones
+    dict(FASTF_BATCH_RECORDS="20000", FASTF_BAM_WINDOW="131072", FASTF_BAM_SCOUT="0", FASTF_ZERO_COPY="0"),   # no scout, staged pushes
+    dict(FASTF_BATCH_RECORDS="300000", FASTF_BAM_WINDOW="1048576", FASTF_LEND_ROWS="0", FASTF_BAM_MMAP="0"),  # read() windows, own row buffer
+])
+def test_cli_decoder_ring_windows_and_slots(tmp_path, env_extra):
+    """bam2db()'s front end under small windows and small slots: the decoder fills a slot across several windows while the
+    engine starts, walks through the ring of slots, hands device-packed batches over between host-packed ones, the scout
+    walks ahead — the outputs stay the oracle's bytes and the counters the file's (record order = draw order)."""
+    case = Case(n=260_000, n_bar=900, n_gene=300, rate_cell=0.6, rate_depth=0.5, umi_len=12, dup_factor=3.0,
+                p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.005, p_multi_gene=0.02)
+    bam, b, f = _write_inputs(tmp_path, case)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out), "-u",
+                        "-c", "0.6", "-r", "0.5"], capture_output=True, text=True, env=dict(os.environ, **env_extra))
+    assert r.returncode == 0, r.stderr
+    assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
+    assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
+    assert "total fastQ reads: %d" % ora["total"] in r.stdout
+
+
 REFMAIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "fastF_refmain")
 
 
