@@ -139,3 +139,44 @@ def test_pipelined_pass_with_asynchronous_loopback_exchange():
         assert eng.dev_error_bits() == 0
     finally:
         eng.close()
+
+
+def _rccl_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from fastf_amd.dist import ShardedPass
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sp = ShardedPass(object(), 64, dev, world=1, rank=0)
+        assert sp._nccl and not sp.host_staged
+        inp = torch.arange(1000, dtype=torch.int64, device=dev) * 3 + 1
+        out = torch.zeros(1000, dtype=torch.int64, device=dev)
+        sp._all_to_all_single(out, inp, [1000], [1000])                 # the key exchange's call: int64 keys, split lists
+        ok = bool(torch.equal(out, inp))
+        sp._all_to_all_single(out[:0], inp[:0], [0], [0])               # a shard that sends and receives nothing
+        cnt_in = torch.tensor([17], dtype=torch.int64, device=dev); cnt_out = torch.zeros(1, dtype=torch.int64, device=dev)
+        sp._all_to_all_single(cnt_out, cnt_in)                          # the count exchange
+        hits = torch.tensor([5], dtype=torch.int64, device=dev); allh = torch.zeros(1, dtype=torch.int64, device=dev)
+        sp._all_gather(allh, hits)                                      # the draw-rank base
+        red = torch.tensor([3, 4, 5, 0], dtype=torch.int64, device=dev)
+        sp._all_reduce(red)                                             # the three counters + error bits
+        torch.cuda.synchronize()
+        q.put((ok, int(cnt_out.item()), int(allh.item()), red.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_on_rccl_with_one_rank():
+    """Every collective the sharded pass issues, through torch.distributed's nccl backend (= RCCL) on the box's GPU with a
+    world of one rank — all a one-GPU box allows: the calls, dtypes and split lists are the ones the 8-GPU run makes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res == (True, 17, 5, [3, 4, 5, 0])
