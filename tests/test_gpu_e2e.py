@@ -83,6 +83,44 @@ def test_cli_decoder_ring_windows_and_slots(tmp_path, env_extra):
     assert "total fastQ reads: %d" % ora["total"] in r.stdout
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n=0, n_bar=10, n_gene=5),                                   # header-only BAM
+    dict(n=1, n_bar=10, n_gene=5),                                   # one record
+    dict(n=3000, n_bar=40, n_gene=20, p_no_cb=1.0),                  # no record carries a CB: an empty matrix with its header
+    dict(n=3000, n_bar=40, n_gene=20, p_bad_xf=1.0),                 # every record fails the xf test
+    dict(n=3000, n_bar=40, n_gene=20, p_n_umi=1.0),                  # only NULL blobs: rows with count 0
+])
+def test_cli_edge_inputs(tmp_path, kw):
+    """the CLI on degenerate inputs: the reference's files all the same (header, dims line with nnz 0, count-0 rows)"""
+    case = Case(**kw)
+    bam, b, f = _write_inputs(tmp_path, case)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out), "-u"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
+    assert _read_gz(out / "barcodes.tsv.gz") == ora["barcodes"]
+    assert _read_gz(out / "features.tsv.gz") == ora["features"]
+    assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
+    assert "total fastQ reads: %d" % ora["total"] in r.stdout
+
+
+def test_cli_truncated_bam_fails_cleanly(tmp_path):
+    """a BAM cut in the middle of a BGZF block: `Error: ...` on stderr, exit status 1 (bam2db_ds.h:60), no crash, no hang"""
+    case = Case(n=40_000, n_bar=100, n_gene=50)
+    bam, b, f = _write_inputs(tmp_path, case)
+    data = open(bam, "rb").read()
+    cut = tmp_path / "cut.bam"
+    cut.write_bytes(data[:len(data) * 2 // 3])
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(cut), "-a", str(b), "-f", str(f), "-o", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "Error" in r.stderr and "truncated" in r.stderr.lower()
+
+
 REFMAIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "fastF_refmain")
 
 
