@@ -61,6 +61,22 @@ __global__ __launch_bounds__(256) void k_wide(const u64* __restrict__ gx, const 
     }
 }
 
+// K1a's mix: 8 bytes read, 2 bytes written per record; lanes take pairs of records (16-byte loads, 4-byte stores) as the kernel does
+template <int U, bool NT>
+__global__ __launch_bounds__(1024) void k_k1a(const u64* __restrict__ cb, u16* __restrict__ cell, size_t n) {
+    const size_t pairs = n / 2, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < pairs; p0 += stride * U) {
+        u64x2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const size_t p = p0 + (size_t)u * stride; if (p < pairs) v[u] = ld<NT>((const u64x2*)cb + p); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t p = p0 + (size_t)u * stride;
+            if (p < pairs) ((u32*)cell)[p] = (u32)(v[u].x * 0x9E3779B97F4A7C15ull >> 48) | ((u32)(v[u].y * 0x9E3779B97F4A7C15ull >> 48) << 16);
+        }
+    }
+}
+
 template <typename F>
 static int timeit(const char* name, size_t bytes, F launch, hipEvent_t e0, hipEvent_t e1) {
     float best = 1e9f;
@@ -88,6 +104,15 @@ int main() {
         timeit("A narrow loads, 8 rows in flight, nt", bytes, [&] { hipLaunchKernelGGL((k_narrow<8, true>), dim3(grid), dim3(256), 0, 0, gx, umi, meta, cell, out, n); }, e0, e1);
         timeit("B wide loads (4 records per lane)", bytes, [&] { hipLaunchKernelGGL((k_wide<false>), dim3(grid), dim3(256), 0, 0, gx, umi, meta, cell, out, n); }, e0, e1);
         timeit("B wide loads (4 records per lane), nt", bytes, [&] { hipLaunchKernelGGL((k_wide<true>), dim3(grid), dim3(256), 0, 0, gx, umi, meta, cell, out, n); }, e0, e1);
+    }
+    const size_t b1 = n * 10;
+    printf("K1a mix: %.2f GB per launch (8 B read + 2 B written per record)\n", b1 / 1e9);
+    for (int grid : {256, 512, 1024, 2048}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "grid %d x 1024, 2 pairs in flight", grid);
+        timeit(nm, b1, [&] { hipLaunchKernelGGL((k_k1a<2, false>), dim3(grid), dim3(1024), 0, 0, gx, cell, n); }, e0, e1);
+        snprintf(nm, sizeof nm, "grid %d x 1024, 4 pairs in flight, nt", grid);
+        timeit(nm, b1, [&] { hipLaunchKernelGGL((k_k1a<4, true>), dim3(grid), dim3(1024), 0, 0, gx, cell, n); }, e0, e1);
     }
     return 0;
 }
