@@ -94,7 +94,7 @@ static uint32_t crc32_route(const unsigned char *buf, size_t len, int use_clmul)
 
 int fastf_crc32_selftest(void)
 {
-    if (g_clmul >= 0) return g_clmul;
+    { const int c = __atomic_load_n(&g_clmul, __ATOMIC_RELAXED); if (c >= 0) return c; }
     int ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
     if (ok) {
         unsigned char t[1024 + 37];
@@ -105,13 +105,14 @@ int fastf_crc32_selftest(void)
             for (size_t off = 0; off < 3 && ok; off++)
                 if (crc32_route(t + off, lens[k] - off, 1) != crc32_route(t + off, lens[k] - off, 0)) ok = 0;
     }
-    g_clmul = ok;
+    __atomic_store_n(&g_clmul, ok, __ATOMIC_RELAXED);
     return ok;
 }
 
 uint32_t fastf_crc32(const unsigned char *buf, size_t len)
 {
-    return crc32_route(buf, len, g_clmul < 0 ? fastf_crc32_selftest() : g_clmul);
+    const int c = __atomic_load_n(&g_clmul, __ATOMIC_RELAXED);      /* (several worker threads may run the self-test at once: same answer) */
+    return crc32_route(buf, len, c < 0 ? fastf_crc32_selftest() : c);
 }
 
 #else   /* other CPUs: zlib */

@@ -17,6 +17,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 uint32_t fastf_crc32(const unsigned char *buf, size_t len);
@@ -244,7 +245,10 @@ size_t fastf_gz_bound(size_t len) { return len + len / 4 + 1024; }
 /* text -> one complete gzip member in out[0, cap); returns its size, 0 when cap was too small */
 size_t fastf_gz_member_fast(const unsigned char *in, size_t len, unsigned char *out, size_t cap)
 {
-    if (!__atomic_load_n(&g_tables_ready, __ATOMIC_ACQUIRE)) init_tables();
+    {   /* sixteen writer threads compress their first members at the same moment: the tables are built by one of them */
+        static pthread_once_t once = PTHREAD_ONCE_INIT;
+        if (!__atomic_load_n(&g_tables_ready, __ATOMIC_ACQUIRE)) (void)pthread_once(&once, init_tables);
+    }
     if (cap < 32) return 0;
     static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 0xff};     /* XFL 4: fastest algorithm; OS unknown */
     memcpy(out, hdr, 10);

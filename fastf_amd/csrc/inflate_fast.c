@@ -326,9 +326,10 @@ static int inflate_generic(const uint8_t *in, size_t in_len, uint8_t *out, size_
 int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 {
 #if defined(__x86_64__)
-    static int have_bmi2 = -1;
-    if (have_bmi2 < 0) have_bmi2 = __builtin_cpu_supports("bmi2") ? 1 : 0;
-    if (have_bmi2) return inflate_bmi2(in, in_len, out, out_len);
+    static int have_bmi2 = -1;                                  /* set once, by whichever worker thread comes first: atomics, not a plain int */
+    int h = __atomic_load_n(&have_bmi2, __ATOMIC_RELAXED);
+    if (h < 0) { h = __builtin_cpu_supports("bmi2") ? 1 : 0; __atomic_store_n(&have_bmi2, h, __ATOMIC_RELAXED); }
+    if (h) return inflate_bmi2(in, in_len, out, out_len);
 #endif
     return inflate_generic(in, in_len, out, out_len);
 }

@@ -36,3 +36,38 @@ def test_reader_batch_path_is_clean_under_sanitizers(tmp_path, san):
         assert len(lines) == 4 and all("40000 records" in l for l in lines)
         sums |= {l.split("checksum")[1].strip() for l in lines}
     assert len(sums) == 1
+
+
+BAM2DB_SRC = [os.path.join(ROOT, "fastf_amd", "csrc", "bam2db_main.c")] + SRC
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_bam2db_host_side_is_clean_under_sanitizers(tmp_path, san):
+    """bam2db()'s threads (decoder and its ring of slots, pin thread, release thread, scout, prefetch, writers and their side thread)
+    around a stub engine that comes up late and checks the push order (tools/san_bam2db.c): clean reports, every record pushed
+    once, in file order — the same checksum whatever the slot and window sizes, and the reader harness's checksum."""
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fastf_amd", "csrc"), "-I" + os.path.join(ROOT, "tools")]
+    exe, rdr = tmp_path / "san_bam2db", tmp_path / "san_reader"
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=" + san] + inc + [os.path.join(ROOT, "tools", "san_bam2db.c")] + BAM2DB_SRC + ["-lz", "-lpthread", "-o", str(exe)])
+    subprocess.check_call(["gcc", "-O1", "-g"] + inc + [os.path.join(ROOT, "tools", "san_reader.c")] + SRC + ["-lz", "-lpthread", "-o", str(rdr)])
+    case = Case(n=150_000, n_bar=500, n_gene=200, umi_pool=512, p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.2, p_n_umi=0.02)
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub)
+    (tmp_path / "b.tsv").write_bytes(case.bt); (tmp_path / "f.tsv").write_bytes(case.ft)
+    out = tmp_path / "out"; out.mkdir()
+    r = subprocess.run([str(rdr), str(bam), str(tmp_path / "b.tsv"), str(tmp_path / "f.tsv")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    want = r.stdout.splitlines()[0].split("checksum")[1].strip()
+    runs = [(dict(FASTF_BATCH_RECORDS="70000", FASTF_BAM_WINDOW="131072"), []),                      # the ring wraps; two windows per slot
+            (dict(FASTF_BATCH_RECORDS="4194304", FASTF_BAM_WINDOW="1048576"), ["x"]),                # one big slot filled across windows; leaves like the CLI
+            (dict(FASTF_BATCH_RECORDS="20000", FASTF_BAM_WINDOW="131072", FASTF_ZERO_COPY="0", FASTF_LEND_ROWS="0", FASTF_BAM_SCOUT="0"), []),
+            (dict(FASTF_BATCH_RECORDS="50000", FASTF_BAM_WINDOW="262144", FASTF_BAM_MMAP="0"), [])]
+    for env_extra, mode in runs:
+        r = subprocess.run([str(exe), str(bam), str(tmp_path / "b.tsv"), str(tmp_path / "f.tsv"), str(out)] + mode, capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=%d" % (0 if mode else 1), **env_extra))
+        assert "Sanitizer" not in r.stderr, r.stderr[-3000:]
+        assert r.returncode == 0, r.stderr[-1000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("bam2db returned")][0]
+        assert "returned 0: pushed %d records" % case.n in line and line.split("checksum")[1].strip() == want, line
+        assert "total fastQ reads: %d" % case.n in r.stdout
+        assert (out / "matrix.mtx.gz").exists() and (out / "features.tsv.gz").exists()
