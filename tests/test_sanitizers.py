@@ -71,3 +71,14 @@ def test_bam2db_host_side_is_clean_under_sanitizers(tmp_path, san):
         assert "returned 0: pushed %d records" % case.n in line and line.split("checksum")[1].strip() == want, line
         assert "total fastQ reads: %d" % case.n in r.stdout
         assert (out / "matrix.mtx.gz").exists() and (out / "features.tsv.gz").exists()
+
+
+def test_reader_refuses_or_parses_mutated_bams_cleanly(tmp_path):
+    """tools/fuzz_reader.py, a short round: damaged BGZF containers are all refused, damaged record payloads (re-wrapped with
+    valid CRCs) either parse to the same records on every thread count or end in an error — no sanitizer report, no hang"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_reader", os.path.join(ROOT, "tools", "fuzz_reader.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    findings, outcomes = mod.run(60, seed=3, workdir=str(tmp_path))
+    assert not findings, findings[:2]
+    assert 0 not in outcomes["container"] and outcomes["records"].get(0, 0) > 10
