@@ -3,7 +3,10 @@
     (every one must be refused: a CRC, a header field or the framing says so);
   * record level — the same kinds of damage applied to the INFLATED payload, re-wrapped in valid BGZF blocks with correct CRCs,
     so that the record hop and the tag parser see it (whatever parses must parse to the same records on 1, 2, 4 and 8 threads).
-A finding is a sanitizer report, a crash, a hang, or thread counts that disagree.
+  * device record functions — every record-level input also goes through gpu_records.hpp's host build (tools/fuzz_records.cpp):
+    the chain walk, the chain-start guess and the tag/key packer over a buffer that ends where the payload ends, compared with
+    what the host reader delivered.
+A finding is a sanitizer report, a crash, a hang, thread counts that disagree, or a record the two packers disagree on.
 
     python tools/fuzz_reader.py [iterations per level] [seed]        (tests/test_sanitizers.py runs a short round)
 """
@@ -26,6 +29,16 @@ def build(exe):
                            os.path.join(ROOT, "tools", "san_reader.c")] + SRC + ["-lz", "-lpthread", "-o", exe])
 
 
+def build_records(exe):
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "fastf_amd", "csrc"), "-I" + os.path.join(ROOT, "tools")]
+    objs = []
+    for c in SRC + [os.path.join(ROOT, "tools", "san_stubs.c")]:
+        o = exe + "_" + os.path.basename(c) + ".o"
+        subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined"] + inc + ["-c", c, "-o", o]); objs.append(o)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined"] + inc +
+                          [os.path.join(ROOT, "tools", "fuzz_records.cpp"), os.path.join(ROOT, "tools", "gr_host.cpp")] + objs + ["-lz", "-lpthread", "-o", exe])
+
+
 def bgzf(data, blk=20000):
     out = bytearray()
     for a in list(range(0, len(data), blk)) + [None]:
@@ -39,8 +52,9 @@ def run(iterations=100, seed=1, workdir=None, log=print):
     from helpers import Case
     from fastf_amd import synth
     d = workdir or tempfile.mkdtemp(prefix="fuzz_reader_")
-    exe = os.path.join(d, "san_reader")
+    exe, exe_rec = os.path.join(d, "san_reader"), os.path.join(d, "fuzz_records")
     build(exe)
+    build_records(exe_rec)
     case = Case(n=6000, n_bar=60, n_gene=30, umi_pool=64, p_no_cb=0.05, p_bad_xf=0.2)
     bam, mb = os.path.join(d, "t.bam"), os.path.join(d, "m.bam")
     synth.write_bam(bam, case.flags, case.xf, case.cb, case.gx, case.ub)
@@ -59,7 +73,18 @@ def run(iterations=100, seed=1, workdir=None, log=print):
         off += 8 + struct.unpack_from("<i", payload, off)[0]
     rng = random.Random(seed)
     env = dict(os.environ, FASTF_BAM_WINDOW="131072", ASAN_OPTIONS="detect_leaks=0")     # (the harness leaks on its error exits)
-    findings, outcomes = [], {"container": {}, "records": {}}
+    findings, outcomes = [], {"container": {}, "records": {}, "device_functions": {}}
+    pb = os.path.join(d, "m.payload")
+
+    def device_functions(it, m):
+        open(pb, "wb").write(bytes(m))
+        try:
+            r = subprocess.run([exe_rec, mb, pb, str(off), bt, ft], capture_output=True, text=True, timeout=120, env=env)
+        except subprocess.TimeoutExpired:
+            findings.append(("device_functions", it, "hang")); return
+        outcomes["device_functions"][r.returncode] = outcomes["device_functions"].get(r.returncode, 0) + 1
+        if "Sanitizer" in r.stderr or "runtime error" in r.stderr or r.returncode != 0:
+            findings.append(("device_functions", it, r.returncode, r.stdout[-200:], r.stderr[:1500]))
 
     def one(level, it, blob):
         open(mb, "wb").write(blob)
@@ -99,6 +124,7 @@ def run(iterations=100, seed=1, workdir=None, log=print):
         else:
             a = rng.randrange(off, len(m) - 64); n = rng.randint(1, 64); m[a:a + n] = bytes(rng.randrange(256) for _ in range(n))
         one("records", it, bgzf(m))
+        device_functions(it, m)
     log("fuzz_reader: %d + %d inputs, return codes %s, findings %d" % (iterations, iterations, outcomes, len(findings)))
     return findings, outcomes
 

@@ -33,7 +33,7 @@ uint64_t gr_host_guess(const uint8_t* buf, uint64_t lo, uint64_t hi, uint64_t en
     for (uint64_t o = lo; o < hi; o++) {
         uint64_t q = o; int k = 0;
         while (k < 3 && gr::rec_plausible(buf, q, end, n_ref)) { q = gr::rec_end(buf, q, end); k++; }
-        if (k == 3 || (k > 0 && q >= end - 36)) return o;
+        if (k == 3 || (k > 0 && gr::chain_meets_window_end(buf, q, end))) return o;
     }
     return ~0ull;
 }
