@@ -364,6 +364,10 @@ static void par_run(int n_threads, void (*fn)(void *, int), void *arg)
     for (int i = 1; i <= started; i++) pthread_join(th[i], NULL);
 }
 
+/* the same helper for the other host-side files (tag_cmds.c) */
+void fastf_par_run(int n_threads, void (*fn)(void *, int), void *arg) { par_run(n_threads, fn, arg); }
+int fastf_host_thread_count(void) { return host_threads(0); }
+
 /* ---- step 2: parallel inflate ---- */
 int fastf_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);   /* inflate_fast.c */
 uint32_t fastf_crc32(const unsigned char *buf, size_t len);                               /* crc32_fast.c */

@@ -132,6 +132,8 @@ void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *fea
 }
 #endif
 /* 2 MiB-aligned allocation that asks for transparent huge pages (big short-lived buffers); release with free() */
+void fastf_par_run(int n_threads, void (*fn)(void *, int), void *arg);   /* fn(arg, worker index) on n_threads threads, joined */
+int  fastf_host_thread_count(void);                                      /* FASTF_HOST_THREADS, else the cores (at most 16) */
 void *fastf_big_alloc(size_t bytes);
 void  fastf_big_drop(void *p, size_t bytes);      /* pages back, range stays allocated */
 void  fastf_big_free(void *p, size_t bytes);      /* pages back slice by slice (MADV_DONTNEED), then free() */
