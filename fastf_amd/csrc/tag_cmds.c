@@ -194,7 +194,10 @@ static void *hist_boot_main(void *vp)
 static int tag_run_bam(const char *bam_file, const char *tag1, const char *tag2, int type, tag_run *r)
 {
     memset(r, 0, sizeof *r);
-    fastf_bam_t *bam = fastf_bam_open(bam_file, 0);
+    /* the BGZF inflate is shared with the device, as in bam2db() (these commands need one anyway); FASTF_TAGS_GPU_INFLATE=0
+     * (or FASTF_GPU_INFLATE=0): host threads only */
+    const char *tgi = getenv("FASTF_TAGS_GPU_INFLATE");
+    fastf_bam_t *bam = (tgi && tgi[0] == '0') ? fastf_bam_open(bam_file, 0) : fastf_bam_open2(bam_file, 0, 1);
     if (!bam) return 1;
     const size_t cap = (size_t)4 << 20;
     /* Batches of tag keys.  While the histogram handle (HIP runtime, device context: 0.2-0.3 s) is still coming up on its own
