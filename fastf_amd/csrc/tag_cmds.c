@@ -61,12 +61,18 @@ static int strs_in_order(const tag_ent *ent, uint32_t m)
 
 /* Shape of the tree the reference would have built: left/right child (index into ent, -1 = none) and the root.
  * sorted[] receives the strcmp order.  All arrays have m entries. */
-static int32_t bst_shape(const tag_ent *ent, uint32_t m, uint32_t *sorted, int32_t *left, int32_t *right)
+/* sorted[] = the entries in strcmp order */
+static void sort_strings(const tag_ent *ent, uint32_t m, uint32_t *sorted)
 {
-    for (uint32_t i = 0; i < m; i++) { sorted[i] = i; left[i] = right[i] = -1; }
+    for (uint32_t i = 0; i < m; i++) sorted[i] = i;
     /* the device hands the distinct keys over in key order, which is strcmp order already for tags of one form and length
      * (UB, CB): one parallel pass finds that out, and 11.7 M strings are not sorted again */
     if (!strs_in_order(ent, m)) qsort_r(sorted, m, sizeof *sorted, cmp_ent_idx, (void *)ent);
+}
+static int32_t bst_shape(const tag_ent *ent, uint32_t m, uint32_t *sorted, int32_t *left, int32_t *right)
+{
+    sort_strings(ent, m, sorted);
+    for (uint32_t i = 0; i < m; i++) left[i] = right[i] = -1;
     /* Cartesian tree (min `first` on top) over the sorted sequence, with the usual right-spine stack */
     uint32_t *stack = (uint32_t *)malloc((m ? m : 1) * sizeof *stack);
     uint32_t top = 0;
@@ -98,15 +104,48 @@ static void bst_preorder(int32_t root, const int32_t *left, const int32_t *right
     free(stack);
 }
 
+/* The same pre-order without building the tree.  In the Cartesian tree over the strcmp-sorted sequence (smallest `first` on
+ * top) the subtree of position j is the open interval between the previous and the next position with a smaller `first`; a node
+ * outside that subtree is printed before j iff it lies to the left of it, or is an ancestor to the right of it, and those
+ * ancestors are exactly the chain of "next smaller" positions starting at j.  So
+ *     rank(j) = (previous smaller position + 1) + (length of j's next-smaller chain),
+ * two monotonic-stack sweeps over the sequence — sequential memory, no pointer chasing (11.7 M UB values: 0.07 s against 0.35 s
+ * for tree + walk).  sorted[] = the strcmp order (positions -> entries). */
+static int preorder_direct(const tag_ent *ent, uint32_t m, const uint32_t *sorted, uint32_t *order)
+{
+    if (!m) return 0;
+    uint64_t *f = (uint64_t *)malloc((size_t)m * sizeof *f);
+    uint32_t *pl1 = (uint32_t *)malloc((size_t)m * sizeof *pl1), *stack = (uint32_t *)malloc((size_t)m * sizeof *stack);
+    if (!f || !pl1 || !stack) { free(f); free(pl1); free(stack); return 1; }
+    for (uint32_t j = 0; j < m; j++) f[j] = ent[sorted[j]].first;
+    uint32_t top = 0;
+    for (uint32_t j = 0; j < m; j++) {                       /* previous smaller, from the left */
+        while (top && f[stack[top - 1]] > f[j]) top--;
+        pl1[j] = top ? stack[top - 1] + 1 : 0;
+        stack[top++] = j;
+    }
+    top = 0;
+    for (uint32_t j = m; j-- > 0;) {                         /* what is left on the stack IS the next-smaller chain of j */
+        while (top && f[stack[top - 1]] > f[j]) top--;
+        order[pl1[j] + top] = sorted[j];
+        stack[top++] = j;
+    }
+    free(f); free(pl1); free(stack);
+    return 0;
+}
+
 /* host-side tree order on its own (exported for the CPU test suite): order[] = pre-order of the insertion-order BST
  * of the m distinct strings whose first occurrences are first[] */
 void fastf_tag_tree_preorder(const char *const *strs, const uint64_t *first, uint32_t m, uint32_t *order)
 {
-    tag_ent *ent = (tag_ent *)malloc((m ? m : 1) * sizeof *ent);
+    if (!m) return;
+    tag_ent *ent = (tag_ent *)calloc(m, sizeof *ent);
     uint32_t *sorted = (uint32_t *)malloc((m ? m : 1) * sizeof *sorted);
     int32_t *left = (int32_t *)malloc((m ? m : 1) * sizeof *left), *right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
     for (uint32_t i = 0; i < m; i++) { ent[i].s = strs[i]; ent[i].first = first[i]; ent[i].count = 1; }
-    bst_preorder(bst_shape(ent, m, sorted, left, right), left, right, m, order);
+    const int32_t root = bst_shape(ent, m, sorted, left, right);
+    /* the direct ranks are what extract / crb print; should the sweep run out of memory, the tree walk gives the same order */
+    if (preorder_direct(ent, m, sorted, order)) bst_preorder(root, left, right, m, order);
     free(ent); free(sorted); free(left); free(right);
 }
 
@@ -123,8 +162,11 @@ static void tb_put(tbuf *b, const char *s, size_t n)
 static void tb_count(tbuf *b, uint64_t v, char after)     /* ",<count><after>" — "%s,%ld" filter.c:145,166 */
 {
     char t[32];
-    int n = snprintf(t, sizeof t, ",%llu%c", (unsigned long long)v, after);
-    tb_put(b, t, (size_t)n);
+    int i = (int)sizeof t;
+    t[--i] = after;
+    do { t[--i] = (char)('0' + v % 10); v /= 10; } while (v);
+    t[--i] = ',';
+    tb_put(b, t + i, sizeof t - (size_t)i);
 }
 
 /* "<string>,<count><after>" (print_tree, filter.c:139-148) for ent[order[0..m)], appended to out: every thread formats a slice
@@ -138,6 +180,9 @@ static void rows_worker(void *vp, int w)
     b->cap = (hi - lo) * 24 + 64; b->p = (char *)malloc(b->cap); b->len = 0;
     if (!b->p) { j->err = 1; b->cap = 0; return; }
     for (size_t k = lo; k < hi; k++) {
+        /* the rows come in tree order, i.e. from all over the entry table and the string pool: ask for them a few rows ahead */
+        if (k + 16 < hi) __builtin_prefetch(&j->ent[j->order[k + 16]]);
+        if (k + 8 < hi) __builtin_prefetch(j->ent[j->order[k + 8]].s);
         const tag_ent *e = &j->ent[j->order[k]];
         tb_put(b, e->s, strlen(e->s));
         tb_count(b, e->count, j->after);
@@ -319,13 +364,17 @@ int fastf_extract_text(const char *bam_file, const char *tag, int type, char **c
     if (!pool) { tag_run_free(&r); return 1; }
     tag_ent *ent = (tag_ent *)malloc((m ? m : 1) * sizeof *ent);
     uint32_t *sorted = (uint32_t *)malloc((m ? m : 1) * sizeof *sorted), *order = (uint32_t *)malloc((m ? m : 1) * sizeof *order);
-    int32_t *left = (int32_t *)malloc((m ? m : 1) * sizeof *left), *right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
+    int32_t *left = NULL, *right = NULL;
     for (size_t i = 0; i < m; i++) { ent[i].s = strs[i]; ent[i].first = r.res.first1[i]; ent[i].count = r.res.count1[i]; }
     tp0 = tnow();
-    int32_t root = bst_shape(ent, (uint32_t)m, sorted, left, right);
+    sort_strings(ent, (uint32_t)m, sorted);
     const double tp_shape = tnow() - tp0;
     tp0 = tnow();
-    bst_preorder(root, left, right, (uint32_t)m, order);
+    if (preorder_direct(ent, (uint32_t)m, sorted, order)) {          /* (out of memory for the sweep: the tree and its walk) */
+        left = (int32_t *)malloc((m ? m : 1) * sizeof *left); right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
+        bst_preorder(bst_shape(ent, (uint32_t)m, sorted, left, right), left, right, (uint32_t)m, order);
+    }
+    const double tp_ranks = tnow() - tp0;
     tbuf out = {0};
     tb_put(&out, "", 0);
     if (rows_text(ent, order, m, '\n', &out)) {
@@ -334,7 +383,7 @@ int fastf_extract_text(const char *bam_file, const char *tag, int type, char **c
         fastf_set_error_("out of memory (tag summary text)");
         return 1;
     }
-    if (tprof()) fprintf(stderr, "[tags] %zu distinct values: decode %.3f s, sort + tree shape %.3f s, pre-order + text %.3f s\n", m, tp_decode, tp_shape, tnow() - tp0);
+    if (tprof()) fprintf(stderr, "[tags] %zu distinct values: decode %.3f s, strcmp order %.3f s, pre-order ranks %.3f s, text %.3f s\n", m, tp_decode, tp_shape, tp_ranks, tnow() - tp0 - tp_ranks);
     if (!out.p) out.p = (char *)calloc(1, 1);
     *csv = out.p; *csv_len = out.len;
     if (n_records) *n_records = r.n_records;
@@ -452,10 +501,13 @@ int fastf_crb_text(const char *bam_file, char **txt, size_t *txt_len, uint64_t *
     const uint32_t m = (uint32_t)c.n_cb;
     const double tc0 = tnow();
     uint32_t *sorted = (uint32_t *)malloc((m ? m : 1) * sizeof *sorted), *order = (uint32_t *)malloc((m ? m : 1) * sizeof *order);
-    int32_t *left = (int32_t *)malloc((m ? m : 1) * sizeof *left), *right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
-    int32_t root = bst_shape(c.cb, m, sorted, left, right);
-    bst_preorder(root, left, right, m, order);
-    free(sorted); free(left); free(right);
+    sort_strings(c.cb, m, sorted);
+    if (preorder_direct(c.cb, m, sorted, order)) {
+        int32_t *left = (int32_t *)malloc((m ? m : 1) * sizeof *left), *right = (int32_t *)malloc((m ? m : 1) * sizeof *right);
+        bst_preorder(bst_shape(c.cb, m, sorted, left, right), left, right, m, order);
+        free(left); free(right);
+    }
+    free(sorted);
     /* one row per CB in that order (print_CB_node, extract.c:47-62): the CB, then its own CR tree in pre-order
      * (print_tree_same_row, filter.c:160-169).  The rows are independent: every thread formats a slice of them. */
     int nt = fastf_host_thread_count();

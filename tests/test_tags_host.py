@@ -89,10 +89,16 @@ def test_bam_tag_reader(tmp_path):
         _read_tags(path, b"TOOLONG", None, 0)
 
 
-@pytest.mark.parametrize("seed,m", [(1, 1), (2, 2), (3, 50), (4, 3000)])
-def test_tree_order_equals_insertion_order_bst(seed, m):
+@pytest.mark.parametrize("seed,m,shuffle", [(1, 1, False), (2, 2, False), (3, 50, False), (4, 3000, False), (5, 3000, True), (6, 70000, True),
+                                            (7, 70000, False)])
+def test_tree_order_equals_insertion_order_bst(seed, m, shuffle):
+    """the pre-order ranks computed without building the tree (two monotonic-stack sweeps over the strcmp order) against the
+    oracle's insert_tree / print_tree; entries handed over in strcmp order (the sort is skipped) and shuffled (it is not);
+    70 000 entries take the parallel order check"""
     rng = np.random.default_rng(seed)
-    strs = sorted(set(random_dna(rng, m, 6, b"ACGTN-1")))
+    strs = sorted(set(random_dna(rng, m, 9, b"ACGTN-1")))
+    if shuffle:
+        strs = [strs[i] for i in rng.permutation(len(strs))]
     m = len(strs)
     first = rng.permutation(10 * m)[:m].astype(np.uint64)                # distinct first-occurrence positions
     L = F.lib()
