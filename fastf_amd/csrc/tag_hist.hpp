@@ -68,6 +68,33 @@ __global__ __launch_bounds__(256) void th_first_index_kernel(const u64* __restri
 
 using namespace fastf;
 
+// the little of std::vector the result arrays need, without value-initialisation on resize
+template <typename T> struct RawVec {
+    T* p = nullptr; size_t n = 0, cap = 0;
+    RawVec() = default;
+    RawVec(const RawVec&) = delete; RawVec& operator=(const RawVec&) = delete;
+    ~RawVec() { free(p); }
+    void resize(size_t k) {
+        if (k > cap) { free(p); p = nullptr; cap = 0; p = (T*)malloc((k ? k : 1) * sizeof(T)); if (!p) throw std::bad_alloc(); cap = k; }
+        n = k;
+    }
+    void assign(size_t k, T v) { resize(k); for (size_t i = 0; i < k; ++i) p[i] = v; }
+    void clear() { n = 0; }
+    T* data() { return p; } const T* data() const { return p; }
+    T* begin() { return p; } T* end() { return p + n; }
+    T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+};
+// fn(lo, hi) over [0, n) on the host threads (results post-processing: widening 20 M counters is not a job for one thread)
+template <typename F> static void th_par_for(u64 n, F fn) {
+    unsigned T = n < (1u << 18) ? 1u : (unsigned)fastf_host_thread_count();
+    if (T > 32) T = 32;
+    if (T <= 1) { fn((u64)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([=] { fn(n * t / T, n * (t + 1) / T); });
+    fn((u64)0, n / T);
+    for (auto& x : th) x.join();
+}
+
 struct fastf_taghist {
     fastf_engine* ws = nullptr;          // workspace engine: streams + sort/reduce scratch
     int device = 0;
@@ -80,9 +107,10 @@ struct fastf_taghist {
     void* h_stage = nullptr; size_t h_stage_bytes = 0;      // pinned bounce buffer
     // device results
     DevBuf d_a, d_b, d_code, d_u1, d_c1, d_u2, d_c2, d_up, d_cp, d_first, d_small;
-    // host results
-    std::vector<u64> h_key1, h_count1, h_first1, h_pair_key2, h_pair_count, h_pair_first, h_u2, h_up;
-    std::vector<u32> h_pair_k1, h_tmp32;
+    // host results (RawVec: resize does not touch the memory — 20 M (CB, CR) pairs are 0.9 GB of arrays that a std::vector
+    // would fill with zeros before the copies from the device overwrite them)
+    RawVec<u64> h_key1, h_count1, h_first1, h_pair_key2, h_pair_count, h_pair_first, h_u2, h_up;
+    RawVec<u32> h_pair_k1, h_tmp32;
 };
 
 extern "C" int fastf_taghist_create(int device, fastf_taghist_t** out) FASTF_TRY {
@@ -243,9 +271,9 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
         h->h_key1.resize(m1); h->h_count1.resize(m1); h->h_first1.resize(m1); h->h_tmp32.resize(m1);
         HIP_OK(hipMemcpy(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_c1.p, m1 * sizeof(u32), hipMemcpyDeviceToHost));
-        for (u64 i = 0; i < m1; ++i) h->h_count1[i] = h->h_tmp32[i];
+        { u64* dst = h->h_count1.data(); const u32* src = h->h_tmp32.data(); th_par_for(m1, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
         HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_first.p, m1 * sizeof(u32), hipMemcpyDeviceToHost));
-        for (u64 i = 0; i < m1; ++i) h->h_first1[i] = h->h_tmp32[i];
+        { u64* dst = h->h_first1.data(); const u32* src = h->h_tmp32.data(); th_par_for(m1, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
         // the absent records were counted under the fill key
         const u64 n_absent = n - h->n_present1;
         if (n_absent) {
@@ -287,9 +315,9 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
     h->h_pair_count.resize(mp); h->h_pair_first.resize(mp); h->h_pair_k1.resize(mp); h->h_pair_key2.resize(mp);
     h->h_tmp32.resize(mp);
     HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_cp.p, mp * sizeof(u32), hipMemcpyDeviceToHost));
-    for (u64 i = 0; i < mp; ++i) h->h_pair_count[i] = h->h_tmp32[i];
+    { u64* dst = h->h_pair_count.data(); const u32* src = h->h_tmp32.data(); th_par_for(mp, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
     HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_first.p, mp * sizeof(u32), hipMemcpyDeviceToHost));
-    for (u64 i = 0; i < mp; ++i) h->h_pair_first[i] = h->h_tmp32[i];
+    { u64* dst = h->h_pair_first.data(); const u32* src = h->h_tmp32.data(); th_par_for(mp, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
     const u64 n_invalid = n - h->n_valid;
     if (n_invalid) {
         u64 fill = 0;
@@ -300,13 +328,26 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
     }
     // key1 values that never occur in a valid pair (their key2 was always absent) drop out of level 1
     h->h_count1.assign(m1, 0); h->h_first1.assign(m1, ~0ull);
-    for (u64 i = 0; i < mp; ++i) {
-        const u64 c = h->h_up[i];
-        const u32 a = (u32)(c >> 32) - 1, b = (u32)c;
-        if (a >= m1 || b >= m2) return set_err("tag histogram: pair code out of range");
-        h->h_pair_k1[i] = a; h->h_pair_key2[i] = h->h_u2[b];
-        h->h_count1[a] += h->h_pair_count[i];
-        h->h_first1[a] = std::min(h->h_first1[a], h->h_pair_first[i]);
+    {
+        // the pairs are sorted by code, i.e. grouped by key1: a slice starts where key1 changes, so that the level-1 sums of
+        // one CB are one thread's
+        const u64* up = h->h_up.data(); const u64* u2 = h->h_u2.data(); const u64 *pc = h->h_pair_count.data(), *pf = h->h_pair_first.data();
+        u32* pk1 = h->h_pair_k1.data(); u64 *pk2 = h->h_pair_key2.data(), *c1 = h->h_count1.data(), *f1 = h->h_first1.data();
+        int bad = 0; int* badp = &bad;
+        th_par_for(mp, [=](u64 lo, u64 hi) {
+            // both ends move forward to the next change of key1 (the same rule on either side of a boundary)
+            while (lo > 0 && lo < mp && (up[lo] >> 32) == (up[lo - 1] >> 32)) ++lo;
+            while (hi > 0 && hi < mp && (up[hi] >> 32) == (up[hi - 1] >> 32)) ++hi;
+            for (u64 i = lo; i < hi; ++i) {
+                const u64 c = up[i];
+                const u32 a = (u32)(c >> 32) - 1, b = (u32)c;
+                if (a >= m1 || b >= m2) { __atomic_store_n(badp, 1, __ATOMIC_RELAXED); return; }
+                pk1[i] = a; pk2[i] = u2[b];
+                c1[a] += pc[i];
+                f1[a] = std::min(f1[a], pf[i]);
+            }
+        });
+        if (bad) return set_err("tag histogram: pair code out of range");
     }
     r->key1 = (const uint64_t*)h->h_key1.data(); r->count1 = (const uint64_t*)h->h_count1.data(); r->first1 = (const uint64_t*)h->h_first1.data(); r->n1 = m1;
     r->pair_k1 = h->h_pair_k1.data(); r->pair_key2 = (const uint64_t*)h->h_pair_key2.data(); r->pair_count = (const uint64_t*)h->h_pair_count.data();
