@@ -187,6 +187,8 @@ GR_FN int64_t aux_int(const uint8_t* p) {
     }
 }
 
+// bam_aux2Z (htslib): 'Z' and 'H' values are NUL-terminated strings
+GR_FN bool aux_is_string(const uint8_t* p) { return *p == 'Z' || *p == 'H'; }
 GR_FN uint32_t zlen(const uint8_t* s) { uint32_t n = 0; while (s[n]) n++; return n; }      // (aux_skip has found the NUL)
 
 // host_io.c pack_worker + pack_record: the record whose block_size field is at p (a structurally valid record: rec_end)
@@ -212,12 +214,12 @@ GR_FN void pack_record(const uint8_t* p, const Dict& cells, const Dict& feats,
     }
     uint32_t m = 0;
     *cb_key = 0; *gx_key = 0; *umi = 0;
-    if (cb && *cb == 'Z') *cb_key = pack_key(cells, cb + 1, zlen(cb + 1));
+    if (cb && aux_is_string(cb)) *cb_key = pack_key(cells, cb + 1, zlen(cb + 1));
     if (xf) { const int64_t q = aux_int(xf); if (q == 25 || q == 17) m |= META_XF_OK_; }
     else if (*cb_key) (*no_xf)++;
-    if (gx && *gx == 'Z') *gx_key = pack_key(feats, gx + 1, zlen(gx + 1));
+    if (gx && aux_is_string(gx)) *gx_key = pack_key(feats, gx + 1, zlen(gx + 1));
     else if (!gx && (m & META_XF_OK_) && *cb_key) (*no_gx)++;
-    if (ub && *ub == 'Z') m |= pack_umi(ub + 1, zlen(ub + 1), umi);
+    if (ub && aux_is_string(ub)) m |= pack_umi(ub + 1, zlen(ub + 1), umi);
     *meta = m;
 }
 

@@ -1104,6 +1104,9 @@ static long aux_skip(const unsigned char *p, const unsigned char *end)
     }
 }
 
+/* bam_aux2Z (htslib): the value is a NUL-terminated string for the types 'Z' and 'H' (hex digits, handed back as text) */
+static inline int aux_is_string(const unsigned char *p) { return *p == 'Z' || *p == 'H'; }
+
 /* bam_aux2i (htslib): integer types convert, anything else yields 0 */
 static int64_t aux_int(const unsigned char *p)
 {
@@ -1137,20 +1140,21 @@ static void pack_record(const unsigned char *aux, const unsigned char *end,
     }
     uint32_t m = 0;
     *cb_key = 0; *gx_key = 0; *umi = 0;
-    /* bam_aux2Z returns NULL for a non-Z tag → hash_table_lookup(NULL) misses (hashtable.c:100) */
-    if (cb && *cb == 'Z') {
+    /* bam_aux2Z (htslib sam.c) hands back the bytes of a 'Z' AND of an 'H' value; for any other type it returns NULL →
+     * hash_table_lookup(NULL) misses (hashtable.c:100) */
+    if (cb && aux_is_string(cb)) {
         const char *s = (const char *)cb + 1;
         *cb_key = fastf_keydict_pack(cells, s, strlen(s));
     }
     if (xf) { int64_t q = aux_int(xf); if (q == 25 || q == 17) m |= FASTF_META_XF_OK; }
     else if (*cb_key) (*n_no_xf)++;               /* reference would dereference NULL if this record is kept */
-    if (gx && *gx == 'Z') {
+    if (gx && aux_is_string(gx)) {
         const char *s = (const char *)gx + 1;
         *gx_key = fastf_keydict_pack(feats, s, strlen(s));
     } else if (!gx && (m & FASTF_META_XF_OK) && *cb_key) (*n_no_gx)++;
     if (ub) {
-        if (*ub == 'Z') { const char *s = (const char *)ub + 1; m |= fastf_pack_umi(s, strlen(s), umi); }
-        /* a non-Z UB makes bam_aux2Z return NULL and encode_DNA(NULL) crash in the reference: treated as absent */
+        if (aux_is_string(ub)) { const char *s = (const char *)ub + 1; m |= fastf_pack_umi(s, strlen(s), umi); }
+        /* a UB that is neither Z nor H makes bam_aux2Z return NULL and encode_DNA(NULL) crash in the reference: treated as absent */
     }
     *meta = m;
 }
@@ -1438,7 +1442,7 @@ typedef struct {
 static uint64_t tag_key(const unsigned char *val, fastf_keydict_t *dict, int type, uint64_t *undef)
 {
     if (type == 1) return (1ull << 32) | (uint32_t)(int32_t)aux_int(val);
-    if (*val != 'Z') { (*undef)++; return 0; }
+    if (!aux_is_string(val)) { (*undef)++; return 0; }
     const char *s = (const char *)val + 1;
     return fastf_keydict_intern(dict, s, strlen(s));
 }

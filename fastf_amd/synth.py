@@ -163,8 +163,9 @@ def bam_record(name: bytes, aux: bytes, seq_len: int = 0, n_cigar: int = 0, ref_
     return struct.pack("<i", len(body)) + body
 
 
-def aux_Z(tag: bytes, val: bytes) -> bytes:
-    return tag + b"Z" + val + b"\0"
+def aux_Z(tag: bytes, val: bytes, typ: bytes = b"Z") -> bytes:
+    """string value; typ b"H" writes the same bytes under the hex-string type (htslib's bam_aux2Z accepts both)"""
+    return tag + typ + val + b"\0"
 
 
 def aux_int(tag: bytes, val: int, typ: bytes = b"C") -> bytes:
@@ -173,9 +174,10 @@ def aux_int(tag: bytes, val: int, typ: bytes = b"C") -> bytes:
 
 
 def write_bam(path: str, flags, xf, cb, gx, ub, xf_type: bytes = b"C", extra_aux=None, header_text: bytes = b"@HD\tVN:1.6\n",
-              refs=(("chr1", 1000),), shape=None):
+              refs=(("chr1", 1000),), shape=None, str_type=None):
     """records → BGZF BAM file.  extra_aux(i) may return bytes inserted BEFORE the tags of record i;
-    shape(i) may return (seq_len, n_cigar, ref_id, pos) for a mapped-read layout."""
+    shape(i) may return (seq_len, n_cigar, ref_id, pos) for a mapped-read layout; str_type(i) may return the type
+    byte (b"Z" / b"H") of record i's CB, GX and UB values."""
     out = bytearray()
     payload = bytearray(b"BAM\1" + struct.pack("<i", len(header_text)) + header_text + struct.pack("<i", len(refs)))
     for nm, ln in refs:
@@ -194,14 +196,15 @@ def write_bam(path: str, flags, xf, cb, gx, ub, xf_type: bytes = b"C", extra_aux
         if extra_aux is not None:
             aux += extra_aux(i)
         f = int(flags[i])
+        st = str_type(i) if str_type is not None else b"Z"
         if f & HAS_CB:
-            aux += aux_Z(b"CB", cbl[i])
+            aux += aux_Z(b"CB", cbl[i], st)
         if f & HAS_XF:
             aux += aux_int(b"xf", int(xf[i]), xf_type)
         if f & HAS_GX:
-            aux += aux_Z(b"GX", gxl[i])
+            aux += aux_Z(b"GX", gxl[i], st)
         if f & HAS_UB:
-            aux += aux_Z(b"UB", ubl[i])
+            aux += aux_Z(b"UB", ubl[i], st)
         payload += bam_record(b"r%d" % i, bytes(aux), *(shape(i) if shape is not None else ()))
         if len(payload) >= 0xff00:
             flush()

@@ -106,6 +106,20 @@ def test_bam_non_integer_xf_and_non_string_cb(tmp_path):
     assert cb[2] != 0 and (me[2] & 1)
 
 
+def test_hex_typed_strings_read_like_Z(tmp_path):
+    """htslib's bam_aux2Z hands back the bytes of an 'H' value exactly as of a 'Z' value (sam.c: `type == 'Z' || type ==
+    'H'`), so the reference looks such a CB / GX up and encodes such a UB (bam2db_ds.c:366,403,412): same packed records"""
+    case = Case(n=20000, n_bar=300, n_gene=120, umi_pool=128, p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.2,
+                p_n_umi=0.02, p_multi_gene=0.05, p_no_ub=0.03)
+    lists = case.lists()
+    bam = tmp_path / "t.bam"
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, str_type=lambda i: b"H" if i % 3 else b"Z")
+    assert b"CBH" in __import__("gzip").decompress(bam.read_bytes())
+    got = read_all(bam, lists, cap=7001)
+    for g, w in zip(got, case.packed(lists)):
+        np.testing.assert_array_equal(g, w)
+
+
 def test_bam_truncated_and_garbage(tmp_path):
     L = _lib.lib()
     p = tmp_path / "g.bam"

@@ -56,7 +56,10 @@ def read_all_dev(path, lists, cap=1000, threads=0, gpu=2):
 
 def check(path, lists, want, monkeypatch, window, cap=50_000, expect_dev=True, threads=0):
     monkeypatch.setenv("FASTF_BAM_WINDOW", str(window))
-    monkeypatch.setenv("FASTF_BAM_PROFILE", "2")
+    if os.environ.get("FASTF_TEST_TRACE"):                           # per-window reader trace: thousands of lines at small windows
+        monkeypatch.setenv("FASTF_BAM_PROFILE", "2")
+    else:
+        monkeypatch.delenv("FASTF_BAM_PROFILE", raising=False)
     *got, n_dev = read_all_dev(path, lists, cap=cap, threads=threads)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
@@ -66,7 +69,7 @@ def check(path, lists, want, monkeypatch, window, cap=50_000, expect_dev=True, t
 
 
 @pytest.mark.parametrize("window", [1 << 17, 1 << 20, 1 << 22, 128 << 20])
-@pytest.mark.parametrize("xf_type", [b"C", b"i"])
+@pytest.mark.parametrize("xf_type", [b"C", b"i", b"H"])          # b"H": xf 'C', every third record's strings of type 'Z', the others 'H'
 def test_device_parse_gives_the_host_readers_records(tmp_path, monkeypatch, window, xf_type):
     case = Case(n=150_000, n_bar=300, n_gene=120, umi_pool=128, p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.2, p_n_umi=0.02,
                 p_multi_gene=0.05, p_no_ub=0.03)
@@ -74,7 +77,8 @@ def test_device_parse_gives_the_host_readers_records(tmp_path, monkeypatch, wind
     bam = tmp_path / "t.bam"
     shape = lambda i: ((28 + 7 * (i % 19)) if i % 11 else 0, i % 4, (i % 2) - 1, 1000 + i)
     extra = lambda i: (b"NHC\x01" if i % 3 == 0 else b"") + (b"ZBBS\x02\x00\x00\x00\x01\x00\x02\x00" if i % 7 == 0 else b"") + (b"RGZgrp\x00" if i % 5 == 0 else b"")
-    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, xf_type=xf_type, shape=shape, extra_aux=extra)
+    synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, xf_type=b"C" if xf_type == b"H" else xf_type, shape=shape,
+                    extra_aux=extra, str_type=(lambda i: b"H" if i % 3 else b"Z") if xf_type == b"H" else None)
     # (the device parse is switched on after the reader is open: with windows as large as the file everything has been
     # prefetched for the host parser by then — still the same records)
     check(bam, lists, case.packed(lists), monkeypatch, window, cap=50_000 if window > (1 << 17) else 7001, expect_dev=window <= (1 << 20))

@@ -60,17 +60,20 @@ def inflated_records(path):
     return raw, o, n_ref
 
 
+@pytest.mark.parametrize("str_type", [None, lambda i: b"H" if i % 3 else b"Z"], ids=["Z", "H_and_Z"])
 @pytest.mark.parametrize("xf_type,shape", [(b"C", None), (b"i", lambda i: ((28 + 7 * (i % 19)) if i % 11 else 0, i % 4, (i % 3) - 1, 1000 + i)),
                                            (b"s", None)])
-def test_chain_and_pack_equal_the_host_reader(gr, tmp_path, xf_type, shape):
+def test_chain_and_pack_equal_the_host_reader(gr, tmp_path, xf_type, shape, str_type):
     case = Case(n=20000, n_bar=300, n_gene=120, umi_pool=128, p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.2,
                 p_n_umi=0.02, p_multi_gene=0.05, p_no_ub=0.03)
     lists = case.lists()
     bam = tmp_path / "t.bam"
     extra = lambda i: (b"NHC\x01" if i % 3 == 0 else b"") + (b"ZBBS\x02\x00\x00\x00\x01\x00\x02\x00" if i % 7 == 0 else b"") + (b"RGZgrp\x00" if i % 5 == 0 else b"")
     synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, xf_type=xf_type, extra_aux=extra, refs=(("chr1", 100000), ("chr2", 100000)),
-                    **({"shape": shape} if shape else {}))
+                    str_type=str_type, **({"shape": shape} if shape else {}))
     want = read_all(bam, lists, cap=7001)
+    for w_, d_ in zip(want, case.packed(lists)):                    # (and the host reader itself against direct packing)
+        np.testing.assert_array_equal(w_, d_)
     raw, start, n_ref = inflated_records(bam)
     vc, vf = views(lists)
     n = case.n
