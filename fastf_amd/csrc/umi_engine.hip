@@ -887,6 +887,7 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream, (flags & FASTF_SORT_SEGMENTED) != 0);
 } FASTF_CATCH_INT
 
+static bool k3_old_hash() { static int v = -1; if (v < 0) v = getenv("FASTF_K3_OLD_HASH") != nullptr; return v != 0; }   // A/B: round 3's hash mode
 // K3 grid: every workgroup owns one contiguous chunk of the keys, so the launch is one round of resident workgroups
 // (LDS: 21 KB per workgroup, 37 KB with the hash set of DEDUP 2; 64 VGPRs: eight waves per SIMD, four workgroups per CU)
 static u32 k3_grid(u64 max_n, int dedup) {
@@ -906,13 +907,14 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     e->rg_n = 0;
     if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
     const int dedup = (UMI_ROWS || low_skip == 0) ? 0 : (e->dedup_hash ? 2 : 1);
-    const u32 G = k3_grid(max_n, dedup);
+    u32 G = k3_grid(max_n, dedup);
+    if (dedup == 2 && e->L.feat_shift > 27 && !k3_old_hash()) G = std::min<u32>(G, 3 * g_cu_count);      // 52 KB of LDS per workgroup: three per CU
     if (e->d_rg_count.ensure(max_n * 4)) return 1;
     if (UMI_ROWS ? e->d_rg_ukeys.ensure(max_n * 8) : (e->d_rg_feature.ensure(max_n * 4) || e->d_rg_cell.ensure(max_n * 4))) return 1;
     if (e->d_spanrows.ensure(4096 * sizeof(u32)) || e->d_spanbase.ensure(4097 * sizeof(u64))) return 1;
     if (dedup == 2 && !e->d_giant.p) {                  // work items of groups longer than a window + their counter (live, frozen)
         if (e->d_giant.ensure((size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64) + 64)) return 1;
-        HIP_OK(hipMemsetAsync((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64), 0, 64, s));
+        HIP_OK(hipMemsetAsync(e->d_giant.p, 0, e->d_giant.bytes, s));       // the list too: no slot of it is ever read unwritten
     }
     u32* const giant_n = dedup == 2 ? (u32*)((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64)) : nullptr;
     ReduceParams p{};
@@ -926,7 +928,9 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 1) hipLaunchKernelGGL((reduce_windows_kernel<false, 1>), dim3(G), dim3(K3_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((reduce_windows_kernel<false, 2>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else if (k3_old_hash()) hipLaunchKernelGGL((reduce_windows_kernel<false, 2>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else if (e->L.feat_shift > 27) hipLaunchKernelGGL((reduce_hashed_kernel<true>), dim3(G), dim3(K3H_THREADS), 0, s, p);    // UMIs beyond 12 bases: 64-bit slots
+    else hipLaunchKernelGGL((reduce_hashed_kernel<false>), dim3(G), dim3(K3H_THREADS), 0, s, p);
     hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows, giant_n);
     if (dedup == 2)
         hipLaunchKernelGGL(giant_groups_kernel, dim3(g_cu_count), dim3(512), 0, s, sorted, (const u64*)e->d_giant.p, (const u32*)(giant_n + 1), e->L,

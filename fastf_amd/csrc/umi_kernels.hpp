@@ -23,6 +23,7 @@
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fastf {
 
@@ -1803,12 +1804,322 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
     if (tid == 0) p.span_rows[b] = rows_so_far;
 }
 
+// ------------------------------------------------------------------------------------
+// K3h: the matrix rows from keys sorted on (cell, feature) ONLY — reduce_hashed_kernel.
+// Same chunks, windows and row regions as reduce_windows_kernel (a window starts at a group head and is cut at one, so
+// no group straddles windows or chunks), rebuilt around what the PMC counters of round 3 said about the hash mode of that
+// kernel: it was bound by instruction issue (134 scalar + 110 vector + 20 LDS instructions per 64 keys, five barriers per
+// window), not by bytes.  Here
+//   * a wave owns 256 CONSECUTIVE keys of the window: the neighbour in front comes over DPP (wave_shr:1), the key in front
+//     of the wave from one extra load — the keys are never staged in LDS;
+//   * a key's group is named by its ROW RANK r inside the window (heads in front of it: two mbcnt), which is also where
+//     its count goes;
+//   * the window-local set is EXACT in one 32-bit word per slot: x = the key bits below feat_shift (NULL flag, UMI,
+//     length; at most 27 bits) splits into lo (12 bits) and hi; slot = (lo ^ f(hi) ^ g(r)) + i * step(hi) and the slot
+//     holds (hi, r, i + 1): two keys that meet in a slot with the same word have the same r, hi, i and home slot, hence
+//     the same lo — the same key of the same group.  One compare-and-swap per probe: 0 back = first occurrence, the own
+//     word back = duplicate, anything else = another key, next slot.  No second read, no 64-bit multiply.
+//     (UMIs beyond 12 bases: 64-bit slots holding (r, x) whole — SLOT64.)
+//   * counts: D = distinct keys of the unit in front of a lane (mbcnt).  A head lane adds +D to the row in front of its
+//     own and -D to its own, the unit adds its total to its last row: every row ends up with D(next head) - D(own head),
+//     across units and waves, through LDS atomics on 16-bit halves (sums are exact modulo 2^32, counts < 2^16);
+//   * two barriers per window (heads published / rows complete), both waiting for LDS traffic only.
+// Groups longer than a window go to giant_groups_kernel as before.
+// ------------------------------------------------------------------------------------
+constexpr int K3H_THREADS = 512, K3H_WAVES = K3H_THREADS / WAVE, K3H_IPT = 4, K3H_TILE = K3H_THREADS * K3H_IPT, K3H_UNITS = K3H_TILE / WAVE;
+constexpr u32 K3H_TAB = 4096, K3H_WAVE_KEYS = K3H_IPT * WAVE;
+static_assert(K3H_TILE == K3_TILE, "same chunk geometry as reduce_windows_kernel (k3_chunk_start, rows_gather_kernel)");
+static_assert(K3H_UNITS == 32 && K3H_TILE <= 2048, "32 head ballots per window; row ranks fit 11 bits");
+
+__device__ __forceinline__ u32 dpp_wave_shr1(u32 lane0, u32 x) {          // lane l gets x of lane l - 1, lane 0 gets lane0
+    return (u32)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ u64 readlane64(u64 v, u32 l) {                 // l wave-uniform
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), (int)l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)v, (int)l);
+}
+// inclusive sum over each row of 16 lanes (DPP row shifts); lanes 15 and 31 hold the totals of rows 0 and 1
+__device__ __forceinline__ u32 row16_incl_sum(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    return x;
+}
+// two 16-bit row counts per word; v may be negative (see above)
+__device__ __forceinline__ void k3h_add(u32* cnt, u32 row, u32 v) {
+    (void)__hip_atomic_fetch_add(&cnt[row >> 1], v << ((row & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool SLOT64>
+__global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_kernel(const ReduceParams p) {
+    typedef typename std::conditional<SLOT64, u64, u32>::type slot_t;
+    __shared__ u64 s_hb[K3H_UNITS];        // head ballots of the 32 units of the window
+    __shared__ u32 s_cnt[K3H_TILE / 2];    // distinct counts by row, two per word; all-zero between windows
+    __shared__ u32 s_feat[K3H_TILE], s_cell[K3H_TILE];   // row identities
+    __shared__ slot_t s_tab[K3H_TAB];      // the set; all-zero between windows
+    __shared__ u32 s_first;
+    __shared__ u64 s_g0;
+
+    const int tid = threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u64 n = *p.n_ptr;
+    const u32 gshift = p.L.feat_shift, nn_shift = p.L.umi_bits + p.L.len_bits;
+    const u32 G = gridDim.x, b = blockIdx.x;
+    const u64 nom_start = k3_chunk_start(n, b, G), nom_end = k3_chunk_start(n, b + 1, G);
+    for (u32 i = tid; i < K3H_TAB; i += K3H_THREADS) s_tab[i] = 0;
+    for (u32 i = tid; i < K3H_TILE / 2; i += K3H_THREADS) s_cnt[i] = 0;
+
+    // ---- chunk start: the first head at or after the nominal start (a group that began earlier belongs to the chunk before) ----
+    u64 cursor = nom_start;
+    if (b > 0 && nom_start < nom_end) {
+        for (;;) {
+            if (tid == 0) s_first = ~0u;
+            __syncthreads();
+            const u64 idx = cursor + tid;
+            bool head = false;
+            if (idx < nom_end) head = (p.keys[idx] >> gshift) != (p.keys[idx - 1] >> gshift);
+            const u64 m = __ballot(head);
+            if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            const u32 f = __builtin_amdgcn_readfirstlane(s_first);
+            __syncthreads();
+            if (f != ~0u) { cursor += f; break; }
+            cursor += K3H_THREADS;
+            if (cursor >= nom_end) break;
+        }
+    }
+    __syncthreads();                                                       // the cleared arrays
+    if (cursor >= nom_end) { if (tid == 0) p.span_rows[b] = 0; return; }   // no group starts in this chunk (or it is empty)
+    cursor = uniform64(cursor);
+
+    const u64 region = nom_start;          // rows of this chunk go to the slots of its own keys
+    const u32 pbase = (u32)w * K3H_WAVE_KEYS;                              // first window position of this wave
+    u32 rows_so_far = 0;
+    bool done = false;
+    // keys of the window about to be processed (lane l of nkey[j]: position pbase + 64 j + l) and the key in front of the wave
+    u64 nkey[K3H_IPT], npk = 0;
+    auto request = [&](const u64 at) {
+        const u32 Wn = (u32)(n - at < (u64)K3H_TILE ? n - at : (u64)K3H_TILE);
+#pragma unroll
+        for (int j = 0; j < K3H_IPT; ++j) {
+            const u32 pos = pbase + (u32)j * WAVE + (u32)lane;
+            nkey[j] = pos < Wn ? ld_once<FASTF_NT_K3 != 0>(p.keys + at + pos) : 0;
+        }
+        // the key in front of the wave: the same address in every lane, but asked for as a VECTOR load (an opaque zero in the
+        // address) — a scalar load counts on lgkmcnt, and the LDS-only barriers below would wait for its memory round trip
+        u32 z = 0;
+        asm volatile("" : "+v"(z));
+        npk = (w > 0 && pbase < Wn) ? p.keys[at + pbase - 1 + z] : 0;
+    };
+    request(cursor);
+    while (!done) {
+        const u64 base = cursor;
+        const u32 W = (u32)(n - base < (u64)K3H_TILE ? n - base : (u64)K3H_TILE);
+        u64 key[K3H_IPT];
+        u32 fl = 0;                                                        // per lane: bit j = key j is a head, bit 4 + j = it equals its neighbour in front
+        // ---- heads (and copies of the neighbour in front) from registers ----
+        {
+            u64 carry = uniform64(npk);
+#pragma unroll
+            for (int j = 0; j < K3H_IPT; ++j) {
+                const u32 pos = pbase + (u32)j * WAVE + (u32)lane;
+                const u64 k = key[j] = nkey[j];
+                const u64 prev = ((u64)dpp_wave_shr1((u32)(carry >> 32), (u32)(k >> 32)) << 32) | dpp_wave_shr1((u32)carry, (u32)k);
+                const bool valid = pos < W;
+                const bool head = valid && (pos == 0 || (k >> gshift) != (prev >> gshift));   // position 0 is a head by construction
+                const u64 hmj = __ballot(head);
+                if (lane == 0) s_hb[w * K3H_IPT + j] = hmj;
+                fl |= (head ? 1u : 0u) << j;
+                fl |= (valid && !head && k == prev ? 16u : 0u) << j;
+                carry = readlane64(k, 63);
+            }
+        }
+        k3_barrier();
+        // ---- the cut, the row ranks in front of this wave, the rows of the window: every wave from the 32 ballots ----
+        //   stop: the first head at or beyond the chunk's nominal end — it and everything after it belong to the next chunk
+        //   else, at the end of the data, the whole window; else the last head of the window (its group is left to the
+        //   next window); else one group fills the window: giant_groups_kernel counts it
+        u32 cut; bool giant = false;
+        u32 R0, n_rows;
+        {
+            const u64 hb = lane < K3H_UNITS ? s_hb[lane] : 0ull;
+            const u32 lim = nom_end > base ? (u32)(nom_end - base < (u64)K3H_TILE ? nom_end - base : (u64)K3H_TILE) : 0u;
+            const u32 ub = (u32)lane * WAVE;
+            u64 at_or_after = hb;
+            if (lim > ub) at_or_after = lim - ub >= 64 ? 0ull : hb & ~((1ull << (lim - ub)) - 1);
+            const u64 not_first = lane == 0 ? hb & ~1ull : hb;
+            const u64 m_stop = __ballot(at_or_after != 0), m_last = __ballot(not_first != 0);
+            if (m_stop) { const u32 fu = (u32)__builtin_ctzll(m_stop); cut = fu * WAVE + (u32)__builtin_ctzll(readlane64(at_or_after, fu)); done = true; }
+            else if (base + W == n) { cut = W; done = true; }
+            else if (m_last) { const u32 lu = 63u - (u32)__builtin_clzll(m_last); cut = lu * WAVE + 63u - (u32)__builtin_clzll(readlane64(not_first, lu)); }
+            else { cut = W; giant = true; }
+            // heads below the cut, per unit; low half: all of them (rows of the window), high half: those in front of this wave
+            const u64 below = cut <= ub ? 0ull : (cut - ub >= 64 ? ~0ull : (1ull << (cut - ub)) - 1);
+            const u32 c = (u32)__popcll(hb & below);
+            const u32 sc = row16_incl_sum(c | (lane < w * K3H_IPT ? c << 16 : 0u));
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)sc, 15) + (u32)__builtin_amdgcn_readlane((int)sc, 31);
+            n_rows = tot & 0xFFFFu; R0 = tot >> 16;
+        }
+        if (giant) {
+            // One group fills the window (and the window starts at its head).  Its row goes out with a count of zero, the next
+            // head is looked for, and giant_groups_kernel counts the group's distinct keys — one work item per hash partition,
+            // added up with atomics on that row's count.
+            if (tid == 0) s_g0 = key[0];
+            u64 pos = base + W;
+            u32 found = ~0u;
+            for (;;) {
+                if (tid == 0) s_first = ~0u;
+                __syncthreads();
+                const u64 g0 = s_g0 >> gshift;
+                const u64 idx = pos + tid;
+                const bool h = idx < n && (p.keys[idx] >> gshift) != g0;
+                const u64 m = __ballot(h);
+                if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __syncthreads();
+                found = __builtin_amdgcn_readfirstlane(s_first);
+                __syncthreads();
+                if (found != ~0u || pos + K3H_THREADS >= n) break;
+                pos += K3H_THREADS;
+            }
+            const u64 next = uniform64(found != ~0u ? pos + found : n);
+            const u64 len = next - base;
+            const u32 parts = (u32)((len + GIANT_PART - 1) / GIANT_PART);
+            const u64 row = region + rows_so_far;
+            if (tid == 0) {
+                const u64 k0 = s_g0;
+                p.count[row] = 0; p.feature[row] = (u32)(k0 >> p.L.feat_shift) & p.feat_mask; p.cell[row] = (u32)(k0 >> p.L.cell_shift);
+            }
+            if (len > GIANT_MAX) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
+            else {
+                if (tid == 0) s_first = atomicAdd(p.giant_n, parts);
+                __syncthreads();
+                const u32 at = __builtin_amdgcn_readfirstlane(s_first);
+                if (at + parts > GIANT_LIST_CAP) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
+                else if ((u32)tid < parts) {
+                    u64* it = p.giant_list + (u64)(at + tid) * GIANT_ITEM_WORDS;
+                    it[0] = base; it[1] = len; it[2] = row; it[3] = (u64)tid | ((u64)parts << 32);
+                }
+                __syncthreads();                                           // s_first is reused by the next search
+            }
+            rows_so_far += 1;
+            cursor = next;
+            done = cursor >= nom_end || cursor >= n;
+            if (!done) request(cursor);
+            continue;
+        }
+        // the next window starts at the cut: request its keys now
+        if (!done) request(base + cut);
+        // ---- the set, the counts, the row identities ----
+        // per unit j: sl[j] = the slot being tried, in the end the slot this key holds (~0: none); st bit j = the key counts as
+        // distinct, bit 4 + j = it still has to be looked up
+        u32 sl[K3H_IPT], row[K3H_IPT], st = 0;
+        {
+            u32 stp[K3H_IPT]; slot_t wd[K3H_IPT], od[K3H_IPT];
+            u32 Ru = R0;
+#pragma unroll
+            for (int j = 0; j < K3H_IPT; ++j) {
+                const u32 pos = pbase + (u32)j * WAVE + (u32)lane;
+                const bool valid = pos < cut;
+                const bool is_head = valid && ((fl >> j) & 1u);
+                const u64 h = __ballot(is_head);
+                const bool single = __builtin_amdgcn_inverse_ballot_w64(h & (h >> 1));      // a head whose neighbour behind is a head too
+                const u64 k = key[j];
+                const u32 r = Ru + rank_below(h) + (is_head ? 1u : 0u) - 1u;                 // row of the key's group (lanes in front of
+                row[j] = r;                                                                  // the unit's first head: the row before)
+                const bool dist = valid && ((k >> nn_shift) & 1) && !((fl >> (4 + j)) & 1u);
+                const bool probe = dist && !single;
+                st |= (dist ? 1u : 0u) << j; st |= (probe ? 16u : 0u) << j;
+                if constexpr (SLOT64) {
+                    const u64 x = k & ((1ull << gshift) - 1);
+                    u32 hh = (u32)x * 0x9E3779B1u + (u32)(x >> 32) * 0x85EBCA77u + r * 0xC2B2AE3Du;
+                    hh ^= hh >> 15;
+                    sl[j] = hh & (K3H_TAB - 1); stp[j] = ((hh >> 20) & 62u) | 1u;
+                    wd[j] = (1ull << 63) | ((u64)r << 40) | x;
+                } else {
+                    const u32 x = (u32)k & ((1u << gshift) - 1u);          // key bits below the group: NULL flag, UMI, length
+                    const u32 hi = x >> 12, f = __umul24(hi, 0x9E3779u);
+                    sl[j] = (x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (K3H_TAB - 1);
+                    stp[j] = ((f >> 20) & 62u) | 1u;                       // odd: the walk visits every slot
+                    wd[j] = hi | (r << 15) | (1u << 26);
+                }
+                Ru += (u32)__popcll(h);
+            }
+            // first probes of the four units back to back (one LDS round trip for all of them) ...
+#pragma unroll
+            for (int j = 0; j < K3H_IPT; ++j) {
+                od[j] = 0;
+                if ((st >> (4 + j)) & 1u) (void)__hip_atomic_compare_exchange_strong(&s_tab[sl[j]], &od[j], wd[j], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // ... then whoever met another key walks on: 0 back = first occurrence (the slot is this key's until the window
+            // ends), the own word back = seen before, anything else = another key
+            u32 overflow = 0;
+#pragma unroll
+            for (int j = 0; j < K3H_IPT; ++j) {
+                bool go = ((st >> (4 + j)) & 1u) && od[j] != 0 && od[j] != wd[j];
+                u32 tries = 1;
+#pragma nounroll
+                while (go) {
+                    sl[j] = (sl[j] + stp[j]) & (K3H_TAB - 1);
+                    if constexpr (!SLOT64) wd[j] += 1u << 26;
+                    od[j] = 0;
+                    (void)__hip_atomic_compare_exchange_strong(&s_tab[sl[j]], &od[j], wd[j], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    go = od[j] != 0 && od[j] != wd[j] && ++tries < 63;
+                }
+                const bool tried = (st >> (4 + j)) & 1u;
+                const bool mine = tried && od[j] == 0, seen = tried && od[j] == wd[j];
+                if (seen) st &= ~(1u << j);
+                if (tried && !mine && !seen) overflow = 1;                 // (a table this crowded is not this path's kind of data)
+                if (!mine) sl[j] = ~0u;
+            }
+            if (__any(overflow) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
+            Ru = R0;
+#pragma unroll
+            for (int j = 0; j < K3H_IPT; ++j) {
+                const u32 pos = pbase + (u32)j * WAVE + (u32)lane;
+                const bool is_head = pos < cut && ((fl >> j) & 1u);
+                const u64 h = __ballot(is_head);
+                const u64 dmj = __ballot((st >> j) & 1u);
+                const u32 D = rank_below(dmj);
+                const u32 r = row[j];
+                if (is_head) {
+                    if (D) { k3h_add(s_cnt, r - 1u, D); k3h_add(s_cnt, r, 0u - D); }
+                    s_feat[r] = (u32)(key[j] >> p.L.feat_shift) & p.feat_mask;
+                    s_cell[r] = (u32)(key[j] >> p.L.cell_shift);
+                }
+                const u32 heads = (u32)__popcll(h), tot = (u32)__popcll(dmj);
+                if (lane == 0 && tot) k3h_add(s_cnt, Ru + heads - 1u, tot);  // (Ru + heads >= 1: position 0 of the window is a head)
+                Ru += heads;
+            }
+        }
+        k3_barrier();
+        // ---- rows out (coalesced), the set and the counts back to all-zero ----
+#pragma unroll
+        for (int j = 0; j < K3H_IPT; ++j) if (sl[j] != ~0u) s_tab[sl[j]] = 0;
+        {
+            const u64 row_base = region + rows_so_far;
+            for (u32 r = tid; r < n_rows; r += K3H_THREADS) {
+                const u32 wd = s_cnt[r >> 1];
+                p.count[row_base + r] = (wd >> ((r & 1u) * 16u)) & 0xFFFFu;
+                p.feature[row_base + r] = s_feat[r]; p.cell[row_base + r] = s_cell[r];
+                // rows 2m and 2m + 1 are read by neighbouring lanes of one instruction; the even one clears the word behind it
+                if (!(r & 1u)) s_cnt[r >> 1] = 0;
+            }
+        }
+        rows_so_far += n_rows;
+        cursor = base + cut;
+        // (no barrier here: the next window's first LDS writes are its head ballots, last read before the barrier above; its
+        //  atomics and probes come after its own first barrier, which every wave reaches after the stores and clears above)
+    }
+    if (tid == 0) p.span_rows[b] = rows_so_far;
+}
+
 // distinct non-NULL keys of one hash partition of a group longer than a window (work items left by DEDUP 2)
 __global__ __launch_bounds__(512) void giant_groups_kernel(const u64* __restrict__ keys, const u64* __restrict__ list, const u32* __restrict__ n_items,
                                                            KeyLayout L, u32* __restrict__ count, u64* __restrict__ err) {
     __shared__ u64 s_set[GIANT_TAB];
     __shared__ u32 s_cnt;
-    const u32 items = *n_items < GIANT_LIST_CAP ? *n_items : GIANT_LIST_CAP;
+    // more items than the list holds: a group that straddled the end of the list left its slots unwritten, and the caller
+    // sorts fully and reduces again anyway (ERR_RUN_TOO_LONG is up) — walk nothing
+    const u32 items = *n_items <= GIANT_LIST_CAP ? *n_items : 0u;
     const u32 nn_shift = L.umi_bits + L.len_bits;
     for (u32 g = blockIdx.x; g < items; g += gridDim.x) {
         const u64* it = list + (u64)g * GIANT_ITEM_WORDS;

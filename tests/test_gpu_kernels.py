@@ -90,18 +90,18 @@ def test_dev_reduce_matches_numpy(env, n, n_groups, seed):
     assert eng.dev_error_bits() == 0
 
 
-@pytest.mark.parametrize("mode", ["hash", "walk"])
+@pytest.mark.parametrize("mode", ["hash", "old_hash"])
 @pytest.mark.parametrize("n,n_groups,low_values,seed", [(200_000, 50_000, 1 << 16, 1), (120_000, 3, 1 << 16, 2),
                                                         (60_000, 1, 5000, 3), (300_000, 200_000, 4, 4), (150_000, 2, 1 << 20, 5)])
 def test_group_only_sort_plus_dedup_in_reduce(mode, n, n_groups, low_values, seed, monkeypatch):
-    """FASTF_SORT_SKIP_LOW: only the high digits are sorted; equal keys are neighbours of their group (hash mode) or of
-    their run (walk mode) but unordered.  The reduce kernel must still count distinct non-NULL keys per (cell, feature)
-    exactly — including groups far longer than a window (hash: counted by giant_groups_kernel up to 65 536 keys) and long
-    runs (walk: thousands of distinct low parts sharing the sorted prefix), and heavy duplication.  What neither can
-    hold raises ERR_RUN_TOO_LONG: sort fully, reduce again."""
+    """FASTF_SORT_SKIP_LOW: only (cell, feature) is sorted; equal keys are neighbours of their group but unordered.  The
+    reduce kernel must still count distinct non-NULL keys per (cell, feature) exactly — including groups far longer than
+    a window (counted by giant_groups_kernel up to 65 536 keys) and heavy duplication.  What it cannot hold raises
+    ERR_RUN_TOO_LONG: sort fully, reduce again.  (old_hash: round 3's reduce_windows_kernel<false, 2>, kept for A/B runs.)"""
     import torch
     import fastf_amd as F
-    monkeypatch.setenv("FASTF_K3_DEDUP", mode)
+    if mode == "old_hash":
+        monkeypatch.setenv("FASTF_K3_OLD_HASH", "1")
     cells = np.arange(1, 1001, dtype=np.uint64) | (np.uint64(1) << np.uint64(62))
     feats = np.arange(1, 501, dtype=np.uint64) | (np.uint64(2) << np.uint64(62))
     eng = F.Engine(cells, feats, umi_max_bases=12)
@@ -114,7 +114,7 @@ def test_group_only_sort_plus_dedup_in_reduce(mode, n, n_groups, low_values, see
 def _group_only_case(torch, eng, mode, n, n_groups, low_values, seed):
     skip = eng.skip_bits
     assert 0 < skip < 27 and eng.sort_passes(True) == (46 - skip + 7) // 8      # 46-bit keys: the digit grid ends at the top bit
-    assert eng.sort_passes(True) == (3 if mode == "hash" else 4)
+    assert eng.sort_passes(True) == 3
     rng = np.random.default_rng(seed)
     fs, cs = 27, 36
     cell = rng.integers(1, 1001, size=n_groups, dtype=np.uint64)
@@ -139,11 +139,7 @@ def _group_only_case(torch, eng, mode, n, n_groups, low_values, seed):
     eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(),
                    stream=s, skip_low=True)
     torch.cuda.synchronize()
-    if mode == "walk":
-        expect = 1000 <= low_values <= (1 << 16) and n_groups <= 3   # thousands of distinct low parts per run (more low
-                                                                     # values spread over the sorted bits too: short runs)
-    else:
-        expect = n // n_groups > 65_536                       # a group beyond what the partition kernel takes
+    expect = n // n_groups > 65_536                           # a group beyond what the partition kernel takes
     flagged = bool(eng.dev_error_bits() & 16)
     assert flagged == expect
     if flagged:                                               # the documented contract: sort fully, reduce again
@@ -227,14 +223,15 @@ def test_reduce_windows_groups_longer_than_a_window_and_regions(env, sizes, seed
                                                  ([100, 2048, 100], False, 3), ([40_000], False, 4), ([65_536, 9, 65_537, 1], True, 6),
                                                  ([5000, 1, 1, 7000, 2048, 2047, 2049, 3, 4096, 1, 30_000, 2], False, 7),
                                                  ([2100] * 2100, True, 8),      # more work items than giant_groups_kernel's list holds
+                                                 ([3100] * 1500, True, 9),      # ... with groups of three items straddling the end of the list
                                                  (list(range(1, 600)), False, 5)])
 def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypatch):
-    """FASTF_K3_DEDUP=hash: the sort orders (cell, feature) only; K3 finds the distinct UMIs of a group through its
-    window-local hash set; a group that does not fit a window is counted by giant_groups_kernel, hash partition by hash
-    partition; beyond 65 536 keys it raises ERR_RUN_TOO_LONG (sort fully, reduce again)."""
+    """The sort orders (cell, feature) only; K3 (reduce_hashed_kernel) finds the distinct UMIs of a group through its
+    window-local exact set; a group that does not fit a window is counted by giant_groups_kernel, hash partition by hash
+    partition; beyond 65 536 keys, or with more work items than the list holds (whose unwritten tail is never walked), it
+    raises ERR_RUN_TOO_LONG (sort fully, reduce again)."""
     import torch
     import fastf_amd as F
-    monkeypatch.setenv("FASTF_K3_DEDUP", "hash")
     cells = np.arange(1, 1001, dtype=np.uint64) | (np.uint64(1) << np.uint64(62))
     feats = np.arange(1, 501, dtype=np.uint64) | (np.uint64(2) << np.uint64(62))
     eng = F.Engine(cells, feats, umi_max_bases=12)
