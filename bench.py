@@ -78,6 +78,7 @@ def main():
                     help="c3 = BASELINE configs[2] (the headline, default); c2 = BASELINE configs[1], 10 M keep-all records (round 1's workload)")
     ap.add_argument("--records", type=int, default=0, help="records of the whole job (all GPUs together); default 200 M (c3) / 10 M (c2)")
     ap.add_argument("--cpu-sample", type=int, default=75_000_000, help="records timed on the CPU oracle (rank 0, N=1): whole segments of the job, about 10 s of one core")
+    ap.add_argument("--soa", action="store_true", help="resident inputs as the four SoA arrays instead of the engine's blocked staging layout")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-devpath", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -129,10 +130,22 @@ def main():
     eng = F.Engine.from_lists(lists, rate_depth=rate_depth, seed=workload.SEED, umi_max_bases=umi_bases,
                               n_shards=G, shard_rank=rank, device=local)
     eng.reserve(n_local, n_local)
-    sp = ShardedPass(HipStages(eng, dev), n_local, dev)
+    stages = HipStages(eng, dev)
+    sp = ShardedPass(stages, n_local, dev)
+    # resident inputs in the engine's own staging layout: the cb keys as an array, gx | umi | meta in blocked runs of 256 records
+    # (include/fastf_amd.h "BLOCKED record layout"; a host batch gets there by pitched copies); --soa keeps the four arrays
+    blk = None if args.soa else stages.block(gx, umi, meta, n_local)
+    if blk is not None:
+        torch.cuda.synchronize()
+        del gx, umi, meta
+        gx = umi = meta = None
+        torch.cuda.empty_cache()
 
     def step():
-        sp.run(cb, gx, umi, meta, n_local, d_draws)
+        if blk is not None:
+            sp.run(cb, blk, None, None, n_local, d_draws)
+        else:
+            sp.run(cb, gx, umi, meta, n_local, d_draws)
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -212,7 +225,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if G > 1 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: %d synthetic records, 10000 barcodes x 30000 genes, --cell 1.0 --depth 1.0 --seed 926, "
-                                    "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (packed SoA + draw stream)",
+                                    "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (%s + draw stream); the step ends at K3's segmented rows (rows_gather, which concatenates them where they are wanted — in the product it IS the device-to-host copy — is timed on its own line)" % ("cb array + blocked gx|umi|meta runs, the engine's staging layout" if blk is not None else "packed SoA"),
+                       "record_layout": "blocked" if blk is not None else "soa",
                        "records_per_gpu": n_local, "key_bits": eng.key_bits, "radix_passes_nominal": P_nom,
                        "radix_passes_executed": P_exe,
                        "sharding": ("cell-hash, one all-to-all, %s" % ("3-stream pipeline" if sp.pipelined else "single stream")) if G > 1 else "single GPU",
@@ -238,7 +252,7 @@ def main():
             out["counters"]["same_as_single_gpu_reference_run"] = got == workload.EXPECTED_200M
 
     # free the resident job before the host-side legs
-    del sp, cb, gx, umi, meta, d_draws
+    del sp, cb, gx, umi, meta, d_draws, blk
     eng.close()
     torch.cuda.empty_cache()
 

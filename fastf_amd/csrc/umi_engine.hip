@@ -401,7 +401,11 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
                              (const void*)filter_pack_stream_kernel<false, false, false>, (const void*)filter_pack_stream_kernel<false, false, true>,
                              (const void*)filter_pack_stream_kernel<false, true, false>, (const void*)filter_pack_stream_kernel<false, true, true>,
                              (const void*)filter_pack_stream_kernel<true, false, false>, (const void*)filter_pack_stream_kernel<true, false, true>,
-                             (const void*)filter_pack_stream_kernel<true, true, false>, (const void*)filter_pack_stream_kernel<true, true, true>};
+                             (const void*)filter_pack_stream_kernel<true, true, false>, (const void*)filter_pack_stream_kernel<true, true, true>,
+                             (const void*)filter_pack_stream_kernel<false, false, false, true>, (const void*)filter_pack_stream_kernel<false, false, true, true>,
+                             (const void*)filter_pack_stream_kernel<false, true, false, true>, (const void*)filter_pack_stream_kernel<false, true, true, true>,
+                             (const void*)filter_pack_stream_kernel<true, false, false, true>, (const void*)filter_pack_stream_kernel<true, false, true, true>,
+                             (const void*)filter_pack_stream_kernel<true, true, false, true>, (const void*)filter_pack_stream_kernel<true, true, true, true>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 0;
     }
@@ -598,8 +602,10 @@ static u32 choose_sort_ipt(u64 n) {
     return (u32)std::min<u64>(max_ipt, std::max<u64>(1, per_thread));
 }
 
-static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys) {
-    const u64 t1 = max_tiles_for(max_records, K1_TILE);
+// max_records: records whose cell indices go to the engine's own scratch array; tile_records (>= max_records): records whose
+// K1 tile counts are kept (a blocked pass keeps its cell indices in the caller's buffer)
+static int reserve_workspace(fastf_engine* e, u64 max_records, u64 max_keys, u64 tile_records = 0) {
+    const u64 t1 = max_tiles_for(std::max(max_records, tile_records), K1_TILE);
     const u64 ts = max_tiles_for(max_keys, (u64)choose_sort_ipt(max_keys) * SORT_THREADS);
     if (max_records && e->d_cellidx.ensure(max_records * sizeof(u32))) return 1;
     if (e->d_tilecnt.bytes < t1 * sizeof(u32)) {                     // (re)allocated: establish the all-zero invariant
@@ -621,6 +627,16 @@ extern "C" int fastf_dev_reserve(fastf_engine_t* e, uint64_t max_records, uint64
     HIP_OK(hipSetDevice(e->device));
     return reserve_workspace(e, max_records, max_keys);
 } FASTF_CATCH_INT
+
+// FASTF_DEBUG_SYNC=1: wait after every stage and name it on stderr — when a kernel faults, the last line says which stage
+// had completed (diagnostic runs only: the waits serialise everything)
+static bool dbg_sync_on() { static int v = -1; if (v < 0) v = getenv("FASTF_DEBUG_SYNC") != nullptr; return v != 0; }
+static void dbg_sync(hipStream_t s, const char* what) {
+    if (!dbg_sync_on()) return;
+    const hipError_t e1 = hipStreamSynchronize(s), e2 = hipGetLastError();
+    fprintf(stderr, "[sync] %s: %s %s\n", what, hipGetErrorString(e1), e2 == hipSuccess ? "" : hipGetErrorString(e2));
+    fflush(stderr);
+}
 
 // per-kernel timing helpers (only active in timing mode; adds event records to the stream)
 static void t_begin(fastf_engine* e, hipStream_t s) { if (e->timing) (void)hipEventRecord(e->t_ev[0], s); }
@@ -672,29 +688,33 @@ static void launch_scan_tiles(fastf_engine* e, int slot, hipStream_t s, u32* in,
     hipLaunchKernelGGL(scan_fix_kernel<16>, dim3(n_blk), dim3(1024), 0, s, out, T, (const u64*)blk, n_blk, total_out, running, base_out);
 }
 
+// blk: the blocked buffer of these records (K1a writes its cell indices into the units' scratch slices), or nullptr
 static int launch_probe_cells(fastf_engine* e, const u64* cb, u64 n, u64* d_total_out, hipStream_t s,
-                              u64* d_running = nullptr, u64* d_base_out = nullptr) {
-    if (reserve_workspace(e, n, 0)) return 1;
+                              u64* d_running = nullptr, u64* d_base_out = nullptr, void* blk = nullptr) {
+    if (reserve_workspace(e, blk ? 0 : n, 0, n)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
+    const CellOut cout = blk ? CellOut{blk, blk_run_bytes(e->cell16)} : CellOut{e->d_cellidx.p, 0u};
     t_begin(e, s);
     if (e->use_lds_cells) {                          // tile counts are all-zero here: scan_tiles_kernel clears what it reads
         const u32 grid = std::min<u32>(e->cells_blocks_per_cu * g_cu_count, (tiles + 1) / 2);
         if (e->cells_blocks_per_cu >= 2)
             hipLaunchKernelGGL(probe_cells_lds_kernel<true>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+                               cout, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
         else
             hipLaunchKernelGGL(probe_cells_lds_kernel<false>, dim3(grid), dim3(1024), e->lds_cells.bytes, s, cb, n, e->lds_cells,
-                               e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+                               cout, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else if (e->cell_filter.bits) {
         const u32 grid = std::min<u32>(tiles, 4 * g_cu_count);
         hipLaunchKernelGGL(probe_cells_filtered_kernel, dim3(grid), dim3(K1_THREADS), (e->cell_filter.mask + 1u) / 8u, s, cb, n,
-                           e->cells, e->cell_filter, e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
+                           e->cells, e->cell_filter, cout, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p, tiles);
     } else {
         hipLaunchKernelGGL(probe_cells_kernel<0>, dim3(tiles), dim3(K1_THREADS), 0, s, cb, n, e->cells,
-                           e->d_cellidx.p, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p);
+                           cout, e->cell16, (u32*)e->d_tilecnt.p, (u32*)e->d_halfhits.p);
     }
     t_end(e, s, &e->t_k1_ms, &e->t_k1_n);
+    dbg_sync(s, "K1a probe_cells");
     launch_scan_tiles(e, 0, s, (u32*)e->d_tilecnt.p, (u64*)e->d_tilebase.p, tiles, d_total_out, d_running, d_base_out);
+    dbg_sync(s, "K1a tile scan");
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -709,15 +729,51 @@ extern "C" int fastf_dev_count_hits(fastf_engine_t* e, const uint64_t* d_cb_key,
     return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s);
 } FASTF_CATCH_INT
 
+static bool stream_k1b_possible(const fastf_engine* e) {
+    return e->use_lds_genes && e->n_shards <= (u32)MAX_SHARDS && !getenv("FASTF_NO_STREAM_K1B");
+}
+
+extern "C" int fastf_dev_block_bytes(const fastf_engine_t* e, uint64_t n, uint64_t* bytes) FASTF_TRY {
+    if (!e || !bytes) return set_err("null argument");
+    *bytes = 0;
+    if (e->multi || !stream_k1b_possible(e)) return 0;
+    *bytes = ((n + BLK_RECS - 1) / BLK_RECS) * (u64)blk_run_bytes(e->cell16);
+    return 0;
+} FASTF_CATCH_INT
+
+extern "C" int fastf_dev_block_records(fastf_engine_t* e, const uint64_t* d_gx_key, const uint32_t* d_umi, const uint32_t* d_meta,
+                                       uint64_t n, void* d_blocked, void* stream) FASTF_TRY {
+    if (!e || !d_blocked) return set_err("null argument");
+    if (e->multi) return set_err("fastf_dev_block_records: device-level calls take a single-device engine");
+    HIP_OK(hipSetDevice(e->device));
+    if (n == 0) return 0;
+    const u64 units = (n + BLK_RECS - 1) / BLK_RECS;
+    hipLaunchKernelGGL(block_records_kernel, dim3((u32)std::min<u64>((units + 3) / 4, 16ull * g_cu_count)), dim3(256), 0, (hipStream_t)stream,
+                       (const u64*)d_gx_key, d_umi, d_meta, (u64)n, (unsigned char*)d_blocked, blk_run_bytes(e->cell16));
+    HIP_OK(hipGetLastError());
+    dbg_sync((hipStream_t)stream, "block_records");
+    return 0;
+} FASTF_CATCH_INT
+
+extern "C" int fastf_dev_count_hits_blocked(fastf_engine_t* e, const uint64_t* d_cb_key, uint64_t n, void* d_blocked,
+                                            uint64_t* d_hits_out, void* stream) FASTF_TRY {
+    if (!e || !d_blocked) return set_err("null argument");
+    if (e->multi) return set_err("fastf_dev_count_hits_blocked: device-level calls take a single-device engine");
+    HIP_OK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { HIP_OK(hipMemsetAsync(d_hits_out, 0, sizeof(u64), s)); return 0; }
+    return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s, nullptr, nullptr, d_blocked);
+} FASTF_CATCH_INT
+
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
                         u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr,
-                        bool segmented = false) {
+                        bool segmented = false, void* blk = nullptr) {
     if (segmented) e->seg_n = 0;
     if (n == 0) return 0;
     // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order).
     // d_running: the scan leaves the running hit total of the earlier chunks at draw_base and adds this chunk's hits.
-    if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s, d_running, d_running ? const_cast<u64*>(draw_base) : nullptr)) return 1;
+    if (!reuse_hits && launch_probe_cells(e, cb, n, nullptr, s, d_running, d_running ? const_cast<u64*>(draw_base) : nullptr, blk)) return 1;
     const u32 tiles = (u32)((n + K1_TILE - 1) / K1_TILE);
     PackParams p{};
     p.cell = e->d_cellidx.p; p.cell16 = e->cell16; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
@@ -730,10 +786,12 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.stamps = g_k1_stamps;
     p.n_tiles = tiles;
     p.genes = e->lds_genes;
+    p.blk = (const unsigned char*)blk;
     // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
     // deals the keys to the per-destination buffers (same interface as the tile form: keys[G][stride], key_counts[G] += ...)
     const bool no_stream = getenv("FASTF_NO_STREAM_K1B") != nullptr;
     const bool stream_shards = !segmented && e->n_shards > 1 && e->n_shards <= (u32)MAX_SHARDS && e->use_lds_genes && !no_stream;
+    if (blk && !(segmented || stream_shards)) return set_err("FASTF_PROBE_BLOCKED needs the streaming K1b (fastf_dev_block_bytes returns 0 otherwise)");
     t_begin(e, s);
     if (segmented || stream_shards) {
         // streaming form: every wave on its own, keys into one private region per workgroup (see filter_pack_stream_kernel)
@@ -748,7 +806,8 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
         StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
         // compile-time: roomy (one workgroup per CU: 128 VGPRs), width of the cell scratch, form of the gene image
         const int variant = (e->genes_blocks_per_cu >= 2 ? 0 : 4) | (e->cell16 ? 2 : 0) | (e->lds_genes.direct ? 1 : 0);
-#define FPS(R, C, D) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp)
+#define FPS(R, C, D) do { if (blk) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp); \
+                          else hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp); } while (0)
         switch (variant) {
         case 0: FPS(false, false, false); break; case 1: FPS(false, false, true); break;
         case 2: FPS(false, true, false); break;  case 3: FPS(false, true, true); break;
@@ -772,6 +831,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     }
     HIP_OK(hipGetLastError());
     t_end(e, s, &e->t_k1b_ms, &e->t_k1b_n);
+    dbg_sync(s, blk ? "K1b filter_pack (blocked)" : "K1b filter_pack");
     return 0;
 }
 
@@ -783,12 +843,14 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_probe_pack: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
-    const bool seg = (flags & FASTF_PROBE_SEGMENTED) != 0;
+    const bool seg = (flags & FASTF_PROBE_SEGMENTED) != 0, blocked = (flags & FASTF_PROBE_BLOCKED) != 0;
     if (seg && !(e->n_shards == 1 && e->use_lds_genes))
         return set_err("FASTF_PROBE_SEGMENTED needs a single shard and the gene table in LDS (fastf_dev_probe_capacity returns 0 otherwise)");
-    return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
+    if (blocked && !d_gx_key) return set_err("FASTF_PROBE_BLOCKED: d_gx_key must point at the blocked buffer");
+    return launch_probe(e, (const u64*)d_cb_key, blocked ? nullptr : (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
-                        (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream, ~0ull, nullptr, seg);
+                        (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream, ~0ull, nullptr, seg,
+                        blocked ? const_cast<uint64_t*>(d_gx_key) : nullptr);
 } FASTF_CATCH_INT
 
 extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uint64_t* key_slots) FASTF_TRY {
@@ -871,6 +933,7 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         t_begin(e, s);
         launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt, q == 0 ? seg : none);
         t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
+        dbg_sync(s, "K2 sort pass");
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -937,6 +1000,7 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
                            (u32*)e->d_rg_count.p, (u64*)e->d_small.p + SM_COUNTERS + 3);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
+    dbg_sync(s, "K3 reduce + span scan + giant groups");
     e->rg_n = G; e->rg_umi = UMI_ROWS;
     return 0;
 }
@@ -1014,7 +1078,8 @@ extern "C" int fastf_dev_clear_error_bits(fastf_engine_t* e, uint64_t mask, void
 
 extern "C" const char* fastf_kernel_names(void) FASTF_TRY {
     return "probe_cells_kernel,probe_cells_lds_kernel,probe_cells_filtered_kernel,scan_tiles_kernel,filter_pack_kernel,filter_pack_stream_kernel,"
-           "tile_count_kernel,row_scan_kernel,scatter_kernel,reduce_windows_kernel,span_scan_kernel,giant_groups_kernel,rows_gather_kernel";
+           "block_records_kernel,tile_count_kernel,row_scan_kernel,scatter_kernel,reduce_windows_kernel,reduce_hashed_kernel,span_scan_kernel,"
+           "giant_groups_kernel,rows_gather_kernel";
 } FASTF_CATCH_ZERO
 
 // ------------------------------------------------------------------------------------

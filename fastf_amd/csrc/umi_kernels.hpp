@@ -295,8 +295,21 @@ static_assert(K1_THREADS == 512 && K1_IPT == 8, "K1a layout: 8 waves x 8 items x
 
 // the cell-index scratch between K1a and K1b holds u16 entries when every cell index fits (n_cells <= 65535): 2 instead of
 // 4 bytes written and read back per record
-__device__ __forceinline__ void put_cell(void* __restrict__ out, bool c16, u64 idx, u32 v) {
-    if (c16) reinterpret_cast<unsigned short*>(out)[idx] = (unsigned short)v; else reinterpret_cast<u32*>(out)[idx] = v;
+// BLOCKED record layout (the engine's own device staging; the SoA of the ABI stays what callers hand over): per 256-record
+// unit ONE contiguous run   gx u64[256] | umi u32[256] | meta u32[256] | cell scratch (u16[256] or u32[256])
+// = 4608 (5120) bytes.  K1a fills the scratch slice of a unit, K1b then reads a unit as one stream instead of four distant
+// ones: tools/hbm_probe_streams.hip measures the same 18 bytes per record at 6.3 TB/s from such runs against 5.2 TB/s from
+// four arrays (profiles/r4_notes/hbm_probe_blocked_layout.txt; a run with dead bytes in it — the cb slice kept inside —
+// loses the gain, which is why cb stays an array of its own).
+constexpr u32 BLK_RECS = 256, BLK_GX = 0, BLK_UMI = 2048, BLK_META = 3072, BLK_CELL = 4096;
+__host__ __device__ __forceinline__ u32 blk_run_bytes(bool c16) { return BLK_CELL + (c16 ? 2u : 4u) * BLK_RECS; }
+// where K1a leaves the cell index of record idx: a plain array (run == 0) or the scratch slices of a blocked buffer
+struct CellOut { void* p; u32 run; };
+__device__ __forceinline__ void put_cell(const CellOut o, bool c16, u64 idx, u32 v) {
+    unsigned char* at = reinterpret_cast<unsigned char*>(o.p);
+    u64 i = idx;
+    if (o.run) { at += (idx / BLK_RECS) * o.run + BLK_CELL; i = idx % BLK_RECS; }
+    if (c16) reinterpret_cast<unsigned short*>(at)[i] = (unsigned short)v; else reinterpret_cast<u32*>(at)[i] = v;
 }
 __device__ __forceinline__ u32 get_cell(const void* __restrict__ in, bool c16, u64 idx) {
     return c16 ? (u32)reinterpret_cast<const unsigned short*>(in)[idx] : reinterpret_cast<const u32*>(in)[idx];
@@ -315,7 +328,7 @@ __device__ __forceinline__ u32 shard_of(u32 cell, u32 n_shards) {
 // tile_base[t] + the halves in front of it, which lets every WAVE of K1b work on its own (filter_pack_stream_kernel)
 template <int AUX>
 __global__ __launch_bounds__(K1_THREADS) void probe_cells_kernel(const u64* __restrict__ cb, u64 n, Table cells,
-                                                                 void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
+                                                                 const CellOut cell_out, bool c16, u32* __restrict__ tile_hits,
                                                                  u32* __restrict__ half_hits) {
     __shared__ u32 s_w[K1_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
@@ -388,7 +401,7 @@ __device__ __forceinline__ u32 filter_bit(u64 key) {
 }
 
 __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(const u64* __restrict__ cb, u64 n, Table cells, MissFilter f,
-                                                                             void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
+                                                                             const CellOut cell_out, bool c16, u32* __restrict__ tile_hits,
                                                                              u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u32 s_w[K1_WAVES];
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(K1_THREADS, 8) void probe_cells_filtered_kernel(con
 // TWO_PER_CU: the image leaves room for two workgroups per CU, which takes 64 VGPRs at most
 template <bool TWO_PER_CU>
 __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kernel(const u64* __restrict__ cb, u64 n, CellLds c,
-                                                               void* __restrict__ cell_out, bool c16, u32* __restrict__ tile_hits,
+                                                               const CellOut cell_dst, bool c16, u32* __restrict__ tile_hits,
                                                                u32* __restrict__ half_hits, u32 n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 S = c.slot_bits, smask = (1u << S) - 1u, lo_mask = (1u << (32u - S)) - 1u;
@@ -458,6 +471,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
     const int lane = lane_id();
     constexpr int PAIRS = K1_IPT / 2;                                    // 4 x 64 lanes x 2 records = one 512-record chunk
     const u32 n_chunks = n_tiles * (u32)K1_WAVES;
+    void* const cell_out = cell_dst.p;
     const bool even = (reinterpret_cast<uintptr_t>(cb) & 15u) == 0 && (reinterpret_cast<uintptr_t>(cell_out) & 7u) == 0;
     for (u32 chunk = blockIdx.x * 16u + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 16u) {
         const u64 base = (u64)chunk * (K1_IPT * WAVE);
@@ -488,7 +502,18 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
             hits += (u32)__popcll(__ballot(v != 0));
             if (j == K1_IPT / 2 - 1) hits_lo = hits;
         }
-        if (whole) {
+        if (whole && cell_dst.run) {
+            // blocked buffer: the chunk is two units; pairs 0, 1 lie in the first, pairs 2, 3 in the second (scalar unit base)
+            static_assert(K1_IPT * WAVE == 2 * (int)BLK_RECS && PAIRS == 4, "a K1a chunk is two blocked units");
+            unsigned char* const u0 = reinterpret_cast<unsigned char*>(cell_out) + (base / BLK_RECS) * cell_dst.run + BLK_CELL;
+#pragma unroll
+            for (int j = 0; j < PAIRS; ++j) {
+                unsigned char* const ub = u0 + (j >> 1) * cell_dst.run;
+                const u32 rec = 2u * ((u32)(j & 1) * WAVE + (u32)lane);
+                if (c16) *reinterpret_cast<u32*>(ub + 2u * rec) = cell[2 * j] | (cell[2 * j + 1] << 16);
+                else *reinterpret_cast<uint2*>(ub + 4u * rec) = make_uint2(cell[2 * j], cell[2 * j + 1]);
+            }
+        } else if (whole) {
             if (c16) {
 #pragma unroll
                 for (int j = 0; j < PAIRS; ++j)
@@ -502,7 +527,7 @@ __global__ __launch_bounds__(1024, TWO_PER_CU ? 8 : 4) void probe_cells_lds_kern
 #pragma unroll
             for (int j = 0; j < K1_IPT; ++j) {
                 const u64 idx = base + 2ull * ((j >> 1) * WAVE + lane) + (j & 1);
-                if (idx < n) put_cell(cell_out, c16, idx, cell[j]);
+                if (idx < n) put_cell(cell_dst, c16, idx, cell[j]);
             }
         }
         if (lane == 0) {
@@ -528,6 +553,7 @@ static_assert(K1B_THREADS * K1B_IPT == K1_TILE, "K1b walks K1a's tiles");
 
 struct PackParams {
     const void* cell; bool cell16;  // K1a's scratch: u16 or u32 entries
+    const unsigned char* blk;      // streaming form, BLOCKED: the units' runs (gx | umi | meta | scratch); cell/gx/umi/meta unused
     const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
     const u32* draws; u64 n_draws; // draw of hit rank r: draws[r & draw_mask], valid while r < n_draws
@@ -788,7 +814,7 @@ __device__ __forceinline__ u32 row16_sum_lane15(u32 x) {
 // C16: the cell scratch holds u16 entries; DIRECT: the gene image is the dense u16 table.  Both are compile-time so that
 // the loop is straight-line code: with run-time flags every load sat in its own branch, with waits between them
 // (PMC on the configs[2] shape: 430 vector + 325 scalar instructions per 256 records, the vector ALU busy 60 % of the kernel).
-template <bool ROOMY, bool C16, bool DIRECT>
+template <bool ROOMY, bool C16, bool DIRECT, bool BLOCKED = false>
 __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
     __shared__ u64 s_tot[3];
     __shared__ u32 s_cursor, s_err;
@@ -828,9 +854,13 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
         const u32 own = (u32)__builtin_amdgcn_readlane((int)hha, w);
         // ---- loads ----
         u64 gxk[K1S_IPT]; u32 umi[K1S_IPT], meta[K1S_IPT], cell[K1S_IPT];
-        const u64* const gx_u = p.gx + base; const u32* const umi_u = p.umi + base; const u32* const meta_u = p.meta + base;
-        const unsigned short* const c16_u = reinterpret_cast<const unsigned short*>(p.cell) + base;
-        const u32* const c32_u = reinterpret_cast<const u32*>(p.cell) + base;
+        // BLOCKED: the unit is one contiguous run of the engine's staging buffer (scalar base)
+        const unsigned char* const run = BLOCKED ? p.blk + ((u64)t * (K1_TILE / K1S_UNIT) + (u64)w) * blk_run_bytes(C16) : nullptr;
+        const u64* const gx_u = BLOCKED ? reinterpret_cast<const u64*>(run + BLK_GX) : p.gx + base;
+        const u32* const umi_u = BLOCKED ? reinterpret_cast<const u32*>(run + BLK_UMI) : p.umi + base;
+        const u32* const meta_u = BLOCKED ? reinterpret_cast<const u32*>(run + BLK_META) : p.meta + base;
+        const unsigned short* const c16_u = BLOCKED ? reinterpret_cast<const unsigned short*>(run + BLK_CELL) : reinterpret_cast<const unsigned short*>(p.cell) + base;
+        const u32* const c32_u = BLOCKED ? reinterpret_cast<const u32*>(run + BLK_CELL) : reinterpret_cast<const u32*>(p.cell) + base;
         if (base + K1S_UNIT <= p.n) {                                      // scalar branch: the whole unit exists
 #pragma unroll
             for (int j = 0; j < K1S_IPT; ++j) {
@@ -952,6 +982,26 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
     if (tid < 3 && s_tot[tid]) atomicAdd(&p.counters[tid], s_tot[tid]);
     if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
     if (tid == 4) sp.seg_count[blockIdx.x] = s_cursor;
+}
+
+// SoA on the device -> blocked runs (callers that hold device-resident SoA and want the blocked K1 path; the push path lands
+// its host batches in this layout with pitched copies instead).  One wave per unit and round.
+__global__ __launch_bounds__(256) void block_records_kernel(const u64* __restrict__ gx, const u32* __restrict__ umi, const u32* __restrict__ meta,
+                                                            u64 n, unsigned char* __restrict__ blk, u32 run) {
+    const u64 units = (n + BLK_RECS - 1) / BLK_RECS, waves = (u64)gridDim.x * (blockDim.x / WAVE);
+    const int lane = lane_id();
+    for (u64 u = (u64)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6); u < units; u += waves) {
+        unsigned char* const r = blk + u * run;
+#pragma unroll
+        for (int j = 0; j < (int)BLK_RECS / WAVE; ++j) {
+            const u32 o = (u32)j * WAVE + (u32)lane;
+            const u64 i = u * BLK_RECS + o;
+            const bool in = i < n;
+            reinterpret_cast<u64*>(r + BLK_GX)[o] = in ? gx[i] : 0;
+            reinterpret_cast<u32*>(r + BLK_UMI)[o] = in ? umi[i] : 0;
+            reinterpret_cast<u32*>(r + BLK_META)[o] = in ? meta[i] : 0;
+        }
+    }
 }
 
 // Several shards (multi-GPU): the streaming K1b above writes its keys unsharded into the workgroup regions of a scratch
@@ -1876,7 +1926,9 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
             __syncthreads();
             const u64 idx = cursor + tid;
             bool head = false;
-            if (idx < nom_end) head = (p.keys[idx] >> gshift) != (p.keys[idx - 1] >> gshift);
+            // (nom_start can be 0 for b > 0: the grid is sized for the caller's bound on the key count, the chunks are cut from
+            //  the actual one, and the first few chunks of a small n are empty)
+            if (idx < nom_end) head = idx == 0 || (p.keys[idx] >> gshift) != (p.keys[idx - 1] >> gshift);
             const u64 m = __ballot(head);
             if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __syncthreads();

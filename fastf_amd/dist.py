@@ -66,8 +66,22 @@ class HipStages:
     def _s(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def count_hits(self, cb, n, out_hits):
-        self.eng.dev_count_hits(cb.data_ptr(), n, out_hits.data_ptr(), self._s())
+    def block(self, gx, umi, meta, n):
+        """the records' gx / umi / meta in the engine's BLOCKED layout (one contiguous run per 256-record unit, with the
+        slice K1a fills): pass the result as `gx` (umi = meta = None) to count_hits / probe_pack.  None when this engine has
+        no streaming K1b to read it."""
+        nb = self.eng.block_bytes(n)
+        if not nb:
+            return None
+        buf = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        self.eng.dev_block_records(gx.data_ptr(), umi.data_ptr(), meta.data_ptr(), n, buf.data_ptr(), self._s())
+        return buf
+
+    def count_hits(self, cb, n, out_hits, blocked=None):
+        if blocked is not None:
+            self.eng.dev_count_hits_blocked(cb.data_ptr(), n, blocked.data_ptr(), out_hits.data_ptr(), self._s())
+        else:
+            self.eng.dev_count_hits(cb.data_ptr(), n, out_hits.data_ptr(), self._s())
 
     def key_slots(self, n, n_shards):
         """key slots per shard buffer: the streaming K1b of a single-shard pass writes one region per workgroup"""
@@ -77,10 +91,11 @@ class HipStages:
 
     def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters, reuse_hits=False):
         self.segmented = self.eng.n_shards == 1 and self.eng.probe_capacity(n) > 0 and stride >= self.eng.probe_capacity(n)
-        self.eng.dev_probe_pack(cb.data_ptr(), gx.data_ptr(), umi.data_ptr(), meta.data_ptr(), n,
+        blocked = umi is None                              # gx is then a buffer made by block()
+        self.eng.dev_probe_pack(cb.data_ptr(), gx.data_ptr(), 0 if blocked else umi.data_ptr(), 0 if blocked else meta.data_ptr(), n,
                                 draws.data_ptr(), draws.numel(), keys_out.data_ptr(), stride,
                                 key_counts.data_ptr(), counters.data_ptr(), self._s(),
-                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, segmented=self.segmented)
+                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, segmented=self.segmented, blocked=blocked)
 
     def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, fresh=True):
         # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs.
@@ -168,7 +183,10 @@ class ShardedPass:
         """hit count → draw-rank base → probe/filter/pack → count exchange; returns (send, recv) counts on the host"""
         G, st = self.G, self.st
         self._small.zero_()
-        st.count_hits(cb, n, self.hits)
+        if umi is None:
+            st.count_hits(cb, n, self.hits, blocked=gx)          # the cell indices go into the blocked buffer's scratch slices
+        else:
+            st.count_hits(cb, n, self.hits)
         if self.pipelined and self.host_small:                               # gloo: host integers
             all_h = torch.empty(G, dtype=torch.int64)
             self._gather_small(all_h, self.hits.cpu())

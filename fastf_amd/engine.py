@@ -300,13 +300,27 @@ class Engine:
     def dev_count_hits(self, d_cb, n, d_out, stream=0):
         check(self._L.fastf_dev_count_hits(self._h, d_cb, n, d_out, stream))
 
+    def dev_count_hits_blocked(self, d_cb, n, d_blocked, d_out, stream=0):
+        check(self._L.fastf_dev_count_hits_blocked(self._h, d_cb, n, d_blocked, d_out, stream))
+
+    def block_bytes(self, n) -> int:
+        """bytes of the blocked record buffer (gx | umi | meta | cell scratch per 256-record unit) for n records;
+        0 = this engine cannot run the streaming K1b that reads it"""
+        v = C.c_uint64()
+        check(self._L.fastf_dev_block_bytes(self._h, n, C.byref(v)))
+        return int(v.value)
+
+    def dev_block_records(self, d_gx, d_umi, d_meta, n, d_blocked, stream=0):
+        check(self._L.fastf_dev_block_records(self._h, d_gx, d_umi, d_meta, n, d_blocked, stream))
+
     def dev_probe_pack(self, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_keys, shard_stride,
-                       d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False, segmented=False):
+                       d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False, segmented=False, blocked=False):
         """reuse_hits: dev_count_hits ran on these very records just before, on the same stream (K1a is skipped);
-        segmented: streaming K1b, keys land in per-workgroup regions (probe_capacity slots; sort with segmented=True)"""
+        segmented: streaming K1b, keys land in per-workgroup regions (probe_capacity slots; sort with segmented=True);
+        blocked: d_gx is a blocked record buffer (block_bytes / dev_block_records), d_umi and d_meta are ignored"""
         check(self._L.fastf_dev_probe_pack(self._h, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_draw_base,
                                            d_keys, shard_stride, d_key_counts, d_counters,
-                                           (1 if reuse_hits else 0) | (2 if segmented else 0), stream))
+                                           (1 if reuse_hits else 0) | (2 if segmented else 0) | (8 if blocked else 0), stream))
 
     def probe_capacity(self, n) -> int:
         """key slots a segmented probe_pack over n records needs; 0 = the streaming form is not available"""

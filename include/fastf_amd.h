@@ -282,6 +282,24 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
  * 0 = this engine cannot run the streaming form (several shards, or a gene list that does not fit LDS) */
 int fastf_dev_probe_capacity(const fastf_engine_t *e, uint64_t n, uint64_t *key_slots);
 
+/* BLOCKED record layout — the engine's own device staging.  Per 256-record unit one contiguous run
+ *     gx u64[256] | umi u32[256] | meta u32[256] | cell scratch (u16[256], or u32[256] when n_cells > 65535)
+ * of 4608 (5120) bytes; the cb keys stay an array of their own.  K1a writes a unit's scratch slice, the streaming K1b reads a
+ * unit as ONE stream instead of four distant ones (the same 18 bytes per record move 18 % faster that way:
+ * tools/hbm_probe_streams.hip).  fastf_batch_t is untouched: a host batch reaches this layout through pitched copies
+ * (three hipMemcpy2DAsync per chunk), device-resident SoA through fastf_dev_block_records.
+ * fastf_dev_block_bytes: size of the buffer for n records; 0 = this engine cannot run the streaming K1b (gene list not in
+ * LDS, FASTF_NO_STREAM_K1B): use the SoA form. */
+int fastf_dev_block_bytes(const fastf_engine_t *e, uint64_t n, uint64_t *bytes);
+int fastf_dev_block_records(fastf_engine_t *e, const uint64_t *d_gx_key, const uint32_t *d_umi, const uint32_t *d_meta,
+                            uint64_t n, void *d_blocked, void *stream);
+/* fastf_dev_probe_pack: d_gx_key points at a blocked buffer of the n records (d_umi, d_meta are ignored).  The cell
+ * scratch lives in that buffer, so with FASTF_PROBE_REUSE_HITS the preceding count must have been
+ * fastf_dev_count_hits_blocked on the same buffer. */
+#define FASTF_PROBE_BLOCKED 8u
+int fastf_dev_count_hits_blocked(fastf_engine_t *e, const uint64_t *d_cb_key, uint64_t n, void *d_blocked,
+                                 uint64_t *d_hits_out, void *stream);
+
 /* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
  * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
  * *sorted_in_tmp tells where the result landed. */

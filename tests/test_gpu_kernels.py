@@ -241,23 +241,26 @@ def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypat
         keys = _group_keys(rng, 10**9, sizes, umi_values=200 if seed != 7 else 1 << 24)   # heavy duplication / nearly all distinct
         keys = keys[rng.permutation(len(keys))]
         n = len(keys)
-        d_keys = _t(torch, keys); d_tmp = torch.empty_like(d_keys)
+        # the launches are sized for the caller's BOUND on the key count (here 1x and 7x the count on the device): with a
+        # loose bound the first chunks of K3 are empty and several workgroups start at key 0
+        max_n = n * (7 if seed in (2, 5) else 1)
+        d_keys = _t(torch, np.concatenate([keys, np.zeros(max_n - n, np.uint64)])); d_tmp = torch.empty_like(d_keys)
         d_n = torch.tensor([n], dtype=torch.int64, device="cuda")
         s = torch.cuda.current_stream().cuda_stream
-        in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), n, stream=s, skip_low=True)
+        in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), max_n, stream=s, skip_low=True)
         src = d_tmp if in_tmp else d_keys
-        d_f = torch.empty(n, dtype=torch.int32, device="cuda"); d_c = torch.empty_like(d_f); d_k = torch.empty_like(d_f)
+        d_f = torch.empty(max_n, dtype=torch.int32, device="cuda"); d_c = torch.empty_like(d_f); d_k = torch.empty_like(d_f)
         d_nnz = torch.zeros(1, dtype=torch.int64, device="cuda")
-        eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s, skip_low=True)
+        eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s, skip_low=True)
         torch.cuda.synchronize()
         flagged = bool(eng.dev_error_bits() & 16)
         assert flagged == too_long
         if flagged:
             eng.dev_clear_error_bits(16, s)
             other = d_keys if in_tmp else d_tmp
-            in_other = eng.dev_sort(src.data_ptr(), other.data_ptr(), d_n.data_ptr(), n, stream=s)
+            in_other = eng.dev_sort(src.data_ptr(), other.data_ptr(), d_n.data_ptr(), max_n, stream=s)
             src = other if in_other else src
-            eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s)
+            eng.dev_reduce(src.data_ptr(), d_n.data_ptr(), max_n, d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), d_nnz.data_ptr(), stream=s)
             torch.cuda.synchronize()
             assert eng.dev_error_bits() == 0
         f, c, k = _want_rows(keys)

@@ -1,5 +1,6 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -325,8 +326,9 @@ STREAM_CASES = {
 
 @pytest.mark.parametrize("name", list(STREAM_CASES))
 def test_resident_pass_streaming_k1b_matches_oracle(name):
-    """fastf_dev_probe_pack(FASTF_PROBE_SEGMENTED) -> fastf_dev_sort(FASTF_SORT_SEGMENTED) -> fastf_dev_reduce through
-    ShardedPass (G = 1), two steps on the same buffers, against the oracle; then the same with the tile form forced"""
+    """fastf_dev_probe_pack(FASTF_PROBE_SEGMENTED [| FASTF_PROBE_BLOCKED]) -> fastf_dev_sort(FASTF_SORT_SEGMENTED) ->
+    fastf_dev_reduce through ShardedPass (G = 1), two steps on the same buffers, against the oracle: from the blocked
+    record layout, from the SoA arrays, and with the tile form of K1b forced"""
     import torch
     from fastf_amd.dist import HipStages, ShardedPass
     case = Case(**STREAM_CASES[name])
@@ -337,18 +339,32 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
     t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
     d = [t(x) for x in (cbk, gxk, umi, meta)]
     draws = t(F.mt_draws(case.seed, lists.mt_skip, case.n))
-    for force_tile_form in (False, True):
-        if force_tile_form:
+    for form in ("blocked", "soa", "tile"):
+        # blocked: the engine's staging layout (one run of gx | umi | meta | cell scratch per 256-record unit, K1a fills the
+        # scratch slice); soa: the four arrays of the ABI; tile: the tile form of K1b forced
+        if form == "tile":
             os.environ["FASTF_NO_STREAM_K1B"] = "1"
+        if os.environ.get("FASTF_TEST_TRACE"):
+            print("[form] %s" % form, file=sys.stderr, flush=True)
         try:
             eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12)
-            sp = ShardedPass(HipStages(eng, dev), case.n, dev)
+            st = HipStages(eng, dev)
+            sp = ShardedPass(st, case.n, dev)
+            lds_genes = "LDS" in eng.table_modes.split("genes:")[1]
+            blk = st.block(d[1], d[2], d[3], case.n) if form == "blocked" else None
+            assert (blk is not None) == (form == "blocked" and lds_genes)
+            if form == "blocked" and blk is None:
+                eng.close()
+                continue
             for _ in range(2):
-                sp.run(d[0], d[1], d[2], d[3], case.n, draws)
+                if blk is not None:
+                    sp.run(d[0], blk, None, None, case.n, draws)
+                else:
+                    sp.run(d[0], d[1], d[2], d[3], case.n, draws)
             f, c, k = sp.local_coo()
             hits, sampled, valid, err = sp.global_counters()
             assert err == 0
-            assert sp.st.segmented == (not force_tile_form and "LDS" in eng.table_modes.split("genes:")[1])
+            assert sp.st.segmented == (form != "tile" and lds_genes)
             assert (sampled, valid) == (ora["sampled"], ora["valid"])
             assert len(f) == ora["nnz"]
             np.testing.assert_array_equal(c, ora["cell"].astype(np.int64))
