@@ -38,6 +38,9 @@ typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv;
     int stop; double t_decode;
     int engine_up;                       /* set by the pusher once it can take batches */
+    /* phase accounting (FASTF_PROFILE): records decoded so far, how many of them before the decoder first saw the engine up,
+     * and when that was / when the last record was decoded (seconds since bam2db() was entered) */
+    uint64_t n_decoded, n_before_engine; double t_saw_engine, t_last_record;
     int trace; double t_origin;          /* FASTF_PROFILE=2: one line per batch, times since bam2db() was entered */
 } dec_ctx;
 
@@ -115,6 +118,12 @@ static void *decoder_main(void *vp)
             if (!accumulate || __atomic_load_n(&d->engine_up, __ATOMIC_ACQUIRE) || d->cap - fill < ((size_t)1 << 16)) break;
         }
         d->t_decode += now_s() - t;
+        {   const uint64_t got = (uint64_t)fill + (n > 0 && on_dev ? (uint64_t)n : 0);
+            if (d->t_saw_engine == 0 && __atomic_load_n(&d->engine_up, __ATOMIC_ACQUIRE)) {
+                d->t_saw_engine = now_s() - d->t_origin; d->n_before_engine = d->n_decoded + got;   /* (this call's records were under way) */
+            }
+            d->n_decoded += got;
+            if (got) d->t_last_record = now_s() - d->t_origin; }
         if (on_dev) accumulate = 0;
         if (fill) {
             sl->on_device = 0;
@@ -217,6 +226,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     memset(&dec, 0, sizeof dec);
     dec.bam = bam; dec.lists = &lists; dec.cap = cap;
     {   const char *pf = getenv("FASTF_PROFILE"); dec.trace = pf && pf[0] == '2'; dec.t_origin = t0; }
+    double t_engine_up = 0, t_closed = 0;
     pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
     /* one slab for the ring of decoder slots (untouched pages cost nothing): each slot is pinned when the decoder reaches
      * it, so that the engine copies the packed records to the device straight from where the decoder wrote them */
@@ -271,6 +281,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
     t_engine = now_s() - tt;
     __atomic_store_n(&dec.engine_up, 1, __ATOMIC_RELEASE);
+    t_engine_up = now_s() - t0;
     if (dec.trace) fprintf(stderr, "[trace] %.3f main: engine up\n", now_s() - t0);
 
     for (int k = 0;; k = (k + 1) % dec.n_slots) {
@@ -336,11 +347,22 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     }
     t_write = now_s() - tt;
     rc = 0;
+    t_closed = now_s() - t0;
     if (prof) { struct timespec rt; clock_gettime(CLOCK_REALTIME, &rt); fprintf(stderr, "[bam2db] outputs closed at %.6f (unix time)\n", rt.tv_sec + rt.tv_nsec * 1e-9); }
     if (rel_started) { tt = now_s(); pthread_join(rel_thread, NULL); rel_started = 0; t_wait_release = now_s() - tt; }
     if (rel.no_xf || rel.no_gx)
         fprintf(stderr, "Note: %llu records with a CB but no xf tag and %llu with a valid xf but no GX tag were skipped "
                         "(the reference dereferences NULL on them).\n", (unsigned long long)rel.no_xf, (unsigned long long)rel.no_gx);
+    if (prof) {
+        /* the three pieces of a run: until the device takes work (the host threads decode alone meanwhile), the steady state
+         * (records decoded from then on, reader windows shared with the device), and what is left after the last record */
+        const double t_se = dec.t_saw_engine > 0 ? dec.t_saw_engine : dec.t_last_record;
+        const uint64_t n_steady = dec.n_decoded - (dec.t_saw_engine > 0 ? dec.n_before_engine : dec.n_decoded);
+        fprintf(stderr, "[bam2db] phases: engine_up_s=%.3f decoder_saw_engine_s=%.3f records_before=%llu steady_records=%llu steady_s=%.3f "
+                        "last_record_s=%.3f outputs_closed_s=%.3f\n", t_engine_up, t_se,
+                (unsigned long long)(dec.n_decoded - n_steady), (unsigned long long)n_steady,
+                dec.t_last_record > t_se ? dec.t_last_record - t_se : 0.0, dec.t_last_record, t_closed);
+    }
     if (prof)
         fprintf(stderr, "[bam2db] lists %.3f s, engine create %.3f s, BAM decode+pack %.3f s (decoder thread; main waited %.3f s), "
                         "push (stage+H2D+K1 enqueue) %.3f s, finish (sort+reduce+D2H) %.3f s, write %.3f s, reader+slab release %.3f s "

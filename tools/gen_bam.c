@@ -1,5 +1,7 @@
 /* gen_bam.c — fast synthetic BAM generator for end-to-end benchmarks (test tooling, not product).
- *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len] [threads]
+ *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len] [threads] [repeat]
+ * repeat > 1 writes the n_records-record body (the 64 pieces: whole BGZF blocks, no record straddles a piece) that many
+ * times behind the one header: a file of n_records x repeat records for the price of generating n_records.
  * The record stream is cut into 64 pieces, each with its own generator state and its own run of BGZF blocks, so the
  * file is the same for every thread count.
  * seq_len > 0 gives records the size and content mix of a Cell Ranger BAM: mapped reads with one CIGAR word, seq_len
@@ -66,11 +68,12 @@ static void *worker(void *vp)
 
 int main(int argc, char **argv)
 {
-    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len] [seq_len] [threads]\n"); return 1; }
+    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len] [seq_len] [threads] [repeat]\n"); return 1; }
     g_bar = read_col1(argv[2], &g_nb); g_gen = read_col1(argv[3], &g_ng);
     g_n = strtoull(argv[4], NULL, 10); g_seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 1; g_ul = argc > 6 ? atoi(argv[6]) : 10;
     g_sl = argc > 7 ? atoi(argv[7]) : 0; if (g_sl > 150) g_sl = 150; if (g_sl > 0) g_level = 6;
     int nt = argc > 8 ? atoi(argv[8]) : 1; if (nt < 1) nt = 1; if (nt > 64) nt = 64;
+    int repeat = argc > 9 ? atoi(argv[9]) : 1; if (repeat < 1) repeat = 1;
     out = fopen(argv[1], "wb"); if (!out) { perror(argv[1]); return 1; }
     for (int i = 0; i <= PIECES; i++) { g_piece[i] = calloc(1, sizeof(piece_t)); if (!g_piece[i]) { perror("calloc"); return 1; } }
     /* the header is a block run of its own (piece PIECES, written first) */
@@ -84,7 +87,8 @@ int main(int argc, char **argv)
     for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, worker, NULL);
     for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
     fwrite(g_piece[PIECES]->out, 1, g_piece[PIECES]->olen, out);
-    for (int i = 0; i < PIECES; i++) fwrite(g_piece[i]->out, 1, g_piece[i]->olen, out);
+    for (int r = 0; r < repeat; r++)
+        for (int i = 0; i < PIECES; i++) fwrite(g_piece[i]->out, 1, g_piece[i]->olen, out);
     static const unsigned char eof[28] = {0x1f,0x8b,8,4,0,0,0,0,0,0xff,6,0,'B','C',2,0,0x1b,0,3,0,0,0,0,0,0,0,0,0};
     fwrite(eof, 1, 28, out); fclose(out);
     return 0;
