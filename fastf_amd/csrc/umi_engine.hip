@@ -939,6 +939,19 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
     return 0;
 }
 
+extern "C" int fastf_dev_set_regions(fastf_engine_t* e, const uint64_t* d_counts, uint32_t n_regions, uint64_t stride,
+                                     uint64_t* d_n_out, void* stream) FASTF_TRY {
+    if (!e || !d_counts || !d_n_out) return set_err("null argument");
+    if (e->multi) return set_err("fastf_dev_set_regions: device-level calls take a single-device engine");
+    if (n_regions == 0 || stride == 0) return set_err("fastf_dev_set_regions: no regions");
+    HIP_OK(hipSetDevice(e->device));
+    if (e->d_segprefix.ensure(((size_t)n_regions + 1) * sizeof(u64))) return 1;
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const u64*)d_counts, (u32)n_regions, (u64*)e->d_segprefix.p, (u64*)d_n_out);
+    HIP_OK(hipGetLastError());
+    e->seg_n = n_regions; e->seg_stride = stride;
+    return 0;
+} FASTF_CATCH_INT
+
 extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_tmp, const uint64_t* d_n,
                               uint64_t max_n, uint32_t key_bits, uint32_t flags, int* sorted_in_tmp, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");

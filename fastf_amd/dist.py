@@ -8,7 +8,13 @@ runs K1 on it; a key belongs to shard hash(cell_index) mod G, so all UMIs of a
      so that the keep/drop decision of record i uses the same MT draw as in a serial run
      (bam2db_ds.c:385 is consumed only by CB hits, in record order);
   2. K1 probe/filter/pack, keys written straight into one buffer per destination shard;
-  3. ONE exchange: all_to_all of the per-destination counts, then of the keys (xGMI);
+  3. ONE exchange of the keys (xGMI).  The first step of a ShardedPass learns the per-destination key counts the exact
+     way (all_to_all of the counts, a host synchronisation for the split sizes, all_to_all_single with splits); every
+     later step runs the FIXED-CAPACITY form: each shard buffer is a row of `cap` key slots + one header slot that carries
+     its count, the exchange is one all_to_all_single with equal splits, and the receiver sorts straight out of the G
+     received rows (the engine's region map, as for the streaming K1b) — two collectives per step (the hit counts, the
+     keys), no host synchronisation, nothing on the host that depends on device results.  A count beyond `cap` shows in
+     the headers; ensure_exact() (always run before results are read) then repeats the step the exact way;
   4. local K2 sort + K3 reduce on the received keys;
   5. COO rows stay on their shard (gather_coo() merges them); the three counters are summed over ranks on demand
      (global_counters(): one all_reduce, outside the data path).
@@ -97,6 +103,12 @@ class HipStages:
                                 key_counts.data_ptr(), counters.data_ptr(), self._s(),
                                 d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, segmented=self.segmented, blocked=blocked)
 
+    def set_regions(self, counts, n_regions, stride, d_n):
+        """the keys of the next sort_reduce lie in n_regions rows of `stride` slots, row r holding counts[r] keys (device
+        tensor); writes the total to d_n on the device"""
+        self.eng.dev_set_regions(counts.data_ptr(), n_regions, stride, d_n.data_ptr(), self._s())
+        self.segmented = True
+
     def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, fresh=True):
         # matrix only: the low digit passes are skipped, K3 resolves the short unsorted runs.
         # fresh: keys come straight from probe_pack (possibly segmented); a re-sort of already sorted keys is contiguous
@@ -170,6 +182,14 @@ class ShardedPass:
         self.sorted = None
         self._verified = False     # the group-only sort was checked against its run cap for the current result
         self._counters_reduced = True
+        # fixed-capacity exchange (see the module docstring): key slots per (source, destination) pair, learned from the
+        # first step; None = the next step runs the exact protocol
+        self.cap = None
+        self.fixed = os.environ.get("FASTF_DIST_FIXED", "1") != "0" and hasattr(stages, "set_regions")
+        self._fixed_step = False   # the last step ran the fixed-capacity form
+        self._overflow = None      # device flag of that step: some count exceeded cap
+        self._last_inputs = None
+        self.n_collectives = 0     # collectives issued so far (tests assert two per fixed-capacity step)
 
     def _use_slot(self, b):
         G = self.G
@@ -178,6 +198,22 @@ class ShardedPass:
         self.key_counts = self._small[:G]
         self.counters = self._small[64:68]
         self.draw_base = self._small[128:129]
+
+    def _k1_fixed(self, cb, gx, umi, meta, n, draws):
+        """fixed-capacity step: hit count → all_gather → draw-rank base → probe/filter/pack into rows of cap + 1 slots →
+        the counts into the rows' header slots.  Nothing comes back to the host."""
+        G, st, cap = self.G, self.st, self.cap
+        self._small.zero_()
+        if umi is None:
+            st.count_hits(cb, n, self.hits, blocked=gx)
+        else:
+            st.count_hits(cb, n, self.hits)
+        self._all_gather(self.all_hits, self.hits)
+        self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
+        rows = self.keys_out.view(-1)[:G * (cap + 1)].view(G, cap + 1)
+        st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, rows, cap + 1, self.key_counts, self.counters, reuse_hits=True)
+        rows[:, cap] = self.key_counts          # (a row that overflowed has lost its last key to the header: the count says so)
+        return rows
 
     def _k1_stage(self, cb, gx, umi, meta, n, draws):
         """hit count → draw-rank base → probe/filter/pack → count exchange; returns (send, recv) counts on the host"""
@@ -206,9 +242,11 @@ class ShardedPass:
         return both[:G], both[G:]
 
     def _gather_small(self, out_cpu, inp_cpu):
+        self.n_collectives += 1
         dist.all_gather_into_tensor(out_cpu, inp_cpu, group=self.small_group)
 
     def _exchange_small(self, out_cpu, inp_cpu):
+        self.n_collectives += 1
         dist.all_to_all_single(out_cpu, inp_cpu, group=self.small_group)
 
     def run(self, cb, gx, umi, meta, n, draws, inputs_ready=None):
@@ -219,6 +257,11 @@ class ShardedPass:
         steps must pass `inputs_ready`, an event recorded on its stream after the writes: K1 waits for it.  Without it
         the inputs must be ready when the first step starts and stay untouched afterwards (bench.py: resident inputs)."""
         G, st = self.G, self.st
+        self._last_inputs = (cb, gx, umi, meta, n, draws)
+        self._fixed_step = False
+        if G > 1 and self.fixed and self.cap is not None:
+            self._run_fixed(cb, gx, umi, meta, n, draws, inputs_ready)
+            return
         if G > 1:
             b = self._step % len(self._small_slots)
             self._step += 1
@@ -255,6 +298,13 @@ class ShardedPass:
             self.d_n.fill_(self.n_recv)
             keys = self.recv
             self._counters_reduced = False              # summed over ranks on demand (global_counters), not per step
+            if self.fixed and self.cap is None:
+                # what this step has learned sizes the fixed-capacity rows of the later ones: the largest count of any
+                # (source, destination) pair of the job, a quarter on top (one more collective, once)
+                m = torch.tensor([max(max(send), max(recv))], dtype=torch.int64, device=self.dev)
+                self._all_reduce(m, op=dist.ReduceOp.MAX)
+                slack = int(os.environ.get("FASTF_DIST_CAP_SLACK", "1024"))
+                self.cap = max(1, min(int(m.item()) * 5 // 4 + slack, self.stride - 1))
         else:
             self._small.zero_()
             st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
@@ -273,6 +323,53 @@ class ShardedPass:
         self._verified = False
         self._gathered = not hasattr(st, "rows_gather")   # stages that reduce straight into feature/cell/count
 
+    def _run_fixed(self, cb, gx, umi, meta, n, draws, inputs_ready):
+        """one step in the fixed-capacity form: two collectives, no host synchronisation"""
+        G, st, cap = self.G, self.st, self.cap
+        b = self._step % len(self._small_slots)
+        self._step += 1
+        self._use_slot(b)
+        self.recv = self._recv_slots[b]
+        recv_rows = self.recv[:G * (cap + 1)].view(G, cap + 1)
+        if self.pipelined:
+            main = torch.cuda.current_stream(self.dev)
+            k1, x = self.k1_stream, self.x_stream
+            if inputs_ready is not None:
+                k1.wait_event(inputs_ready)
+            elif self._step == 1:
+                k1.wait_stream(main)
+            with torch.cuda.stream(k1):
+                if self._slot_free[b] is not None:
+                    k1.wait_event(self._slot_free[b])
+                rows = self._k1_fixed(cb, gx, umi, meta, n, draws)
+            with torch.cuda.stream(x):
+                x.wait_stream(k1)
+                if self._recv_free[b] is not None:
+                    x.wait_event(self._recv_free[b])
+                self._all_to_all_single(recv_rows.view(-1), rows.view(-1))
+                ev = torch.cuda.Event()
+                ev.record(x)
+            self._slot_free[b] = ev
+            main.wait_event(ev)
+        else:
+            rows = self._k1_fixed(cb, gx, umi, meta, n, draws)
+            self._all_to_all_single(recv_rows.view(-1), rows.view(-1))
+        counts = recv_rows[:, cap].contiguous()
+        self._overflow = (counts > cap).any() | (rows[:, cap] > cap).any()
+        self.d_n = self._d_n_buf
+        st.set_regions(counts.clamp(max=cap), G, cap + 1, self.d_n)
+        self.n_recv = G * cap                           # the host knows a bound only; the device reads the count at d_n
+        self.sorted = st.sort_reduce(self.recv, self.tmp, self.d_n, self.n_recv, self.feature, self.cell, self.count, self.nnz)
+        if self.pipelined:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._recv_free[b] = ev
+        self._keys_buf = self.recv
+        self._counters_reduced = False
+        self._verified = False
+        self._fixed_step = True
+        self._gathered = not hasattr(st, "rows_gather")
+
     def _exchange_keys(self, send, recv):
         """the one exchange of the pass: shard buffer g of this rank → rank g; what arrives lands in self.recv"""
         G = self.G
@@ -284,6 +381,7 @@ class ShardedPass:
 
     # ---- collectives: direct on RCCL (and on CPU tensors over gloo), staged through the host otherwise ----
     def _all_gather(self, out, inp):
+        self.n_collectives += 1
         if self.host_staged:
             o = out.cpu()
             dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
@@ -292,6 +390,7 @@ class ShardedPass:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def _all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        self.n_collectives += 1
         if self.host_staged:
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
@@ -299,19 +398,30 @@ class ShardedPass:
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
-    def _all_reduce(self, t):
+    def _all_reduce(self, t, op=None):
+        self.n_collectives += 1
+        op = dist.ReduceOp.SUM if op is None else op
         if self.host_staged:
             h = t.cpu()
-            dist.all_reduce(h, group=self.group)
+            dist.all_reduce(h, op=op, group=self.group)
             t.copy_(h)
         else:
-            dist.all_reduce(t, group=self.group)
+            dist.all_reduce(t, op=op, group=self.group)
 
     def ensure_exact(self):
         """If the group-only sort met runs beyond its cap, finish the sort and reduce again (every key is still in
         the buffers, permuted).  Costs one synchronisation; called before results are read."""
         if self._verified:
             return
+        if self._fixed_step:
+            # did a count outgrow the rows (the input changed since the capacity was learned)?  A rank sees the headers of its
+            # own rows only, so the ranks agree first (results are being read: a collective and a synchronisation are due
+            # anyway); if so, this step again, the exact way, which also learns the new capacity
+            o = self._overflow.to(torch.int64).reshape(1)
+            self._all_reduce(o, op=dist.ReduceOp.MAX)
+            if int(o.item()):
+                self.cap = None
+                self.run(*self._last_inputs)
         self._verified = True
         st = self.st
         if getattr(st, "run_too_long", None) and st.run_too_long():

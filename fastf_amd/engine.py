@@ -328,6 +328,10 @@ class Engine:
         check(self._L.fastf_dev_probe_capacity(self._h, n, C.byref(v)))
         return int(v.value)
 
+    def dev_set_regions(self, d_counts, n_regions, stride, d_n_out, stream=0):
+        """the next segmented dev_sort reads n_regions rows of `stride` key slots, row r holding d_counts[r] keys"""
+        check(self._L.fastf_dev_set_regions(self._h, d_counts, n_regions, stride, d_n_out, stream))
+
     def dev_sort(self, d_keys, d_tmp, d_n, max_n, key_bits=None, stream=0, skip_low=False, segmented=False) -> bool:
         in_tmp = C.c_int(0)
         check(self._L.fastf_dev_sort(self._h, d_keys, d_tmp, d_n, max_n,

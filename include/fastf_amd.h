@@ -307,6 +307,11 @@ int fastf_dev_count_hits_blocked(fastf_engine_t *e, const uint64_t *d_cb_key, ui
                                       (equal keys stay neighbours of their (cell, feature, top-UMI-bits) run);
                                       pass the same flag to fastf_dev_reduce.  Not for fastf_dev_umi_rows.        */
 #define FASTF_SORT_SEGMENTED  4u   /* d_keys is the output of the last FASTF_PROBE_SEGMENTED fastf_dev_probe_pack */
+/* The keys of the next FASTF_SORT_SEGMENTED fastf_dev_sort lie in n_regions rows of `stride` slots of its d_keys, row r
+ * holding d_counts[r] keys at its front (device array, u64): the receive buffer of a fixed-capacity key exchange is sorted
+ * where it landed, no compaction pass.  Writes the total to *d_n_out on the device. */
+int fastf_dev_set_regions(fastf_engine_t *e, const uint64_t *d_counts, uint32_t n_regions, uint64_t stride,
+                          uint64_t *d_n_out, void *stream);
 int fastf_engine_skip_bits(const fastf_engine_t *e, uint32_t *bits);
 /* number of 8-bit LSD passes fastf_dev_sort runs for this engine's keys with the given flags: the digit grid starts at
  * the skip bit (not necessarily a byte boundary) when FASTF_SORT_SKIP_LOW is set, at bit 0 otherwise */

@@ -49,12 +49,26 @@ class NumpyStages:
         for s in range(G):
             ks = key[valid & (own == s)]
             c = int(key_counts[s])
-            keys_out[s, c:c + len(ks)] = torch.from_numpy(ks.view(np.int64))
+            room = max(0, min(len(ks), stride - c))          # like the device: what does not fit the row is lost, the count goes on
+            keys_out[s, c:c + room] = torch.from_numpy(ks[:room].view(np.int64))
             key_counts[s] = c + len(ks)
         counters[0] += int(hit.sum()); counters[1] += int(keep.sum()); counters[2] += int(valid.sum())
 
+    def set_regions(self, counts, n_regions, stride, d_n):
+        self.regions = (counts.clone(), n_regions, stride)
+        d_n[0] = int(counts.sum())
+
     def sort_reduce(self, keys, tmp, d_n, max_n, feature, cell, count, nnz, fresh=True):
         n = int(d_n[0])
+        if fresh and getattr(self, "regions", None) is not None:      # the keys lie in rows (fixed-capacity exchange)
+            counts, R, stride = self.regions
+            self.regions = None
+            flat = keys.view(-1)
+            rows = [flat[r * stride:r * stride + int(counts[r])] for r in range(R)]
+            src = torch.cat(rows) if rows else flat[:0]
+            assert len(src) == n
+            keys = tmp
+            keys[:n] = src
         k = np.sort(keys[:n].numpy().view(np.uint64))
         keys[:n] = torch.from_numpy(k.view(np.int64))
         grp = k >> np.uint64(self.feat_shift)

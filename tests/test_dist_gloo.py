@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_kw, q):
+def _worker(rank, world, port, case_kw, q, mode="steps"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,32 +37,62 @@ def _worker(rank, world, port, case_kw, q):
         st = NumpyStages(lists.cell_keys, lists.feature_keys, F.draw_threshold(case.rate_depth))
         sp = ShardedPass(st, max(b - a, 1), torch.device("cpu"))
         t = lambda x: torch.from_numpy(x[a:b].copy().view(np.int64) if x.dtype == np.uint64 else x[a:b].copy().view(np.int32))
-        sp.run(t(cbk), t(gxk), t(umi), t(meta), b - a, draws)
-        f, c, k = sp.gather_coo()
+        d = (t(cbk), t(gxk), t(umi), t(meta))
+        info = {}
+        if mode == "overflow":
+            os.environ["FASTF_DIST_CAP_SLACK"] = "0"
+            # the capacity of the fixed-size rows is learned from a step over a tenth of the slice; the full slice then
+            # outgrows it: ensure_exact() (behind every result) must notice and repeat the step the exact way
+            m = max((b - a) // 10, 1)
+            sp.run(*(x[:m] for x in d), m, draws)
+            sp.ensure_exact()
+            small_cap = sp.cap
+            sp.run(*d, b - a, draws)
+            info["fixed_then_redone"] = bool(sp._fixed_step)          # before the results are asked for
+            f, c, k = sp.gather_coo()
+            info["cap_grew"] = sp.cap is not None and sp.cap >= small_cap
+            info["redone_exactly"] = not sp._fixed_step
+        else:
+            sp.run(*d, b - a, draws)                                  # learns the capacity (exact protocol)
+            sp.ensure_exact()
+            per_step = []
+            for _ in range(3):
+                c0 = sp.n_collectives
+                sp.run(*d, b - a, draws)
+                per_step.append(sp.n_collectives - c0)
+            info["collectives_per_step"] = per_step
+            info["fixed"] = bool(sp._fixed_step)
+            f, c, k = sp.gather_coo()
         lf, lc, _ = sp.local_coo()
         owners_ok = bool((owner_of_cell(lc, world) == rank).all()) if len(lc) else True
-        q.put((rank, f, c, k, sp.global_counters(), owners_ok))
+        q.put((rank, f, c, k, sp.global_counters(), owners_ok, info))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_pass_over_gloo(world):
+@pytest.mark.parametrize("world,mode", [(2, "steps"), (3, "steps"), (2, "overflow")])
+def test_sharded_pass_over_gloo(world, mode):
+    """the first step learns the per-destination key counts the exact way; every later step is the fixed-capacity form:
+    TWO collectives (hit counts, keys), nothing on the host that waits for the device — and the oracle's rows"""
     case_kw = dict(n=6000, n_bar=60, n_gene=25, rate_cell=0.7, rate_depth=0.6, umi_pool=40,
                    p_no_cb=0.05, p_unlisted_cb=0.1, p_bad_xf=0.1, p_n_umi=0.05, p_no_ub=0.02)
     ora = Case(**case_kw).oracle()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case_kw, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_kw, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, f, c, k, counters, owners_ok in res:
+    for rank, f, c, k, counters, owners_ok, info in res:
         assert owners_ok
+        if mode == "steps":
+            assert info["fixed"] and info["collectives_per_step"] == [2, 2, 2], info
+        else:
+            assert info["fixed_then_redone"] and info["redone_exactly"] and info["cap_grew"], info
         np.testing.assert_array_equal(f, ora["feature"].astype(np.int64))
         np.testing.assert_array_equal(c, ora["cell"].astype(np.int64))
         np.testing.assert_array_equal(k, ora["count"].astype(np.int64))

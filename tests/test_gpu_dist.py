@@ -63,7 +63,7 @@ def test_sharded_pass_ranks_share_one_gpu(world, kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kw, 2, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kw, 3, q)) for r in range(world)]     # one exact step, two fixed-capacity ones
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -79,21 +79,32 @@ def test_sharded_pass_ranks_share_one_gpu(world, kw):
         assert (sampled, valid) == (ora["sampled"], ora["valid"])
 
 
-def test_pipelined_pass_with_asynchronous_loopback_exchange():
+@pytest.mark.parametrize("fixed", [False, True], ids=["exact_protocol", "fixed_capacity_rows"])
+def test_pipelined_pass_with_asynchronous_loopback_exchange(fixed):
     """The two-stream pipeline of ShardedPass under real asynchrony: one process plays shard 0 of 2, the collectives
-    are device-side copies on the current stream (nothing synchronises the host but the count read-back), and the
-    input alternates between two different record slices from step to step — a shard buffer or counter slot reused
-    too early shows up as a wrong matrix.  Each step's rows are checked against the oracle restricted to shard 0's cells."""
+    are device-side copies on the current stream (nothing synchronises the host but the count read-back — and in the
+    fixed-capacity form, after the first step, nothing at all), and the input alternates between two different record slices
+    from step to step — a shard buffer or counter slot reused too early shows up as a wrong matrix.  Each step's rows
+    are checked against the oracle restricted to shard 0's cells."""
     import torch
     import fastf_amd as F
     from fastf_amd.dist import HipStages, ShardedPass, owner_of_cell
 
     class Loopback(ShardedPass):
         def _all_gather(self, out, inp):
+            self.n_collectives += 1
             out.zero_(); out[self.rank:self.rank + 1].copy_(inp)          # the other shard holds no records
 
         def _all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
-            out.zero_(); out[:1].copy_(inp[:1])                           # only my own shard-0 count comes back
+            self.n_collectives += 1
+            if out.numel() == self.G:
+                out.zero_(); out[:1].copy_(inp[:1])                       # only my own shard-0 count comes back
+            else:                                                         # the key rows: mine comes back, the other shard's is empty
+                row = out.numel() // self.G
+                out.zero_(); out[:row].copy_(inp[:row])
+
+        def _all_reduce(self, t, op=None):
+            self.n_collectives += 1                                       # (the other shard has nothing to add)
 
         def _exchange_keys(self, send, recv):
             self.recv[:send[0]].copy_(self.keys_out[0, :send[0]])
@@ -125,10 +136,14 @@ def test_pipelined_pass_with_asynchronous_loopback_exchange():
     eng.reserve(n, n)
     try:
         sp = Loopback(HipStages(eng, dev), n, dev, world=2, rank=0)
+        sp.fixed = fixed
         assert sp.pipelined
         for step in range(12):
             k = step % 2
+            c0 = sp.n_collectives
             sp.run(packed[k][0], packed[k][1], packed[k][2], packed[k][3], n, draws)
+            if fixed and step >= 1:
+                assert sp._fixed_step and sp.n_collectives - c0 == 2          # the hit counts and the keys, nothing else
             if step in (5, 10, 11):                                   # mid-stream and final results
                 f, c, cnt = sp.local_coo()
                 ora = oras[k]
