@@ -182,10 +182,11 @@ static void *release_main(void *vp)
 
 static uint32_t bits_for(uint64_t v) { uint32_t b = 0; while (b < 64 && (v >> b)) b++; return b ? b : 1; }
 
-int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, char *features_file,
-           float rate_cell, float rate_depth, unsigned int seed)
+/* umi_bases: 0 = choose (16 bases if the packed key then fits 64 bits, else 12 with a second run at 16 — keys wider than 64
+ * bits — should the file hold longer UMIs: *longer_umis is set and everything is torn down for that run) */
+static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char *features_file,
+                      float rate_cell, float rate_depth, unsigned int seed, uint32_t umi_bases, int *longer_umis)
 {
-    (void)db_file;                      /* no SQLite in this engine */
     int rc = 1;
     {   extern int fastf_worker_nice_;
         const char *wn = getenv("FASTF_WORKER_NICE");
@@ -272,10 +273,15 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         if (n_dev >= 2) { cfg.n_devices = n_dev; cfg.devices = dev_list; }
         else if (n_dev == 1) cfg.device = dev_list[0];
     }
-    /* widest UMI field the 64-bit key allows (16 bases need 36 bits, 12 need 27) */
+    /* 16-base UMIs (36 key bits) when the packed key then fits 64 bits; else 12 bases (27 bits: what 10x chemistry writes) if
+     * THAT fits — the fast 64-bit path — with a second run should the file turn out to hold longer UMIs (umi_bases = 16 then);
+     * else 16 bases with keys wider than 64 bits (the engine sorts the (cell, feature) word and carries the rest beside it) */
     const char *ul = getenv("FASTF_UMI_MAX_BASES");
-    if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);
-    else cfg.umi_max_bases = (bits_for(cfg.n_cells) + bits_for(cfg.n_features) + 36 <= 64) ? 16 : 12;
+    const uint32_t group_bits = bits_for(cfg.n_cells) + bits_for(cfg.n_features);
+    if (umi_bases) cfg.umi_max_bases = umi_bases;
+    else if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);
+    else cfg.umi_max_bases = (group_bits + 36 <= 64 || group_bits + 27 > 64) ? 16 : 12;
+    const int may_rerun = !umi_bases && !ul && cfg.umi_max_bases == 12;
     cfg.batch_records = cap;
     tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
@@ -302,6 +308,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
         tt = now_s();
         /* pinned slots: queue the copies, and hand the slot back to the decoder once they have left it */
         if ((slot_pinned || on_dev) ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
+            if (may_rerun && strstr(fastf_last_error(), "UMI longer")) { *longer_umis = 1; goto done; }
             fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
         }
         t_push += now_s() - tt;
@@ -330,7 +337,10 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     }
     fastf_coo_t coo; uint64_t counters[3];
     tt = now_s();
-    if (fastf_engine_finish(eng, &coo, counters)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
+    if (fastf_engine_finish(eng, &coo, counters)) {
+        if (may_rerun && strstr(fastf_last_error(), "UMI longer")) { *longer_umis = 1; goto done; }
+        fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
+    }
     t_finish = now_s() - tt;
     printf("In %s, total fastQ reads: %zu\n", bam_file, (size_t)counters[0]);
     printf("In %s, sampled fastQ reads: %zu\n", bam_file, (size_t)counters[1]);
@@ -377,7 +387,7 @@ done:
         pthread_join(dec_thread, NULL);
     }
     if (pin_started) { pin_thread_stop(&dec, pin_thread); pin_started = 0; }
-    if (fastf_process_is_exiting_) {
+    if (fastf_process_is_exiting_ && !*longer_umis) {
         /* the fastF CLI leaves through _exit() right after this call: device memory, pinned pages and the BAM mapping
          * go back with the process, and unmapping them one by one first costs 0.1-0.2 s */
         if (bam) fastf_bam_print_profile(bam);
@@ -389,6 +399,22 @@ done:
     if (bam) fastf_bam_close(bam);
     fastf_lists_free(&lists);
     if (prof) fprintf(stderr, "[bam2db] teardown (engine, pinned slab, BAM mapping, lists) %.3f s\n", now_s() - tt);
+    return rc;
+}
+
+int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, char *features_file,
+           float rate_cell, float rate_depth, unsigned int seed)
+{
+    (void)db_file;                      /* no SQLite in this engine */
+    int longer_umis = 0;
+    int rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, 0, &longer_umis);
+    if (longer_umis) {
+        /* the reference takes a UMI of any length (bam2db_ds.c:417-419); the first run assumed at most 12 bases to keep the
+         * key within 64 bits: once more, with 16-base UMIs and the key wider than 64 bits */
+        fprintf(stderr, "Note: UMIs longer than 12 bases in %s: running again with 16-base UMIs (keys wider than 64 bits)\n", bam_file);
+        longer_umis = 0;
+        rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, 16, &longer_umis);
+    }
     return rc;
 }
 

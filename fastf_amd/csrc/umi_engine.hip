@@ -174,6 +174,10 @@ struct fastf_engine {
     DevBuf d_rg_feature, d_rg_cell, d_rg_count, d_rg_ukeys, d_spanrows, d_spanbase, d_giant;
     u32 rg_n = 0; bool rg_umi = false;   // chunks of the last reduce (0: none) and its kind
     bool dedup_hash = false;             // matrix path: sort on (cell, feature) only, dedup through K3's hash set (else: run walk)
+    // keys wider than 64 bits (cell bits + feature bits + UMI field > 64): the sort key is the GROUP (cell << feat_bits |
+    // feature, group_bits wide), the rest of the key (NULL flag, UMI, length: feat_shift bits) travels beside it as a value
+    bool wide = false; u32 group_bits = 0;
+    DevBuf d_vals, d_vtmp;
     // timing
     bool timing = false;
     hipEvent_t t_ev[2] = {nullptr, nullptr};
@@ -431,6 +435,12 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     if (he != hipSuccess || ndev == 0)
         return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
     if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 16) return set_err("umi_max_bases must be 1..16");
+    {   // keys wider than 64 bits run on the single-device engine (the group word is sorted, the rest rides along)
+        const u32 tb = bits_for(cfg->n_cells) + bits_for(cfg->n_features) + 1 + 2 * cfg->umi_max_bases + bits_for((cfg->umi_max_bases + 3) / 4);
+        if (tb > 64 && (cfg->n_devices > 1 || cfg->n_shards > 1))
+            return set_err("packed key needs %u bits (> 64): the sharded and multi-device engines take keys of at most 64 bits "
+                           "(lower umi_max_bases, or run the single-device engine)", tb);
+    }
     if (cfg->n_devices > 1 || (cfg->n_devices == 1 && getenv("FASTF_FORCE_MULTI"))) {
         fastf_engine* me = new fastf_engine();
         if (multi_create(cfg, me)) { multi_destroy(me); delete me; return 1; }
@@ -455,11 +465,8 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     e->L.feat_shift = 1 + e->L.umi_bits + e->L.len_bits;
     e->L.cell_shift = e->L.feat_shift + e->feat_bits;
     e->L.total_bits = e->L.cell_shift + e->cell_bits;
-    if (e->L.total_bits > 64) {
-        set_err("packed key needs %u bits (cell %u + feature %u + umi %u) > 64: lower umi_max_bases",
-                e->L.total_bits, e->cell_bits, e->feat_bits, 1 + e->L.umi_bits + e->L.len_bits);
-        delete e; return 1;
-    }
+    e->wide = e->L.total_bits > 64 || getenv("FASTF_FORCE_WIDE_KEYS") != nullptr;
+    e->group_bits = e->cell_bits + e->feat_bits;
     e->threshold = cfg->draw_threshold;
     {   // Matrix path: the sorted part must hold (cell, feature, NULL flag) and at least 7 bits of the UMI field, i.e. the
         // key bits from feat_shift - 8 upwards; the digit grid is anchored at the TOP of the key, so the number of 8-bit
@@ -475,6 +482,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         const u32 passes = (kb - need_from + 7) / 8;
         e->skip_bits = sk ? (u32)atoi(sk) : (kb > 8 * passes ? kb - 8 * passes : 0);
         if (e->skip_bits >= fs) e->skip_bits = 0;
+        if (e->wide) e->skip_bits = 0;                               // the group word is sorted whole
     }
     e->n_shards = cfg->n_shards; e->shard_rank = cfg->shard_rank;
     e->mt_seed0 = cfg->mt_seed; e->mt_skip0 = cfg->mt_skip;
@@ -541,7 +549,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     e->d_ring.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
-                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys};
+                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -736,7 +744,7 @@ static bool stream_k1b_possible(const fastf_engine* e) {
 extern "C" int fastf_dev_block_bytes(const fastf_engine_t* e, uint64_t n, uint64_t* bytes) FASTF_TRY {
     if (!e || !bytes) return set_err("null argument");
     *bytes = 0;
-    if (e->multi || !stream_k1b_possible(e)) return 0;
+    if (e->multi || e->wide || !stream_k1b_possible(e)) return 0;
     *bytes = ((n + BLK_RECS - 1) / BLK_RECS) * (u64)blk_run_bytes(e->cell16);
     return 0;
 } FASTF_CATCH_INT
@@ -765,6 +773,8 @@ extern "C" int fastf_dev_count_hits_blocked(fastf_engine_t* e, const uint64_t* d
     return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s, nullptr, nullptr, d_blocked);
 } FASTF_CATCH_INT
 
+#define NO_WIDE(e, what) do { if ((e)->wide) return set_err(what ": this engine's keys are wider than 64 bits — the device-level calls take keys of at most 64 bits (the host-buffer API handles wide keys)"); } while (0)
+
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
                         u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr,
@@ -787,6 +797,10 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.n_tiles = tiles;
     p.genes = e->lds_genes;
     p.blk = (const unsigned char*)blk;
+    if (e->wide) {                                      // wide keys: group word into keys[], the rest into d_vals[] (tile form, one shard)
+        if (segmented || blk || e->n_shards != 1 || keys != (u64*)e->d_keys.p) return set_err("internal error: wide keys go through the engine's own key store");
+        p.vals = (u64*)e->d_vals.p; p.wide_feat_bits = e->feat_bits;
+    }
     // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
     // deals the keys to the per-destination buffers (same interface as the tile form: keys[G][stride], key_counts[G] += ...)
     const bool no_stream = getenv("FASTF_NO_STREAM_K1B") != nullptr;
@@ -843,6 +857,7 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_probe_pack: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
+    NO_WIDE(e, "fastf_dev_probe_pack");
     const bool seg = (flags & FASTF_PROBE_SEGMENTED) != 0, blocked = (flags & FASTF_PROBE_BLOCKED) != 0;
     if (seg && !(e->n_shards == 1 && e->use_lds_genes))
         return set_err("FASTF_PROBE_SEGMENTED needs a single shard and the gene table in LDS (fastf_dev_probe_capacity returns 0 otherwise)");
@@ -856,6 +871,7 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
 extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uint64_t* key_slots) FASTF_TRY {
     if (!e || !key_slots) return set_err("null argument");
     *key_slots = 0;
+    if (e->wide) return 0;
     if (!(e->n_shards == 1 && e->use_lds_genes) || getenv("FASTF_NO_STREAM_K1B")) return 0;
     const u64 tiles = (n + K1_TILE - 1) / K1_TILE;
     const u64 grid = std::min<u64>(std::max<u64>(tiles, 1), (u64)e->genes_blocks_per_cu * g_cu_count);
@@ -871,9 +887,16 @@ static u32 tile_grid(u32 T) {
     if (cap < 0) { const char* c = getenv("FASTF_TILE_GRID_CAP"); cap = c ? atoi(c) : 32 * (int)g_cu_count; if (cap < 8) cap = 8; }
     return std::min<u32>((T + 7u) & ~7u, (u32)cap & ~7u);
 }
+static size_t scatter_smem_bytes_vals(u32 ipt) { return scatter_smem_bytes(ipt) + (size_t)ipt * SORT_THREADS * 8; }
 static void launch_scatter(u32 shift, u32 T, hipStream_t s, const u64* src, u64* dst, const u64* d_n, const u32* cnt,
-                           const u32* bin_tot, u32 ipt, const SegMap seg = SegMap{nullptr, nullptr, 0, 0}) {
+                           const u32* bin_tot, u32 ipt, const SegMap seg = SegMap{nullptr, nullptr, 0, 0},
+                           const u64* vsrc = nullptr, u64* vdst = nullptr) {
     T = tile_grid(T);
+    if (vsrc) {                         // keys with values (wide keys): one instantiation, run-time shift
+        hipLaunchKernelGGL((scatter_kernel<-1, false, true>), dim3(T), dim3(SORT_THREADS), scatter_smem_bytes_vals(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift,
+                           SegMap{nullptr, nullptr, 0, 0}, (u64*)nullptr, vsrc, vdst);
+        return;
+    }
 #define SC(SH) hipLaunchKernelGGL(scatter_kernel<SH>, dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, seg, g_stamps)
     if (seg.prefix) {                   // the one segmented pass: run-time shift, map lookup compiled in
         hipLaunchKernelGGL((scatter_kernel<-1, true>), dim3(T), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst, d_n, cnt, bin_tot, ipt, shift, seg, g_stamps);
@@ -895,13 +918,15 @@ static int set_scatter_lds_limit() {
                            (const void*)scatter_kernel<-1, true>};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)scatter_kernel<-1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes_vals(SORT_IPT)) != hipSuccess) return 1;
     return 0;
 }
 
 // 8-bit LSD passes over the key bits [low_bit, key_bits): pass q sorts the digit at low_bit + 8q (the last one may reach
 // past key_bits, where every key holds zeros).  low_bit = 0 is the full sort.
+// vals / vtmp: 64-bit values that move with the keys (wide keys), ping-pong like the keys
 static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64 max_n, u32 key_bits, u32 low_bit,
-                       int* sorted_in_tmp, hipStream_t s, bool segmented_input = false) {
+                       int* sorted_in_tmp, hipStream_t s, bool segmented_input = false, u64* vals = nullptr, u64* vtmp = nullptr) {
     if (key_bits > 64) return set_err("key_bits %u > 64", key_bits);
     const u32 passes = sort_passes(key_bits, low_bit);
     *sorted_in_tmp = (int)(passes & 1);
@@ -931,7 +956,8 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
         t_end(e, s, &e->t_count_ms, &e->t_count_n);
         hipLaunchKernelGGL(row_scan_kernel, dim3(RADIX), dim3(1024), 0, s, cnt, d_n, bintot, ipt);
         t_begin(e, s);
-        launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt, q == 0 ? seg : none);
+        if (vals) launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt, none, (q & 1) ? vtmp : vals, (q & 1) ? vals : vtmp);
+        else launch_scatter(shift, T, s, src, dst, d_n, (const u32*)cnt, (const u32*)bintot, ipt, q == 0 ? seg : none);
         t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
         dbg_sync(s, "K2 sort pass");
     }
@@ -956,6 +982,7 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
                               uint64_t max_n, uint32_t key_bits, uint32_t flags, int* sorted_in_tmp, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_sort: device-level calls take a single-device engine");
+    NO_WIDE(e, "fastf_dev_sort");
     HIP_OK(hipSetDevice(e->device));
     int dummy = 0;
     return launch_sort(e, (u64*)d_keys, (u64*)d_tmp, (const u64*)d_n, max_n, key_bits,
@@ -978,13 +1005,16 @@ static u32 k3_grid(u64 max_n, int dedup) {
 }
 
 // rows into the engine's row regions (one per workgroup chunk), chunk row counts -> bases, total -> *nrows
+// wide_vals: the values beside `sorted` (wide keys: sorted = group words); the matrix rows only
 template <bool UMI_ROWS>
-static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u64* nrows, u32 low_skip, hipStream_t s) {
+static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* d_n, u64 max_n, u64* nrows, u32 low_skip, hipStream_t s,
+                                 const u64* wide_vals = nullptr) {
     e->rg_n = 0;
     if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
-    const int dedup = (UMI_ROWS || low_skip == 0) ? 0 : (e->dedup_hash ? 2 : 1);
+    if (wide_vals && UMI_ROWS) return set_err("internal error: -u rows of wide keys");
+    const int dedup = wide_vals ? 2 : (UMI_ROWS || low_skip == 0) ? 0 : (e->dedup_hash ? 2 : 1);
     u32 G = k3_grid(max_n, dedup);
-    if (dedup == 2 && e->L.feat_shift > 27 && !k3_old_hash()) G = std::min<u32>(G, 3 * g_cu_count);      // 52 KB of LDS per workgroup: three per CU
+    if (dedup == 2 && (e->L.feat_shift > 27 || wide_vals) && !k3_old_hash()) G = std::min<u32>(G, (wide_vals ? 2 : 3) * g_cu_count);      // 52 KB of LDS per workgroup: three per CU
     if (e->d_rg_count.ensure(max_n * 4)) return 1;
     if (UMI_ROWS ? e->d_rg_ukeys.ensure(max_n * 8) : (e->d_rg_feature.ensure(max_n * 4) || e->d_rg_cell.ensure(max_n * 4))) return 1;
     if (e->d_spanrows.ensure(4096 * sizeof(u32)) || e->d_spanbase.ensure(4097 * sizeof(u64))) return 1;
@@ -1000,16 +1030,21 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     p.feature = (u32*)e->d_rg_feature.p; p.cell = (u32*)e->d_rg_cell.p; p.count = (u32*)e->d_rg_count.p; p.ukeys = (u64*)e->d_rg_ukeys.p;
     p.span_rows = (u32*)e->d_spanrows.p;
     p.giant_list = (u64*)e->d_giant.p; p.giant_n = giant_n;
+    // groups beyond giant_max send the caller to the full sort; wide keys have no full-sort path, and giant_groups_kernel takes
+    // any length (one work item per ~1536 keys, GIANT_LIST_CAP items per launch): 4 M reads of one gene in one cell
+    p.giant_max = wide_vals ? (1u << 22) : GIANT_MAX;
+    p.vals = wide_vals; p.wide_feat_bits = e->feat_bits;
     t_begin(e, s);
     if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 1) hipLaunchKernelGGL((reduce_windows_kernel<false, 1>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else if (wide_vals) hipLaunchKernelGGL((reduce_hashed_kernel<true, true>), dim3(G), dim3(K3H_THREADS), 0, s, p);
     else if (k3_old_hash()) hipLaunchKernelGGL((reduce_windows_kernel<false, 2>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (e->L.feat_shift > 27) hipLaunchKernelGGL((reduce_hashed_kernel<true>), dim3(G), dim3(K3H_THREADS), 0, s, p);    // UMIs beyond 12 bases: 64-bit slots
     else hipLaunchKernelGGL((reduce_hashed_kernel<false>), dim3(G), dim3(K3H_THREADS), 0, s, p);
     hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows, giant_n);
     if (dedup == 2)
-        hipLaunchKernelGGL(giant_groups_kernel, dim3(g_cu_count), dim3(512), 0, s, sorted, (const u64*)e->d_giant.p, (const u32*)(giant_n + 1), e->L,
+        hipLaunchKernelGGL(giant_groups_kernel, dim3(g_cu_count), dim3(512), 0, s, wide_vals ? wide_vals : sorted, (const u64*)e->d_giant.p, (const u32*)(giant_n + 1), e->L,
                            (u32*)e->d_rg_count.p, (u64*)e->d_small.p + SM_COUNTERS + 3);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
@@ -1045,6 +1080,7 @@ extern "C" int fastf_dev_reduce(fastf_engine_t* e, const uint64_t* d_sorted, con
                                 void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_reduce: device-level calls take a single-device engine");
+    NO_WIDE(e, "fastf_dev_reduce");
     HIP_OK(hipSetDevice(e->device));
     const u32 low = (flags & FASTF_SORT_SKIP_LOW) ? e->skip_bits : 0;
     if (flags & FASTF_REDUCE_SEGMENTED)
@@ -1065,6 +1101,7 @@ extern "C" int fastf_dev_umi_rows(fastf_engine_t* e, const uint64_t* d_sorted, c
                                   uint64_t* d_ukeys, uint32_t* d_ncopy, uint64_t* d_nrows, void* stream) FASTF_TRY {
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_umi_rows: device-level calls take a single-device engine");
+    NO_WIDE(e, "fastf_dev_umi_rows");
     HIP_OK(hipSetDevice(e->device));
     return launch_reduce<true>(e, (const u64*)d_sorted, (const u64*)d_n, max_n, nullptr, nullptr, d_ncopy,
                                (u64*)d_ukeys, (u64*)d_nrows, 0, (hipStream_t)stream);
@@ -1103,7 +1140,7 @@ static const char* err_bits_text(u64 bits) {
     snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s%s", (unsigned long long)bits,
              (bits & 1) ? " (unknown bit 0);" : "",
              (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
-             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it; key must still fit 64 bits);" : "",
+             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it: up to 16);" : "",
              (bits & ERR_KEYS_FULL) ? " key store full;" : "",
              (bits & ERR_RUN_TOO_LONG) ? " unsorted run longer than the group-only path handles: sort fully (drop FASTF_SORT_SKIP_LOW);" : "");
     return buf;
@@ -1158,6 +1195,14 @@ static int grow_keys(fastf_engine* e, u64 need) {
         HIP_OK(hipMemcpy(np, e->d_keys.p, e->keys_so_far * sizeof(u64), hipMemcpyDeviceToDevice));
     e->d_keys.release();
     e->d_keys.p = np; e->d_keys.bytes = ncap * sizeof(u64);
+    if (e->wide) {                                       // the rest of every key, beside it
+        void* nv = nullptr;
+        HIP_OK(hipMalloc(&nv, ncap * sizeof(u64)));
+        if (e->d_vals.p && e->keys_so_far) HIP_OK(hipMemcpy(nv, e->d_vals.p, e->keys_so_far * sizeof(u64), hipMemcpyDeviceToDevice));
+        e->d_vals.release();
+        e->d_vals.p = nv; e->d_vals.bytes = ncap * sizeof(u64);
+        if (e->d_vtmp.ensure(ncap * sizeof(u64))) return 1;
+    }
     e->key_cap = ncap;
     // what fastf_engine_finish needs for this many keys (sort buffer, row arrays, tile workspace) is allocated here, while
     // the caller is still decoding, and not on the way out (a dozen hipMallocs: 10-15 ms of a 0.5 s end-to-end run)
@@ -1341,6 +1386,18 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             if (e->d_feature.ensure(n * 4) || e->d_cell.ensure(n * 4) || e->d_count.ensure(n * 4)) return 1;
             // the matrix only needs equal keys to be neighbours inside a (cell, feature) group: the lowest digit
             // passes are skipped and K3 resolves the short unsorted runs (fastf_engine_umi_rows sorts fully)
+            if (e->wide) {
+                // keys wider than 64 bits: the group words are sorted (the rest of each key moves with its group word), K3 finds
+                // the distinct rest-of-keys of a group in its window set
+                if (e->d_vtmp.ensure(e->key_cap * sizeof(u64))) return 1;
+                if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->group_bits, 0, &e->sorted_in_tmp, s, false,
+                                (u64*)e->d_vals.p, (u64*)e->d_vtmp.p))
+                    return 1;
+                e->fully_sorted = false;
+                if (launch_reduce_regions<false>(e, e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p, small + SM_KEYCOUNT, n, small + SM_NNZ, 0, s,
+                                                 e->sorted_in_tmp ? (u64*)e->d_vtmp.p : (u64*)e->d_vals.p))
+                    return 1;
+            } else {
             if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
                             &e->sorted_in_tmp, s))
                 return 1;
@@ -1348,11 +1405,14 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
             // the rows stay in K3's regions until the host buffer is known to be large enough (the gather below)
             if (launch_reduce_regions<false>(e, sorted, small + SM_KEYCOUNT, n, small + SM_NNZ, e->skip_bits, s)) return 1;
+            }
         } else {
             HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
         }
         HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        if (n && e->wide && (e->h_small[SM_COUNTERS + 3] & ERR_RUN_TOO_LONG))
+            return set_err("a (cell, feature) group of more than 4 M reads (or more than 6 M reads in groups beyond 2048) with keys wider than 64 bits: not supported");
         if (n && (e->h_small[SM_COUNTERS + 3] & ERR_RUN_TOO_LONG)) {
             // runs of keys that agree on the sorted bits are long in this data (very deep (cell, feature) groups):
             // finish the sort and reduce exactly; every key is still in the store, permuted
@@ -1419,6 +1479,73 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
     return 0;
 } FASTF_CATCH_INT
 
+// -u rows with keys wider than 64 bits: sort the pairs fully (by the rest of the key, then by the group word: two stable LSD
+// sorts), one row per distinct pair (pair_*_kernel)
+static int umi_rows_wide(fastf_engine* e, fastf_umi_rows_t* rows) {
+    hipStream_t s = e->s_compute;
+    u64* small = (u64*)e->d_small.p;
+    const u64 n = e->n_sorted;
+    u64 nrows = 0;
+    std::vector<u64> uk, uv;
+    if (n) {
+        u64 *kc = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p, *ko = e->sorted_in_tmp ? (u64*)e->d_keys.p : (u64*)e->d_tmp.p;
+        u64 *vc = e->sorted_in_tmp ? (u64*)e->d_vtmp.p : (u64*)e->d_vals.p, *vo = e->sorted_in_tmp ? (u64*)e->d_vals.p : (u64*)e->d_vtmp.p;
+        if (!e->fully_sorted) {
+            int f = 0;
+            if (launch_sort(e, vc, vo, small + SM_KEYCOUNT, n, e->L.feat_shift, 0, &f, s, false, kc, ko)) return 1;   // by the rest of the key (the group words ride along)
+            if (f) { std::swap(kc, ko); std::swap(vc, vo); }
+            if (launch_sort(e, kc, ko, small + SM_KEYCOUNT, n, e->group_bits, 0, &f, s, false, vc, vo)) return 1;      // then, stably, by the group word
+            if (f) { std::swap(kc, ko); std::swap(vc, vo); }
+            e->sorted_in_tmp = kc == (u64*)e->d_tmp.p;
+            e->fully_sorted = true;
+        }
+        const u64 T = (n + UW_TILE - 1) / UW_TILE;
+        // rows: the group words into d_ukeys, the rests and the head positions into two halves of one scratch buffer
+        if (e->d_ukeys.ensure(n * 8) || e->d_ncopy.ensure(n * 4) || e->d_rg_ukeys.ensure(2 * n * 8) || e->d_scanblk.ensure(2 * 64 * sizeof(u64))) return 1;
+        DevBuf cnt, base;
+        if (cnt.ensure((T + 16) * 4) || base.ensure((T + 16) * 8)) { cnt.release(); base.release(); return 1; }
+        int rc = 0;
+        do {
+            if (hipMemsetAsync(cnt.p, 0, (T + 16) * 4, s) != hipSuccess) { rc = set_err("memset failed"); break; }
+            const u32 grid = (u32)std::min<u64>(T, 16ull * g_cu_count);
+            hipLaunchKernelGGL(pair_heads_kernel, dim3(grid), dim3(UW_THREADS), 0, s, (const u64*)kc, (const u64*)vc, (const u64*)(small + SM_KEYCOUNT), (u32*)cnt.p);
+            launch_scan_tiles(e, 1, s, (u32*)cnt.p, (u64*)base.p, (u32)T, small + SM_NROWS_U, nullptr, nullptr);
+            u64* uvals = (u64*)e->d_rg_ukeys.p; u64* hpos = uvals + n;
+            hipLaunchKernelGGL(pair_rows_kernel, dim3(grid), dim3(UW_THREADS), 0, s, (const u64*)kc, (const u64*)vc, (const u64*)(small + SM_KEYCOUNT),
+                               (const u64*)base.p, (u64*)e->d_ukeys.p, uvals, hpos);
+            hipLaunchKernelGGL(pair_copies_kernel, dim3(grid), dim3(UW_THREADS), 0, s, (const u64*)hpos, (const u64*)(small + SM_NROWS_U),
+                               (const u64*)(small + SM_KEYCOUNT), (u32*)e->d_ncopy.p);
+            if (hipGetLastError() != hipSuccess) { rc = set_err("kernel launch failed (-u rows of wide keys)"); break; }
+            if (hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = set_err("device error in the -u rows of wide keys"); break; }
+            if (e->h_small[SM_COUNTERS + 3]) { rc = set_err("%s", err_bits_text(e->h_small[SM_COUNTERS + 3])); break; }
+            nrows = e->h_small[SM_NROWS_U];
+            if (nrows > n) { rc = set_err("internal error: %llu -u rows out of %llu keys", (unsigned long long)nrows, (unsigned long long)n); break; }
+            uk.resize(nrows); uv.resize(nrows); e->h_ncopy.resize(nrows);
+            if (nrows) {
+                if (hipMemcpy(uk.data(), e->d_ukeys.p, nrows * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(uv.data(), uvals, nrows * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(e->h_ncopy.data(), e->d_ncopy.p, nrows * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy of the -u rows failed"); break; }
+            }
+        } while (0);
+        cnt.release(); base.release();
+        if (rc) return 1;
+    } else {
+        e->h_ncopy.clear();
+    }
+    e->h_ufeature.resize(nrows); e->h_ucell.resize(nrows); e->h_uumi.resize(nrows); e->h_unonnull.resize(nrows);
+    const u32 fmask = (u32)((1ull << e->feat_bits) - 1);
+    const u64 umask = e->L.umi_bits >= 64 ? ~0ull : ((1ull << e->L.umi_bits) - 1);
+    for (u64 i = 0; i < nrows; ++i) {
+        e->h_ufeature[i] = (u32)uk[i] & fmask;
+        e->h_ucell[i] = (u32)(uk[i] >> e->feat_bits);
+        e->h_unonnull[i] = (uint8_t)((uv[i] >> (e->L.umi_bits + e->L.len_bits)) & 1);
+        e->h_uumi[i] = (u32)(((uv[i] >> e->L.len_bits) & umask) << (32 - e->L.umi_bits));
+    }
+    rows->feature = e->h_ufeature.data(); rows->cell = e->h_ucell.data(); rows->n_copy = e->h_ncopy.data();
+    rows->umi = e->h_uumi.data(); rows->nonnull = e->h_unonnull.data(); rows->n = nrows;
+    return 0;
+}
+
 extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) FASTF_TRY {
     if (!e || !rows) return set_err("null argument");
     if (e->multi) return multi_umi_rows(e, rows);
@@ -1428,6 +1555,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
     u64* small = (u64*)e->d_small.p;
     const u64 n = e->n_sorted;
     u64 nrows = 0;
+    if (e->wide) return umi_rows_wide(e, rows);
     std::vector<u64> ukeys;
     if (n) {
         if (e->d_ukeys.ensure(n * 8) || e->d_ncopy.ensure(n * 4)) return 1;

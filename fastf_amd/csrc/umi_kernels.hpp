@@ -566,6 +566,9 @@ struct PackParams {
     KeyLayout L;
     u32 n_shards;
     u64* keys; u64 shard_stride;   // keys + s*shard_stride
+    // keys wider than 64 bits (tile form, one shard): keys[] takes the GROUP (cell << wide_feat_bits | feature) and vals[]
+    // the rest of the key — NULL flag, UMI, length, laid out as the low feat_shift bits of a narrow key; vals == nullptr: narrow
+    u64* vals; u32 wide_feat_bits;
     u64* key_counts;               // [n_shards], appended
     u64* counters;                 // {hits, sampled, valid, err}
     u64* stamps;                   // diagnostic builds only (-DFASTF_STAMPS)
@@ -714,7 +717,8 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
         if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
         if (alive) {
             n_valid++;                                               // E12 :435
-            key[j] = make_key(p.L, cell[j], feat[j], umi[j], meta[j]);
+            // (wide keys: the low part only here — cell and feature go into the group word at the store below)
+            key[j] = make_key(p.L, p.vals ? 0u : cell[j], p.vals ? 0u : feat[j], umi[j], meta[j]);
             shard[j] = p.n_shards > 1 ? shard_of(cell[j], p.n_shards) : 0;
         }
         emit[j] = alive;
@@ -757,7 +761,12 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
     for (int j = 0; j < K1B_IPT; ++j) {
         if (emit[j]) {
             const u64 b = s_shard_base[shard[j]];
-            if (b != ~0ULL) p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];
+            if (b != ~0ULL) {
+                if (p.vals) {                                            // wide key: group and rest side by side
+                    p.vals[b + pos[j]] = key[j];
+                    p.keys[b + pos[j]] = ((u64)cell[j] << p.wide_feat_bits) | feat[j];
+                } else p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];
+            }
         }
     }
     K1STAMP(6);
@@ -1260,11 +1269,14 @@ __device__ __forceinline__ u32 digit_of(u64 key, u32 rshift) {
 
 // scatter: stable within the tile (wave-major, item, lane == memory order).  FULL tiles skip every
 // bounds check (only the last tile of a pass is partial).
-template <int SHIFT, bool FULL, bool SEG>
+// VALS: every key carries a 64-bit value (vin -> vout) that moves with it (keys wider than 64 bits: the group is sorted, the
+// rest of the key rides along); the values take a second tile-sized LDS array behind everything else
+template <int SHIFT, bool FULL, bool SEG, bool VALS = false>
 __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
                                              u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
                                              const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, const int tid,
-                                             const bool streams, u64* stamps = nullptr) {
+                                             const bool streams, u64* stamps = nullptr,
+                                             const u64* __restrict__ vin = nullptr, u64* __restrict__ vout = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1276,6 +1288,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     u32* s_delta = s_whist + SORT_WAVES * RADIX;                                   // [256] global - local start
     u32* s_start = s_delta + RADIX;                                                // [256] local bin start
     u32* s_wtot  = s_start + RADIX;                                                // [4] tile-local, [4] global
+    u64* s_vals  = reinterpret_cast<u64*>(s_wtot + 16);                            // VALS: SORT_TILE values (8-byte aligned: all the sizes above are multiples of 8)
     const int lane = tid & (WAVE - 1), w = tid >> 6;       // (tid comes in opaque, see scatter_kernel)
 
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
@@ -1304,6 +1317,14 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         for (int j = 0; j < SORT_IPT; ++j) {
             const u32 li = wbase + j * WAVE + lane;
             key[j] = (j < ipt && (FULL || li < n_valid)) ? in[base + li] : ~0ULL;
+        }
+    }
+    u64 val[SORT_IPT];
+    if constexpr (VALS) {
+#pragma unroll
+        for (int j = 0; j < SORT_IPT; ++j) {
+            const u32 li = wbase + j * WAVE + lane;
+            val[j] = (j < ipt && (FULL || li < n_valid)) ? vin[base + li] : 0;
         }
     }
     __syncthreads();
@@ -1361,6 +1382,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
         const u32 d = (FULL || li < n_valid) ? digit_of<SHIFT>(key[j], rshift) : 255u;
         const u32 p = s_start[d] + wh[d] + rnk[j];
         s_keys[p] = key[j];
+        if constexpr (VALS) s_vals[p] = val[j];
     }
     __syncthreads();
     STAMP(4);
@@ -1374,6 +1396,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
             const u64 k = s_keys[pidx];
             const u32 d = digit_of<SHIFT>(k, rshift);
             out[(u64)(u32)(s_delta[d] + pidx)] = k;
+            if constexpr (VALS) vout[(u64)(u32)(s_delta[d] + pidx)] = s_vals[pidx];
         }
     }
     STAMP(5);
@@ -1386,11 +1409,12 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
 
 // SEG: the input is the segmented key buffer of the streaming K1b (first pass only; its own instantiation, so that the
 // map lookup does not cost the other passes registers: 47 VGPRs keep four workgroups on a CU)
-template <int SHIFT, bool SEG = false>
-__global__ __launch_bounds__(SORT_THREADS, 8) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
+template <int SHIFT, bool SEG = false, bool VALS = false>
+__global__ __launch_bounds__(SORT_THREADS, VALS ? 4 : 8) void scatter_kernel(const u64* __restrict__ in, u64* __restrict__ out,
                                                                const u64* __restrict__ n_ptr,
                                                                const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                                               u32 ipt, u32 rshift, const SegMap seg, u64* stamps) {
+                                                               u32 ipt, u32 rshift, const SegMap seg, u64* stamps,
+                                                               const u64* __restrict__ vin = nullptr, u64* __restrict__ vout = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u64 n = *n_ptr;
     const u32 T = num_tiles(n, ipt);
@@ -1413,8 +1437,9 @@ __global__ __launch_bounds__(SORT_THREADS, 8) void scatter_kernel(const u64* __r
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
         // (no barrier between tiles: whatever a tile reads last from LDS is rewritten only after two barriers of the next)
-        if (n_valid == tile_keys) scatter_tile<SHIFT, true, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps);
-        else scatter_tile<SHIFT, false, SEG>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps);
+        if (n_valid == tile_keys) scatter_tile<SHIFT, true, SEG, VALS>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps, vin, vout);
+        else scatter_tile<SHIFT, false, SEG, VALS>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps, vin, vout);
+        if constexpr (VALS) __syncthreads();                 // the value array is read last and rewritten before the next tile's second barrier
     }
 }
 
@@ -1450,6 +1475,10 @@ struct ReduceParams {
     u32* span_rows;                        // rows per workgroup chunk [gridDim.x]
     // DEDUP 2: groups longer than a window are counted by giant_groups_kernel: one work item per (group, hash partition)
     u64* giant_list; u32* giant_n;         // items {start, len, row slot, partition | partitions << 32} (GIANT_ITEM_WORDS u64 each)
+    u32 giant_max;                         // longest group handed to giant_groups_kernel (beyond: ERR_RUN_TOO_LONG)
+    // keys wider than 64 bits (reduce_hashed_kernel<true, true>): keys[] = the group (cell << wide_feat_bits | feature), sorted;
+    // vals[] = the rest of each key (NULL flag, UMI, length: the low feat_shift bits of a narrow key), in the keys' order
+    const u64* vals; u32 wide_feat_bits;
 };
 
 // a (cell, feature) group longer than a window (DEDUP 2) is cut into hash partitions of about GIANT_PART keys: each partition
@@ -1900,8 +1929,11 @@ __device__ __forceinline__ void k3h_add(u32* cnt, u32 row, u32 v) {
     (void)__hip_atomic_fetch_add(&cnt[row >> 1], v << ((row & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool SLOT64>
-__global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_kernel(const ReduceParams p) {
+// WIDE (keys wider than 64 bits; always with SLOT64): the group word is compared whole, everything below the group comes
+// from vals[]; a slot holds (x >> 12, row rank, probe number + 1) — the quotient form of the 32-bit slots with 40 bits of x
+template <bool SLOT64, bool WIDE = false>
+__global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void reduce_hashed_kernel(const ReduceParams p) {
+    static_assert(!WIDE || SLOT64, "wide keys use the 64-bit slots");
     typedef typename std::conditional<SLOT64, u64, u32>::type slot_t;
     __shared__ u64 s_hb[K3H_UNITS];        // head ballots of the 32 units of the window
     __shared__ u32 s_cnt[K3H_TILE / 2];    // distinct counts by row, two per word; all-zero between windows
@@ -1912,7 +1944,7 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
 
     const int tid = threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u64 n = *p.n_ptr;
-    const u32 gshift = p.L.feat_shift, nn_shift = p.L.umi_bits + p.L.len_bits;
+    const u32 gshift = WIDE ? 0u : p.L.feat_shift, nn_shift = p.L.umi_bits + p.L.len_bits;
     const u32 G = gridDim.x, b = blockIdx.x;
     const u64 nom_start = k3_chunk_start(n, b, G), nom_end = k3_chunk_start(n, b + 1, G);
     for (u32 i = tid; i < K3H_TAB; i += K3H_THREADS) s_tab[i] = 0;
@@ -1949,28 +1981,32 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
     bool done = false;
     // keys of the window about to be processed (lane l of nkey[j]: position pbase + 64 j + l) and the key in front of the wave
     u64 nkey[K3H_IPT], npk = 0;
+    u64 nval[WIDE ? K3H_IPT : 1], npv = 0;                               // WIDE: the rest of each key, and of the key in front of the wave
     auto request = [&](const u64 at) {
         const u32 Wn = (u32)(n - at < (u64)K3H_TILE ? n - at : (u64)K3H_TILE);
 #pragma unroll
         for (int j = 0; j < K3H_IPT; ++j) {
             const u32 pos = pbase + (u32)j * WAVE + (u32)lane;
             nkey[j] = pos < Wn ? ld_once<FASTF_NT_K3 != 0>(p.keys + at + pos) : 0;
+            if constexpr (WIDE) nval[j] = pos < Wn ? ld_once<FASTF_NT_K3 != 0>(p.vals + at + pos) : 0;
         }
         // the key in front of the wave: the same address in every lane, but asked for as a VECTOR load (an opaque zero in the
         // address) — a scalar load counts on lgkmcnt, and the LDS-only barriers below would wait for its memory round trip
         u32 z = 0;
         asm volatile("" : "+v"(z));
         npk = (w > 0 && pbase < Wn) ? p.keys[at + pbase - 1 + z] : 0;
+        if constexpr (WIDE) npv = (w > 0 && pbase < Wn) ? p.vals[at + pbase - 1 + z] : 0;
     };
     request(cursor);
     while (!done) {
         const u64 base = cursor;
         const u32 W = (u32)(n - base < (u64)K3H_TILE ? n - base : (u64)K3H_TILE);
         u64 key[K3H_IPT];
+        u64 val[WIDE ? K3H_IPT : 1];
         u32 fl = 0;                                                        // per lane: bit j = key j is a head, bit 4 + j = it equals its neighbour in front
         // ---- heads (and copies of the neighbour in front) from registers ----
         {
-            u64 carry = uniform64(npk);
+            u64 carry = uniform64(npk), vcarry = WIDE ? uniform64(npv) : 0;
 #pragma unroll
             for (int j = 0; j < K3H_IPT; ++j) {
                 const u32 pos = pbase + (u32)j * WAVE + (u32)lane;
@@ -1981,7 +2017,14 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
                 const u64 hmj = __ballot(head);
                 if (lane == 0) s_hb[w * K3H_IPT + j] = hmj;
                 fl |= (head ? 1u : 0u) << j;
-                fl |= (valid && !head && k == prev ? 16u : 0u) << j;
+                bool same = k == prev;                                     // a copy of the neighbour in front
+                if constexpr (WIDE) {
+                    const u64 v = val[j] = nval[j];
+                    const u64 pv = ((u64)dpp_wave_shr1((u32)(vcarry >> 32), (u32)(v >> 32)) << 32) | dpp_wave_shr1((u32)vcarry, (u32)v);
+                    same = v == pv;                                        // (the group is the same: not a head)
+                    vcarry = readlane64(v, 63);
+                }
+                fl |= (valid && !head && same ? 16u : 0u) << j;
                 carry = readlane64(k, 63);
             }
         }
@@ -2038,9 +2081,11 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
             const u64 row = region + rows_so_far;
             if (tid == 0) {
                 const u64 k0 = s_g0;
-                p.count[row] = 0; p.feature[row] = (u32)(k0 >> p.L.feat_shift) & p.feat_mask; p.cell[row] = (u32)(k0 >> p.L.cell_shift);
+                p.count[row] = 0;
+                p.feature[row] = (WIDE ? (u32)k0 : (u32)(k0 >> p.L.feat_shift)) & p.feat_mask;
+                p.cell[row] = (u32)(k0 >> (WIDE ? p.wide_feat_bits : p.L.cell_shift));
             }
-            if (len > GIANT_MAX) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
+            if (len > p.giant_max) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
             else {
                 if (tid == 0) s_first = atomicAdd(p.giant_n, parts);
                 __syncthreads();
@@ -2074,13 +2119,19 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
                 const bool is_head = valid && ((fl >> j) & 1u);
                 const u64 h = __ballot(is_head);
                 const bool single = __builtin_amdgcn_inverse_ballot_w64(h & (h >> 1));      // a head whose neighbour behind is a head too
-                const u64 k = key[j];
+                const u64 k = WIDE ? val[j] : key[j];                                        // where the NULL flag, the UMI and the length are
                 const u32 r = Ru + rank_below(h) + (is_head ? 1u : 0u) - 1u;                 // row of the key's group (lanes in front of
                 row[j] = r;                                                                  // the unit's first head: the row before)
                 const bool dist = valid && ((k >> nn_shift) & 1) && !((fl >> (4 + j)) & 1u);
                 const bool probe = dist && !single;
                 st |= (dist ? 1u : 0u) << j; st |= (probe ? 16u : 0u) << j;
-                if constexpr (SLOT64) {
+                if constexpr (WIDE) {
+                    const u64 x = k, hi = x >> 12;                         // x < 2^52 (UMIs of at most 24 bases)
+                    const u32 f = (u32)hi * 0x9E3779B1u + (u32)(hi >> 32) * 0x85EBCA77u;
+                    sl[j] = ((u32)x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (K3H_TAB - 1);
+                    stp[j] = ((f >> 20) & 62u) | 1u;
+                    wd[j] = hi | ((u64)r << 40) | (1ull << 51);            // hi: 40 bits, row rank: 11, probe number + 1: 6
+                } else if constexpr (SLOT64) {
                     const u64 x = k & ((1ull << gshift) - 1);
                     u32 hh = (u32)x * 0x9E3779B1u + (u32)(x >> 32) * 0x85EBCA77u + r * 0xC2B2AE3Du;
                     hh ^= hh >> 15;
@@ -2111,7 +2162,8 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
 #pragma nounroll
                 while (go) {
                     sl[j] = (sl[j] + stp[j]) & (K3H_TAB - 1);
-                    if constexpr (!SLOT64) wd[j] += 1u << 26;
+                    if constexpr (WIDE) wd[j] += 1ull << 51;
+                    else if constexpr (!SLOT64) wd[j] += 1u << 26;
                     od[j] = 0;
                     (void)__hip_atomic_compare_exchange_strong(&s_tab[sl[j]], &od[j], wd[j], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     go = od[j] != 0 && od[j] != wd[j] && ++tries < 63;
@@ -2134,8 +2186,8 @@ __global__ __launch_bounds__(K3H_THREADS, SLOT64 ? 6 : 8) void reduce_hashed_ker
                 const u32 r = row[j];
                 if (is_head) {
                     if (D) { k3h_add(s_cnt, r - 1u, D); k3h_add(s_cnt, r, 0u - D); }
-                    s_feat[r] = (u32)(key[j] >> p.L.feat_shift) & p.feat_mask;
-                    s_cell[r] = (u32)(key[j] >> p.L.cell_shift);
+                    s_feat[r] = (WIDE ? (u32)key[j] : (u32)(key[j] >> p.L.feat_shift)) & p.feat_mask;
+                    s_cell[r] = (u32)(key[j] >> (WIDE ? p.wide_feat_bits : p.L.cell_shift));
                 }
                 const u32 heads = (u32)__popcll(h), tot = (u32)__popcll(dmj);
                 if (lane == 0 && tot) k3h_add(s_cnt, Ru + heads - 1u, tot);  // (Ru + heads >= 1: position 0 of the window is a head)
@@ -2209,6 +2261,57 @@ __global__ __launch_bounds__(512) void giant_groups_kernel(const u64* __restrict
         if (threadIdx.x == 0 && s_cnt) atomicAdd(&count[row], s_cnt);
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------
+// -u rows of keys wider than 64 bits: the pairs (group word, rest of the key) are fully sorted (two LSD sorts: by the rest,
+// then by the group word); one row per distinct pair, with the number of its copies.  Three small kernels around the tile
+// scan — this path is about not refusing such inputs, not about speed:
+//   pair_heads_kernel   heads (a pair that differs from the one in front) per 2048-pair tile
+//   pair_rows_kernel    row r of a head: its pair and its position
+//   pair_copies_kernel  copies of row r = position of row r + 1 (or n) - position of row r
+// ------------------------------------------------------------------------------------
+constexpr int UW_THREADS = 256, UW_IPT = 8, UW_TILE = UW_THREADS * UW_IPT;
+__device__ __forceinline__ bool pair_head(const u64* __restrict__ keys, const u64* __restrict__ vals, u64 i) {
+    return i == 0 || keys[i] != keys[i - 1] || vals[i] != vals[i - 1];
+}
+__global__ __launch_bounds__(UW_THREADS) void pair_heads_kernel(const u64* __restrict__ keys, const u64* __restrict__ vals, const u64* __restrict__ n_ptr,
+                                                                u32* __restrict__ tile_cnt) {
+    const u64 n = *n_ptr, T = (n + UW_TILE - 1) / UW_TILE;
+    for (u64 t = blockIdx.x; t < T; t += gridDim.x) {
+        u32 c = 0;
+#pragma unroll
+        for (int j = 0; j < UW_IPT; ++j) { const u64 i = t * UW_TILE + (u64)threadIdx.x * UW_IPT + j; if (i < n && pair_head(keys, vals, i)) ++c; }
+        c = wave_sum32(c);
+        if (lane_id() == 0 && c) atomicAdd(&tile_cnt[t], c);
+    }
+}
+__global__ __launch_bounds__(UW_THREADS) void pair_rows_kernel(const u64* __restrict__ keys, const u64* __restrict__ vals, const u64* __restrict__ n_ptr,
+                                                               const u64* __restrict__ tile_base, u64* __restrict__ ukeys, u64* __restrict__ uvals,
+                                                               u64* __restrict__ hpos) {
+    __shared__ u32 s_w[UW_THREADS / WAVE];
+    const u64 n = *n_ptr, T = (n + UW_TILE - 1) / UW_TILE;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    for (u64 t = blockIdx.x; t < T; t += gridDim.x) {
+        const u64 i0 = t * UW_TILE + (u64)threadIdx.x * UW_IPT;
+        u32 flags = 0, c = 0;
+#pragma unroll
+        for (int j = 0; j < UW_IPT; ++j) if (i0 + j < n && pair_head(keys, vals, i0 + j)) { flags |= 1u << j; ++c; }
+        const u32 inc = wave_incl_scan32(c, lane);
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        u64 r = tile_base[t] + inc - c;
+        for (int x = 0; x < w; ++x) r += s_w[x];
+#pragma unroll
+        for (int j = 0; j < UW_IPT; ++j) if ((flags >> j) & 1u) { ukeys[r] = keys[i0 + j]; uvals[r] = vals[i0 + j]; hpos[r] = i0 + j; ++r; }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(UW_THREADS) void pair_copies_kernel(const u64* __restrict__ hpos, const u64* __restrict__ nrows_ptr, const u64* __restrict__ n_ptr,
+                                                                 u32* __restrict__ ncopy) {
+    const u64 rows = *nrows_ptr, n = *n_ptr;
+    for (u64 r = (u64)blockIdx.x * UW_THREADS + threadIdx.x; r < rows; r += (u64)gridDim.x * UW_THREADS)
+        ncopy[r] = (u32)((r + 1 < rows ? hpos[r + 1] : n) - hpos[r]);
 }
 
 // row bases of the chunks (exclusive scan of span_rows, G <= 4096) and the total; the work-item counter of the giant

@@ -59,6 +59,39 @@ def test_cli_outputs_equal_oracle_bytes(tmp_path, name, kw, args, gz):
     assert not (tmp_path / "unused.db").exists()
 
 
+def test_cli_with_a_multi_million_line_barcode_list(tmp_path):
+    """A raw whitelist instead of the filtered barcodes: 2.2 M lines x 36 601 genes = 22 + 16 key bits, which leaves room for
+    12-base UMIs (27 bits: 65 > 64) only with keys wider than 64 bits — hashtable.c:70-115 takes any number of barcodes, so
+    does bam2db() here (the engine sorts the (cell, feature) word and carries the rest of the key beside it).  -u rows too."""
+    case = Case(n=150_000, n_bar=2_200_000, n_gene=36_601, rate_cell=1.0, rate_depth=0.8, umi_len=12, dup_factor=3.0,
+                gene_dist="zipf", p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.01, data_seed=31)
+    bam, b, f = _write_inputs(tmp_path, case)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out), "-c", "1", "-r", "0.8", "-u"],
+                       capture_output=True, text=True, env=dict(os.environ, FASTF_BATCH_RECORDS="40000"))
+    assert r.returncode == 0, r.stderr
+    assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
+    assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
+    assert _read_gz(out / "barcodes.tsv.gz") == ora["barcodes"]
+
+
+def test_cli_runs_again_when_the_umis_are_longer_than_the_64_bit_key_holds(tmp_path):
+    """70 k x 70 k lists leave 27 key bits: bam2db() starts with 12-base UMIs (the 64-bit path) and, when the file holds
+    16-base UMIs, runs once more with keys wider than 64 bits — the reference takes a UMI of any length (bam2db_ds.c:417-419)"""
+    case = Case(n=80_000, n_bar=70_000, n_gene=70_000, rate_cell=0.9, rate_depth=0.9, umi_len=16, umi_pool=2048, p_n_umi=0.01, data_seed=33)
+    bam, b, f = _write_inputs(tmp_path, case)
+    out = tmp_path / "out"; out.mkdir()
+    case.label = str(bam).encode()
+    ora = case.oracle()
+    r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out), "-c", "0.9", "-r", "0.9"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "running again" in r.stderr
+    assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
+
+
 @pytest.mark.parametrize("env_extra", [
     dict(FASTF_BATCH_RECORDS="70000", FASTF_BAM_WINDOW="262144"),                           # the slot ring wraps, many windows per slot
     dict(FASTF_BATCH_RECORDS="70000", FASTF_BAM_WINDOW="262144", FASTF_GPU_INFLATE="2"),    # every window on the device: device-packed batches between host ones

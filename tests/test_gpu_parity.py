@@ -297,12 +297,55 @@ def test_key_widths(n_bar, n_gene, umi_max, bits):
         eng.close()
 
 
-def test_key_wider_than_64_bits_is_refused():
+# keys wider than 64 bits (hashtable.c:70-115 takes any number of barcodes and features, bam2db_ds.c:417-419 any UMI): the
+# engine sorts the (cell, feature) word and carries the rest of the key beside it
+WIDE_CASES = {
+    # 18 + 17 + 36 = 71 bits: L2 tables for both lists, 32-bit cell scratch, the tile form of K1b
+    "200k barcodes x 70k genes, 16-base UMIs": (dict(n=300_000, n_bar=210_000, n_gene=70_000, umi_len=16, rate_depth=0.8, dup_factor=3.0,
+                                                     cell_dist="lognormal", gene_dist="zipf", p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.01, data_seed=71), 16, 71),
+    "70k x 70k, 12 bases (61 bits) forced wide": (dict(n=200_000, n_bar=70_000, n_gene=70_000, umi_len=12, rate_cell=0.8, rate_depth=0.7, umi_pool=4096,
+                                                       p_no_cb=0.03, p_unlisted_cb=0.1, p_n_umi=0.02, data_seed=72), 12, None),
+    # LDS tables, deep groups: windows full of one group (giant_groups_kernel on the values), all duplicates, NULL UMIs only
+    "huge groups": (dict(n=400_000, n_bar=3, n_gene=2, umi_len=12, data_seed=11), 12, None),
+    "one group, all duplicates": (dict(n=100_000, n_bar=1, n_gene=1, umi_pool=1), 12, None),
+    "one group, NULL UMIs": (dict(n=30_000, n_bar=1, n_gene=1, umi_pool=3, p_n_umi=0.9), 12, None),
+    "mixed": (dict(n=250_000, n_bar=3000, n_gene=1500, rate_cell=0.5, rate_depth=0.5, umi_pool=64, p_no_cb=0.05, p_unlisted_cb=0.05,
+                   p_bad_xf=0.15, p_n_umi=0.02, p_multi_gene=0.05, p_no_ub=0.02), 16, None),
+    "tiny": (dict(n=37, n_bar=5, n_gene=3, umi_pool=4, p_n_umi=0.2), 16, None),
+}
+
+
+@pytest.mark.parametrize("name", list(WIDE_CASES))
+def test_keys_wider_than_64_bits_match_oracle(name, monkeypatch):
+    kw, umi_max, bits = WIDE_CASES[name]
+    if bits is None:
+        monkeypatch.setenv("FASTF_FORCE_WIDE_KEYS", "1")              # the wide path on lists whose keys would fit
+    case = Case(**kw)
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=umi_max)
+    try:
+        if bits is not None:
+            assert eng.key_bits == bits > 64
+        packed = case.packed(lists)
+        h = len(packed[0]) // 3
+        eng.push(*(a[:h] for a in packed))                            # (two pushes: the key store grows with its values)
+        eng.push(*(a[h:] for a in packed))
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+        with pytest.raises(F.FastfError):                             # the device-level calls stay with 64-bit keys
+            eng.probe_capacity(1000) or eng.dev_sort(0, 0, 0, 1)
+    finally:
+        eng.close()
+
+
+def test_wide_keys_are_refused_where_they_cannot_go():
+    """sharded and multi-device engines take keys of at most 64 bits: a clear refusal, not a wrong matrix"""
     case = Case(n=10, n_bar=70_000, n_gene=70_000)
     lists = case.lists()
     with pytest.raises(F.FastfError) as ei:
-        F.Engine.from_lists(lists, umi_max_bases=16)
-    assert "bits" in str(ei.value)
+        F.Engine.from_lists(lists, umi_max_bases=16, n_shards=2, shard_rank=0)
+    assert "64 bits" in str(ei.value)
 
 
 # ---- the resident single-GPU pass (what bench.py times): streaming K1b -> segmented keys -> sort through the region map ----
