@@ -43,7 +43,7 @@ class EngineConfig(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("cb_key", C.c_void_p), ("gx_key", C.c_void_p), ("umi", C.c_void_p),
-                ("meta", C.c_void_p), ("n", C.c_size_t)]
+                ("meta", C.c_void_p), ("n", C.c_size_t), ("umi_ext", C.c_void_p)]
 
 
 class Coo(C.Structure):
@@ -87,7 +87,7 @@ _lib = None
 ABI_SYMBOLS = [
     "bam2db", "_umi_copies_flag", "cmd_bam2db", "fastf_last_error", "fastf_version",
     "fastf_mt_seed", "fastf_mt_next", "fastf_mt_fill", "fastf_mt_skip",
-    "fastf_draw_threshold", "fastf_sample_cells", "fastf_pack_umi",
+    "fastf_draw_threshold", "fastf_sample_cells", "fastf_pack_umi", "fastf_pack_umi_long",
     "fastf_keydict_create", "fastf_keydict_destroy", "fastf_keydict_add", "fastf_keydict_pack",
     "fastf_keydict_pack_many",
     "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",

@@ -26,7 +26,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 /* decoder thread: BAM → packed SoA batches, double-buffered, while the caller pushes the previous batch
  * (and, for the first batch, while the HIP runtime and the engine come up) */
-typedef struct { uint64_t *cb, *gx; uint32_t *umi, *meta; long n; int on_device; fastf_batch_t dev; } dec_slot;   /* on_device: the batch lies packed in device memory (dev) */
+typedef struct { uint64_t *cb, *gx; uint32_t *umi, *meta, *ext; long n; int on_device; fastf_batch_t dev; } dec_slot;   /* on_device: the batch lies packed in device memory (dev); ext: bases 17.. of the UMIs (runs with UMIs beyond 16 bases only) */
 #define DEC_SLOTS 6                      /* ring of decoder slots; only those the decoder reaches are ever touched or pinned */
 typedef struct {
     fastf_bam_t *bam; const fastf_lists_t *lists; size_t cap;
@@ -111,6 +111,7 @@ static void *decoder_main(void *vp)
         int on_dev = 0;
         fastf_batch_t dev; memset(&dev, 0, sizeof dev);
         for (;;) {
+            if (sl->ext) fastf_bam_set_umi_ext(d->bam, sl->ext + fill);
             n = fastf_bam_read_batch_dev(d->bam, d->lists->cell_dict, d->lists->feat_dict, sl->cb + fill, sl->gx + fill,
                                          sl->umi + fill, sl->meta + fill, d->cap - fill, &on_dev, &dev);
             if (n <= 0 || on_dev) break;
@@ -231,17 +232,20 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
     pthread_mutex_init(&dec.mu, NULL); pthread_cond_init(&dec.cv, NULL);
     /* one slab for the ring of decoder slots (untouched pages cost nothing): each slot is pinned when the decoder reaches
      * it, so that the engine copies the packed records to the device straight from where the decoder wrote them */
-    dec.n_slots = DEC_SLOTS; dec.slot_bytes = cap * 24;
+    /* UMIs beyond 16 bases (the third attempt of bam2db(), or FASTF_UMI_MAX_BASES): the slots carry a fifth array, the host packs */
+    const int long_umis = umi_bases > 16 || (getenv("FASTF_UMI_MAX_BASES") && atoi(getenv("FASTF_UMI_MAX_BASES")) > 16);
+    dec.n_slots = DEC_SLOTS; dec.slot_bytes = cap * (long_umis ? 28 : 24);
     if (!(dec.slab = (unsigned char *)fastf_big_alloc((size_t)dec.n_slots * dec.slot_bytes))) { fprintf(stderr, "out of memory\n"); goto done; }
     for (int k = 0; k < dec.n_slots; k++) {
         unsigned char *base = dec.slab + (size_t)k * dec.slot_bytes;
         dec.slot[k].cb = (uint64_t *)base; dec.slot[k].gx = (uint64_t *)(base + cap * 8);
         dec.slot[k].umi = (uint32_t *)(base + cap * 16); dec.slot[k].meta = (uint32_t *)(base + cap * 20);
+        dec.slot[k].ext = long_umis ? (uint32_t *)(base + cap * 24) : NULL;
     }
     /* the windows the device inflates are hopped and packed there as well (one device; lists the device packer can hold) */
     {   const char *dvs = getenv("FASTF_DEVICES");
         const int several = dvs && *dvs && (strchr(dvs, ',') || atoi(dvs) >= 2);
-        if (!several) (void)fastf_bam_enable_device_parse(bam, lists.cell_dict, lists.feat_dict);
+        if (!several && !long_umis) (void)fastf_bam_enable_device_parse(bam, lists.cell_dict, lists.feat_dict);
     }
     printf("Start to convert bam file to UMI keys on the device...\n");
     if (pthread_create(&dec_thread, NULL, decoder_main, &dec) != 0) { fprintf(stderr, "cannot start decoder thread\n"); goto done; }
@@ -281,7 +285,7 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
     if (umi_bases) cfg.umi_max_bases = umi_bases;
     else if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);
     else cfg.umi_max_bases = (group_bits + 36 <= 64 || group_bits + 27 > 64) ? 16 : 12;
-    const int may_rerun = !umi_bases && !ul && cfg.umi_max_bases == 12;
+    const int may_rerun = !ul && cfg.umi_max_bases < 24;
     cfg.batch_records = cap;
     tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
@@ -302,13 +306,13 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
         const long n = dec.slot[k].n;
         if (n < 0) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
         if (n == 0) break;
-        fastf_batch_t batch = { dec.slot[k].cb, dec.slot[k].gx, dec.slot[k].umi, dec.slot[k].meta, (size_t)n };
+        fastf_batch_t batch = { dec.slot[k].cb, dec.slot[k].gx, dec.slot[k].umi, dec.slot[k].meta, (size_t)n, dec.slot[k].ext };
         const int on_dev = dec.slot[k].on_device;
         if (on_dev) batch = dec.slot[k].dev;                  /* packed on the device: a device-to-device copy into the engine's staging */
         tt = now_s();
         /* pinned slots: queue the copies, and hand the slot back to the decoder once they have left it */
         if ((slot_pinned || on_dev) ? (fastf_engine_push_pinned(eng, &batch) || fastf_engine_wait_input(eng)) : fastf_engine_push(eng, &batch)) {
-            if (may_rerun && strstr(fastf_last_error(), "UMI longer")) { *longer_umis = 1; goto done; }
+            if (may_rerun && strstr(fastf_last_error(), "UMI longer")) { *longer_umis = (int)cfg.umi_max_bases; goto done; }
             fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
         }
         t_push += now_s() - tt;
@@ -338,7 +342,7 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
     fastf_coo_t coo; uint64_t counters[3];
     tt = now_s();
     if (fastf_engine_finish(eng, &coo, counters)) {
-        if (may_rerun && strstr(fastf_last_error(), "UMI longer")) { *longer_umis = 1; goto done; }
+        if (may_rerun && strstr(fastf_last_error(), "UMI longer")) { *longer_umis = (int)cfg.umi_max_bases; goto done; }
         fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done;
     }
     t_finish = now_s() - tt;
@@ -406,14 +410,16 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
            float rate_cell, float rate_depth, unsigned int seed)
 {
     (void)db_file;                      /* no SQLite in this engine */
+    /* the reference takes a UMI of any length (bam2db_ds.c:417-419).  The first run assumes what keeps the key within 64 bits
+     * where it can (12 or 16 bases); a file with longer UMIs is run again with room for 16, then 24 bases — keys wider than 64
+     * bits, and from 17 bases on a fifth array beside the packed records.  Beyond 24 bases: an error. */
     int longer_umis = 0;
     int rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, 0, &longer_umis);
-    if (longer_umis) {
-        /* the reference takes a UMI of any length (bam2db_ds.c:417-419); the first run assumed at most 12 bases to keep the
-         * key within 64 bits: once more, with 16-base UMIs and the key wider than 64 bits */
-        fprintf(stderr, "Note: UMIs longer than 12 bases in %s: running again with 16-base UMIs (keys wider than 64 bits)\n", bam_file);
+    while (longer_umis) {
+        const uint32_t next = longer_umis < 16 ? 16 : 24;
+        fprintf(stderr, "Note: UMIs longer than %d bases in %s: running again with room for %u (keys wider than 64 bits)\n", longer_umis, bam_file, next);
         longer_umis = 0;
-        rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, 16, &longer_umis);
+        rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, next, &longer_umis);
     }
     return rc;
 }

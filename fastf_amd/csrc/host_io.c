@@ -216,6 +216,7 @@ typedef struct { size_t coff; uint32_t clen, isize; size_t uoff; } bgzf_blk;
 struct fastf_bam {
     FILE *fp;
     int n_threads;
+    uint32_t *umi_ext;                           /* fastf_bam_set_umi_ext: where bases 17..28 of the next batch's UMIs go (NULL: UMIs of at most 16 bases) */
     int file_eof;
     unsigned char *cbuf; size_t ccap, clen;      /* compressed window (whole blocks + a partial tail) */
     unsigned char *map; size_t map_len, map_pos; unsigned char *cbuf_own;   /* the file mapped read-only: windows are views, nothing is copied */
@@ -1122,10 +1123,11 @@ static int64_t aux_int(const unsigned char *p)
 }
 
 /* one record's aux block → packed fields; first occurrence of a tag wins (bam_aux_get) */
+/* ext: NULL, or where bases 17..28 of the UMI go (readers of engines with umi_max_bases > 16: fastf_bam_set_umi_ext) */
 static void pack_record(const unsigned char *aux, const unsigned char *end,
                         const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                         uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta,
-                        uint64_t *n_no_xf, uint64_t *n_no_gx)
+                        uint64_t *n_no_xf, uint64_t *n_no_gx, uint32_t *ext)
 {
     const unsigned char *cb = NULL, *xf = NULL, *gx = NULL, *ub = NULL;
     while (end - aux >= 3) {
@@ -1140,6 +1142,7 @@ static void pack_record(const unsigned char *aux, const unsigned char *end,
     }
     uint32_t m = 0;
     *cb_key = 0; *gx_key = 0; *umi = 0;
+    if (ext) *ext = 0;
     /* bam_aux2Z (htslib sam.c) hands back the bytes of a 'Z' AND of an 'H' value; for any other type it returns NULL →
      * hash_table_lookup(NULL) misses (hashtable.c:100) */
     if (cb && aux_is_string(cb)) {
@@ -1153,7 +1156,10 @@ static void pack_record(const unsigned char *aux, const unsigned char *end,
         *gx_key = fastf_keydict_pack(feats, s, strlen(s));
     } else if (!gx && (m & FASTF_META_XF_OK) && *cb_key) (*n_no_gx)++;
     if (ub) {
-        if (aux_is_string(ub)) { const char *s = (const char *)ub + 1; m |= fastf_pack_umi(s, strlen(s), umi); }
+        if (aux_is_string(ub)) {
+            const char *s = (const char *)ub + 1;
+            m |= ext ? fastf_pack_umi_long(s, strlen(s), umi, ext) : fastf_pack_umi(s, strlen(s), umi);
+        }
         /* a UB that is neither Z nor H makes bam_aux2Z return NULL and encode_DNA(NULL) crash in the reference: treated as absent */
     }
     *meta = m;
@@ -1162,7 +1168,7 @@ static void pack_record(const unsigned char *aux, const unsigned char *end,
 /* ---- step 4: parallel tag extraction + packing ---- */
 typedef struct {
     fastf_bam_t *b; const fastf_keydict_t *cells, *feats;
-    uint64_t *cb_key, *gx_key; uint32_t *umi, *meta; size_t n; size_t next;
+    uint64_t *cb_key, *gx_key; uint32_t *umi, *meta, *umi_ext; size_t n; size_t next;
     uint64_t no_xf[64], no_gx[64];
 } pack_job;
 
@@ -1181,7 +1187,8 @@ static void pack_worker(void *vp, int widx)
             uint32_t l_read_name = rec[8], n_cigar = rd16(rec + 12), l_seq = rd32(rec + 16);
             uint64_t fixed = 32ull + l_read_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
             if (fixed > bs) fixed = bs;            /* corrupt layout: no aux (validated again by the caller) */
-            pack_record(rec + fixed, rec + bs, j->cells, j->feats, j->cb_key + i, j->gx_key + i, j->umi + i, j->meta + i, &nxf, &ngx);
+            pack_record(rec + fixed, rec + bs, j->cells, j->feats, j->cb_key + i, j->gx_key + i, j->umi + i, j->meta + i, &nxf, &ngx,
+                        j->umi_ext ? j->umi_ext + i : NULL);
         }
     }
     j->no_xf[widx] = nxf; j->no_gx[widx] = ngx;
@@ -1415,7 +1422,7 @@ long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fa
         double t0 = now_s();
         pack_job job; memset(&job, 0, sizeof job);
         job.b = b; job.cells = cells; job.feats = feats;
-        job.cb_key = cb_key; job.gx_key = gx_key; job.umi = umi; job.meta = meta; job.n = n;
+        job.cb_key = cb_key; job.gx_key = gx_key; job.umi = umi; job.meta = meta; job.n = n; job.umi_ext = b->umi_ext;
         par_run(n < 8192 ? 1 : b->n_threads, pack_worker, &job);
         for (int i = 0; i < 64; i++) { b->n_no_xf += job.no_xf[i]; b->n_no_gx += job.no_gx[i]; }
         b->n_records += n;
@@ -1782,6 +1789,24 @@ int fastf_write_outputs(const char *path_out, const char *bam_label, float rate_
 /* flags: 1 = CB present, 2 = xf present, 4 = GX present, 8 = UB present; strings are
  * fixed-stride and NUL-terminated.  Used by the synthetic generators and parity tests so
  * that the very strings the CPU oracle sees go through the product's packer. */
+void fastf_bam_set_umi_ext(fastf_bam_t *b, uint32_t *umi_ext) { b->umi_ext = umi_ext; }
+
+void fastf_pack_records_ext(const fastf_keydict_t *cells, const fastf_keydict_t *feats, size_t n,
+                            const uint8_t *flags, const int32_t *xf,
+                            const char *cb, size_t cb_stride, const char *gx, size_t gx_stride,
+                            const char *ub, size_t ub_stride,
+                            uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, uint32_t *umi_ext)
+{
+    fastf_pack_records(cells, feats, n, flags, xf, cb, cb_stride, gx, gx_stride, ub, ub_stride, cb_key, gx_key, umi, meta);
+    for (size_t i = 0; i < n; i++) {                              /* the UMIs again, with room for 28 bases */
+        umi_ext[i] = 0;
+        if (flags[i] & 8) {
+            const char *s = ub + i * ub_stride;
+            meta[i] = (meta[i] & FASTF_META_XF_OK) | fastf_pack_umi_long(s, strnlen(s, ub_stride), &umi[i], &umi_ext[i]);
+        }
+    }
+}
+
 void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *feats, size_t n,
                         const uint8_t *flags, const int32_t *xf,
                         const char *cb, size_t cb_stride, const char *gx, size_t gx_stride,

@@ -89,6 +89,9 @@ long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fa
 int  fastf_bam_enable_device_parse(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats);
 /* as fastf_bam_read_batch; a batch either fills the host arrays (*on_device = 0) or lies packed in device memory already
  * (*on_device = 1, dev: valid until the second next call) */
+/* the next fastf_bam_read_batch / _dev call packs UMIs of up to 28 bases: bases 1..16 into umi[i] as always, bases 17..28 into
+ * umi_ext[i] (same index).  NULL (the default): fastf_pack_umi, 16 bases at most.  Host-packed batches only. */
+void fastf_bam_set_umi_ext(fastf_bam_t *b, uint32_t *umi_ext);
 long fastf_bam_read_batch_dev(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                               uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, size_t cap,
                               int *on_device, fastf_batch_t *dev);
@@ -122,6 +125,11 @@ void fastf_tag_tree_preorder(const char *const *strs, const uint64_t *first, uin
 int fastf_write_gz_text(const char *path, const char *text, size_t len);
 
 /* string-level records → packed SoA (flags: 1 CB, 2 xf, 4 GX, 8 UB present) */
+void fastf_pack_records_ext(const fastf_keydict_t *cells, const fastf_keydict_t *feats, size_t n,
+                            const uint8_t *flags, const int32_t *xf,
+                            const char *cb, size_t cb_stride, const char *gx, size_t gx_stride,
+                            const char *ub, size_t ub_stride,
+                            uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, uint32_t *umi_ext);
 void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *feats, size_t n,
                         const uint8_t *flags, const int32_t *xf,
                         const char *cb, size_t cb_stride, const char *gx, size_t gx_stride,

@@ -187,6 +187,23 @@ uint32_t fastf_pack_umi(const char *ub, size_t len, uint32_t *umi_out)
     return meta;
 }
 
+uint32_t fastf_pack_umi_long(const char *ub, size_t len, uint32_t *umi_out, uint32_t *ext_out)
+{
+    uint32_t meta = FASTF_META_HAS_UB;
+    *umi_out = 0; *ext_out = 0;
+    if (len > 28) return meta | FASTF_META_UMI_TOOLONG;      /* (7 blob bytes: what the 3-bit length field holds) */
+    uint64_t packed = 0; uint32_t bad = 0;
+    for (size_t i = 0; i < len; i++) {
+        const uint32_t code = k_base_code[(unsigned char)ub[i]];
+        bad |= code;
+        packed = (packed << 2) | (code & 3);
+    }
+    if (len) packed <<= 64 - 2 * len;
+    if (!(bad & 4)) { meta |= FASTF_META_UMI_NONNULL; *umi_out = (uint32_t)(packed >> 32); *ext_out = (uint32_t)packed; }
+    meta |= (uint32_t)((len + 3) / 4) << FASTF_META_LEN_SHIFT;
+    return meta;
+}
+
 /* ------------------------------------------------------------------ */
 /* exact string → key                                                  */
 /* ------------------------------------------------------------------ */

@@ -145,6 +145,7 @@ struct fastf_engine {
         bool busy = false; u64 n = 0; bool external = false;
     } slot[2];
     int cur = 0;
+    const u32* cur_umi_ext = nullptr;    // (umi_max_bases > 16) the chunk being pushed: bases 17.. of its UMIs in the device staging
     u64 inflight_records = 0;            // records of the chunks not yet retired
     // key store + results
     u64 key_cap = 0;
@@ -176,7 +177,7 @@ struct fastf_engine {
     bool dedup_hash = false;             // matrix path: sort on (cell, feature) only, dedup through K3's hash set (else: run walk)
     // keys wider than 64 bits (cell bits + feature bits + UMI field > 64): the sort key is the GROUP (cell << feat_bits |
     // feature, group_bits wide), the rest of the key (NULL flag, UMI, length: feat_shift bits) travels beside it as a value
-    bool wide = false; u32 group_bits = 0;
+    bool wide = false, long_umi = false; u32 group_bits = 0;
     DevBuf d_vals, d_vtmp;
     // timing
     bool timing = false;
@@ -434,10 +435,10 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     lap("device count");
     if (he != hipSuccess || ndev == 0)
         return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
-    if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 16) return set_err("umi_max_bases must be 1..16");
+    if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 24) return set_err("umi_max_bases must be 1..24");
     {   // keys wider than 64 bits run on the single-device engine (the group word is sorted, the rest rides along)
         const u32 tb = bits_for(cfg->n_cells) + bits_for(cfg->n_features) + 1 + 2 * cfg->umi_max_bases + bits_for((cfg->umi_max_bases + 3) / 4);
-        if (tb > 64 && (cfg->n_devices > 1 || cfg->n_shards > 1))
+        if ((tb > 64 || cfg->umi_max_bases > 16) && (cfg->n_devices > 1 || cfg->n_shards > 1))
             return set_err("packed key needs %u bits (> 64): the sharded and multi-device engines take keys of at most 64 bits "
                            "(lower umi_max_bases, or run the single-device engine)", tb);
     }
@@ -465,7 +466,8 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     e->L.feat_shift = 1 + e->L.umi_bits + e->L.len_bits;
     e->L.cell_shift = e->L.feat_shift + e->feat_bits;
     e->L.total_bits = e->L.cell_shift + e->cell_bits;
-    e->wide = e->L.total_bits > 64 || getenv("FASTF_FORCE_WIDE_KEYS") != nullptr;
+    e->wide = e->L.total_bits > 64 || cfg->umi_max_bases > 16 || getenv("FASTF_FORCE_WIDE_KEYS") != nullptr;
+    e->long_umi = cfg->umi_max_bases > 16;               // batches carry bases 17.. in fastf_batch_t.umi_ext
     e->group_bits = e->cell_bits + e->feat_bits;
     e->threshold = cfg->draw_threshold;
     {   // Matrix path: the sorted part must hold (cell, feature, NULL flag) and at least 7 bits of the UMI field, i.e. the
@@ -800,6 +802,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     if (e->wide) {                                      // wide keys: group word into keys[], the rest into d_vals[] (tile form, one shard)
         if (segmented || blk || e->n_shards != 1 || keys != (u64*)e->d_keys.p) return set_err("internal error: wide keys go through the engine's own key store");
         p.vals = (u64*)e->d_vals.p; p.wide_feat_bits = e->feat_bits;
+        p.umi_ext = e->cur_umi_ext;
     }
     // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
     // deals the keys to the per-destination buffers (same interface as the tile form: keys[G][stride], key_counts[G] += ...)
@@ -1140,13 +1143,13 @@ static const char* err_bits_text(u64 bits) {
     snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s%s", (unsigned long long)bits,
              (bits & 1) ? " (unknown bit 0);" : "",
              (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
-             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it: up to 16);" : "",
+             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it: up to 24, with fastf_batch_t.umi_ext from 17 on);" : "",
              (bits & ERR_KEYS_FULL) ? " key store full;" : "",
              (bits & ERR_RUN_TOO_LONG) ? " unsorted run longer than the group-only path handles: sort fully (drop FASTF_SORT_SKIP_LOW);" : "");
     return buf;
 }
 
-static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4); }
+static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4 + 4); }     // (+ 4: umi_ext of engines with umi_max_bases > 16)
 
 // Streaming push path.
 //   chunk i:  [host staging, pageable input only]  ->  H2D on s_copy  ->  K1a + scan + K1b on s_compute
@@ -1246,8 +1249,9 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     if (grow_keys(e, keys_ub + n)) return 1;
     const u64 cap = e->batch_cap;
     char* ds = (char*)sl.d_stage.p;
-    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_ext = cap * 24;
     const void *s_cb = b->cb_key + off, *s_gx = b->gx_key + off, *s_umi = b->umi + off, *s_meta = b->meta + off;
+    const void *s_ext = (e->long_umi && b->umi_ext) ? b->umi_ext + off : nullptr;
     if (!pinned) {
         // staging: three streams of 8 bytes per record, copied side by side
         char* hs = (char*)sl.h_stage;
@@ -1260,6 +1264,7 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
             memcpy(hs + o_gx, s_gx, n * 8); memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4);
         }
         memcpy(hs, s_cb, n * 8);
+        if (s_ext) { memcpy(hs + o_ext, s_ext, n * 4); s_ext = hs + o_ext; }
         if (par) { t_gx.join(); t_um.join(); }
         s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
     }
@@ -1269,6 +1274,11 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyDefault, sc));
     HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyDefault, sc));
     HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyDefault, sc));
+    if (e->long_umi) {                                                  // bases 17.. (zeros when the batch has none)
+        if (s_ext) HIP_OK(hipMemcpyAsync(ds + o_ext, s_ext, n * 4, hipMemcpyDefault, sc));
+        else HIP_OK(hipMemsetAsync(ds + o_ext, 0, n * 4, sc));
+    }
+    e->cur_umi_ext = e->long_umi ? (const u32*)(ds + o_ext) : nullptr;
     if (upload_draws(e, sl, src, hits_ub + n)) return 1;               // generated while the record copies are in flight
     if (!src.ext) e->draws_valid = e->draws_up;
     HIP_OK(hipEventRecord(sl.ev_copy, sc));
@@ -1539,7 +1549,8 @@ static int umi_rows_wide(fastf_engine* e, fastf_umi_rows_t* rows) {
         e->h_ufeature[i] = (u32)uk[i] & fmask;
         e->h_ucell[i] = (u32)(uk[i] >> e->feat_bits);
         e->h_unonnull[i] = (uint8_t)((uv[i] >> (e->L.umi_bits + e->L.len_bits)) & 1);
-        e->h_uumi[i] = (u32)(((uv[i] >> e->L.len_bits) & umask) << (32 - e->L.umi_bits));
+        const u64 field = (uv[i] >> e->L.len_bits) & umask;              // the first 16 bases are what fastf_umi_rows_t carries
+        e->h_uumi[i] = e->L.umi_bits > 32 ? (u32)(field >> (e->L.umi_bits - 32)) : (u32)(field << (32 - e->L.umi_bits));
     }
     rows->feature = e->h_ufeature.data(); rows->cell = e->h_ucell.data(); rows->n_copy = e->h_ncopy.data();
     rows->umi = e->h_uumi.data(); rows->nonnull = e->h_unonnull.data(); rows->n = nrows;

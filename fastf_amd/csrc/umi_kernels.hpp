@@ -155,6 +155,19 @@ __device__ __forceinline__ u64 make_key(const KeyLayout L, u32 cell, u32 feat, u
     return k;
 }
 
+// the rest of a wide key (everything below the group word) from a UMI of up to 32 bases in 64 bits (first base on top)
+__device__ __forceinline__ u64 make_val64(const KeyLayout L, u64 umi, u32 meta) {
+    if (!(meta & META_UMI_NONNULL)) return 0;
+    const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+    return (1ULL << (L.umi_bits + L.len_bits)) | ((umi >> (64 - L.umi_bits)) << L.len_bits) | len;
+}
+__device__ __forceinline__ bool umi_overflows64(const KeyLayout L, u64 umi, u32 meta) {
+    if (meta & META_UMI_TOOLONG) return true;
+    if (!(meta & META_UMI_NONNULL)) return false;
+    const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+    return len > L.umi_max_bytes || (L.umi_bits < 64 && (umi << L.umi_bits) != 0);
+}
+
 // a UMI the chosen layout cannot hold exactly (longer than umi_max_bases with non-zero tail,
 // or more blob bytes than the length field encodes)
 __device__ __forceinline__ bool umi_overflows(const KeyLayout L, u32 umi, u32 meta) {
@@ -569,6 +582,7 @@ struct PackParams {
     // keys wider than 64 bits (tile form, one shard): keys[] takes the GROUP (cell << wide_feat_bits | feature) and vals[]
     // the rest of the key — NULL flag, UMI, length, laid out as the low feat_shift bits of a narrow key; vals == nullptr: narrow
     u64* vals; u32 wide_feat_bits;
+    const u32* umi_ext;            // wide keys, umi_max_bases > 16: bases 17.. of every UMI (nullptr: none)
     u64* key_counts;               // [n_shards], appended
     u64* counters;                 // {hits, sampled, valid, err}
     u64* stamps;                   // diagnostic builds only (-DFASTF_STAMPS)
@@ -714,11 +728,16 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
     for (int j = 0; j < K1B_IPT; ++j) {
         key[j] = 0; pos[j] = 0; shard[j] = 0;
         const bool alive = feat[j] != 0 && (meta[j] & META_HAS_UB);
-        if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
+        u64 umi_w = 0;                                                 // wide keys: the UMI in 64 bits
+        if (p.vals) {
+            const u64 idx = base + (u64)j * K1B_THREADS + tid;
+            umi_w = ((u64)umi[j] << 32) | ((p.umi_ext && alive && idx < p.n) ? p.umi_ext[idx] : 0u);
+        }
+        if (alive && (p.vals ? umi_overflows64(p.L, umi_w, meta[j]) : umi_overflows(p.L, umi[j], meta[j]))) errs |= (u32)ERR_UMI_TOOLONG;
         if (alive) {
             n_valid++;                                               // E12 :435
             // (wide keys: the low part only here — cell and feature go into the group word at the store below)
-            key[j] = make_key(p.L, p.vals ? 0u : cell[j], p.vals ? 0u : feat[j], umi[j], meta[j]);
+            key[j] = p.vals ? make_val64(p.L, umi_w, meta[j]) : make_key(p.L, cell[j], feat[j], umi[j], meta[j]);
             shard[j] = p.n_shards > 1 ? shard_of(cell[j], p.n_shards) : 0;
         }
         emit[j] = alive;

@@ -85,9 +85,22 @@ class Lists:
             pass
 
 
-def pack_records(lists: Lists, flags, xf, cb, gx, ub):
-    """String-level records → packed SoA via the product's own packer (host_io.c)."""
+def pack_records(lists: Lists, flags, xf, cb, gx, ub, long_umis=False):
+    """String-level records → packed SoA via the product's own packer (host_io.c).  long_umis: UMIs of up to 28 bases, a
+    fifth array (bases 17..) is returned behind the four"""
     L = _lib.lib()
+    if long_umis:
+        L.fastf_pack_records_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fastf_pack_records_ext.restype = None
+        flags = np.ascontiguousarray(flags, dtype=np.uint8); xf = np.ascontiguousarray(xf, dtype=np.int32)
+        cb, gx, ub = (np.ascontiguousarray(a) for a in (cb, gx, ub))
+        n = len(flags)
+        out = (np.empty(n, np.uint64), np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint32))
+        L.fastf_pack_records_ext(lists.cell_dict, lists.feat_dict, n, flags.ctypes.data, xf.ctypes.data, cb.ctypes.data, cb.dtype.itemsize,
+                                 gx.ctypes.data, gx.dtype.itemsize, ub.ctypes.data, ub.dtype.itemsize, *(a.ctypes.data for a in out))
+        return out
     L.fastf_pack_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -192,14 +205,17 @@ class Engine:
 
     # ---- host-buffer streaming API ----
     @staticmethod
-    def _batch(cb_key, gx_key, umi, meta):
+    def _batch(cb_key, gx_key, umi, meta, umi_ext=None):
         arrs = (np.ascontiguousarray(cb_key, dtype=np.uint64), np.ascontiguousarray(gx_key, dtype=np.uint64),
-                np.ascontiguousarray(umi, dtype=np.uint32), np.ascontiguousarray(meta, dtype=np.uint32))
-        b = Batch(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, len(arrs[0]))
+                np.ascontiguousarray(umi, dtype=np.uint32), np.ascontiguousarray(meta, dtype=np.uint32),
+                None if umi_ext is None else np.ascontiguousarray(umi_ext, dtype=np.uint32))
+        b = Batch(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, len(arrs[0]),
+                  None if arrs[4] is None else arrs[4].ctypes.data)
         return b, arrs
 
-    def push(self, cb_key, gx_key, umi, meta, draws=None):
-        b, keep = self._batch(cb_key, gx_key, umi, meta)
+    def push(self, cb_key, gx_key, umi, meta, draws=None, umi_ext=None):
+        """umi_ext: bases 17.. of every UMI (pack_records(..., long_umis=True)) for an engine with umi_max_bases > 16"""
+        b, keep = self._batch(cb_key, gx_key, umi, meta, umi_ext)
         if draws is None:
             check(self._L.fastf_engine_push(self._h, C.byref(b)))
         else:

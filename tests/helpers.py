@@ -27,6 +27,10 @@ class Case:
     def packed(self, lists):
         return F.pack_records(lists, self.flags, self.xf, self.cb, self.gx, self.ub)
 
+    def packed_long(self, lists):
+        """five arrays: the fifth holds bases 17.. of every UMI (engines with umi_max_bases > 16)"""
+        return F.pack_records(lists, self.flags, self.xf, self.cb, self.gx, self.ub, long_umis=True)
+
 
 def assert_matches_oracle(res, ora, eng=None, case=None, lists=None, rows=None):
     assert (res["total"], res["sampled"], res["valid"]) == (ora["total"], ora["sampled"], ora["valid"])

@@ -339,6 +339,65 @@ def test_keys_wider_than_64_bits_match_oracle(name, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("umi_len,kw", [
+    (20, dict(n=200_000, n_bar=2000, n_gene=900, rate_cell=0.7, rate_depth=0.8, dup_factor=3.0, p_no_cb=0.03, p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.02)),
+    (24, dict(n=120_000, n_bar=300, n_gene=100, umi_pool=256, p_n_umi=0.05)),
+    (17, dict(n=60_000, n_bar=70_000, n_gene=70_000, rate_depth=0.9, umi_pool=4096)),
+])
+def test_umis_of_17_to_24_bases_match_oracle(umi_len, kw):
+    """bam2db_ds.c:417-419 binds a blob of (len + 3) / 4 bytes for a UMI of any length: with umi_max_bases 24 the engine takes
+    bases 17.. beside the packed record (fastf_batch_t.umi_ext) and carries 52 bits of UMI field beside the group word"""
+    case = Case(umi_len=umi_len, **kw)
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=24)
+    try:
+        cb, gx, umi, meta, ext = case.packed_long(lists)
+        assert ext.any()
+        eng.push(cb, gx, umi, meta, umi_ext=ext)
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
+
+
+def test_mixed_umi_lengths_0_to_28_with_room_for_24():
+    """lengths 0..28 in one run against an engine with room for 24 bases: the blob byte length and the zero padding decide
+    equality (ACGT x 5 and ACGT x 5 + A: 5 and 6 bytes, different blobs; 21 and 24 bases of the same prefix padded with A: the
+    same 6-byte blob); 25..28 bases (7 bytes) do not fit and must raise the error bit, not a wrong count"""
+    from fastf_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    n = 40_000
+    bt, ft, bar, genes = synth.make_lists(40, 30, seed=5)
+    flags, xf, cb, gx, _ = synth.make_records(n, bar, genes, seed=6)
+    pool = [b"", b"ACGT", b"ACGTACGTACGTACGT", b"ACGTACGTACGTACGTA", b"ACGTACGTACGTACGTAAAA", b"ACGTACGTACGTACGTACGT", b"ACGTACGTACGTACGTACGTA",
+            b"ACGTACGTACGTACGTACGTAAAA", b"ACGTACGTACGTACGTACGTACGT", b"TTTTTTTTTTTTTTTTTTTTTTTT", b"TTTTTTTTTTTTTTTTTTTTTTTN", b"ACGTACGTACGTACGTN",
+            b"GGGGGGGGGGGGGGGGGGGGG", b"GGGGGGGGGGGGGGGGGGGGGA", b"GGGGGGGGGGGGGGGGC"]
+    ub = np.array([pool[i] for i in rng.integers(0, len(pool), size=n)], dtype="S30")
+    lists = F.Lists(bt, ft, 1.0, 926)
+    ora = O.run_bam2db(bt, ft, flags, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub), 1.0, 1.0, 926, b"x.bam", True)
+    eng = F.Engine.from_lists(lists, umi_max_bases=24)
+    try:
+        c, g, u, m, e = F.pack_records(lists, flags, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub), long_umis=True)
+        eng.push(c, g, u, m, umi_ext=e)
+        res = eng.finish()
+        assert_matches_oracle(res, ora)
+        assert eng.format_umi_rows(eng.umi_rows()) == ora["umi"]
+        # a 25-base UMI (7 blob bytes) is beyond this engine: refused loudly
+        eng.reset()
+        ub2 = ub.copy(); ub2[0] = b"A" * 25
+        flags2 = flags.copy(); flags2[0] |= 1 | 2 | 4 | 8; xf2 = xf.copy(); xf2[0] = 25
+        cb2 = synth.as_cstr(cb).copy(); cb2[0] = bar[0]; gx2 = synth.as_cstr(gx).copy(); gx2[0] = genes[0]
+        c, g, u, m, e = F.pack_records(lists, flags2, xf2, cb2, gx2, synth.as_cstr(ub2), long_umis=True)
+        eng.push(c, g, u, m, umi_ext=e)
+        with pytest.raises(F.FastfError) as ei:
+            eng.finish()
+        assert "umi_max_bases" in str(ei.value)
+    finally:
+        eng.close()
+
+
 def test_wide_keys_are_refused_where_they_cannot_go():
     """sharded and multi-device engines take keys of at most 64 bits: a clear refusal, not a wrong matrix"""
     case = Case(n=10, n_bar=70_000, n_gene=70_000)

@@ -175,3 +175,31 @@ def test_format_matrix_matches_oracle_text():
 class _FakeEngine:
     """format_matrix only needs the library handle (pure host formatting, no device)"""
     _L = _lib.lib()
+
+
+def test_pack_umi_long_matches_the_codec_up_to_28_bases():
+    """fastf_pack_umi_long: bases 1..16 in the first word, 17..28 left-aligned in the second — together the zero-padded
+    2-bit blob of encode_DNA (bam2db_ds.c:22-51) for lengths up to 28; N anywhere makes it NULL; 29 bases: too long"""
+    import ctypes as C
+    from fastf_amd import _lib
+    L = _lib.lib()
+    L.fastf_pack_umi_long.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.fastf_pack_umi_long.restype = C.c_uint32
+    rng = np.random.default_rng(8)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    for ln in list(range(0, 29)) * 4:
+        sq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=ln))
+        u, e = C.c_uint32(), C.c_uint32()
+        m = L.fastf_pack_umi_long(sq.encode(), ln, C.byref(u), C.byref(e))
+        want = 0
+        for ch in sq:
+            want = (want << 2) | code[ch]
+        want <<= 64 - 2 * ln if ln else 0
+        assert (u.value << 32 | e.value) == want and (m & 2) and (m & 4) and not (m & 8)
+        assert (m >> 4) & 7 == (ln + 3) // 4
+        if ln <= 16:                                          # the short packer agrees on what it can hold
+            u2 = C.c_uint32()
+            assert L.fastf_pack_umi(sq.encode(), ln, C.byref(u2)) == m and u2.value == u.value and e.value == 0
+    u, e = C.c_uint32(), C.c_uint32()
+    assert L.fastf_pack_umi_long(b"ACGTNACGTACGTACGTACG", 20, C.byref(u), C.byref(e)) & 4 == 0 and (u.value, e.value) == (0, 0)
+    assert L.fastf_pack_umi_long(b"A" * 29, 29, C.byref(u), C.byref(e)) & 8
