@@ -203,10 +203,17 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
 
     /* bam2db needs a device anyway: unless told otherwise (FASTF_GPU_INFLATE=0) the BGZF inflate of big windows is
      * shared between the host threads and the device (host_io.c: hybrid inflate, every block CRC-checked on the host) */
+    /* ONE device ordinal for the reader's device side and the engine (several devices: the first of them): FASTF_DEVICES
+     * ("0,1,2,3", or a count = devices 0..count-1), else FASTF_DEVICE, else device 0 */
+    int dev0 = 0;
+    {   const char *dvs = getenv("FASTF_DEVICES"), *dv1 = getenv("FASTF_DEVICE");
+        if (dvs && *dvs) dev0 = strchr(dvs, ',') ? (int)strtol(dvs, NULL, 10) : 0;
+        else if (dv1) dev0 = atoi(dv1);
+        if (dvs && *dvs && !strchr(dvs, ',') && atoi(dvs) == 1 && dv1) dev0 = atoi(dv1);      /* FASTF_DEVICES=1: one device, FASTF_DEVICE says which */
+        if (dev0 < 0 || dev0 > 254) dev0 = 0; }
     {   /* | 4: the device-side parse will be asked for (below, once the lists are known) unless it is switched off */
-        const char *gp = getenv("FASTF_GPU_PARSE"), *dvs = getenv("FASTF_DEVICES");
-        const int several = dvs && *dvs && (strchr(dvs, ',') || atoi(dvs) >= 2);
-        bam = fastf_bam_open2(bam_file, 0, 1 | ((gp && gp[0] == '0') || several ? 0 : 4));
+        const char *gp = getenv("FASTF_GPU_PARSE");
+        bam = fastf_bam_open2(bam_file, 0, 1 | ((gp && gp[0] == '0') ? 0 : 4) | ((dev0 + 1) << 8));
     }
     if (!bam) { fprintf(stderr, "Fail to open BAM file %s (%s)\n", bam_file, fastf_last_error()); goto done; }
     fprintf(stderr, "Opened BAM file %s successfully\n", bam_file);
@@ -243,10 +250,8 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
         dec.slot[k].ext = long_umis ? (uint32_t *)(base + cap * 24) : NULL;
     }
     /* the windows the device inflates are hopped and packed there as well (one device; lists the device packer can hold) */
-    {   const char *dvs = getenv("FASTF_DEVICES");
-        const int several = dvs && *dvs && (strchr(dvs, ',') || atoi(dvs) >= 2);
-        if (!several && !long_umis) (void)fastf_bam_enable_device_parse(bam, lists.cell_dict, lists.feat_dict);
-    }
+    /* (several devices: the batches the first device packs go to whichever device their chunk is dealt to, device to device) */
+    if (!long_umis) (void)fastf_bam_enable_device_parse(bam, lists.cell_dict, lists.feat_dict);
     printf("Start to convert bam file to UMI keys on the device...\n");
     if (pthread_create(&dec_thread, NULL, decoder_main, &dec) != 0) { fprintf(stderr, "cannot start decoder thread\n"); goto done; }
     dec_started = 1;
@@ -261,8 +266,7 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
     cfg.draw_threshold = fastf_draw_threshold(rate_depth);
     cfg.mt_seed = seed; cfg.mt_skip = lists.mt_skip;
     cfg.n_shards = 1; cfg.shard_rank = 0;
-    const char *dev = getenv("FASTF_DEVICE");
-    cfg.device = dev ? atoi(dev) : 0;
+    cfg.device = dev0;
     /* FASTF_DEVICES: "4" = devices 0..3, or an explicit list "0,1,2,3" (ordinals may repeat: all shards on one GPU).
      * Two or more entries make this one process drive that many GPUs (cell-hash shards, one key exchange). */
     int32_t dev_list[8]; uint32_t n_dev = 0;
@@ -275,7 +279,6 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
             for (uint32_t i = 0; i < n_dev; i++) dev_list[i] = (int32_t)i;
         }
         if (n_dev >= 2) { cfg.n_devices = n_dev; cfg.devices = dev_list; }
-        else if (n_dev == 1) cfg.device = dev_list[0];
     }
     /* 16-base UMIs (36 key bits) when the packed key then fits 64 bits; else 12 bases (27 bits: what 10x chemistry writes) if
      * THAT fits — the fast 64-bit path — with a second run should the file turn out to hold longer UMIs (umi_bases = 16 then);

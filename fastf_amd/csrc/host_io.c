@@ -949,7 +949,7 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
         const int want = gpu_inflate < 0 ? 0 : (gpu_inflate & 3);
         b->parse_expected = gpu_inflate > 0 && (gpu_inflate & 4) != 0;
         b->gpu_wanted = gi ? (gi[0] == '1' ? 1 : gi[0] == '2' ? 2 : 0) : (want == 1 || want == 2 ? want : 0);
-        b->gpu_device = dv ? atoi(dv) : 0;
+        b->gpu_device = ((gpu_inflate >> 8) & 0xff) ? ((gpu_inflate >> 8) & 0xff) - 1 : (dv ? atoi(dv) : 0);   /* bits 8..15 of the flags: ordinal + 1 (bam2db(): the engine's device) */
         const char *sh2 = getenv("FASTF_GPU_INFLATE_SHARE"), *sh3 = getenv("FASTF_GPU_INFLATE_MAX");
         b->gpu_share_max = sh3 ? atof(sh3) : 0.60;
         b->gpu_share_cap_keep = sh3 ? atof(sh3) : 0.95;

@@ -80,7 +80,8 @@ void fastf_pinned_unregister(void *p);
 void fastf_bam_print_profile(const fastf_bam_t *b);   /* FASTF_BAM_PROFILE=1: stage times of the reader on stderr */
 fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
 /* gpu_inflate: what to do when FASTF_GPU_INFLATE is unset — 0/-1 host threads only, 1 inflate shared with the device, 2 wait for
- * the device; | 4: the caller will call fastf_bam_enable_device_parse (nothing is pinned for copy-back windows up front) */
+ * the device; | 4: the caller will call fastf_bam_enable_device_parse (nothing is pinned for copy-back windows up front);
+ * | (ordinal + 1) << 8: the device the reader's device side runs on (0 in those bits: FASTF_DEVICE, else device 0) */
 fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate);
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,

@@ -31,7 +31,12 @@ struct MultiDev {
     // per stage slot: copy done / K1a counted and the snapshot is on the host / K1b done (the slot may be refilled)
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cnt[2] = {nullptr, nullptr}, ev_k1b[2] = {nullptr, nullptr}, ev_sent = nullptr;
     bool k1b_queued[2] = {false, false};
-    u32* h_draws[2] = {nullptr, nullptr}; DevBuf d_draws[2];     // the draws of the chunk in that slot
+    u32* h_draws[2] = {nullptr, nullptr}; DevBuf d_draws[2];     // FASTF_HOST_DRAWS=1: the draws of the chunk in that slot, generated on the host
+    // the draw stream on the device: EVERY device continues the one MT19937 stream by the hits of EVERY chunk, in stream order
+    // (mt_fill_kernel on its compute stream: a few hundred microseconds per chunk), into a ring addressed by absolute hit rank,
+    // so the draws of its own chunks are there when its K1b runs and nothing about them crosses PCIe or waits for a host loop
+    DevBuf d_mt, d_ring; u64 ring_len = 0;
+    u64* h_base[2] = {nullptr, nullptr};       // pinned: absolute hit-rank base of the chunk in that slot (copied beside the K1b launch)
     u64* h_cnt[2] = {nullptr, nullptr};        // pinned snapshot of the sub-engine's d_small behind that slot's K1a
     int next_slot = 0;
     u64* h_info = nullptr;                     // pinned mirror of the sub-engine's d_small (finish)
@@ -62,6 +67,7 @@ struct fastf_multi {
     struct InFlight { u32 dev; int slot; u64 n; };
     std::vector<InFlight> fifo;                                  // counted, not yet retired (stream order)
     fastf_mt_t mt{}; u32 mt_seed0 = 0; u64 mt_skip0 = 0;
+    bool device_mt = false, mt_uploaded = false;                 // the stream continues on the devices (else: on the host, FASTF_HOST_DRAWS=1)
     u64 hits = 0, total_records = 0, c_sampled = 0, c_valid = 0;
     bool finished = false, aliased = false;
     int use_rccl = 0; RcclApi rccl; std::vector<ncclComm_t> comms;
@@ -111,6 +117,7 @@ static void multi_destroy(fastf_engine* e) {
         for (int i = 0; i < 2; ++i) {
             if (md.h_stage[i]) (void)hipHostFree(md.h_stage[i]);
             md.d_stage[i].release(); md.d_draws[i].release();
+            if (md.h_base[i]) (void)hipHostFree(md.h_base[i]);
             if (md.ev_in[i]) (void)hipEventDestroy(md.ev_in[i]);
             if (md.ev_cnt[i]) (void)hipEventDestroy(md.ev_cnt[i]);
             if (md.ev_k1b[i]) (void)hipEventDestroy(md.ev_k1b[i]);
@@ -120,7 +127,7 @@ static void multi_destroy(fastf_engine* e) {
         if (md.ev_sent) (void)hipEventDestroy(md.ev_sent);
         if (md.h_info) (void)hipHostFree(md.h_info);
         multi_free_old_shards(md);
-        DevBuf* all[] = {&md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy};
+        DevBuf* all[] = {&md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy, &md.d_mt, &md.d_ring};
         for (DevBuf* b : all) b->release();
         if (md.e) fastf_engine_destroy(md.e);
     }
@@ -139,6 +146,7 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
     m->cap = cfg->batch_records ? cfg->batch_records : (4ull << 20);
     m->mt_seed0 = cfg->mt_seed; m->mt_skip0 = cfg->mt_skip;
     fastf_mt_seed(&m->mt, cfg->mt_seed); fastf_mt_skip(&m->mt, cfg->mt_skip);
+    m->device_mt = device_mt_wanted();
     for (u32 g = 0; g < G; ++g) {
         const int dev = cfg->devices ? cfg->devices[g] : (int)g;
         if (dev < 0 || dev >= ndev) return set_err("device %d out of range (have %d)", dev, ndev);
@@ -246,15 +254,47 @@ static int multi_retire_chunk(fastf_multi* m) {
     md.keys_exact = most; md.recs_since = c.n;             // (later chunks of this device are not in flight: see enqueue)
     if (multi_grow_shards(m, md, md.keys_exact + md.recs_since)) return 1;
     // exactly this chunk's draws, in stream order (the chunks are retired in stream order)
+    u64* small = (u64*)se->d_small.p;
+    char* ds = (char*)md.d_stage[c.slot].p;
+    if (m->device_mt) {
+        // every device moves the stream on by this chunk's hits (its own copy of the state, its own ring); the owner of the
+        // chunk then runs K1b against its ring, hit ranks counted from the stream's start
+        const u64 base = m->hits;
+        if (hits) for (u32 g = 0; g < m->G; ++g) {
+            MultiDev& mg = m->d[g];
+            HIP_OK(hipSetDevice(mg.dev));
+            if (!m->mt_uploaded || !mg.d_mt.p) {
+                u64 r = 1; while (r < 2 * cap) r <<= 1;
+                if (mg.d_mt.ensure(sizeof(fastf_mt_t)) || mg.d_ring.ensure(r * 4)) return 1;
+                mg.ring_len = r;
+                HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
+                HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)
+            }
+            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, mg.e->s_compute, (u32*)mg.d_mt.p, (u32*)mg.d_ring.p, base, hits, (u64)(mg.ring_len - 1));
+            HIP_OK(hipGetLastError());
+        }
+        if (hits) m->mt_uploaded = true;
+        m->hits += hits;
+        HIP_OK(hipSetDevice(md.dev));
+        if (!md.h_base[c.slot]) HIP_OK(hipHostMalloc((void**)&md.h_base[c.slot], 64, hipHostMallocDefault));
+        if (md.k1b_queued[c.slot]) HIP_OK(hipEventSynchronize(md.ev_k1b[c.slot]));      // (the copy below that last read this word has long gone)
+        *md.h_base[c.slot] = base;
+        HIP_OK(hipMemcpyAsync(small + SM_DRAWBASE, md.h_base[c.slot], sizeof(u64), hipMemcpyHostToDevice, se->s_compute));
+        if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), c.n,
+                         (const u32*)md.d_ring.p, base + hits, small + SM_DRAWBASE, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
+                         small + SM_COUNTERS, true, se->s_compute, md.ring_len ? md.ring_len - 1 : ~0ull))
+            return 1;
+    } else {
+    if (md.d_draws[c.slot].ensure(std::max<u64>(cap, 1) * 4)) return 1;
+    if (!md.h_draws[c.slot]) HIP_OK(hipHostMalloc((void**)&md.h_draws[c.slot], std::max<u64>(cap, 1) * 4, hipHostMallocDefault));
     fastf_mt_fill(&m->mt, md.h_draws[c.slot], hits);
     m->hits += hits;
     if (hits) HIP_OK(hipMemcpyAsync(md.d_draws[c.slot].p, md.h_draws[c.slot], hits * 4, hipMemcpyHostToDevice, se->s_compute));
-    u64* small = (u64*)se->d_small.p;
-    char* ds = (char*)md.d_stage[c.slot].p;
     if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), c.n,
                      (const u32*)md.d_draws[c.slot].p, hits, nullptr, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
                      small + SM_COUNTERS, true, se->s_compute))
         return 1;
+    }
     HIP_OK(hipEventRecord(md.ev_k1b[c.slot], se->s_compute));
     md.k1b_queued[c.slot] = true;
     return 0;
@@ -277,8 +317,7 @@ static int multi_enqueue_chunk(fastf_multi* m, const fastf_batch_t* b, size_t of
     }
     HIP_OK(hipSetDevice(md.dev));
     const int slot = md.next_slot; md.next_slot ^= 1;
-    if (md.d_stage[slot].ensure(stage_bytes(cap)) || md.d_draws[slot].ensure(std::max<u64>(cap, 1) * 4)) return 1;
-    if (!md.h_draws[slot]) HIP_OK(hipHostMalloc((void**)&md.h_draws[slot], std::max<u64>(cap, 1) * 4, hipHostMallocDefault));
+    if (md.d_stage[slot].ensure(stage_bytes(cap))) return 1;
     if (!md.h_cnt[slot]) HIP_OK(hipHostMalloc((void**)&md.h_cnt[slot], SM_WORDS * sizeof(u64), hipHostMallocDefault));
     // the slot is refilled behind the K1b that read it (two chunks of this device ago)
     if (md.k1b_queued[slot]) HIP_OK(hipStreamWaitEvent(se->s_copy, md.ev_k1b[slot], 0));
@@ -291,10 +330,12 @@ static int multi_enqueue_chunk(fastf_multi* m, const fastf_batch_t* b, size_t of
         s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
     }
     char* ds = (char*)md.d_stage[slot].p;
-    HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyHostToDevice, se->s_copy));
-    HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyHostToDevice, se->s_copy));
-    HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyHostToDevice, se->s_copy));
-    HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyHostToDevice, se->s_copy));
+    // (hipMemcpyDefault: a "pinned" batch may also be DEVICE memory — the records the BAM front end packed on the first device —
+    // then this is a device-to-device copy, over xGMI when the chunk's device is another one)
+    HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyDefault, se->s_copy));
+    HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyDefault, se->s_copy));
+    HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyDefault, se->s_copy));
+    HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyDefault, se->s_copy));
     HIP_OK(hipEventRecord(md.ev_in[slot], se->s_copy));
     HIP_OK(hipStreamWaitEvent(se->s_compute, md.ev_in[slot], 0));
     u64* small = (u64*)se->d_small.p;
@@ -556,6 +597,8 @@ static int multi_reset(fastf_engine* e, bool reseed, u32 seed, u64 skip) {
     if (reseed) {
         if (multi_retire_all(m)) return 1;                   // chunks in flight take their draws from the stream as it was
         m->mt_seed0 = seed; m->mt_skip0 = skip; fastf_mt_seed(&m->mt, seed); fastf_mt_skip(&m->mt, skip);
+        m->mt_uploaded = false;                              // the devices take the new position with the next chunk; ranks count from it
+        m->hits = 0;
         return 0;
     }
     if (multi_retire_all(m)) return 1;                        // (what is in flight is finished, then forgotten)

@@ -132,6 +132,7 @@ struct fastf_engine {
     u64 mt_abs0 = 0;                     // absolute hit rank a  <->  draw number a - mt_abs0 of the engine-owned stream
     bool mt_live = false;                // the generator stands at draw number draws_up - mt_abs0
     DevBuf d_ring; u64 ring_len = 0;     // u32[ring_len], power of two
+    DevBuf d_mt; bool mt_on_device = false;  // the engine-owned stream continues on the device (mt_fill_kernel): state words + read index
     u64 draws_up = 0;                    // absolute ranks below this are (being) uploaded
     u64 draws_valid = 0;                 // ranks below this carry a real draw (caller-supplied streams can run short)
     // staging: chunks in flight, double buffered
@@ -548,7 +549,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
-    e->d_ring.release();
+    e->d_ring.release(); e->d_mt.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp};
@@ -1160,7 +1161,6 @@ static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4 + 4); }
 
 static int slot_alloc(fastf_engine* e, fastf_engine::Slot& sl, bool need_host_stage) {
     if (!sl.h_small) HIP_OK(hipHostMalloc((void**)&sl.h_small, SM_WORDS * sizeof(u64), hipHostMallocDefault));
-    if (!sl.h_draws) HIP_OK(hipHostMalloc(&sl.h_draws, e->batch_cap * 4, hipHostMallocDefault));
     if (sl.d_stage.ensure(stage_bytes(e->batch_cap))) return 1;
     if (need_host_stage && !sl.h_stage) HIP_OK(hipHostMalloc(&sl.h_stage, stage_bytes(e->batch_cap), hipHostMallocDefault));
     return 0;
@@ -1218,7 +1218,20 @@ static int grow_keys(fastf_engine* e, u64 need) {
 struct DrawSource { const u32* ext; u64 ext_abs0; u64 ext_n; };
 
 // make the ring hold every absolute rank below `upto`
+static bool device_mt_wanted() { static int v = -1; if (v < 0) { const char* h = getenv("FASTF_HOST_DRAWS"); v = !(h && h[0] == '1'); } return v != 0; }
+
 static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSource& src, u64 upto) {
+    if (!src.ext && e->mt_on_device) {
+        // the engine-owned stream lives on the device: one launch continues it by exactly the ranks that are missing
+        if (e->draws_up < upto) {
+            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, e->s_copy, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up, (u64)(upto - e->draws_up),
+                               (u64)(e->ring_len - 1));
+            HIP_OK(hipGetLastError());
+            e->draws_up = upto;
+        }
+        return 0;
+    }
+    if (!sl.h_draws) HIP_OK(hipHostMalloc(&sl.h_draws, e->batch_cap * 4, hipHostMallocDefault));   // (host-generated or caller-supplied draws only)
     while (e->draws_up < upto) {
         const u64 n = std::min<u64>(upto - e->draws_up, e->batch_cap);
         u32* h = (u32*)sl.h_draws;
@@ -1319,7 +1332,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
         HIP_OK(hipStreamSynchronize(e->s_copy));
         src.ext = draws; src.ext_abs0 = e->hits_so_far; src.ext_n = n_draws;
         e->draws_up = e->hits_so_far; e->draws_valid = e->hits_so_far + n_draws;
-        e->mt_live = false;
+        e->mt_live = false; e->mt_on_device = false;
     } else if (!e->mt_live) {
         // (re)position the engine-owned stream: rank a takes draw number a - mt_abs0, and mt_hits draws are spent
         if (retire_all(e)) return 1;
@@ -1329,6 +1342,14 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
         e->mt_abs0 = e->hits_so_far - e->mt_hits;
         e->draws_up = e->hits_so_far; e->draws_valid = e->hits_so_far;
         e->mt_live = true;
+        // from here on the stream continues on the device (FASTF_HOST_DRAWS=1: on the host, 4 bytes per hit over PCIe)
+        e->mt_on_device = false;
+        if (device_mt_wanted()) {
+            static_assert(sizeof(fastf_mt_t) == (MT_N + 1) * 4, "fastf_mt_t: 624 state words + the read index");
+            if (e->d_mt.ensure(sizeof(fastf_mt_t))) return 1;
+            HIP_OK(hipMemcpy(e->d_mt.p, &e->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice));
+            e->mt_on_device = true;
+        }
     }
     size_t off = 0;
     while (off < batch->n) {
@@ -1344,6 +1365,30 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
     }
     return 0;
 }
+
+// test hook: the device's MT19937 (mt_fill_kernel) from init_genrand(seed) advanced by `skip` draws on the host, continued by
+// n_calls launches of counts[i] draws each; all draws, in order, into out (host memory, sum of counts words)
+extern "C" int fastf_debug_mt_fill(int device, uint32_t seed, uint64_t skip, const uint64_t* counts, uint32_t n_calls, uint32_t* out) FASTF_TRY {
+    HIP_OK(hipSetDevice(device));
+    fastf_mt_t mt; fastf_mt_seed(&mt, seed); fastf_mt_skip(&mt, skip);
+    u64 total = 0;
+    for (u32 i = 0; i < n_calls; ++i) total += counts[i];
+    DevBuf st, buf;
+    int rc = 0;
+    do {
+        if (st.ensure(sizeof mt) || buf.ensure(std::max<u64>(total, 1) * 4)) { rc = 1; break; }
+        if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess) { rc = set_err("copy failed"); break; }
+        u64 at = 0;
+        for (u32 i = 0; i < n_calls; ++i) {
+            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ~0ull);
+            at += counts[i];
+        }
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
+        if (total && hipMemcpy(out, buf.p, total * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy back failed"); break; }
+    } while (0);
+    st.release(); buf.release();
+    return rc;
+} FASTF_CATCH_INT
 
 extern "C" int fastf_engine_push(fastf_engine_t* e, const fastf_batch_t* batch) FASTF_TRY {
     return push_impl(e, batch, nullptr, 0, false);

@@ -109,6 +109,62 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 __global__ void clear_bits_kernel(u64* word, u64 mask) { atomicAnd(word, ~mask); }
 
 // ------------------------------------------------------------------------------------
+// MT19937 on the device (mt19937ar.c:105-140): the depth draws of the CB hits (bam2db_ds.c:385) are generated where they are
+// consumed — no host loop (about a nanosecond per draw on one core), no 4 bytes per hit over PCIe.  One workgroup continues
+// the stream held in `state` (the 624 words + the read index, fastf_mt_t's layout: the host seeds and skips, rarely) by
+// `count` draws and writes the tempered values to out[(first + i) & mask] (a ring addressed by absolute hit rank).  A block
+// of 624 words is regenerated in three dependent sweeps — words 0..226 need old words only, 227..453 the new 0..226, 454..623
+// the new 227..396 (and word 623 the new word 0) — each sweep reading everything it needs before any of it is overwritten.
+// ------------------------------------------------------------------------------------
+constexpr u32 MT_N = 624, MT_M = 397;
+__device__ __forceinline__ u32 mt_mix(u32 hi, u32 lo) {
+    const u32 y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
+    __shared__ u32 mt[MT_N];
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i < MT_N; i += 256) mt[i] = state[i];
+    u32 idx = state[MT_N];
+    __syncthreads();
+    u64 done = 0;
+    while (done < count) {                                   // (uniform)
+        if (idx >= MT_N) {
+            // sweep 1: k = 0..226   s[k] = s[k + 397] ^ mix(s[k], s[k + 1])
+            u32 v = 0;
+            if (tid < MT_N - MT_M) v = mt[tid + MT_M] ^ mt_mix(mt[tid], mt[tid + 1]);
+            __syncthreads();
+            if (tid < MT_N - MT_M) mt[tid] = v;
+            __syncthreads();
+            // sweep 2: k = 227..453  s[k] = s[k - 227] ^ mix(s[k], s[k + 1])   (s[k - 227] new, s[k + 1] still old for k = 453)
+            const u32 k2 = tid + (MT_N - MT_M);
+            if (tid < MT_N - MT_M) v = mt[k2 - (MT_N - MT_M)] ^ mt_mix(mt[k2], mt[k2 + 1]);
+            __syncthreads();
+            if (tid < MT_N - MT_M) mt[k2] = v;
+            __syncthreads();
+            // sweep 3: k = 454..622 the same with s[k - 227] from sweep 2; k = 623: s[623] = s[396] ^ mix(s[623], s[0])
+            const u32 k3 = tid + 2 * (MT_N - MT_M);
+            if (k3 < MT_N - 1) v = mt[k3 - (MT_N - MT_M)] ^ mt_mix(mt[k3], mt[k3 + 1]);
+            else if (k3 == MT_N - 1) v = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
+            __syncthreads();
+            if (k3 < MT_N) mt[k3] = v;
+            __syncthreads();
+            idx = 0;
+        }
+        const u32 take = (u32)(count - done < (u64)(MT_N - idx) ? count - done : (u64)(MT_N - idx));
+        for (u32 i = tid; i < take; i += 256) {
+            u32 y = mt[idx + i];
+            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+            out[(first + done + i) & mask] = y;
+        }
+        idx += take; done += take;
+        __syncthreads();
+    }
+    for (u32 i = tid; i < MT_N; i += 256) state[i] = mt[i];
+    if (tid == 0) state[MT_N] = idx;
+}
+
+// ------------------------------------------------------------------------------------
 // device-resident open-addressed table: 16-byte slots {key lo, key hi, value, 0},
 // key 0 = empty, linear probing, load <= 0.5.  A few hundred KB: lives in L2.
 // ------------------------------------------------------------------------------------

@@ -270,3 +270,24 @@ def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypat
         np.testing.assert_array_equal(d_k.cpu().numpy()[:len(f)].astype(np.int64), k)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed,skip,counts", [
+    (926, 0, [1, 622, 1, 1, 623, 624, 625, 1248, 7, 100_000]),          # every position of a block boundary
+    (926, 25_000, [3, 50_000, 0, 1_000_003]),                           # behind the draws of a cell sub-sampling (SampleInt)
+    (0x39e, 624 * 1000 - 1, [1, 1, 624 * 3, 5]),
+    (1, 623, [2_000_000]),
+])
+def test_device_mt19937_is_the_reference_stream(env, seed, skip, counts):
+    """mt_fill_kernel (three sweeps per 624-word block) against the host generator, which tests/test_oracle_pins.py pins to the
+    reference's own mt19937ar.c: launches of every size across block boundaries, continued from a host-side skip"""
+    import ctypes as C
+    torch, F, eng = env
+    from fastf_amd import _lib
+    L = _lib.lib()
+    L.fastf_debug_mt_fill.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    n = int(sum(counts))
+    out = np.zeros(max(n, 1), np.uint32)
+    cs = np.asarray(counts, np.uint64)
+    assert L.fastf_debug_mt_fill(0, seed, skip, cs.ctypes.data, len(counts), out.ctypes.data) == 0, L.fastf_last_error()
+    np.testing.assert_array_equal(out[:n], F.mt_draws(seed, skip, n))
