@@ -1760,8 +1760,10 @@ int fastf_write_outputs(const char *path_out, const char *bam_label, float rate_
     if (hl < 0) return io_err("matrix header too long");
     side_files sf = { path_out, lists, 0, 0 };
     pthread_t side; const int side_started = pthread_create(&side, NULL, side_files_main, &sf) == 0;
-    /* rows per gzip member: enough members for every thread to take several (an even finish), none below 32 Ki rows */
-    size_t per = coo->nnz / ((size_t)host_threads(0) * 4) + 1;
+    /* rows per gzip member: from the row count ALONE — the compressed bytes (and the md5 of the .gz) of a given matrix are then
+     * the same on every machine and under every FASTF_HOST_THREADS; 64 members give 16 threads four each (an even finish),
+     * none below 32 Ki rows (a member's fixed cost) or above 256 Ki */
+    size_t per = coo->nnz / 64 + 1;
     if (per < (1u << 15)) per = 1u << 15;
     if (per > (1u << 18)) per = 1u << 18;
     const int rc_mtx = write_gz_chunks(path_out, "matrix.mtx.gz", hdr, (size_t)hl, coo->nnz, per, fmt_mtx_rows, (void *)coo);
@@ -1774,7 +1776,7 @@ int fastf_write_outputs(const char *path_out, const char *bam_label, float rate_
     if (sf.rc_feat) return 1;
     printf("features.tsv.gz is generated.\n");
     if (umi_rows) {                                                                                      /* :527-556 */
-        size_t peru = umi_rows->n / ((size_t)host_threads(0) * 4) + 1;
+        size_t peru = umi_rows->n / 64 + 1;                                          /* (from the row count alone, as above) */
         if (peru < (1u << 15)) peru = 1u << 15;
         if (peru > (1u << 18)) peru = 1u << 18;
         if (write_gz_chunks(path_out, "umi.tsv.gz", NULL, 0, umi_rows->n, peru, fmt_umi_rows, (void *)umi_rows)) return 1;

@@ -89,9 +89,17 @@ template <typename F> static void th_par_for(u64 n, F fn) {
     unsigned T = n < (1u << 18) ? 1u : (unsigned)fastf_host_thread_count();
     if (T > 32) T = 32;
     if (T <= 1) { fn((u64)0, n); return; }
+    // a thread that cannot be started (EAGAIN, a cgroup's limit) must not unwind past joinable threads — that is
+    // std::terminate, which no exception barrier of the C ABI can turn into an error code: its slice runs here instead
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back([=] { fn(n * t / T, n * (t + 1) / T); });
+    th.reserve(T);
+    std::vector<unsigned> inline_slices;
+    for (unsigned t = 1; t < T; ++t) {
+        try { th.emplace_back([=] { fn(n * t / T, n * (t + 1) / T); }); }
+        catch (...) { inline_slices.push_back(t); }
+    }
     fn((u64)0, n / T);
+    for (unsigned t : inline_slices) fn(n * t / T, n * (t + 1) / T);
     for (auto& x : th) x.join();
 }
 

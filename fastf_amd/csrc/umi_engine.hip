@@ -72,7 +72,11 @@ extern "C" const char* fastf_last_error(void) {
     memcpy(snap, g_err, sizeof snap);
     return snap;
 }
-extern "C" const char* fastf_version(void) { return "fastf_amd 0.3 (gfx950)"; }
+#ifdef FASTF_EXPERIMENT
+extern "C" const char* fastf_version(void) { return "fastf_amd 0.4 (gfx950) EXPERIMENT BUILD: results may be wrong"; }
+#else
+extern "C" const char* fastf_version(void) { return "fastf_amd 0.4 (gfx950)"; }
+#endif
 extern "C" void fastf_set_error_(const char* msg) { set_err("%s", msg); }
 
 #define HIP_OK(call)                                                                        \
@@ -175,7 +179,6 @@ struct fastf_engine {
     // K3: row regions (one slot per key: a workgroup's rows go to the slots of its own chunk), rows per chunk and their bases
     DevBuf d_rg_feature, d_rg_cell, d_rg_count, d_rg_ukeys, d_spanrows, d_spanbase, d_giant;
     u32 rg_n = 0; bool rg_umi = false;   // chunks of the last reduce (0: none) and its kind
-    bool dedup_hash = false;             // matrix path: sort on (cell, feature) only, dedup through K3's hash set (else: run walk)
     // keys wider than 64 bits (cell bits + feature bits + UMI field > 64): the sort key is the GROUP (cell << feat_bits |
     // feature, group_bits wide), the rest of the key (NULL flag, UMI, length: feat_shift bits) travels beside it as a value
     bool wide = false, long_umi = false; u32 group_bits = 0;
@@ -471,18 +474,13 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     e->long_umi = cfg->umi_max_bases > 16;               // batches carry bases 17.. in fastf_batch_t.umi_ext
     e->group_bits = e->cell_bits + e->feat_bits;
     e->threshold = cfg->draw_threshold;
-    {   // Matrix path: the sorted part must hold (cell, feature, NULL flag) and at least 7 bits of the UMI field, i.e. the
-        // key bits from feat_shift - 8 upwards; the digit grid is anchored at the TOP of the key, so the number of 8-bit
-        // passes is the minimum for that range whatever the key width (a byte-aligned grid spends a whole pass on the
-        // one or two top bits of a 57/58-bit key).  Everything below the grid stays unsorted (K3 resolves those runs).
-        // FASTF_K3_DEDUP=hash: only (cell, feature) is sorted — every bit below feat_shift may stay unsorted — and K3 finds
-        // the distinct UMIs of a group through a hash set (one digit pass less on 57/58-bit keys); =walk: the run walk
+    {   // Matrix path: only (cell, feature) is sorted — every bit below feat_shift may stay unsorted, K3 (reduce_hashed_kernel)
+        // finds the distinct UMIs of a group through its window set.  The digit grid is anchored at the TOP of the key, so
+        // the number of 8-bit passes is the minimum for that range whatever the key width (a byte-aligned grid spends a whole
+        // pass on the one or two top bits of a 57/58-bit key); everything below the grid stays unsorted.
         const char* sk = getenv("FASTF_SORT_SKIP_BITS");
-        const char* dd = getenv("FASTF_K3_DEDUP");
-        e->dedup_hash = dd ? strcmp(dd, "hash") == 0 : true;
         const u32 fs = e->L.feat_shift, kb = e->L.total_bits;
-        const u32 need_from = e->dedup_hash ? fs : (fs > 8 ? fs - 8 : 0);
-        const u32 passes = (kb - need_from + 7) / 8;
+        const u32 passes = (kb - fs + 7) / 8;
         e->skip_bits = sk ? (u32)atoi(sk) : (kb > 8 * passes ? kb - 8 * passes : 0);
         if (e->skip_bits >= fs) e->skip_bits = 0;
         if (e->wide) e->skip_bits = 0;                               // the group word is sorted whole
@@ -994,7 +992,6 @@ extern "C" int fastf_dev_sort(fastf_engine_t* e, uint64_t* d_keys, uint64_t* d_t
                        sorted_in_tmp ? sorted_in_tmp : &dummy, (hipStream_t)stream, (flags & FASTF_SORT_SEGMENTED) != 0);
 } FASTF_CATCH_INT
 
-static bool k3_old_hash() { static int v = -1; if (v < 0) v = getenv("FASTF_K3_OLD_HASH") != nullptr; return v != 0; }   // A/B: round 3's hash mode
 // K3 grid: every workgroup owns one contiguous chunk of the keys, so the launch is one round of resident workgroups
 // (LDS: 21 KB per workgroup, 37 KB with the hash set of DEDUP 2; 64 VGPRs: eight waves per SIMD, four workgroups per CU)
 static u32 k3_grid(u64 max_n, int dedup) {
@@ -1016,9 +1013,9 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     e->rg_n = 0;
     if (max_n == 0) { HIP_OK(hipMemsetAsync(nrows, 0, sizeof(u64), s)); return 0; }
     if (wide_vals && UMI_ROWS) return set_err("internal error: -u rows of wide keys");
-    const int dedup = wide_vals ? 2 : (UMI_ROWS || low_skip == 0) ? 0 : (e->dedup_hash ? 2 : 1);
+    const int dedup = wide_vals ? 2 : (UMI_ROWS || low_skip == 0) ? 0 : 2;      // 2: keys sorted on (cell, feature) only (reduce_hashed_kernel)
     u32 G = k3_grid(max_n, dedup);
-    if (dedup == 2 && (e->L.feat_shift > 27 || wide_vals) && !k3_old_hash()) G = std::min<u32>(G, (wide_vals ? 2 : 3) * g_cu_count);      // 52 KB of LDS per workgroup: three per CU
+    if (dedup == 2 && (e->L.feat_shift > 27 || wide_vals)) G = std::min<u32>(G, (wide_vals ? 2 : 3) * g_cu_count);      // 52 KB of LDS per workgroup: three per CU
     if (e->d_rg_count.ensure(max_n * 4)) return 1;
     if (UMI_ROWS ? e->d_rg_ukeys.ensure(max_n * 8) : (e->d_rg_feature.ensure(max_n * 4) || e->d_rg_cell.ensure(max_n * 4))) return 1;
     if (e->d_spanrows.ensure(4096 * sizeof(u32)) || e->d_spanbase.ensure(4097 * sizeof(u64))) return 1;
@@ -1029,7 +1026,6 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     u32* const giant_n = dedup == 2 ? (u32*)((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64)) : nullptr;
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
-    p.low_skip = UMI_ROWS ? 0 : low_skip;
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
     p.feature = (u32*)e->d_rg_feature.p; p.cell = (u32*)e->d_rg_cell.p; p.count = (u32*)e->d_rg_count.p; p.ukeys = (u64*)e->d_rg_ukeys.p;
     p.span_rows = (u32*)e->d_spanrows.p;
@@ -1039,11 +1035,9 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     p.giant_max = wide_vals ? (1u << 22) : GIANT_MAX;
     p.vals = wide_vals; p.wide_feat_bits = e->feat_bits;
     t_begin(e, s);
-    if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
-    else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false, 0>), dim3(G), dim3(K3_THREADS), 0, s, p);
-    else if (dedup == 1) hipLaunchKernelGGL((reduce_windows_kernel<false, 1>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true>), dim3(G), dim3(K3_THREADS), 0, s, p);
+    else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (wide_vals) hipLaunchKernelGGL((reduce_hashed_kernel<true, true>), dim3(G), dim3(K3H_THREADS), 0, s, p);
-    else if (k3_old_hash()) hipLaunchKernelGGL((reduce_windows_kernel<false, 2>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (e->L.feat_shift > 27) hipLaunchKernelGGL((reduce_hashed_kernel<true>), dim3(G), dim3(K3H_THREADS), 0, s, p);    // UMIs beyond 12 bases: 64-bit slots
     else hipLaunchKernelGGL((reduce_hashed_kernel<false>), dim3(G), dim3(K3H_THREADS), 0, s, p);
     hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows, giant_n);

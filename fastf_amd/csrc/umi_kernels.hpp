@@ -15,6 +15,16 @@
 // All of it is integer indexing: wave64 ballots/mbcnt for ranking, LDS for the
 // tile-local reorder, coalesced 8-byte streams to HBM.  No MFMA by design.
 #pragma once
+// Build knobs.  -DFASTF_<NAME> macros of this file tune or instrument (tile shapes, non-temporal hints, time stamps): the
+// results stay bit-exact.  A knob that CHANGES results (elimination and timing experiments: "what does this kernel cost
+// without its hash set") must be named FASTF_X_<NAME> and tested as `#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_...)`:
+// `make all` never defines FASTF_EXPERIMENT, a library built with it says so in fastf_version(), and tests/test_abi.py checks
+// all three (round 3's FASTF_K3_NOHASH / _HASH_NOFLAG / _DEBUG went with the kernel modes they lived in).
+#if !defined(FASTF_EXPERIMENT)
+#  if defined(FASTF_X_ANY)
+#    error "FASTF_X_* knobs need -DFASTF_EXPERIMENT (experiment builds only: tools/build_variant.sh)"
+#  endif
+#endif
 #ifndef FASTF_K1_IPT
 #define FASTF_K1_IPT 8
 #endif
@@ -36,8 +46,7 @@ constexpr int WAVE = 64;
 constexpr u64 ERR_DRAWS_SHORT  = 2;
 constexpr u64 ERR_UMI_TOOLONG  = 4;
 constexpr u64 ERR_KEYS_FULL    = 8;
-constexpr u64 ERR_RUN_TOO_LONG = 16;       // group-only sort: an unsorted run exceeded RUN_CAP steps → caller must sort fully
-constexpr u32 RUN_CAP = 128;
+constexpr u64 ERR_RUN_TOO_LONG = 16;       // group-only sort: a (cell, feature) group beyond what the hash path takes → the caller must sort fully
 
 // meta bits (mirror of fastf_amd.h)
 constexpr u32 META_XF_OK = 1, META_HAS_UB = 2, META_UMI_NONNULL = 4, META_UMI_TOOLONG = 8;
@@ -1520,9 +1529,11 @@ __global__ __launch_bounds__(SORT_THREADS, VALS ? 4 : 8) void scatter_kernel(con
 
 
 // ------------------------------------------------------------------------------------
-// K3 / K3u: segmented unique + reduce over the sorted keys — the keys are read ONCE.
-//   UMI_ROWS = false: one row per (cell, feature); count = distinct non-NULL umi keys
-//   UMI_ROWS = true : one row per distinct key;    count = copies of that key
+// K3 / K3u over FULLY SORTED keys — reduce_windows_kernel — the keys are read ONCE.
+//   UMI_ROWS = false: one row per (cell, feature); count = distinct non-NULL umi keys (a key is new iff it differs from its
+//                     neighbour in front): the exact fallback when the group-only path raises ERR_RUN_TOO_LONG
+//   UMI_ROWS = true : one row per distinct key;    count = copies of that key (-u)
+// (The matrix normally comes from keys sorted on (cell, feature) only: reduce_hashed_kernel below.)
 // Each workgroup owns a contiguous chunk of the key array and walks it in windows of K3_TILE keys.  A window always
 // starts at the head of a group and is CUT at a head: the group that is still open at the end of a window is not
 // processed, the next window starts at its head (those few keys are read again: they are the tail of a tile this
@@ -1533,17 +1544,11 @@ __global__ __launch_bounds__(SORT_THREADS, VALS ? 4 : 8) void scatter_kernel(con
 // span_scan_kernel turns them into row bases + the total, and rows_gather_kernel concatenates the regions wherever the
 // rows are wanted — into device arrays, or straight into pinned host memory, where it IS the device-to-host copy.
 // Traffic: 8 bytes per key in, 12 (16 for -u) bytes per row out: SURVEY 8d's K3 bytes.
-// A group longer than a window (only one head in it) is carried as an "open row" across windows in the modes that can
-// (DEDUP 0/1); the hash mode flags ERR_RUN_TOO_LONG and the caller finishes the sort (same contract as the run cap).
-//   DEDUP 0: keys fully sorted              -> a key is new iff it differs from its neighbour in front
-//   DEDUP 1: sorted on bits >= low_skip     -> equal keys sit in one unsorted run: walk back over the run (cap RUN_CAP)
-//   DEDUP 2: sorted on (cell, feature) only -> exact dedup through a window-local hash set in LDS (the table holds
-//            positions into the staged keys, a hit compares the full 64-bit keys): one digit pass less for the sort
+// A group longer than a window (only one head in it) is carried as an "open row" across windows.
 // ------------------------------------------------------------------------------------
 struct ReduceParams {
     const u64* keys; const u64* n_ptr;
     KeyLayout L; u32 feat_mask;
-    u32 low_skip;                          // the keys are sorted on bits >= low_skip only (0 = fully sorted)
     u64* err;                              // error bits (ERR_RUN_TOO_LONG)
     u32* feature; u32* cell; u32* count;   // row REGIONS (capacity: one slot per key); UMI_ROWS: feature/cell unused
     u64* ukeys;                            // UMI_ROWS only
@@ -1568,14 +1573,9 @@ constexpr u32 GIANT_MAX = 1u << 16, GIANT_PART = 1536, GIANT_LIST_CAP = 4096, GI
 #ifndef FASTF_K3_THREADS
 #define FASTF_K3_THREADS 512
 #endif
-#ifndef FASTF_K3_TAB
-#define FASTF_K3_TAB 4096                  // hash-set slots of DEDUP 2 (u32 each): at most K3_TILE keys go in
-#endif
 constexpr int K3_THREADS = FASTF_K3_THREADS, K3_IPT = FASTF_K3_IPT, K3_TILE = K3_THREADS * K3_IPT, K3_WAVES = K3_THREADS / WAVE;
 constexpr int K3_UNITS = K3_IPT * K3_WAVES;
-constexpr u32 K3_TAB = FASTF_K3_TAB;
 static_assert(K3_UNITS <= WAVE, "one wave scans the (item, wave) units");
-static_assert((K3_TAB & (K3_TAB - 1)) == 0 && K3_TAB >= (u32)K3_TILE, "hash set: power of two, room for a whole window");
 
 // nominal chunk of workgroup b of G: whole tiles, spread evenly; [start, end) in keys
 __host__ __device__ __forceinline__ u64 k3_chunk_start(u64 n, u32 b, u32 G) {
@@ -1602,28 +1602,21 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
 // workgroup barrier that waits for this wave's LDS traffic only (not for its global loads and stores)
 __device__ __forceinline__ void k3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// register budget: 64 VGPRs (eight waves per SIMD, four workgroups per CU).  The hash probe needs 80 to stay out of scratch
-// (three spilled registers at 64), but the fourth workgroup per CU is worth more than that: 0.261 ms against 0.280 on the
-// configs[2] shape (profiles/r3_notes/ab_k3_hash_occupancy.txt).  FASTF_K3_MINW_DEDUP=6 gives the 80-register build.
-#ifndef FASTF_K3_MINW_DEDUP
-#define FASTF_K3_MINW_DEDUP 8
-#endif
+// register budget: 64 VGPRs (eight waves per SIMD, four workgroups per CU)
 #ifndef FASTF_K3_PD32
 typedef unsigned short k3_pd_t;
 #else
 typedef u32 k3_pd_t;
 #endif
 static_assert(K3_TILE <= 65535 || sizeof(k3_pd_t) == 4, "distinct prefixes of a window must fit k3_pd_t");
-template <bool UMI_ROWS, int DEDUP>
-__global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) void reduce_windows_kernel(const ReduceParams p) {
-    static_assert(!UMI_ROWS || DEDUP == 0, "-u rows come from fully sorted keys");
+template <bool UMI_ROWS>
+__global__ __launch_bounds__(K3_THREADS, 8) void reduce_windows_kernel(const ReduceParams p) {
     // (item, wave) units in window order: heads / distinct flags per unit, then their exclusive scans
     __shared__ u32 s_h[K3_UNITS], s_d[K3_UNITS];
     __shared__ u64 s_hb[K3_UNITS];         // head ballots of the units (the cut is found from these)
     __shared__ u32 s_tot[2];
     __shared__ k3_pd_t s_pd[K3_TILE + 2];  // by local row: distinct-prefix at the head (at most K3_TILE: 16 bits do)
     __shared__ u64 s_id[K3_TILE];          // the window's keys, later the row identities (UMI_ROWS: the key; else (cell << 32) | feature)
-    __shared__ u32 s_tab[DEDUP == 2 ? K3_TAB : 1];
     __shared__ u32 s_first;                // chunk start search
 
     // everything that is the same for the whole wave is kept in scalar registers (readfirstlane): the wave index, what
@@ -1636,7 +1629,6 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
     const u32 G = gridDim.x, b = blockIdx.x;
     const u64 nom_start = k3_chunk_start(n, b, G), nom_end = k3_chunk_start(n, b + 1, G);
     u32 rows_so_far = 0;                   // (uniform) rows of this chunk written so far
-    if (DEDUP == 2) { for (u32 i = tid; i < K3_TAB; i += K3_THREADS) s_tab[i] = 0; }
 
     // ---- chunk start: the first head at or after the nominal start (a group that began earlier belongs to the chunk before) ----
     u64 cursor = nom_start;
@@ -1682,8 +1674,6 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
         const u64 base = cursor;
         const u32 W = (u32)(n - base < (u64)K3_TILE ? n - base : (u64)K3_TILE);
         u64 key[K3_IPT], hm[K3_IPT], dm[K3_IPT];
-        u32 slot[K3_IPT];
-        bool too_long = false;
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
             key[j] = nkey[j];
@@ -1699,95 +1689,10 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
             const u64 prev = (valid && idx > 0) ? (loc > 0 ? s_id[loc - 1] : prev0) : ~k;
             const bool head = valid && (idx == 0 || (k >> gshift) != (prev >> gshift));
             bool dist;
-            slot[j] = ~0u;
             if (UMI_ROWS) dist = valid;
             else {
                 dist = valid && ((k >> nn_shift) & 1);
-                if (DEDUP == 0) { if (dist && idx > 0) dist = k != prev; }
-                else if (DEDUP == 2) {
-                    // a group of one key (a head whose neighbour behind is a head too) needs no set: about a tenth of the keys
-                    const u64 hnow = __ballot(head);
-                    bool single = head && lane < WAVE - 1 && ((hnow >> (lane + 1)) & 1);
-#ifdef FASTF_K3_NOHASH   /* elimination experiment only (wrong counts): what the window structure costs without the set (0.138 ms) */
-                    single = true;
-#endif
-                    // a key equal to its neighbour in front is a copy of it (coordinate-sorted BAMs keep the reads of one molecule
-                    // together, and the sort is stable): no set needed either
-                    if (dist && !head && k == prev) dist = false;
-                    else if (dist && !single) {
-                        // window-local hash set: the first key to take a slot is the one that counts
-                        const u64 hk = k * 0x9E3779B97F4A7C15ull;
-                        u32 h = (u32)(hk >> 40) & (K3_TAB - 1);
-#ifdef FASTF_K3_LINEAR_PROBE
-                        const u32 step = 1;
-#else
-                        const u32 step = ((u32)(hk >> 24) & 0xFFu) | 1u;        // double hashing: an odd stride walks the whole table, no clusters
-#endif
-                        for (;;) {
-                            // claim first, look afterwards: a first occurrence (two keys out of three) is done after ONE LDS
-                            // round trip; the compare-and-swap of a taken slot hands back its occupant
-                            u32 v = 0;
-                            if (__hip_atomic_compare_exchange_strong(&s_tab[h], &v, loc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { slot[j] = h; break; }
-                            if (s_id[v - 1] == k) { dist = false; break; }
-                            h = (h + step) & (K3_TAB - 1);
-                        }
-                    }
-                } else if (dist && idx > 0) {
-                    // keys that agree on the sorted bits are neighbours but in arbitrary order: this key is a new UMI
-                    // iff no earlier key of that little run equals it.  The run is (cell, feature, top UMI bits), i.e.
-                    // 1/2^(sorted UMI bits) of a group plus its exact duplicates — a step or two in practice.
-                    const u64 run = k >> p.low_skip;
-                    // most runs are a single key: only a key whose neighbour in front belongs to the same run (a few
-                    // percent of them) reads further back — the walk costs LDS bandwidth, not just latency
-                    if ((prev >> p.low_skip) == run) {
-                        if (prev == k) dist = false;
-                        else {
-                            u64 q = prev, at = idx - 1;
-                            u32 steps = 0;
-                            bool open = true;                      // still inside the run, no equal key met yet
-                            constexpr u32 NEAR = 4;
-                            if (loc >= NEAR + 1) {
-                                // the next neighbours in front, read from LDS in one go (no load waits for the one before it)
-                                u64 nb[NEAR];
-#pragma unroll
-                                for (u32 t = 0; t < NEAR; ++t) nb[t] = s_id[loc - 2 - t];
-#pragma unroll
-                                for (u32 t = 0; t < NEAR; ++t) {
-                                    if (open) {
-                                        if ((nb[t] >> p.low_skip) != run) open = false;
-                                        else if (nb[t] == k) { dist = false; open = false; }
-                                    }
-                                }
-                                at = idx - 1 - NEAR; q = nb[NEAR - 1]; steps = NEAR;
-                            }
-                            if (open) {
-                                // inside the window the walk reads LDS; a run that began in front of it goes on in memory
-                                // (two loops, not one load through a selected pointer: an LDS/global pointer select becomes a
-                                // flat access and trips the gfx950 backend)
-                                bool in_lds = true;
-                                for (;; ++steps) {
-                                    if ((q >> p.low_skip) != run) { in_lds = false; break; }
-                                    if (q == k) { dist = false; in_lds = false; break; }
-                                    if (at == 0) { in_lds = false; break; }
-                                    if (steps >= RUN_CAP) { too_long = true; in_lds = false; break; }   // not this path's kind of data: sort fully instead
-                                    if (at <= base) break;                 // the next key lies in front of the window
-                                    --at;
-                                    q = s_id[(u32)(at - base)];
-                                }
-                                if (in_lds) {
-                                    for (;; ++steps) {
-                                        --at;
-                                        q = __builtin_nontemporal_load(p.keys + at);
-                                        if ((q >> p.low_skip) != run) break;
-                                        if (q == k) { dist = false; break; }
-                                        if (at == 0) break;
-                                        if (steps >= RUN_CAP) { too_long = true; break; }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
+                if (dist && idx > 0) dist = k != prev;                 // fully sorted keys: new iff it differs from the key in front
             }
             hm[j] = __ballot(head); dm[j] = __ballot(dist);
             if (lane == 0) s_hb[j * K3_WAVES + w] = hm[j];
@@ -1813,15 +1718,9 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
         if (c_stop != ~0u) { cut = c_stop; closed = true; done = true; }
         else if (base + W == n) { cut = W; closed = true; done = true; }
         else if (c_last > 0) { cut = c_last; closed = true; }
-#ifdef FASTF_K3_HASH_NOFLAG   /* timing experiment only: counts of groups longer than a window are wrong */
         else { cut = W; closed = false; }
-#else
-        else { cut = W; closed = false; }
-#endif
-        if (__any(too_long) && lane == 0) atomicOr(p.err, ERR_RUN_TOO_LONG);
         // the next window starts at the cut: request its keys now, and keep the key in front of it (s_id is restaged below)
-        const u64 g0 = DEDUP == 2 ? uniform64(s_id[0]) >> gshift : 0;      // the group at the head of the window
-        if (!done && !(DEDUP == 2 && !closed)) {
+        if (!done) {
             const u64 nb = base + cut;
             const u32 Wn = (u32)(n - nb < (u64)K3_TILE ? n - nb : (u64)K3_TILE);
 #pragma unroll
@@ -1851,7 +1750,6 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
         const u32 n_rows = __builtin_amdgcn_readfirstlane(s_tot[0]), d_all = __builtin_amdgcn_readfirstlane(s_tot[1]);
 #pragma unroll
         for (int j = 0; j < K3_IPT; ++j) {
-            if (DEDUP == 2 && slot[j] != ~0u) s_tab[slot[j]] = 0;        // the set is empty again for the next window
             if ((hm[j] >> lane) & 1) {
                 const u32 r = s_h[j * K3_WAVES + w] + rank_below(hm[j]);
                 s_pd[r] = (k3_pd_t)(s_d[j * K3_WAVES + w] + rank_below(dm[j]));
@@ -1862,9 +1760,6 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
         k3_barrier();
         // distinct flags in front of the window's first head belong to the open row (none unless a group is being carried)
         const u32 lead = n_rows ? (u32)__builtin_amdgcn_readfirstlane((int)s_pd[0]) : d_all;
-#ifdef FASTF_K3_DEBUG
-        if (tid == 0) printf("b %u base %llu W %u lim %u cstop %u clast %u cut %u closed %d done %d n_rows %u d_all %u lead %u open %d cnt %u prev0 %llx key0 %llx\n", b, (unsigned long long)base, W, lim, c_stop, c_last, cut, (int)closed, (int)done, n_rows, d_all, lead, (int)open_valid, open_cnt, (unsigned long long)prev0, (unsigned long long)key[0]);
-#endif
         if (open_valid) open_cnt += lead;
         u32 first_row = 0, last_row = n_rows;              // rows [first_row, last_row) of the window are written now
         if (open_valid && (n_rows > 0 || done)) {
@@ -1876,56 +1771,6 @@ __global__ __launch_bounds__(K3_THREADS, DEDUP == 0 ? 8 : FASTF_K3_MINW_DEDUP) v
                 else { p.feature[at] = (u32)open_id; p.cell[at] = (u32)(open_id >> 32); }
             }
             rows_so_far += 1; open_valid = false;
-        }
-        if (DEDUP == 2 && !closed) {
-            // One group fills the window (and the window starts at its head: this mode never carries a group).  Its row goes
-            // out with a count of zero, the next head is looked for, and giant_groups_kernel counts the group's distinct
-            // keys — one work item per hash partition, added up with atomics on that row's count.
-            u64 pos = base + W;
-            u32 found = ~0u;
-            for (;;) {
-                if (tid == 0) s_first = ~0u;
-                __syncthreads();
-                const u64 idx = pos + tid;
-                const bool h = idx < n && (p.keys[idx] >> gshift) != g0;
-                const u64 m = __ballot(h);
-                if (m && lane == 0) __hip_atomic_fetch_min(&s_first, (u32)(w * WAVE + __builtin_ctzll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __syncthreads();
-                found = __builtin_amdgcn_readfirstlane(s_first);
-                __syncthreads();
-                if (found != ~0u || pos + K3_THREADS >= n) break;
-                pos += K3_THREADS;
-            }
-            const u64 next = found != ~0u ? pos + found : n;
-            const u64 len = next - base;
-            const u32 parts = (u32)((len + GIANT_PART - 1) / GIANT_PART);
-            const u64 row = region + rows_so_far;
-            if (tid == 0) { const u64 id = s_id[0]; p.count[row] = 0; p.feature[row] = (u32)id; p.cell[row] = (u32)(id >> 32); }
-            if (len > GIANT_MAX) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
-            else {
-                if (tid == 0) s_first = atomicAdd(p.giant_n, parts);
-                __syncthreads();
-                const u32 at = __builtin_amdgcn_readfirstlane(s_first);
-                if (at + parts > GIANT_LIST_CAP) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
-                else if ((u32)tid < parts) {
-                    u64* it = p.giant_list + (u64)(at + tid) * GIANT_ITEM_WORDS;
-                    it[0] = base; it[1] = len; it[2] = row; it[3] = (u64)tid | ((u64)parts << 32);
-                }
-            }
-            rows_so_far += 1; first_row = last_row = 0;
-            cursor = next;
-            if (cursor >= nom_end || cursor >= n) done = true;
-            else {
-                const u32 Wn = (u32)(n - cursor < (u64)K3_TILE ? n - cursor : (u64)K3_TILE);
-#pragma unroll
-                for (int j = 0; j < K3_IPT; ++j) {
-                    const u32 loc = (u32)j * K3_THREADS + tid;
-                    nkey[j] = loc < Wn ? ld_once<FASTF_NT_K3 != 0>(p.keys + cursor + loc) : 0;
-                }
-                prev0 = uniform64(p.keys[cursor - 1]);
-            }
-            k3_barrier();
-            continue;
         }
         if (!closed && n_rows > 0) {                       // one group fills the window and goes on: carry it
             last_row = n_rows - 1;

@@ -134,3 +134,22 @@ def test_every_extern_c_body_in_the_cpp_unit_is_behind_the_barrier():
             assert lines[k].startswith("} FASTF_CATCH_"), "%s:%d" % (name, k + 1)
             n += 1
     assert n >= 40
+
+
+def test_no_result_changing_build_knob_in_the_product():
+    """knobs that change results are experiment-only: named FASTF_X_*, compiled only under FASTF_EXPERIMENT, which `make all`
+    never defines and which the library would announce in its version string"""
+    csrc = os.path.join(ROOT, "fastf_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "FASTF_EXPERIMENT" not in mk and "FASTF_X_" not in mk
+    L = C.CDLL(_lib.lib_path())
+    L.fastf_version.restype = C.c_char_p
+    assert b"EXPERIMENT" not in L.fastf_version()
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hpp", ".hip", ".c", ".h")):
+            continue
+        for i, line in enumerate(open(os.path.join(csrc, fn), errors="replace"), 1):
+            if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line) and "FASTF_X_" in line and "FASTF_X_ANY" not in line:
+                assert "FASTF_EXPERIMENT" in line, "%s:%d: FASTF_X_ knob outside FASTF_EXPERIMENT" % (fn, i)
+            # the names round 3's verdict listed must not come back under another guard
+            assert not re.search(r"FASTF_K3_(NOHASH|HASH_NOFLAG|DEBUG)\b", line) or line.lstrip().startswith("//"), "%s:%d" % (fn, i)

@@ -90,18 +90,16 @@ def test_dev_reduce_matches_numpy(env, n, n_groups, seed):
     assert eng.dev_error_bits() == 0
 
 
-@pytest.mark.parametrize("mode", ["hash", "old_hash"])
+@pytest.mark.parametrize("mode", ["hash"])
 @pytest.mark.parametrize("n,n_groups,low_values,seed", [(200_000, 50_000, 1 << 16, 1), (120_000, 3, 1 << 16, 2),
                                                         (60_000, 1, 5000, 3), (300_000, 200_000, 4, 4), (150_000, 2, 1 << 20, 5)])
 def test_group_only_sort_plus_dedup_in_reduce(mode, n, n_groups, low_values, seed, monkeypatch):
     """FASTF_SORT_SKIP_LOW: only (cell, feature) is sorted; equal keys are neighbours of their group but unordered.  The
     reduce kernel must still count distinct non-NULL keys per (cell, feature) exactly — including groups far longer than
     a window (counted by giant_groups_kernel up to 65 536 keys) and heavy duplication.  What it cannot hold raises
-    ERR_RUN_TOO_LONG: sort fully, reduce again.  (old_hash: round 3's reduce_windows_kernel<false, 2>, kept for A/B runs.)"""
+    ERR_RUN_TOO_LONG: sort fully, reduce again."""
     import torch
     import fastf_amd as F
-    if mode == "old_hash":
-        monkeypatch.setenv("FASTF_K3_OLD_HASH", "1")
     cells = np.arange(1, 1001, dtype=np.uint64) | (np.uint64(1) << np.uint64(62))
     feats = np.arange(1, 501, dtype=np.uint64) | (np.uint64(2) << np.uint64(62))
     eng = F.Engine(cells, feats, umi_max_bases=12)

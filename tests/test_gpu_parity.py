@@ -131,7 +131,7 @@ def test_umi_longer_than_engine_limit_is_an_error_not_a_wrong_answer():
 
 @pytest.mark.parametrize("name", ["c1_half", "mixed", "skewed", "tile_plus_one", "huge_groups"])
 @pytest.mark.parametrize("env", [{"FASTF_LDS_TABLES": "0"}, {"FASTF_LDS_CELLS": "0"}, {"FASTF_SORT_SKIP_BITS": "0"},
-                                 {"FASTF_GENES_NO_DIRECT": "1"}, {"FASTF_K3_OLD_HASH": "1"}])
+                                 {"FASTF_GENES_NO_DIRECT": "1"}, {"FASTF_FORCE_WIDE_KEYS": "1"}, {"FASTF_HOST_DRAWS": "1"}])
 def test_general_paths_match_oracle(name, env, monkeypatch):
     """the same cases with the LDS tables off (L2 open-addressed probes) and with the full 7-pass sort"""
     for k, v in env.items():
