@@ -1015,7 +1015,7 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     if (wide_vals && UMI_ROWS) return set_err("internal error: -u rows of wide keys");
     const int dedup = wide_vals ? 2 : (UMI_ROWS || low_skip == 0) ? 0 : 2;      // 2: keys sorted on (cell, feature) only (reduce_hashed_kernel)
     u32 G = k3_grid(max_n, dedup);
-    if (dedup == 2 && (e->L.feat_shift > 27 || wide_vals)) G = std::min<u32>(G, (wide_vals ? 2 : 3) * g_cu_count);      // 52 KB of LDS per workgroup: three per CU
+    if (dedup == 2) G = std::min<u32>(G, (wide_vals ? 2u : 3u) * g_cu_count);      // reduce_hashed_kernel: 40-58 KB of LDS and 80+ VGPRs, three workgroups per CU (wide keys: two)
     if (e->d_rg_count.ensure(max_n * 4)) return 1;
     if (UMI_ROWS ? e->d_rg_ukeys.ensure(max_n * 8) : (e->d_rg_feature.ensure(max_n * 4) || e->d_rg_cell.ensure(max_n * 4))) return 1;
     if (e->d_spanrows.ensure(4096 * sizeof(u32)) || e->d_spanbase.ensure(4097 * sizeof(u64))) return 1;

@@ -1821,7 +1821,8 @@ __global__ __launch_bounds__(K3_THREADS, 8) void reduce_windows_kernel(const Red
 //     (UMIs beyond 12 bases: 64-bit slots holding (r, x) whole — SLOT64.)
 //   * counts: D = distinct keys of the unit in front of a lane (mbcnt).  A head lane adds +D to the row in front of its
 //     own and -D to its own, the unit adds its total to its last row: every row ends up with D(next head) - D(own head),
-//     across units and waves, through LDS atomics on 16-bit halves (sums are exact modulo 2^32, counts < 2^16);
+//     across units and waves, through LDS atomics (a head may add its -D before the +D of its successor arrives: the sums are
+//     exact modulo 2^32);
 //   * two barriers per window (heads published / rows complete), both waiting for LDS traffic only.
 // Groups longer than a window go to giant_groups_kernel as before.
 // ------------------------------------------------------------------------------------
@@ -1844,19 +1845,25 @@ __device__ __forceinline__ u32 row16_incl_sum(u32 x) {
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
     return x;
 }
-// two 16-bit row counts per word; v may be negative (see above)
-__device__ __forceinline__ void k3h_add(u32* cnt, u32 row, u32 v) {
-    (void)__hip_atomic_fetch_add(&cnt[row >> 1], v << ((row & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// Register budget and occupancy (A/B on configs[2], profiles/r4_notes/ab_k3h_occupancy.txt): 64 VGPRs / four workgroups per
+// CU spill six registers in the window loop and take 0.215 ms; 80 VGPRs / three per CU 0.200; and with the LDS that frees,
+// one 32-bit count per row instead of two 16-bit halves per word (fewer address and shift instructions around every LDS
+// atomic) 0.192 ms.  FASTF_K3H_MINW=8 gives the 64-register build back.
+#ifndef FASTF_K3H_MINW
+#define FASTF_K3H_MINW 6
+#endif
+__device__ __forceinline__ void k3h_add(u32* cnt, u32 row, u32 v) {        // v may be "negative": sums are exact modulo 2^32
+    (void)__hip_atomic_fetch_add(&cnt[row], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // WIDE (keys wider than 64 bits; always with SLOT64): the group word is compared whole, everything below the group comes
 // from vals[]; a slot holds (x >> 12, row rank, probe number + 1) — the quotient form of the 32-bit slots with 40 bits of x
 template <bool SLOT64, bool WIDE = false>
-__global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void reduce_hashed_kernel(const ReduceParams p) {
+__global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MINW)) void reduce_hashed_kernel(const ReduceParams p) {
     static_assert(!WIDE || SLOT64, "wide keys use the 64-bit slots");
     typedef typename std::conditional<SLOT64, u64, u32>::type slot_t;
     __shared__ u64 s_hb[K3H_UNITS];        // head ballots of the 32 units of the window
-    __shared__ u32 s_cnt[K3H_TILE / 2];    // distinct counts by row, two per word; all-zero between windows
+    __shared__ u32 s_cnt[K3H_TILE];        // distinct counts by row; all-zero between windows
     __shared__ u32 s_feat[K3H_TILE], s_cell[K3H_TILE];   // row identities
     __shared__ slot_t s_tab[K3H_TAB];      // the set; all-zero between windows
     __shared__ u32 s_first;
@@ -1868,7 +1875,7 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void redu
     const u32 G = gridDim.x, b = blockIdx.x;
     const u64 nom_start = k3_chunk_start(n, b, G), nom_end = k3_chunk_start(n, b + 1, G);
     for (u32 i = tid; i < K3H_TAB; i += K3H_THREADS) s_tab[i] = 0;
-    for (u32 i = tid; i < K3H_TILE / 2; i += K3H_THREADS) s_cnt[i] = 0;
+    for (u32 i = tid; i < K3H_TILE; i += K3H_THREADS) s_cnt[i] = 0;
 
     // ---- chunk start: the first head at or after the nominal start (a group that began earlier belongs to the chunk before) ----
     u64 cursor = nom_start;
@@ -1933,7 +1940,8 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void redu
                 const u64 k = key[j] = nkey[j];
                 const u64 prev = ((u64)dpp_wave_shr1((u32)(carry >> 32), (u32)(k >> 32)) << 32) | dpp_wave_shr1((u32)carry, (u32)k);
                 const bool valid = pos < W;
-                const bool head = valid && (pos == 0 || (k >> gshift) != (prev >> gshift));   // position 0 is a head by construction
+                // (bitwise, not short-circuit: straight-line code instead of an exec-mask branch per term)
+                const bool head = valid & ((pos == 0) | (((k ^ prev) >> gshift) != 0));        // position 0 is a head by construction
                 const u64 hmj = __ballot(head);
                 if (lane == 0) s_hb[w * K3H_IPT + j] = hmj;
                 fl |= (head ? 1u : 0u) << j;
@@ -1944,7 +1952,7 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void redu
                     same = v == pv;                                        // (the group is the same: not a head)
                     vcarry = readlane64(v, 63);
                 }
-                fl |= (valid && !head && same ? 16u : 0u) << j;
+                fl |= ((valid & !head & same) ? 16u : 0u) << j;
                 carry = readlane64(k, 63);
             }
         }
@@ -1959,10 +1967,13 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void redu
             const u64 hb = lane < K3H_UNITS ? s_hb[lane] : 0ull;
             const u32 lim = nom_end > base ? (u32)(nom_end - base < (u64)K3H_TILE ? nom_end - base : (u64)K3H_TILE) : 0u;
             const u32 ub = (u32)lane * WAVE;
-            u64 at_or_after = hb;
-            if (lim > ub) at_or_after = lim - ub >= 64 ? 0ull : hb & ~((1ull << (lim - ub)) - 1);
+            u64 at_or_after = 0;                                           // heads at or beyond the chunk's nominal end (its last windows only)
+            if (lim < (u32)K3H_TILE) {                                     // (uniform)
+                at_or_after = hb;
+                if (lim > ub) at_or_after = lim - ub >= 64 ? 0ull : hb & ~((1ull << (lim - ub)) - 1);
+            }
             const u64 not_first = lane == 0 ? hb & ~1ull : hb;
-            const u64 m_stop = __ballot(at_or_after != 0), m_last = __ballot(not_first != 0);
+            const u64 m_stop = lim < (u32)K3H_TILE ? __ballot(at_or_after != 0) : 0ull, m_last = __ballot(not_first != 0);
             if (m_stop) { const u32 fu = (u32)__builtin_ctzll(m_stop); cut = fu * WAVE + (u32)__builtin_ctzll(readlane64(at_or_after, fu)); done = true; }
             else if (base + W == n) { cut = W; done = true; }
             else if (m_last) { const u32 lu = 63u - (u32)__builtin_clzll(m_last); cut = lu * WAVE + 63u - (u32)__builtin_clzll(readlane64(not_first, lu)); }
@@ -2121,11 +2132,9 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : 8)) void redu
         {
             const u64 row_base = region + rows_so_far;
             for (u32 r = tid; r < n_rows; r += K3H_THREADS) {
-                const u32 wd = s_cnt[r >> 1];
-                p.count[row_base + r] = (wd >> ((r & 1u) * 16u)) & 0xFFFFu;
+                p.count[row_base + r] = s_cnt[r];
                 p.feature[row_base + r] = s_feat[r]; p.cell[row_base + r] = s_cell[r];
-                // rows 2m and 2m + 1 are read by neighbouring lanes of one instruction; the even one clears the word behind it
-                if (!(r & 1u)) s_cnt[r >> 1] = 0;
+                s_cnt[r] = 0;
             }
         }
         rows_so_far += n_rows;
