@@ -33,10 +33,13 @@ constexpr int GI_LANES = 1;
 constexpr int GI_LANES = 64;
 #define GI_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
 // byte read that must see what this wave stored earlier: agent-scope load of the containing dword (bypasses the CU's L1)
+// (the dword's address is formed by pointer arithmetic, not through an integer: a pointer that went through uintptr_t has lost
+//  its address space and the access becomes a FLAT one, which counts on the LDS counter too — every wait for an LDS read then
+//  also waits for these loads)
 __device__ __forceinline__ uint8_t gi_coherent_load8(const uint8_t* p) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (uint8_t)(w >> (8 * (a & 3)));
+    const uint32_t k = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint8_t)(w >> (8 * k));
 }
 #define GI_COHERENT_LOAD8(p) gi_coherent_load8(p)
 #define gi_lane0() (GI_LANE() == 0)
@@ -52,6 +55,11 @@ __device__ __forceinline__ uint8_t gi_coherent_load8(const uint8_t* p) {
 // lanes of one wave exchange data through LDS without a workgroup barrier: keep the compiler from moving LDS accesses
 // across the hand-over (the hardware runs a wave's LDS instructions in order)
 #define GI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
+
+#ifndef GI_STATS_MATCH            /* tools: token statistics of the host build */
+#define GI_STATS_MATCH(len, dist) do { } while (0)
+#define GI_STATS_LIT() do { } while (0)
 #endif
 
 namespace gi {
@@ -101,9 +109,9 @@ GI_FN uint32_t fetch_word(Bits& b) {
     return w;
 }
 GI_FN void bits_open(Bits& b, const uint8_t* in, uint32_t in_len) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(in);
-    b.in32 = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    b.pos = 0; b.n_words = GI_UNIFORM((uint32_t)((a & 3) + in_len + 3) / 4 + 2); b.buf = 0; b.cnt = 0;
+    const uint32_t k = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u);
+    b.in32 = reinterpret_cast<const uint32_t*>(in - k);       // (pointer arithmetic keeps the address space: global loads, not flat ones)
+    b.pos = 0; b.n_words = GI_UNIFORM((uint32_t)(k + in_len + 3) / 4 + 2); b.buf = 0; b.cnt = 0;
     b.cur = chunk_load(b, 0); b.nxt = chunk_load(b, 1);
 }
 #endif
@@ -333,6 +341,7 @@ GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* ou
                 const int sym = decode(b, w.lit_tab, LIT_TB, w.lit_sorted, w.lit_count);
                 if (sym < 256) {
                     if (sym < 0) return E_CODE;
+                    GI_STATS_LIT();
                     if (lane == 0) w.ring[o.op & RMASK] = (uint8_t)sym;
                     o.op++;
                     if ((o.op & 63u) == 0) { flush_lines(w, o, false); if (o.over) return E_OVERRUN; }
@@ -348,6 +357,7 @@ GI_FN int inflate_block(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* ou
                 if (ds < 0 || ds >= 30) return E_CODE;
                 dist_code((uint32_t)ds, db, de);
                 const uint32_t dist = db + take(b, (int)de);
+                GI_STATS_MATCH(len, dist);
                 const int rc = copy_match(w, o, len, dist);
                 if (rc) return rc;
             }
