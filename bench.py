@@ -57,7 +57,7 @@ def kernel_table(eng, N, H, K, Z):
     c = eng.cell_scratch_bytes
     names = {0: ("probe_cells (K1a)", (8 + c) * N), 4: ("filter_pack (K1b)", (16 + c) * N + 4 * H + 8 * K),
              3: ("tile_count (K2, per pass)", 8 * K), 1: ("scatter (K2, per pass)", 16 * K),
-             2: ("reduce_windows+span_scan (K3)", 8 * K + 12 * Z),
+             2: ("reduce_hashed+span_scan+giant_groups (K3)", 8 * K + 12 * Z),
              5: ("rows_gather (not part of the step: concatenates K3's row regions where the rows are wanted)", 24 * Z)}
     out = {}
     for which, (nm, b) in names.items():
@@ -193,9 +193,9 @@ def main():
     # their own, gfx950 corrections applied there); only a profile of this very workload counts
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    kernels_of = {"probe_cells": ["probe_cells_lds_kernel", "probe_cells_filtered_kernel", "probe_cells_kernel"],
+    kernels_of = {"reduce_hashed+span_scan+giant_groups": ["reduce_hashed_kernel", "span_scan_kernel", "giant_groups_kernel"], "probe_cells": ["probe_cells_lds_kernel", "probe_cells_filtered_kernel", "probe_cells_kernel"],
                   "filter_pack": ["filter_pack_stream_kernel", "filter_pack_kernel"], "tile_count": ["tile_count_kernel"],
-                  "scatter": ["scatter_kernel"], "reduce_windows+span_scan": ["reduce_windows_kernel", "span_scan_kernel"]}
+                  "scatter": ["scatter_kernel"], "reduce_windows+span_scan": ["reduce_hashed_kernel", "reduce_windows_kernel", "span_scan_kernel", "giant_groups_kernel"]}
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -203,7 +203,7 @@ def main():
                 names = kernels_of.get(dom.split(" ")[0], [])
                 got = [tj["kernels"][k]["hbm_bytes_per_launch"] for k in names if k in tj.get("kernels", {})]
                 if got:
-                    traffic = sum(got) if dom.startswith("reduce_windows") else got[0]
+                    traffic = sum(got) if dom.startswith("reduce_") else got[0]
         except Exception:
             traffic = None
 
@@ -312,11 +312,14 @@ def device_path_leg(job, dev, local, N_total, want):
         pb.close()
     same = (res["total"], res["sampled"], res["valid"], res["nnz"]) == (want["total"], want["sampled"], want["valid"], want["rows"])
     best = min(runs)
-    bytes_h2d = 24 * N_total + 4 * want["hits"]
+    # the depth draws are generated on the device (mt_fill_kernel) unless FASTF_HOST_DRAWS=1 sends them over PCIe, 4 bytes per hit
+    host_draws = os.environ.get("FASTF_HOST_DRAWS", "")[:1] == "1"
+    bytes_h2d = 24 * N_total + (4 * want["hits"] if host_draws else 0)
     return {"value": N_total / best[0], "unit": "records/s", "seconds": best[0], "push_s": best[1], "finish_s": best[2],
             "runs_s": [r[0] for r in runs], "h2d_bytes": bytes_h2d, "h2d_GBs": bytes_h2d / best[1] / 1e9,
             "frac_of_pcie": (bytes_h2d / best[0] / 1e9) / PCIE_GBS, "pcie_peak_GBs_assumed": PCIE_GBS,
             "scope": "pinned host SoA (8 M-record chunks) -> hipMemcpyAsync on the copy stream -> K1 per chunk -> sort + reduce -> COO D2H",
+            "draws": "host MT19937, 4 bytes per hit over PCIe" if host_draws else "device MT19937 (mt_fill_kernel on its own stream)",
             "same_result_as_resident_steps": bool(same)}
 
 

@@ -116,7 +116,8 @@ struct fastf_multi;
 struct fastf_engine {
     fastf_multi* multi = nullptr;        // n_devices > 1: this handle only dispatches (multi_engine.hpp)
     int device = 0;
-    hipStream_t s_compute = nullptr, s_copy = nullptr;
+    hipStream_t s_compute = nullptr, s_copy = nullptr, s_mt = nullptr;   // s_mt: the draw stream's generator (mt_fill_kernel), beside the copies
+    hipEvent_t ev_mt = nullptr;
     KeyLayout L{};
     u32 cell_bits = 0, feat_bits = 0, n_cells = 0, n_features = 0;
     u64 threshold = 0;
@@ -492,6 +493,8 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     do {
         if (hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&e->s_mt, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_mt, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->slot[0].ev_copy, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->slot[1].ev_copy, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->slot[0].ev_done, hipEventDisableTiming) != hipSuccess ||
@@ -554,6 +557,8 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
+    if (e->s_mt) (void)hipStreamDestroy(e->s_mt);
+    if (e->ev_mt) (void)hipEventDestroy(e->ev_mt);
     delete e;
 } FASTF_CATCH_VOID
 
@@ -1217,10 +1222,14 @@ static bool device_mt_wanted() { static int v = -1; if (v < 0) { const char* h =
 static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSource& src, u64 upto) {
     if (!src.ext && e->mt_on_device) {
         // the engine-owned stream lives on the device: one launch continues it by exactly the ranks that are missing
+        // (on a stream of its own: one workgroup walks the stream block by block, about a nanosecond per two draws — beside
+        //  the record copies, not in front of them; K1 waits for both)
         if (e->draws_up < upto) {
-            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, e->s_copy, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up, (u64)(upto - e->draws_up),
+            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, e->s_mt, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up, (u64)(upto - e->draws_up),
                                (u64)(e->ring_len - 1));
             HIP_OK(hipGetLastError());
+            HIP_OK(hipEventRecord(e->ev_mt, e->s_mt));
+            HIP_OK(hipStreamWaitEvent(e->s_compute, e->ev_mt, 0));
             e->draws_up = upto;
         }
         return 0;
@@ -1340,6 +1349,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
         e->mt_on_device = false;
         if (device_mt_wanted()) {
             static_assert(sizeof(fastf_mt_t) == (MT_N + 1) * 4, "fastf_mt_t: 624 state words + the read index");
+            HIP_OK(hipStreamSynchronize(e->s_mt));                          // (idle already: every chunk that waited for it is retired)
             if (e->d_mt.ensure(sizeof(fastf_mt_t))) return 1;
             HIP_OK(hipMemcpy(e->d_mt.p, &e->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice));
             e->mt_on_device = true;

@@ -130,46 +130,50 @@ __device__ __forceinline__ u32 mt_mix(u32 hi, u32 lo) {
     const u32 y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
     return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
 }
+__device__ __forceinline__ u32 mt_temper(u32 y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
 __global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
-    __shared__ u32 mt[MT_N];
+    // two copies of the state: a block is regenerated FROM one INTO the other, so a sweep never overwrites what it still
+    // reads: three barriers per block.  A word goes out (tempered, to its rank's ring slot) the moment it is computed — no
+    // second pass over the block; only what is left of the block the kernel starts in is handed out by a loop of its own.
+    __shared__ u32 buf[2][MT_N];
     const u32 tid = threadIdx.x;
-    for (u32 i = tid; i < MT_N; i += 256) mt[i] = state[i];
+    for (u32 i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
     u32 idx = state[MT_N];
+    u32 cur = 0;                                             // buf[cur] holds the current block
     __syncthreads();
     u64 done = 0;
-    while (done < count) {                                   // (uniform)
-        if (idx >= MT_N) {
-            // sweep 1: k = 0..226   s[k] = s[k + 397] ^ mix(s[k], s[k + 1])
-            u32 v = 0;
-            if (tid < MT_N - MT_M) v = mt[tid + MT_M] ^ mt_mix(mt[tid], mt[tid + 1]);
-            __syncthreads();
-            if (tid < MT_N - MT_M) mt[tid] = v;
-            __syncthreads();
-            // sweep 2: k = 227..453  s[k] = s[k - 227] ^ mix(s[k], s[k + 1])   (s[k - 227] new, s[k + 1] still old for k = 453)
-            const u32 k2 = tid + (MT_N - MT_M);
-            if (tid < MT_N - MT_M) v = mt[k2 - (MT_N - MT_M)] ^ mt_mix(mt[k2], mt[k2 + 1]);
-            __syncthreads();
-            if (tid < MT_N - MT_M) mt[k2] = v;
-            __syncthreads();
-            // sweep 3: k = 454..622 the same with s[k - 227] from sweep 2; k = 623: s[623] = s[396] ^ mix(s[623], s[0])
-            const u32 k3 = tid + 2 * (MT_N - MT_M);
-            if (k3 < MT_N - 1) v = mt[k3 - (MT_N - MT_M)] ^ mt_mix(mt[k3], mt[k3 + 1]);
-            else if (k3 == MT_N - 1) v = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
-            __syncthreads();
-            if (k3 < MT_N) mt[k3] = v;
-            __syncthreads();
-            idx = 0;
-        }
-        const u32 take = (u32)(count - done < (u64)(MT_N - idx) ? count - done : (u64)(MT_N - idx));
-        for (u32 i = tid; i < take; i += 256) {
-            u32 y = mt[idx + i];
-            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-            out[(first + done + i) & mask] = y;
-        }
-        idx += take; done += take;
-        __syncthreads();
+    if (idx < MT_N && count) {                               // the rest of the block the stream stands in
+        const u32 take = (u32)(count < (u64)(MT_N - idx) ? count : (u64)(MT_N - idx));
+        for (u32 i = tid; i < take; i += 256) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
+        idx += take; done = take;
     }
-    for (u32 i = tid; i < MT_N; i += 256) state[i] = mt[i];
+    while (done < count) {                                   // (uniform) whole blocks; the last one may be handed out in part
+        const u32* o = buf[cur]; u32* n = buf[cur ^ 1];
+        const u64 left = count - done;                       // words of this block that go out: k < left
+        const u64 at = first + done;
+        // sweep 1: k = 0..226   n[k] = o[k + 397] ^ mix(o[k], o[k + 1])
+        if (tid < MT_N - MT_M) { const u32 v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; if (tid < left) out[(at + tid) & mask] = mt_temper(v); }
+        __syncthreads();
+        // sweep 2: k = 227..453  n[k] = n[k - 227] ^ mix(o[k], o[k + 1])
+        const u32 k2 = tid + (MT_N - MT_M);
+        if (tid < MT_N - MT_M) { const u32 v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; if (k2 < left) out[(at + k2) & mask] = mt_temper(v); }
+        __syncthreads();
+        // sweep 3: k = 454..622 the same with n[k - 227] from sweep 2; k = 623: n[623] = n[396] ^ mix(o[623], n[0])
+        const u32 k3 = tid + 2 * (MT_N - MT_M);
+        if (k3 < MT_N) {
+            const u32 v = k3 < MT_N - 1 ? n[k3 - (MT_N - MT_M)] ^ mt_mix(o[k3], o[k3 + 1]) : n[MT_M - 1] ^ mt_mix(o[MT_N - 1], n[0]);
+            n[k3] = v;
+            if (k3 < left) out[(at + k3) & mask] = mt_temper(v);
+        }
+        __syncthreads();
+        cur ^= 1;
+        idx = (u32)(left < (u64)MT_N ? left : (u64)MT_N);
+        done += idx;
+    }
+    for (u32 i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
     if (tid == 0) state[MT_N] = idx;
 }
 

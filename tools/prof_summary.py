@@ -15,7 +15,8 @@ from collections import defaultdict
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("fastf::", "")
-    for k in ("scatter_kernel", "filter_pack_stream_kernel", "filter_pack_kernel", "probe_cells_lds_kernel", "reduce_windows_kernel", "rows_gather_kernel"):
+    for k in ("scatter_kernel", "filter_pack_stream_kernel", "filter_pack_kernel", "probe_cells_lds_kernel", "reduce_windows_kernel",
+              "reduce_hashed_kernel", "rows_gather_kernel"):
         if n.startswith(k + "<"):
             return k                                                          # template instantiations of one kernel
     return n

@@ -3,7 +3,7 @@
 # (counters are never combined with tracing).  Run on the GPU box from the repo root:  tools/profile_round.sh r2_c3
 # The profiled command is bench.py on its default workload (BASELINE configs[2], 200 M records), device steps only.
 set -e
-tag=${1:-r3_c3}
+tag=${1:-r4_c3}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
