@@ -65,7 +65,11 @@ __device__ __forceinline__ uint8_t gi_coherent_load8(const uint8_t* p) {
 namespace gi {
 
 constexpr int LIT_TB = 10, DIST_TB = 8;
-constexpr uint32_t RING = 4096, RMASK = RING - 1, RING_SAFE = RING - 64;
+#ifndef GI_RING_BYTES
+#define GI_RING_BYTES 4096            /* output ring per wave (a power of two): matches that reach further back read memory */
+#endif
+constexpr uint32_t RING = GI_RING_BYTES, RMASK = RING - 1, RING_SAFE = RING - 64;
+static_assert((RING & (RING - 1)) == 0 && RING >= 1024, "ring: a power of two");
 constexpr uint16_t LONG_CODE = 0xFFFF, NO_CODE = 0xFFFE;      // both >= 0xFFFE: one compare on the symbol path
 
 // error codes (0 = ok)

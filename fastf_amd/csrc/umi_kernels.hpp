@@ -981,12 +981,15 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
         }
         // the unit's draws, lane l of dr[q] holding the draw of local hit rank 64 q + l
         u32 dr[K1S_IPT];
+        // draws left in the stream from this unit's first rank on (scalar; capped: a unit has 256 hits at most) — ranks beyond
+        // the stream are caught below, the loads stay in bounds
+        const u32 avail = rank0 < p.n_draws ? (u32)(p.n_draws - rank0 < 1024 ? p.n_draws - rank0 : 1024) : 0u;
 #pragma unroll
         for (int q = 0; q < K1S_IPT; ++q) {
             dr[q] = 0;
-            if ((u32)q * WAVE < own) {                                     // wave-uniform
-                const u64 r = rank0 + (u32)q * WAVE + lane;
-                if (r < p.n_draws) dr[q] = p.draws[r & p.draw_mask];
+            if ((u32)q * WAVE < own && avail) {                            // wave-uniform
+                const u32 o = (u32)q * WAVE + (u32)lane;
+                dr[q] = p.draws[(rank0 + (o < avail ? o : avail - 1u)) & p.draw_mask];
             }
         }
         {   // next round's small inputs
@@ -1008,32 +1011,34 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
             const u32 a = q0 == 0 ? dr[0] : q0 == 1 ? dr[1] : q0 == 2 ? dr[2] : dr[3];
             const u32 b = q0 == 0 ? dr[1] : q0 == 1 ? dr[2] : dr[3];
             const u32 va = (u32)__shfl((int)a, (int)(rl & 63u), WAVE), vb = (u32)__shfl((int)b, (int)(rl & 63u), WAVE);
-            draw[j] = 0;
-            if (cell[j] != 0) {
-                if (rank0 + rl < p.n_draws) draw[j] = (rl >> 6) == q0 ? va : vb;
-                else { cell[j] = 0; errs |= (u32)ERR_DRAWS_SHORT; }
-            }
+            draw[j] = (rl >> 6) == q0 ? va : vb;                           // (only read where cell[j] != 0)
+            const bool dry = (cell[j] != 0) & (rl >= avail);               // a hit beyond the draw stream: an error, the record is dropped
+            if (__ballot(dry)) { errs |= (u32)ERR_DRAWS_SHORT; cell[j] = dry ? 0u : cell[j]; }     // (uniform branch, never taken on a complete stream)
             const u32 c = (u32)__popcll(hm);
             pre += c; w_hit += c;
         }
         // ---- E8: gene lookup in LDS ----
+        // straight-line: every lane reads the table (index 0 when it has no business there) and the result is selected — an
+        // exec-mask branch per condition costs more instructions than the lookup; ids of other families (rare: the L2 table)
+        // are left to a wave-uniform branch
         u32 feat[K1S_IPT];
 #pragma unroll
         for (int j = 0; j < K1S_IPT; ++j) {
-            u32 f = 0;
-            const u64 k = (cell[j] != 0 && (meta[j] & META_XF_OK)) ? gxk[j] : 0;
-            if (k != 0) {
-                if ((u32)(k >> 44) == p.genes.family) {
-                    const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;                 // wraps to huge when below vmin
-                    if (v < p.genes.range) {
-                        if (DIRECT) f = s_direct[(u32)v];
-                        else {
-                            const u32 wd = s_bitmap[(u32)v >> 5], rk = s_rank[(u32)v >> 5], bit = (u32)v & 31u;
-                            if ((wd >> bit) & 1u) f = s_perm[rk + __popc(wd & ((1u << bit) - 1u))];
-                        }
-                    }
-                } else f = table_probe(p.feats, k);                                      // other id families / escaped strings
+            const u64 k = gxk[j];
+            const bool want = (cell[j] != 0) & ((meta[j] & META_XF_OK) != 0) & (k != 0);
+            const bool fam = (u32)(k >> 44) == p.genes.family;
+            const u64 v = (k & 0xFFFFFFFFFFFull) - p.genes.vmin;                         // wraps to huge when below vmin
+            const bool in = want & fam & (v < p.genes.range);
+            const u32 vi = in ? (u32)v : 0u;
+            u32 f;
+            if (DIRECT) f = s_direct[vi];
+            else {
+                const u32 wd = s_bitmap[vi >> 5], rk = s_rank[vi >> 5], bit = vi & 31u;
+                const u32 pi = ((wd >> bit) & 1u) ? rk + __popc(wd & ((1u << bit) - 1u)) : 0u;
+                f = ((wd >> bit) & 1u) ? s_perm[pi] : 0u;
             }
+            f = in ? f : 0u;
+            if (__ballot(want & !fam)) { if (want & !fam) f = table_probe(p.feats, k); }  // other id families / escaped strings
             feat[j] = f;
         }
         // ---- E5..E12: keep/drop, key; slots of the wave inside the workgroup's region ----
@@ -1043,8 +1048,8 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
         for (int j = 0; j < K1S_IPT; ++j) {
             bool alive = cell[j] != 0 && (u64)draw[j] < p.threshold;
             w_samp += (u32)__popcll(__ballot(alive));                                      // E6
-            alive = alive && feat[j] != 0 && (meta[j] & META_HAS_UB);
-            if (alive && umi_overflows(p.L, umi[j], meta[j])) errs |= (u32)ERR_UMI_TOOLONG;
+            alive = alive & (feat[j] != 0) & ((meta[j] & META_HAS_UB) != 0);
+            if (__ballot(alive & umi_overflows(p.L, umi[j], meta[j]))) errs |= (u32)ERR_UMI_TOOLONG;      // (uniform branch, never taken on good data)
             key[j] = alive ? make_key(p.L, cell[j], feat[j], umi[j], meta[j]) : 0;
             em[j] = __ballot(alive);
             n_keys += (u32)__popcll(em[j]);
@@ -1058,7 +1063,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
             else {
 #pragma unroll
                 for (int j = 0; j < K1S_IPT; ++j) {
-                    if ((em[j] >> lane) & 1) region[pos0 + rank_below(em[j])] = key[j];
+                    if (__builtin_amdgcn_inverse_ballot_w64(em[j])) region[pos0 + rank_below(em[j])] = key[j];   // (32-bit index off the region's scalar base)
                     pos0 += (u32)__popcll(em[j]);
                 }
             }
