@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--records", type=int, default=0, help="records of the whole job (all GPUs together); default 200 M (c3) / 10 M (c2)")
     ap.add_argument("--cpu-sample", type=int, default=75_000_000, help="records timed on the CPU oracle (rank 0, N=1): whole segments of the job, about 10 s of one core")
     ap.add_argument("--soa", action="store_true", help="resident inputs as the four SoA arrays instead of the engine's blocked staging layout")
+    ap.add_argument("--draw-words", action="store_true", help="hand K1 the 32-bit draws every step (converted to decision bits per step) instead of the bits made once")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-devpath", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -141,11 +142,17 @@ def main():
         gx = umi = meta = None
         torch.cuda.empty_cache()
 
+    # the draw stream as K1b reads it: one decision bit per CB hit (draw < threshold), made once from the resident draws —
+    # in the product mt_fill_kernel writes these bits itself (include/fastf_amd.h "The decision stream"); --draw-words hands
+    # the 32-bit draws to every step instead (one conversion pass per step)
+    d_stream = d_draws if args.draw_words else sp.prepare_draws(d_draws)
+    torch.cuda.synchronize()
+
     def step():
         if blk is not None:
-            sp.run(cb, blk, None, None, n_local, d_draws)
+            sp.run(cb, blk, None, None, n_local, d_stream)
         else:
-            sp.run(cb, gx, umi, meta, n_local, d_draws)
+            sp.run(cb, gx, umi, meta, n_local, d_stream)
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -225,7 +232,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if G > 1 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: %d synthetic records, 10000 barcodes x 30000 genes, --cell 1.0 --depth 1.0 --seed 926, "
-                                    "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (%s + draw stream); the step ends at K3's segmented rows (rows_gather, which concatenates them where they are wanted — in the product it IS the device-to-host copy — is timed on its own line)" % ("cb array + blocked gx|umi|meta runs, the engine's staging layout" if blk is not None else "packed SoA"),
+                                    "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (%s + the draw stream%s); the step ends at K3's segmented rows (rows_gather, which concatenates them where they are wanted — in the product it IS the device-to-host copy — is timed on its own line)" % ("cb array + blocked gx|umi|meta runs, the engine's staging layout" if blk is not None else "packed SoA",
+                                                                                           " as 32-bit draws, turned into decisions every step" if args.draw_words else " as K1b reads it: one keep/drop decision bit per CB hit, what mt_fill_kernel writes in the product; K1b's algorithmic bytes still count 4 bytes per hit (SURVEY 8d)"),
                        "record_layout": "blocked" if blk is not None else "soa",
                        "records_per_gpu": n_local, "key_bits": eng.key_bits, "radix_passes_nominal": P_nom,
                        "radix_passes_executed": P_exe,
@@ -252,7 +260,7 @@ def main():
             out["counters"]["same_as_single_gpu_reference_run"] = got == workload.EXPECTED_200M
 
     # free the resident job before the host-side legs
-    del sp, cb, gx, umi, meta, d_draws, blk
+    del sp, cb, gx, umi, meta, d_draws, d_stream, blk
     eng.close()
     torch.cuda.empty_cache()
 

@@ -33,7 +33,7 @@ struct MultiDev {
     bool k1b_queued[2] = {false, false};
     u32* h_draws[2] = {nullptr, nullptr}; DevBuf d_draws[2];     // FASTF_HOST_DRAWS=1: the draws of the chunk in that slot, generated on the host
     // the draw stream on the device: EVERY device continues the one MT19937 stream by the hits of EVERY chunk, in stream order
-    // (mt_fill_kernel on its compute stream: a few hundred microseconds per chunk), into a ring addressed by absolute hit rank,
+    // (mt_fill_kernel on its compute stream: a few hundred microseconds per chunk), into a ring of decisions addressed by absolute hit rank,
     // so the draws of its own chunks are there when its K1b runs and nothing about them crosses PCIe or waits for a host loop
     DevBuf d_mt, d_ring; u64 ring_len = 0;
     u64* h_base[2] = {nullptr, nullptr};       // pinned: absolute hit-rank base of the chunk in that slot (copied beside the K1b launch)
@@ -264,13 +264,14 @@ static int multi_retire_chunk(fastf_multi* m) {
             MultiDev& mg = m->d[g];
             HIP_OK(hipSetDevice(mg.dev));
             if (!m->mt_uploaded || !mg.d_mt.p) {
-                u64 r = 1; while (r < 2 * cap) r <<= 1;
-                if (mg.d_mt.ensure(sizeof(fastf_mt_t)) || mg.d_ring.ensure(r * 4)) return 1;
+                u64 r = 1024; while (r < 2 * cap) r <<= 1;
+                if (mg.d_mt.ensure(sizeof(fastf_mt_t)) || mg.d_ring.ensure(r / 8)) return 1;      // the decision stream: one bit per rank
                 mg.ring_len = r;
                 HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
                 HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)
             }
-            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, mg.e->s_compute, (u32*)mg.d_mt.p, (u32*)mg.d_ring.p, base, hits, (u64)(mg.ring_len - 1));
+            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(256), 0, mg.e->s_compute, (u32*)mg.d_mt.p, (u32*)mg.d_ring.p, base, hits, (u64)(mg.ring_len - 1),
+                               mg.e->threshold);
             HIP_OK(hipGetLastError());
         }
         if (hits) m->mt_uploaded = true;
@@ -289,7 +290,17 @@ static int multi_retire_chunk(fastf_multi* m) {
     if (!md.h_draws[c.slot]) HIP_OK(hipHostMalloc((void**)&md.h_draws[c.slot], std::max<u64>(cap, 1) * 4, hipHostMallocDefault));
     fastf_mt_fill(&m->mt, md.h_draws[c.slot], hits);
     m->hits += hits;
-    if (hits) HIP_OK(hipMemcpyAsync(md.d_draws[c.slot].p, md.h_draws[c.slot], hits * 4, hipMemcpyHostToDevice, se->s_compute));
+    {   // only the decisions go up: bit i = draw i < threshold, packed in place (word i >> 5 is written after draw i was read)
+        u32* h = md.h_draws[c.slot];
+        const u64 thr = se->threshold;
+        u32 wcur = 0;
+        for (u64 i = 0; i < hits; ++i) {
+            wcur |= (u32)((u64)h[i] < thr) << (i & 31);
+            if ((i & 31) == 31) { h[i >> 5] = wcur; wcur = 0; }
+        }
+        if (hits & 31) h[hits >> 5] = wcur;
+    }
+    if (hits) HIP_OK(hipMemcpyAsync(md.d_draws[c.slot].p, md.h_draws[c.slot], ((hits + 31) / 32) * 4, hipMemcpyHostToDevice, se->s_compute));
     if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), c.n,
                      (const u32*)md.d_draws[c.slot].p, hits, nullptr, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
                      small + SM_COUNTERS, true, se->s_compute))

@@ -136,7 +136,9 @@ struct fastf_engine {
     u64 mt_hits = 0;                     // hits served from the engine-owned stream so far
     u64 mt_abs0 = 0;                     // absolute hit rank a  <->  draw number a - mt_abs0 of the engine-owned stream
     bool mt_live = false;                // the generator stands at draw number draws_up - mt_abs0
-    DevBuf d_ring; u64 ring_len = 0;     // u32[ring_len], power of two
+    DevBuf d_ring; u64 ring_len = 0;     // the decision stream: ring_len bits (u32[ring_len / 32]), ring_len a power of two
+    u32 ring_carry = 0;                  // host-packed decisions: the bits of the word draws_up stands in (below bit draws_up & 31)
+    DevBuf d_dbits;                      // device-level calls that bring 32-bit draws: their decisions (draw_bits_kernel)
     DevBuf d_mt; bool mt_on_device = false;  // the engine-owned stream continues on the device (mt_fill_kernel): state words + read index
     u64 draws_up = 0;                    // absolute ranks below this are (being) uploaded
     u64 draws_valid = 0;                 // ranks below this carry a real draw (caller-supplied streams can run short)
@@ -550,7 +552,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
-    e->d_ring.release(); e->d_mt.release();
+    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp};
@@ -779,10 +781,34 @@ extern "C" int fastf_dev_count_hits_blocked(fastf_engine_t* e, const uint64_t* d
     return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s, nullptr, nullptr, d_blocked);
 } FASTF_CATCH_INT
 
+static int launch_draw_bits(fastf_engine* e, const u32* d_draws, u64 n, u32* d_bits, hipStream_t s) {
+    if (n == 0) return 0;
+    const u32 grid = (u32)std::min<u64>((n + 255) / 256, 8ull * g_cu_count);
+    hipLaunchKernelGGL(draw_bits_kernel, dim3(grid), dim3(256), 0, s, d_draws, n, e->threshold, d_bits);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+extern "C" int fastf_dev_draw_bits(fastf_engine_t* e, const uint32_t* d_draws, uint64_t n_draws, uint32_t* d_bits_out, void* stream) FASTF_TRY {
+    if (!e || (n_draws && (!d_draws || !d_bits_out))) return set_err("null argument");
+    if (e->multi) return set_err("fastf_dev_draw_bits: device-level calls take a single-device engine");
+    HIP_OK(hipSetDevice(e->device));
+    return launch_draw_bits(e, d_draws, n_draws, d_bits_out, (hipStream_t)stream);
+} FASTF_CATCH_INT
+
 #define NO_WIDE(e, what) do { if ((e)->wide) return set_err(what ": this engine's keys are wider than 64 bits — the device-level calls take keys of at most 64 bits (the host-buffer API handles wide keys)"); } while (0)
 
+// the streaming K1b over `tiles` K1a tiles: workgroups (at most two per CU: 12 or 16 waves each) and the key slots of one
+// workgroup's region (every record of the units its waves walk: waves x rounds units)
+static void stream_geometry(const fastf_engine* e, u64 tiles, u32* grid, u64* region) {
+    const u32 waves = (e->genes_blocks_per_cu >= 2 ? K1S_THREADS : K1S_THREADS_ROOMY) / WAVE;
+    const u64 units = std::max<u64>(tiles, 1) * (K1_TILE / K1S_UNIT);
+    const u64 g = std::min<u64>((units + waves - 1) / waves, (u64)std::min<u32>(e->genes_blocks_per_cu, 2) * g_cu_count);
+    const u64 rounds = (units + g * waves - 1) / (g * waves);
+    *grid = (u32)g; *region = rounds * waves * K1S_UNIT;
+}
+
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
-                        const u32* draws, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
+                        const u32* dbits, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
                         u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr,
                         bool segmented = false, void* blk = nullptr) {
     if (segmented) e->seg_n = 0;
@@ -794,9 +820,10 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     PackParams p{};
     p.cell = e->d_cellidx.p; p.cell16 = e->cell16; p.gx = gx; p.umi = umi; p.meta = meta; p.n = n;
     p.tile_base = (const u64*)e->d_tilebase.p;
-    p.draws = draws; p.n_draws = n_draws; p.draw_base = draw_base; p.draw_mask = draw_mask;
+    // (the streaming K1b reads a unit's decision words unconditionally: a stream without a decision still needs a word to read)
+    p.dbits = dbits && n_draws ? dbits : (const u32*)e->d_small.p; p.n_draws = dbits ? n_draws : 0; p.draw_base = draw_base; p.draw_mask = draw_mask;
     p.feats = e->feats;
-    p.threshold = e->threshold; p.L = e->L;
+    p.L = e->L;
     p.n_shards = e->n_shards;
     p.keys = keys; p.shard_stride = stride; p.key_counts = key_counts; p.counters = counters;
     p.stamps = g_k1_stamps;
@@ -816,8 +843,8 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     t_begin(e, s);
     if (segmented || stream_shards) {
         // streaming form: every wave on its own, keys into one private region per workgroup (see filter_pack_stream_kernel)
-        const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
-        const u64 region = (u64)((tiles + grid - 1) / grid) * K1_TILE;
+        u32 grid; u64 region;
+        stream_geometry(e, tiles, &grid, &region);
         if (stream_shards) {
             if (e->d_segkeys.ensure((size_t)grid * region * sizeof(u64))) return 1;
             p.keys = (u64*)e->d_segkeys.p;
@@ -827,8 +854,8 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
         StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
         // compile-time: roomy (one workgroup per CU: 128 VGPRs), width of the cell scratch, form of the gene image
         const int variant = (e->genes_blocks_per_cu >= 2 ? 0 : 4) | (e->cell16 ? 2 : 0) | (e->lds_genes.direct ? 1 : 0);
-#define FPS(R, C, D) do { if (blk) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, true>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp); \
-                          else hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, false>), dim3(grid), dim3(K1B_THREADS), e->lds_genes.bytes, s, p, sp); } while (0)
+#define FPS(R, C, D) do { if (blk) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, true>), dim3(grid), dim3(R ? K1S_THREADS_ROOMY : K1S_THREADS), e->lds_genes.bytes, s, p, sp); \
+                          else hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, false>), dim3(grid), dim3(R ? K1S_THREADS_ROOMY : K1S_THREADS), e->lds_genes.bytes, s, p, sp); } while (0)
         switch (variant) {
         case 0: FPS(false, false, false); break; case 1: FPS(false, false, true); break;
         case 2: FPS(false, true, false); break;  case 3: FPS(false, true, true); break;
@@ -869,6 +896,14 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
     if (seg && !(e->n_shards == 1 && e->use_lds_genes))
         return set_err("FASTF_PROBE_SEGMENTED needs a single shard and the gene table in LDS (fastf_dev_probe_capacity returns 0 otherwise)");
     if (blocked && !d_gx_key) return set_err("FASTF_PROBE_BLOCKED: d_gx_key must point at the blocked buffer");
+    if (n && n_draws && !d_draws) return set_err("null d_draws");
+    if (!(flags & FASTF_PROBE_DRAW_BITS) && n && n_draws) {
+        // 32-bit draws: K1b reads decisions — one pass over the draws on the caller's stream first (a caller that runs the same
+        // stream again and again converts it once with fastf_dev_draw_bits and passes FASTF_PROBE_DRAW_BITS)
+        if (e->d_dbits.ensure(((n_draws + 31) / 32) * 4)) return 1;
+        if (launch_draw_bits(e, d_draws, n_draws, (u32*)e->d_dbits.p, (hipStream_t)stream)) return 1;
+        d_draws = (const uint32_t*)e->d_dbits.p;
+    }
     return launch_probe(e, (const u64*)d_cb_key, blocked ? nullptr : (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
                         (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream, ~0ull, nullptr, seg,
@@ -880,9 +915,9 @@ extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uin
     *key_slots = 0;
     if (e->wide) return 0;
     if (!(e->n_shards == 1 && e->use_lds_genes) || getenv("FASTF_NO_STREAM_K1B")) return 0;
-    const u64 tiles = (n + K1_TILE - 1) / K1_TILE;
-    const u64 grid = std::min<u64>(std::max<u64>(tiles, 1), (u64)e->genes_blocks_per_cu * g_cu_count);
-    *key_slots = grid * ((tiles + grid - 1) / grid) * K1_TILE;
+    u32 grid; u64 region;
+    stream_geometry(e, (n + K1_TILE - 1) / K1_TILE, &grid, &region);
+    *key_slots = (u64)grid * region;
     return 0;
 } FASTF_CATCH_INT
 
@@ -1217,16 +1252,16 @@ static int grow_keys(fastf_engine* e, u64 need) {
 struct DrawSource { const u32* ext; u64 ext_abs0; u64 ext_n; };
 
 // make the ring hold every absolute rank below `upto`
-static bool device_mt_wanted() { static int v = -1; if (v < 0) { const char* h = getenv("FASTF_HOST_DRAWS"); v = !(h && h[0] == '1'); } return v != 0; }
+static bool device_mt_wanted() { const char* h = getenv("FASTF_HOST_DRAWS"); return !(h && h[0] == '1'); }   // (read where a stream is positioned: once per job)
 
 static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSource& src, u64 upto) {
     if (!src.ext && e->mt_on_device) {
-        // the engine-owned stream lives on the device: one launch continues it by exactly the ranks that are missing
-        // (on a stream of its own: one workgroup walks the stream block by block, about a nanosecond per two draws — beside
-        //  the record copies, not in front of them; K1 waits for both)
+        // the engine-owned stream lives on the device: one launch continues it by exactly the ranks that are missing and leaves
+        // their decisions in the ring (on a stream of its own: one workgroup walks the stream block by block, about a
+        // nanosecond per two draws — beside the record copies, not in front of them; K1 waits for both)
         if (e->draws_up < upto) {
-            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, e->s_mt, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up, (u64)(upto - e->draws_up),
-                               (u64)(e->ring_len - 1));
+            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(256), 0, e->s_mt, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up,
+                               (u64)(upto - e->draws_up), (u64)(e->ring_len - 1), e->threshold);
             HIP_OK(hipGetLastError());
             HIP_OK(hipEventRecord(e->ev_mt, e->s_mt));
             HIP_OK(hipStreamWaitEvent(e->s_compute, e->ev_mt, 0));
@@ -1234,7 +1269,11 @@ static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSourc
         }
         return 0;
     }
-    if (!sl.h_draws) HIP_OK(hipHostMalloc(&sl.h_draws, e->batch_cap * 4, hipHostMallocDefault));   // (host-generated or caller-supplied draws only)
+    // host-generated or caller-supplied draws: the decisions are packed here and only they go up — whole words; the word a
+    // chunk ends in is kept (ring_carry) and goes up again, completed, with the next one (a kernel that is still reading its
+    // low bits sees the same bits)
+    if (!sl.h_draws) HIP_OK(hipHostMalloc(&sl.h_draws, e->batch_cap * 4, hipHostMallocDefault));
+    const u64 ring_words = e->ring_len >> 5;
     while (e->draws_up < upto) {
         const u64 n = std::min<u64>(upto - e->draws_up, e->batch_cap);
         u32* h = (u32*)sl.h_draws;
@@ -1246,9 +1285,21 @@ static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSourc
         } else {
             fastf_mt_fill(&e->mt, h, n);
         }
-        const u64 pos = e->draws_up & (e->ring_len - 1), first = std::min<u64>(n, e->ring_len - pos);
-        HIP_OK(hipMemcpyAsync((u32*)e->d_ring.p + pos, h, first * 4, hipMemcpyHostToDevice, e->s_copy));
-        if (first < n) HIP_OK(hipMemcpyAsync((u32*)e->d_ring.p, h + first, (n - first) * 4, hipMemcpyHostToDevice, e->s_copy));
+        // in place: word (s + i) >> 5 is written after draw i was read, and never ahead of it
+        const u32 s0 = (u32)(e->draws_up & 31);
+        const u64 thr = e->threshold;
+        u32 wcur = s0 ? e->ring_carry : 0u;
+        u64 nw = 0;
+        for (u64 i = 0; i < n; ++i) {
+            const u32 b = (u32)((s0 + i) & 31);
+            wcur |= (u32)((u64)h[i] < thr) << b;
+            if (b == 31) { h[nw++] = wcur; wcur = 0; }
+        }
+        e->ring_carry = wcur;
+        if ((s0 + n) & 31) h[nw++] = wcur;
+        const u64 wpos = (e->draws_up & (e->ring_len - 1)) >> 5, first = std::min<u64>(nw, ring_words - wpos);
+        HIP_OK(hipMemcpyAsync((u32*)e->d_ring.p + wpos, h, first * 4, hipMemcpyHostToDevice, e->s_copy));
+        if (first < nw) HIP_OK(hipMemcpyAsync((u32*)e->d_ring.p, h + first, (nw - first) * 4, hipMemcpyHostToDevice, e->s_copy));
         e->draws_up += n;
         if (e->draws_up < upto) HIP_OK(hipStreamSynchronize(e->s_copy));   // the staging buffer is about to be refilled (uneven chunk sizes only)
     }
@@ -1324,8 +1375,8 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
     HIP_OK(hipSetDevice(e->device));
     if (batch->n == 0) return 0;
     if (!e->d_ring.p) {
-        u64 r = 1; while (r < 4 * e->batch_cap) r <<= 1;               // three chunks of ranks can be live at once
-        if (e->d_ring.ensure(r * 4)) return 1;
+        u64 r = 1024; while (r < 4 * e->batch_cap) r <<= 1;            // three chunks of ranks can be live at once
+        if (e->d_ring.ensure(r / 8)) return 1;                         // one bit per rank
         e->ring_len = r;
     }
     DrawSource src{nullptr, 0, 0};
@@ -1335,6 +1386,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
         HIP_OK(hipStreamSynchronize(e->s_copy));
         src.ext = draws; src.ext_abs0 = e->hits_so_far; src.ext_n = n_draws;
         e->draws_up = e->hits_so_far; e->draws_valid = e->hits_so_far + n_draws;
+        e->ring_carry = 0;                                              // (the bits below draws_up in its word belong to ranks nobody reads again)
         e->mt_live = false; e->mt_on_device = false;
     } else if (!e->mt_live) {
         // (re)position the engine-owned stream: rank a takes draw number a - mt_abs0, and mt_hits draws are spent
@@ -1344,6 +1396,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
         fastf_mt_skip(&e->mt, e->mt_skip0 + e->mt_hits);
         e->mt_abs0 = e->hits_so_far - e->mt_hits;
         e->draws_up = e->hits_so_far; e->draws_valid = e->hits_so_far;
+        e->ring_carry = 0;
         e->mt_live = true;
         // from here on the stream continues on the device (FASTF_HOST_DRAWS=1: on the host, 4 bytes per hit over PCIe)
         e->mt_on_device = false;
@@ -1384,11 +1437,36 @@ extern "C" int fastf_debug_mt_fill(int device, uint32_t seed, uint64_t skip, con
         if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess) { rc = set_err("copy failed"); break; }
         u64 at = 0;
         for (u32 i = 0; i < n_calls; ++i) {
-            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ~0ull);
+            hipLaunchKernelGGL(mt_fill_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ~0ull, 0ull);
             at += counts[i];
         }
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
         if (total && hipMemcpy(out, buf.p, total * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy back failed"); break; }
+    } while (0);
+    st.release(); buf.release();
+    return rc;
+} FASTF_CATCH_INT
+
+// test hook: the product form of the same kernel — the DECISIONS (draw < threshold) of the stream from init_genrand(seed)
+// advanced by `skip` draws, n_calls launches of counts[i] draws each, the first of them at absolute rank `first`, into a ring of
+// ring_bits bits (a power of two >= 32) that starts out as 0xFF bytes; the ring's words into out (ring_bits / 32 words)
+extern "C" int fastf_debug_mt_fill_bits(int device, uint32_t seed, uint64_t skip, uint64_t first, const uint64_t* counts, uint32_t n_calls,
+                                        uint64_t threshold, uint64_t ring_bits, uint32_t* out) FASTF_TRY {
+    if (ring_bits < 32 || (ring_bits & (ring_bits - 1))) return set_err("ring_bits must be a power of two >= 32");
+    HIP_OK(hipSetDevice(device));
+    fastf_mt_t mt; fastf_mt_seed(&mt, seed); fastf_mt_skip(&mt, skip);
+    DevBuf st, buf;
+    int rc = 0;
+    do {
+        if (st.ensure(sizeof mt) || buf.ensure(ring_bits / 8)) { rc = 1; break; }
+        if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess || hipMemset(buf.p, 0xFF, ring_bits / 8) != hipSuccess) { rc = set_err("copy failed"); break; }
+        u64 at = first;
+        for (u32 i = 0; i < n_calls; ++i) {
+            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ring_bits - 1, threshold);
+            at += counts[i];
+        }
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
+        if (hipMemcpy(out, buf.p, ring_bits / 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy back failed"); break; }
     } while (0);
     st.release(); buf.release();
     return rc;

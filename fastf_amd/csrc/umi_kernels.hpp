@@ -108,6 +108,10 @@ __device__ __forceinline__ u32 wave_incl_scan32(u32 v, int lane) {
     }
     return v;
 }
+// a wave-uniform 64-bit value into scalar registers (readfirstlane returns int: the halves are widened unsigned)
+__device__ __forceinline__ u64 uniform64(u64 v) {
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
 __device__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
     x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
@@ -119,11 +123,19 @@ __global__ void clear_bits_kernel(u64* word, u64 mask) { atomicAnd(word, ~mask);
 
 // ------------------------------------------------------------------------------------
 // MT19937 on the device (mt19937ar.c:105-140): the depth draws of the CB hits (bam2db_ds.c:385) are generated where they are
-// consumed — no host loop (about a nanosecond per draw on one core), no 4 bytes per hit over PCIe.  One workgroup continues
+// consumed — no host loop (about a nanosecond per draw on one core), no bytes per hit over PCIe.  One workgroup continues
 // the stream held in `state` (the 624 words + the read index, fastf_mt_t's layout: the host seeds and skips, rarely) by
-// `count` draws and writes the tempered values to out[(first + i) & mask] (a ring addressed by absolute hit rank).  A block
-// of 624 words is regenerated in three dependent sweeps — words 0..226 need old words only, 227..453 the new 0..226, 454..623
-// the new 227..396 (and word 623 the new word 0) — each sweep reading everything it needs before any of it is overwritten.
+// `count` draws.  A block of 624 words is regenerated in three dependent sweeps — words 0..226 need old words only, 227..453
+// the new 0..226, 454..623 the new 227..396 (and word 623 the new word 0) — each sweep reading everything it needs before any
+// of it is overwritten.
+//
+// What K1b wants from a draw is ONE BIT — keep the read iff genrand_real1() <= rate, i.e. draw < threshold
+// (bam2db_ds.c:385-390, fastf_depth_threshold) — so that bit is what the product form (BITS) writes: the DECISION STREAM,
+// bit (r & 31) of word ((r & mask) >> 5) for absolute hit rank r.  K1b then reads 1/32 of the bytes per hit (configs[2]:
+// 0.72 GB of draws per 200 M records become 23 MB) and one word per lane and unit instead of four.  The bits of a block gather
+// in LDS (one ballot per wave and sweep, three LDS atomics) and go out as whole words; a word that straddles two blocks —
+// or two launches — is carried.  BITS = false writes the tempered words themselves to out[(first + i) & mask]
+// (fastf_debug_mt_fill: the stream checked word for word against the reference's generator).
 // ------------------------------------------------------------------------------------
 constexpr u32 MT_N = 624, MT_M = 397;
 __device__ __forceinline__ u32 mt_mix(u32 hi, u32 lo) {
@@ -134,47 +146,119 @@ __device__ __forceinline__ u32 mt_temper(u32 y) {
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     return y;
 }
-__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
+constexpr u32 MT_SEG_WORDS = 24;                             // decision words of one block: (31 + 624 + 31) / 32, and two of slack for a wave's deposit
+// the decisions of 64 consecutive stream positions (bit l of m: position o + l of the segment) into the segment's LDS words
+__device__ __forceinline__ void mt_deposit(u32* seg, u32 o, u64 m, int lane) {
+    const u32 wi = o >> 5, sh = o & 31u;
+    const u64 lo = m << sh;
+    const u32 hi = sh ? (u32)(m >> (64u - sh)) : 0u;
+    const u32 piece = lane == 0 ? (u32)lo : lane == 1 ? (u32)(lo >> 32) : hi;
+    if (lane < 3 && piece) (void)__hip_atomic_fetch_or(&seg[wi + (u32)lane], piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool BITS>
+__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask, u64 threshold) {
     // two copies of the state: a block is regenerated FROM one INTO the other, so a sweep never overwrites what it still
-    // reads: three barriers per block.  A word goes out (tempered, to its rank's ring slot) the moment it is computed — no
-    // second pass over the block; only what is left of the block the kernel starts in is handed out by a loop of its own.
+    // reads: three barriers per block.  A word goes out the moment it is computed — no second pass over the block; only
+    // what is left of the block the kernel starts in is handed out by a loop of its own.
+    // BITS: two copies of the segment's decision words as well.  Segment g (the rest of the first block, then every block)
+    // gathers in sb[g & 1]; after its last barrier the whole words are stored and the partial last word is OR-ed into word 0
+    // of the other copy, which was cleared one barrier interval earlier (during sweep 2) — no barrier of its own.
     __shared__ u32 buf[2][MT_N];
+    __shared__ u32 sb[2][MT_SEG_WORDS];
     const u32 tid = threadIdx.x;
+    const int lane = lane_id();
+    const u32 kb = tid & ~63u;                               // stream position of this wave's lane 0 inside a sweep
+    const u64 wmask = mask >> 5;
     for (u32 i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
+    // (word 0 of the first segment: the word the stream stands in, if the launch before left it partial)
+    if (BITS && tid < 2 * MT_SEG_WORDS) (&sb[0][0])[tid] = (tid == 0 && (first & 31u)) ? out[(first >> 5) & wmask] & ((1u << (first & 31u)) - 1u) : 0u;
     u32 idx = state[MT_N];
     u32 cur = 0;                                             // buf[cur] holds the current block
+    u32 sc = 0;                                              // sb[sc] gathers the current segment
     __syncthreads();
+    // store the whole words of a finished segment [at, at + len), carry its partial last word (after the segment's last barrier)
+    auto flush = [&](const u64 at, const u32 len) {
+        const u32 s = (u32)at & 31u, full = (s + len) >> 5;
+        if (tid < full) out[((at >> 5) + tid) & wmask] = sb[sc][tid];
+        if (tid == full && ((s + len) & 31u) && sb[sc][full]) (void)__hip_atomic_fetch_or(&sb[sc ^ 1][0], sb[sc][full], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     u64 done = 0;
     if (idx < MT_N && count) {                               // the rest of the block the stream stands in
         const u32 take = (u32)(count < (u64)(MT_N - idx) ? count : (u64)(MT_N - idx));
-        for (u32 i = tid; i < take; i += 256) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
+        if (BITS) {
+            for (u32 i0 = 0; i0 < take; i0 += 256) {         // (uniform)
+                const u32 i = i0 + tid;
+                const u64 m = __ballot(i < take && (u64)mt_temper(buf[0][idx + (i < take ? i : 0u)]) < threshold);
+                mt_deposit(sb[0], ((u32)first & 31u) + i0 + kb, m, lane);
+            }
+            __syncthreads();
+            flush(first, take);
+            sc = 1;
+        } else {
+            for (u32 i = tid; i < take; i += 256) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
+        }
         idx += take; done = take;
     }
     while (done < count) {                                   // (uniform) whole blocks; the last one may be handed out in part
         const u32* o = buf[cur]; u32* n = buf[cur ^ 1];
         const u64 left = count - done;                       // words of this block that go out: k < left
         const u64 at = first + done;
+        const u32 s = (u32)at & 31u;
         // sweep 1: k = 0..226   n[k] = o[k + 397] ^ mix(o[k], o[k + 1])
-        if (tid < MT_N - MT_M) { const u32 v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; if (tid < left) out[(at + tid) & mask] = mt_temper(v); }
+        {
+            u32 v = 0;
+            if (tid < MT_N - MT_M) { v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; }
+            if (BITS) mt_deposit(sb[sc], s + kb, __ballot(tid < MT_N - MT_M && tid < left && (u64)mt_temper(v) < threshold), lane);
+            else if (tid < MT_N - MT_M && tid < left) out[(at + tid) & mask] = mt_temper(v);
+        }
         __syncthreads();
         // sweep 2: k = 227..453  n[k] = n[k - 227] ^ mix(o[k], o[k + 1])
-        const u32 k2 = tid + (MT_N - MT_M);
-        if (tid < MT_N - MT_M) { const u32 v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; if (k2 < left) out[(at + k2) & mask] = mt_temper(v); }
+        {
+            const u32 k2 = tid + (MT_N - MT_M);
+            u32 v = 0;
+            if (tid < MT_N - MT_M) { v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; }
+            if (BITS) {
+                mt_deposit(sb[sc], s + (MT_N - MT_M) + kb, __ballot(tid < MT_N - MT_M && k2 < left && (u64)mt_temper(v) < threshold), lane);
+                if (tid < MT_SEG_WORDS) sb[sc ^ 1][tid] = 0;   // the next segment's copy: its words were stored before this block's first barrier
+            } else if (tid < MT_N - MT_M && k2 < left) out[(at + k2) & mask] = mt_temper(v);
+        }
         __syncthreads();
         // sweep 3: k = 454..622 the same with n[k - 227] from sweep 2; k = 623: n[623] = n[396] ^ mix(o[623], n[0])
-        const u32 k3 = tid + 2 * (MT_N - MT_M);
-        if (k3 < MT_N) {
-            const u32 v = k3 < MT_N - 1 ? n[k3 - (MT_N - MT_M)] ^ mt_mix(o[k3], o[k3 + 1]) : n[MT_M - 1] ^ mt_mix(o[MT_N - 1], n[0]);
-            n[k3] = v;
-            if (k3 < left) out[(at + k3) & mask] = mt_temper(v);
+        {
+            const u32 k3 = tid + 2 * (MT_N - MT_M);
+            u32 v = 0;
+            if (k3 < MT_N) {
+                v = k3 < MT_N - 1 ? n[k3 - (MT_N - MT_M)] ^ mt_mix(o[k3], o[k3 + 1]) : n[MT_M - 1] ^ mt_mix(o[MT_N - 1], n[0]);
+                n[k3] = v;
+            }
+            if (BITS) mt_deposit(sb[sc], s + 2 * (MT_N - MT_M) + kb, __ballot(k3 < MT_N && k3 < left && (u64)mt_temper(v) < threshold), lane);
+            else if (k3 < MT_N && k3 < left) out[(at + k3) & mask] = mt_temper(v);
         }
         __syncthreads();
         cur ^= 1;
         idx = (u32)(left < (u64)MT_N ? left : (u64)MT_N);
+        if (BITS) { flush(at, idx); sc ^= 1; }
         done += idx;
     }
     for (u32 i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
     if (tid == 0) state[MT_N] = idx;
+    if (BITS) {
+        __syncthreads();                                     // the carry of the last segment
+        if (tid == 0 && ((first + count) & 31u) && count) out[((first + count) >> 5) & wmask] = sb[sc][0];
+    }
+}
+
+// caller-supplied draws (and the host's own stream, FASTF_HOST_DRAWS=1) as decisions: bits[i >> 5] bit (i & 31) = draws[i] <
+// threshold, i < n; the last word is zero-filled.  One wave per 64 draws and round.
+__global__ __launch_bounds__(256) void draw_bits_kernel(const u32* __restrict__ draws, u64 n, u64 threshold, u32* __restrict__ bits) {
+    const int lane = lane_id();
+    const u64 waves = (u64)gridDim.x * (256 / WAVE), w0 = (u64)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    for (u64 c = w0; c * WAVE < n; c += waves) {
+        const u64 i = c * WAVE + (u64)lane;
+        const u64 m = __ballot(i < n && (u64)draws[i < n ? i : 0] < threshold);
+        if (lane == 0) bits[2 * c] = (u32)m;
+        if (lane == 1 && c * WAVE + 32 < n) bits[2 * c + 1] = (u32)(m >> 32);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -638,13 +722,13 @@ struct PackParams {
     const unsigned char* blk;      // streaming form, BLOCKED: the units' runs (gx | umi | meta | scratch); cell/gx/umi/meta unused
     const u64* gx; const u32* umi; const u32* meta; u64 n;
     const u64* tile_base;          // exclusive scan of tile_hits
-    const u32* draws; u64 n_draws; // draw of hit rank r: draws[r & draw_mask], valid while r < n_draws
-    u64 draw_mask;                 // ~0 for a linear array; ring size - 1 for the streaming push path
+    const u32* dbits; u64 n_draws; // the decision stream (mt_fill_kernel<true>, draw_bits_kernel): hit rank r is kept iff bit (r & 31) of
+                                   // dbits[(r & draw_mask) >> 5] is set; valid while r < n_draws
+    u64 draw_mask;                 // ~0 for a linear array; ring size (in ranks, a power of two >= 32) - 1 for the streaming push path
     const u64* draw_base;          // optional device-side offset into draws (sharded runs, streaming pushes)
     Table feats;
     GeneLds genes;                 // LDS fast path of the feature lookup (LDS_GENES instantiation)
     u32 n_tiles;
-    u64 threshold;                 // keep iff draw < threshold
     KeyLayout L;
     u32 n_shards;
     u64* keys; u64 shard_stride;   // keys + s*shard_stride
@@ -722,13 +806,13 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
 
     // ---- depth draw (E4/E5 :385-390): the loads are issued here and consumed after the feature lookup ----
     u32 n_hit = 0, n_samp = 0, n_valid = 0, errs = 0;
-    u32 draw[K1B_IPT];
+    u32 draw[K1B_IPT], dbit[K1B_IPT];                                 // the decision word of a hit's rank and the bit in it
 #pragma unroll
     for (int j = 0; j < K1B_IPT; ++j) {
-        draw[j] = 0;
+        draw[j] = 0; dbit[j] = 0;
         if (cell[j] != 0) {
             const u64 r = tile_base + s_cnt[j * K1B_WAVES + w] + hrank[j];
-            if (r < p.n_draws) draw[j] = p.draws[r & p.draw_mask];
+            if (r < p.n_draws) { draw[j] = p.dbits[(r & p.draw_mask) >> 5]; dbit[j] = (u32)r & 31u; }
             else { cell[j] = 0; n_hit++; errs |= (u32)ERR_DRAWS_SHORT; }
         }
     }
@@ -773,7 +857,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
         for (int j = 0; j < K1B_IPT; ++j) {
             bool alive = cell[j] != 0;
             n_hit += alive;
-            alive = alive && (u64)draw[j] < p.threshold;
+            alive = alive && ((draw[j] >> dbit[j]) & 1u);
             n_samp += alive;                                         // E6 :392
             if (!alive) feat[j] = 0;
         }
@@ -782,7 +866,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
         for (int j = 0; j < K1B_IPT; ++j) {
             bool alive = cell[j] != 0;
             n_hit += alive;
-            alive = alive && (u64)draw[j] < p.threshold;
+            alive = alive && ((draw[j] >> dbit[j]) & 1u);
             n_samp += alive;                                         // E6 :392
             alive = alive && (meta[j] & META_XF_OK);                 // E7 :394-400
             fkey[j] = alive ? gxk[j] : 0;
@@ -892,6 +976,16 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
 // ------------------------------------------------------------------------------------
 constexpr int K1S_IPT = 4, K1S_UNIT = K1S_IPT * WAVE;                       // 256 records per wave and step
 static_assert(K1_TILE % K1S_UNIT == 0 && K1_TILE / K1S_UNIT == 16, "16 units per K1a tile");
+// Waves per workgroup.  Two workgroups share a CU when the gene image allows it (2 x 73 KB on configs[2]); with 16 waves each
+// that is 8 waves per SIMD and a budget of 64 VGPRs and 78 SGPRs per wave (the trap handler keeps 16 of the 96): the loop wants
+// about 70 of the first and 120 of the second, so three vector registers went to scratch and 45 scalars into the lanes of a
+// vector register — 90 v_readlane per unit, a quarter of the loop's vector instructions, only to fetch them back.  12 waves
+// per workgroup = 6 per SIMD = 80 VGPRs and 102 SGPRs: nothing spills.
+#ifndef FASTF_K1S_THREADS
+#define FASTF_K1S_THREADS 768
+#endif
+constexpr int K1S_THREADS = FASTF_K1S_THREADS, K1S_THREADS_ROOMY = 1024;
+static_assert(K1S_THREADS % (4 * WAVE) == 0 && K1S_THREADS <= 1024, "whole waves on every SIMD");
 
 struct StreamParams {
     const u32* half_hits;          // [16 * n_tiles]
@@ -912,7 +1006,8 @@ __device__ __forceinline__ u32 row16_sum_lane15(u32 x) {
 // the loop is straight-line code: with run-time flags every load sat in its own branch, with waits between them
 // (PMC on the configs[2] shape: 430 vector + 325 scalar instructions per 256 records, the vector ALU busy 60 % of the kernel).
 template <bool ROOMY, bool C16, bool DIRECT, bool BLOCKED = false>
-__global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
+__global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 : 2 * K1S_THREADS / (4 * WAVE)) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
+    constexpr int THREADS = ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, WAVES = THREADS / WAVE;
     __shared__ u64 s_tot[3];
     __shared__ u32 s_cursor, s_err;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the gene image
@@ -925,7 +1020,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.genes.image);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += K1B_THREADS) dst[i] = src[i];
+        for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += THREADS) dst[i] = src[i];
     }
     if (tid < 3) s_tot[tid] = 0;
     if (tid == 0) { s_cursor = 0; s_err = 0; }
@@ -935,84 +1030,122 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
     u64* const region = p.keys + (u64)blockIdx.x * sp.region_stride;
     const u64 draw_off = p.draw_base ? *p.draw_base : 0;
     u32 w_hit = 0, w_samp = 0, w_valid = 0, errs = 0;                      // wave-uniform running counts
-    // the workgroup's 16 waves take the 16 units of one K1a tile per round: the same locality as the tile form.
-    // The two small inputs of a round — the tile's hit-rank base and its line of per-unit hit counts — are fetched one
-    // round ahead, so that the draws of a unit (a CONTIGUOUS range of the draw stream: ranks rank0 .. rank0 + own) are
-    // requested together with the unit's records instead of behind them.
-    u64 tb = 0; u32 hha = 0;
-    if (blockIdx.x < p.n_tiles) {
-        tb = p.tile_base[blockIdx.x];
-        hha = lane < 16 ? sp.half_hits[16ull * blockIdx.x + lane] : 0u;
-    }
-    for (u32 t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
-        const u64 base = (u64)t * K1_TILE + (u64)w * K1S_UNIT;             // scalar
-        // hit-rank base of this unit: the tile's base + the units in front of it inside the tile; own = this unit's hits
-        u64 rank0 = tb + draw_off + row16_sum_lane15(lane < w ? hha : 0u);  // w <= 15
-        const u32 own = (u32)__builtin_amdgcn_readlane((int)hha, w);
-        // ---- loads ----
-        u64 gxk[K1S_IPT]; u32 umi[K1S_IPT], meta[K1S_IPT], cell[K1S_IPT];
-        // BLOCKED: the unit is one contiguous run of the engine's staging buffer (scalar base)
-        const unsigned char* const run = BLOCKED ? p.blk + ((u64)t * (K1_TILE / K1S_UNIT) + (u64)w) * blk_run_bytes(C16) : nullptr;
-        const u64* const gx_u = BLOCKED ? reinterpret_cast<const u64*>(run + BLK_GX) : p.gx + base;
+    // the workgroup's waves take consecutive units per round (unit u: tile u >> 4, place u & 15 in it): the same locality as
+    // the tile form.
+    //
+    // The loop is software-pipelined BY HAND: a unit's inputs are requested during the unit before —
+    //   cell, umi, meta and the unit's     at the top of the unit before, into a second set of registers (13 of them: with 12
+    //   decision words                     waves per workgroup the budget is 80 and the loop needs 60)
+    //   gx                                 behind the gene lookup of the unit before, into the registers it just vacated
+    //   tile base, hit counts of the tile  two units ahead: they place the unit in the decision stream when its words are asked for
+    // — and every one of those loads is unconditional (a unit that does not exist reads the last one that does, a lane beyond
+    // the records its unit's last record): the compiler's wait counters then stay exact, each wait covers the loads it needs
+    // and not the ones just issued.  Before this a wave asked for its 4.6 KB, waited two to three microseconds with nothing
+    // else of its own in flight, and worked for six: eight waves per SIMD covered that only in part (12 waves per workgroup
+    // without a spill ran no faster than 16 with 90 spill reloads per unit — the loop was latency-bound,
+    // profiles/r4_notes/ab_k1b_pipelined.txt).
+    const u32 n_units = p.n_tiles * (u32)(K1_TILE / K1S_UNIT), ustep = gridDim.x * (u32)WAVES;
+    const u32 n_live = (u32)((p.n + K1S_UNIT - 1) / K1S_UNIT);            // units that hold records (the tiles are whole: the rest is empty); >= 1
+    u32 u = blockIdx.x * (u32)WAVES + (u32)w;                              // scalar
+    // one unit's inputs apart from gx: the records' cell / umi / meta, the unit's decision words, and (wave-uniform) the
+    // decisions left in the stream from its first rank on, that rank's bit in its word, the records the unit holds
+    struct UnitRegs { u32 cell[K1S_IPT], umi[K1S_IPT], meta[K1S_IPT], dw, avail, sbit, nvalid; };
+    UnitRegs ra, rb;                                                       // the unit in work and the one after it, by turns
+    u64 gxk[K1S_IPT];
+    u64 tb = 0; u32 hha = 0;                                               // small inputs of the unit after it (tb: the same value in every lane)
+    u32 zlane = 0;
+    asm volatile("" : "+v"(zlane));                                        // an opaque zero per lane, see small_inputs
+    // records a unit holds (0: none), and the unit whose memory stands in for it when it holds none
+    auto records_of = [&](const u32 uu) { return uu < n_live ? (u32)(p.n - (u64)uu * K1S_UNIT < (u64)K1S_UNIT ? p.n - (u64)uu * K1S_UNIT : (u64)K1S_UNIT) : 0u; };
+    auto unit_run = [&](const u32 uu) { return BLOCKED ? p.blk + (u64)uu * blk_run_bytes(C16) : nullptr; };
+    // (nv >= 1 records of unit uu exist; a blocked run is whole even when its unit is not)
+    auto load_gx = [&](u64 (&g)[K1S_IPT], const u32 uu, const u32 nv) {
+        const u64* const gx_u = BLOCKED ? reinterpret_cast<const u64*>(unit_run(uu) + BLK_GX) : p.gx + (u64)uu * K1S_UNIT;
+#pragma unroll
+        for (int j = 0; j < K1S_IPT; ++j) {
+            const u32 o = (u32)j * WAVE + (u32)lane;
+            g[j] = ld_once<NT>(gx_u + (BLOCKED || o < nv ? o : nv - 1u));
+        }
+    };
+    auto load_rest = [&](u32 (&c)[K1S_IPT], u32 (&um)[K1S_IPT], u32 (&me)[K1S_IPT], const u32 uu, const u32 nv) {
+        const unsigned char* const run = unit_run(uu);
+        const u64 base = (u64)uu * K1S_UNIT;
         const u32* const umi_u = BLOCKED ? reinterpret_cast<const u32*>(run + BLK_UMI) : p.umi + base;
         const u32* const meta_u = BLOCKED ? reinterpret_cast<const u32*>(run + BLK_META) : p.meta + base;
         const unsigned short* const c16_u = BLOCKED ? reinterpret_cast<const unsigned short*>(run + BLK_CELL) : reinterpret_cast<const unsigned short*>(p.cell) + base;
         const u32* const c32_u = BLOCKED ? reinterpret_cast<const u32*>(run + BLK_CELL) : reinterpret_cast<const u32*>(p.cell) + base;
-        if (base + K1S_UNIT <= p.n) {                                      // scalar branch: the whole unit exists
 #pragma unroll
-            for (int j = 0; j < K1S_IPT; ++j) {
-                const u32 o = (u32)j * WAVE + (u32)lane;
-                cell[j] = C16 ? (u32)ld_once<NT>(c16_u + o) : ld_once<NT>(c32_u + o);
-                gxk[j]  = ld_once<NT>(gx_u + o);
-                umi[j]  = ld_once<NT>(umi_u + o);
-                meta[j] = ld_once<NT>(meta_u + o);
-            }
-        } else {
+        for (int j = 0; j < K1S_IPT; ++j) {
+            const u32 o = (u32)j * WAVE + (u32)lane, oc = BLOCKED || o < nv ? o : nv - 1u;
+            c[j] = C16 ? (u32)ld_once<NT>(c16_u + oc) : ld_once<NT>(c32_u + oc);
+            um[j] = ld_once<NT>(umi_u + oc);
+            me[j] = ld_once<NT>(meta_u + oc);
+        }
+    };
+    // place a unit in the decision stream from its tile's small inputs and ask for its decision words: bits rank0 .. rank0 +
+    // its hits of the stream — nine 32-bit words at most, word i in lane i (the lanes behind repeat them; one or two cache lines).
+    // avail: decisions left in the stream from the unit's first rank on (capped: a unit has 256 hits at most) — ranks beyond
+    // the stream are caught in the loop, the load stays in bounds (the stream holds at least one word: launch_probe)
+    struct Place { u32 avail, sbit; };
+    auto place_unit = [&](u32& words, const u32 uu, const u64 tbv, const u32 hhu) {
+        const u32 place = uu & 15u;
+        const u64 rank0 = uniform64(tbv) + draw_off + row16_sum_lane15((u32)lane < place ? hhu : 0u);
+        Place q;
+        q.avail = rank0 < p.n_draws ? (u32)(p.n_draws - rank0 < 1024 ? p.n_draws - rank0 : 1024) : 0u;
+        q.sbit = (u32)rank0 & 31u;
+        const u64 last = p.n_draws ? (p.n_draws - 1) >> 5 : 0;             // last word of the stream that holds a decision
+        const u64 wi = (rank0 >> 5) + ((u32)lane & 15u);
+        words = p.dbits[(wi < last ? wi : last) & (p.draw_mask >> 5)];
+        return q;
+    };
+    // (asked for as VECTOR loads, the tile base through an opaque zero in its address: a load the compiler knows to be
+    //  uniform is moved to scalar registers right behind its issue, and that wait would cover every load in flight — the
+    //  records just asked for; lanes 16.. repeat the hit counts, place_unit() reads lanes < 16 only)
+    auto small_inputs = [&](const u32 uu) {
+        const u32 t = (uu < n_units ? uu : n_units - 1u) >> 4;
+        tb = p.tile_base[t + zlane];
+        hha = sp.half_hits[16ull * t + ((u32)lane & 15u)];
+    };
+    if (u < n_units) {                                                     // the first unit: everything at once
+        small_inputs(u);
+        ra.nvalid = records_of(u);
+        const u32 us = ra.nvalid ? u : n_live - 1u, ns = ra.nvalid ? ra.nvalid : records_of(n_live - 1u);
+        load_rest(ra.cell, ra.umi, ra.meta, us, ns);
+        const Place q = place_unit(ra.dw, u, tb, hha);
+        ra.avail = q.avail; ra.sbit = q.sbit;
+        small_inputs(u + ustep);
+        load_gx(gxk, us, ns);                                              // (last, as in the loop: the same loads are in flight behind the small inputs either way in)
+    }
+    // one unit: `cur` holds it, `nxt` receives the unit after it.  The loop below runs the body twice per turn with the two
+    // register sets exchanged — a copy at the end of the body would have to wait for the loads it copies
+    auto one_unit = [&](UnitRegs& cur, UnitRegs& nxt) {
+        u32 (&cell)[K1S_IPT] = cur.cell; u32 (&umi)[K1S_IPT] = cur.umi; u32 (&meta)[K1S_IPT] = cur.meta;
+        const u32 dw = cur.dw, avail = cur.avail, sbit = cur.sbit, nvalid = cur.nvalid;
+        const u32 un = u + ustep;                                          // the unit after this one
+        const u32 nv_n = un < n_units ? records_of(un) : 0u;
+        // the unit whose memory the loads for `un` read: itself, or (no such unit, no records in it) the last one with records
+        const u32 us = nv_n ? un : n_live - 1u, ns = nv_n ? nv_n : records_of(n_live - 1u);
+        // ---- the unit after this one: its place in the decision stream and its decision words (from the small inputs asked
+        //      for a unit ago), cell / umi / meta into the second register set, the small inputs of the unit after that ----
+        const Place qn = place_unit(nxt.dw, un < n_units ? un : u, tb, hha);
+        nxt.avail = qn.avail; nxt.sbit = qn.sbit; nxt.nvalid = nv_n;
+        load_rest(nxt.cell, nxt.umi, nxt.meta, us, ns);
+        small_inputs(un + ustep);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nvalid < (u32)K1S_UNIT) {                                      // (uniform) the last unit with records, or an empty one
 #pragma unroll
-            for (int j = 0; j < K1S_IPT; ++j) {
-                const u32 o = (u32)j * WAVE + (u32)lane;
-                const bool in = base + o < p.n;
-                cell[j] = 0; gxk[j] = 0; umi[j] = 0; meta[j] = 0;
-                if (in) {
-                    cell[j] = C16 ? (u32)c16_u[o] : c32_u[o];
-                    gxk[j] = gx_u[o]; umi[j] = umi_u[o]; meta[j] = meta_u[o];
-                }
-            }
+            for (int j = 0; j < K1S_IPT; ++j) cell[j] = (u32)j * WAVE + (u32)lane < nvalid ? cell[j] : 0u;
         }
-        // the unit's draws, lane l of dr[q] holding the draw of local hit rank 64 q + l
-        u32 dr[K1S_IPT];
-        // draws left in the stream from this unit's first rank on (scalar; capped: a unit has 256 hits at most) — ranks beyond
-        // the stream are caught below, the loads stay in bounds
-        const u32 avail = rank0 < p.n_draws ? (u32)(p.n_draws - rank0 < 1024 ? p.n_draws - rank0 : 1024) : 0u;
-#pragma unroll
-        for (int q = 0; q < K1S_IPT; ++q) {
-            dr[q] = 0;
-            if ((u32)q * WAVE < own && avail) {                            // wave-uniform
-                const u32 o = (u32)q * WAVE + (u32)lane;
-                dr[q] = p.draws[(rank0 + (o < avail ? o : avail - 1u)) & p.draw_mask];
-            }
-        }
-        {   // next round's small inputs
-            const u32 tn = t + gridDim.x;
-            if (tn < p.n_tiles) {
-                tb = p.tile_base[tn];
-                hha = lane < 16 ? sp.half_hits[16ull * tn + lane] : 0u;
-            }
-        }
-        // ---- depth draw (E4/E5): ranks in record order; a record's draw comes from the lane that fetched its rank ----
-        u32 draw[K1S_IPT];
+        // ---- depth draw (E4/E5): ranks in record order; a record's decision comes from the lane that fetched its word ----
+        u32 keep[K1S_IPT];
         u32 pre = 0;                                                       // hits of the unit in front of item j
 #pragma unroll
         for (int j = 0; j < K1S_IPT; ++j) {
             const u64 hm = __ballot(cell[j] != 0);
             const u32 rl = pre + rank_below(hm);                           // local hit rank (meaningful on hit lanes)
-            // the hits of one item span at most two of the dr[] registers: q0 and q0 + 1 (q0 wave-uniform)
-            const u32 q0 = pre >> 6;
-            const u32 a = q0 == 0 ? dr[0] : q0 == 1 ? dr[1] : q0 == 2 ? dr[2] : dr[3];
-            const u32 b = q0 == 0 ? dr[1] : q0 == 1 ? dr[2] : dr[3];
-            const u32 va = (u32)__shfl((int)a, (int)(rl & 63u), WAVE), vb = (u32)__shfl((int)b, (int)(rl & 63u), WAVE);
-            draw[j] = (rl >> 6) == q0 ? va : vb;                           // (only read where cell[j] != 0)
-            const bool dry = (cell[j] != 0) & (rl >= avail);               // a hit beyond the draw stream: an error, the record is dropped
+            const u32 bpos = sbit + rl;                                    // < 32 + 256: words 0..8
+            keep[j] = ((u32)__builtin_amdgcn_ds_bpermute((int)((bpos >> 5) << 2), (int)dw) >> (bpos & 31u)) & 1u;    // (only read where cell[j] != 0)
+            const bool dry = (cell[j] != 0) & (rl >= avail);               // a hit beyond the stream: an error, the record is dropped
             if (__ballot(dry)) { errs |= (u32)ERR_DRAWS_SHORT; cell[j] = dry ? 0u : cell[j]; }     // (uniform branch, never taken on a complete stream)
             const u32 c = (u32)__popcll(hm);
             pre += c; w_hit += c;
@@ -1041,12 +1174,16 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
             if (__ballot(want & !fam)) { if (want & !fam) f = table_probe(p.feats, k); }  // other id families / escaped strings
             feat[j] = f;
         }
+        // gx has done its work: the gx of the unit after this one into its registers
+        __builtin_amdgcn_sched_barrier(0);
+        load_gx(gxk, us, ns);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- E5..E12: keep/drop, key; slots of the wave inside the workgroup's region ----
         u64 key[K1S_IPT], em[K1S_IPT];
         u32 n_keys = 0;
 #pragma unroll
         for (int j = 0; j < K1S_IPT; ++j) {
-            bool alive = cell[j] != 0 && (u64)draw[j] < p.threshold;
+            bool alive = (cell[j] != 0) & (keep[j] != 0);
             w_samp += (u32)__popcll(__ballot(alive));                                      // E6
             alive = alive & (feat[j] != 0) & ((meta[j] & META_HAS_UB) != 0);
             if (__ballot(alive & umi_overflows(p.L, umi[j], meta[j]))) errs |= (u32)ERR_UMI_TOOLONG;      // (uniform branch, never taken on good data)
@@ -1068,6 +1205,12 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : FASTF_K1B_MINWAVES) void f
                 }
             }
         }
+        u = un;
+    };
+    while (u < n_units) {
+        one_unit(ra, rb);
+        if (u >= n_units) break;
+        one_unit(rb, ra);
     }
     if (lane == 0) {
         if (w_hit) atomicAdd(&s_tot[0], (u64)w_hit);
@@ -1604,10 +1747,6 @@ __device__ __forceinline__ u32 wave_max32(u32 v) {
     return v;
 }
 
-// a wave-uniform 64-bit value into scalar registers (readfirstlane returns int: the halves are widened unsigned)
-__device__ __forceinline__ u64 uniform64(u64 v) {
-    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
-}
 // workgroup barrier that waits for this wave's LDS traffic only (not for its global loads and stores)
 __device__ __forceinline__ void k3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

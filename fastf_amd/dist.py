@@ -53,6 +53,13 @@ def owner_of_cell(cell_index: np.ndarray, n_shards: int) -> np.ndarray:
 RUN_TOO_LONG = 16      # FASTF_ERR_RUN_TOO_LONG
 
 
+class DrawBits:
+    """the decisions of a draw stream on the device (HipStages.draw_bits): bit i = draw i < the engine's threshold"""
+
+    def __init__(self, words, n_draws):
+        self.words, self.n_draws = words, n_draws
+
+
 class HipStages:
     """device stages backed by libfastf_amd.so (fastf_dev_* entry points)"""
 
@@ -95,13 +102,25 @@ class HipStages:
             return max(n, self.eng.probe_capacity(n))
         return n
 
+    def draw_bits(self, draws):
+        """K1b reads one bit per CB hit (kept or not); a stream of 32-bit draws that is used for more than one step is turned
+        into those bits ONCE (fastf_dev_draw_bits) and the result passed to probe_pack in its place"""
+        n = draws.numel()
+        words = torch.zeros((n + 31) // 32 + 1, dtype=torch.int32, device=self.device)
+        self.eng.dev_draw_bits(draws.data_ptr(), n, words.data_ptr(), self._s())
+        return DrawBits(words, n)
+
     def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters, reuse_hits=False):
+        """draws: a tensor of 32-bit draws (converted on every call) or the DrawBits made from one"""
         self.segmented = self.eng.n_shards == 1 and self.eng.probe_capacity(n) > 0 and stride >= self.eng.probe_capacity(n)
         blocked = umi is None                              # gx is then a buffer made by block()
+        bits = isinstance(draws, DrawBits)
         self.eng.dev_probe_pack(cb.data_ptr(), gx.data_ptr(), 0 if blocked else umi.data_ptr(), 0 if blocked else meta.data_ptr(), n,
-                                draws.data_ptr(), draws.numel(), keys_out.data_ptr(), stride,
+                                draws.words.data_ptr() if bits else draws.data_ptr(), draws.n_draws if bits else draws.numel(),
+                                keys_out.data_ptr(), stride,
                                 key_counts.data_ptr(), counters.data_ptr(), self._s(),
-                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, segmented=self.segmented, blocked=blocked)
+                                d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, segmented=self.segmented, blocked=blocked,
+                                draw_bits=bits)
 
     def set_regions(self, counts, n_regions, stride, d_n):
         """the keys of the next sort_reduce lie in n_regions rows of `stride` slots, row r holding counts[r] keys (device
@@ -249,8 +268,13 @@ class ShardedPass:
         self.n_collectives += 1
         dist.all_to_all_single(out_cpu, inp_cpu, group=self.small_group)
 
+    def prepare_draws(self, draws):
+        """a resident draw stream in the form the stages read fastest (HIP: the decision bits, made once); pass the result
+        to run() in place of `draws`"""
+        return self.st.draw_bits(draws) if hasattr(self.st, "draw_bits") else draws
+
     def run(self, cb, gx, umi, meta, n, draws, inputs_ready=None):
-        """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident).
+        """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident), or prepare_draws() of it.
 
         Pipelined mode runs K1 on its own stream so that it overlaps the previous step's sort on the caller's stream;
         it therefore cannot wait for everything the caller has queued.  A caller that REWRITES the input tensors between

@@ -330,13 +330,20 @@ class Engine:
         check(self._L.fastf_dev_block_records(self._h, d_gx, d_umi, d_meta, n, d_blocked, stream))
 
     def dev_probe_pack(self, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_keys, shard_stride,
-                       d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False, segmented=False, blocked=False):
+                       d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False, segmented=False, blocked=False,
+                       draw_bits=False):
         """reuse_hits: dev_count_hits ran on these very records just before, on the same stream (K1a is skipped);
         segmented: streaming K1b, keys land in per-workgroup regions (probe_capacity slots; sort with segmented=True);
-        blocked: d_gx is a blocked record buffer (block_bytes / dev_block_records), d_umi and d_meta are ignored"""
+        blocked: d_gx is a blocked record buffer (block_bytes / dev_block_records), d_umi and d_meta are ignored;
+        draw_bits: d_draws holds the decisions of n_draws draws (dev_draw_bits), not the 32-bit draws themselves"""
         check(self._L.fastf_dev_probe_pack(self._h, d_cb, d_gx, d_umi, d_meta, n, d_draws, n_draws, d_draw_base,
                                            d_keys, shard_stride, d_key_counts, d_counters,
-                                           (1 if reuse_hits else 0) | (2 if segmented else 0) | (8 if blocked else 0), stream))
+                                           (1 if reuse_hits else 0) | (2 if segmented else 0) | (8 if blocked else 0) | (16 if draw_bits else 0),
+                                           stream))
+
+    def dev_draw_bits(self, d_draws, n_draws, d_bits_out, stream=0):
+        """bit i of d_bits_out (u32 words, (n_draws + 31) // 32 of them) = d_draws[i] < this engine's keep threshold"""
+        check(self._L.fastf_dev_draw_bits(self._h, d_draws, n_draws, d_bits_out, stream))
 
     def probe_capacity(self, n) -> int:
         """key slots a segmented probe_pack over n records needs; 0 = the streaming form is not available"""

@@ -289,3 +289,37 @@ def test_device_mt19937_is_the_reference_stream(env, seed, skip, counts):
     cs = np.asarray(counts, np.uint64)
     assert L.fastf_debug_mt_fill(0, seed, skip, cs.ctypes.data, len(counts), out.ctypes.data) == 0, L.fastf_last_error()
     np.testing.assert_array_equal(out[:n], F.mt_draws(seed, skip, n))
+
+
+@pytest.mark.parametrize("seed,skip,first,counts,rate,ring_bits", [
+    (926, 0, 0, [1, 622, 1, 1, 623, 624, 625, 1248, 7, 100_000], 0.5, 1 << 17),     # every position of a block boundary
+    (926, 25_000, 13, [3, 50_000, 0, 31, 1, 32, 33, 1_000_003], 0.5, 1 << 21),      # launches that start and end inside a word
+    (0x39e, 624 * 1000 - 1, 4095, [1, 1, 624 * 3, 5, 59, 64], 0.123, 4096),         # the ring wraps inside the third launch
+    (1, 623, 31, [2_000_000], 0.9, 1 << 21),
+    (7, 5, 1000, [40, 700, 3], 1.0, 1024),                                          # rate 1: the threshold is 2^32, every bit set
+])
+def test_device_decision_stream(env, seed, skip, first, counts, rate, ring_bits):
+    """mt_fill_kernel<true> — what K1b reads: bit (r & 31) of ring word (r mod ring) >> 5 = draw (r - first) < threshold, for every
+    absolute rank r the launches cover; the bits gather per block in LDS, whole words are stored, the word a block or a launch
+    ends in is carried.  Ranks never written keep the 0xFF the hook fills the ring with, except the zero tail of the last word."""
+    import ctypes as C
+    torch, F, eng = env
+    from fastf_amd import _lib
+    L = _lib.lib()
+    thr = int(L.fastf_draw_threshold(rate))
+    L.fastf_debug_mt_fill_bits.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+    n = int(sum(counts))
+    out = np.zeros(ring_bits // 32, np.uint32)
+    cs = np.asarray(counts, np.uint64)
+    assert L.fastf_debug_mt_fill_bits(0, seed, skip, first, cs.ctypes.data, len(counts), thr, ring_bits, out.ctypes.data) == 0, L.fastf_last_error()
+    got = np.unpackbits(out.view(np.uint8), bitorder="little")
+    want = (F.mt_draws(seed, skip, n).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
+    keep = min(n, ring_bits - 32)                      # the newest ranks; older ones may have been overwritten by the wrap
+    r = np.arange(first + n - keep, first + n, dtype=np.uint64)
+    np.testing.assert_array_equal(got[(r % np.uint64(ring_bits)).astype(np.int64)], want[n - keep:])
+    end = first + n
+    if end % 32 and keep == n and n < ring_bits - 64:
+        tail = np.arange(end, (end // 32 + 1) * 32, dtype=np.uint64) % np.uint64(ring_bits)
+        assert not got[tail.astype(np.int64)].any()                                  # the rest of the last word: zeros
+        beyond = np.arange((end // 32 + 1) * 32, (end // 32 + 2) * 32, dtype=np.uint64) % np.uint64(ring_bits)
+        assert got[beyond.astype(np.int64)].all()                                    # the word after it: untouched

@@ -182,7 +182,12 @@ def test_mixed_name_forms_use_both_lookup_paths():
         eng.close()
 
 
-def test_multi_batch_push_equals_single():
+@pytest.mark.parametrize("host_draws", ["0", "1"])
+def test_multi_batch_push_equals_single(host_draws, monkeypatch):
+    """pushes cut at odd places, chunks of 20 000 records: the decision stream is continued chunk by chunk — by mt_fill_kernel
+    (a word of 32 decisions straddles two launches) and, with FASTF_HOST_DRAWS=1, by the host packer (the same word goes up
+    twice) — then the same records with caller-supplied draws"""
+    monkeypatch.setenv("FASTF_HOST_DRAWS", host_draws)
     case = Case(n=150_000, n_bar=800, n_gene=400, rate_depth=0.7, umi_pool=256, p_unlisted_cb=0.1, p_bad_xf=0.1)
     ora = case.oracle()
     lists = case.lists()
@@ -458,11 +463,12 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
             if form == "blocked" and blk is None:
                 eng.close()
                 continue
-            for _ in range(2):
+            # (first step: the 32-bit draws, turned into decisions by the call; second: the decision bits made once)
+            for dr in (draws, sp.prepare_draws(draws)):
                 if blk is not None:
-                    sp.run(d[0], blk, None, None, case.n, draws)
+                    sp.run(d[0], blk, None, None, case.n, dr)
                 else:
-                    sp.run(d[0], d[1], d[2], d[3], case.n, draws)
+                    sp.run(d[0], d[1], d[2], d[3], case.n, dr)
             f, c, k = sp.local_coo()
             hits, sampled, valid, err = sp.global_counters()
             assert err == 0

@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B: K1b with one byte per draw (timing probe: wrong draws, same keep rate) against the product build
+set -o pipefail
+mkdir -p gpurun_out/r4
+for r in 1 2; do for v in main drawbytes; do
+  if [ $v = main ]; then lib=""; else lib="FASTF_LIB_OVERRIDE=$PWD/build/$v/libfastf_amd.so"; fi
+  env $lib python3 bench.py --steps 40 --no-e2e --no-cpu --no-devpath 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],4), d['counters']['same_as_single_gpu_reference_run'], [(k.split()[0], round(v['avg_ms'],4), round(v['frac'],3)) for k,v in d['kernels'].items()])"
+done; done 2>&1 | tee gpurun_out/r4/s16_ab_drawbytes.txt
