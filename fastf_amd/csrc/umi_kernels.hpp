@@ -308,6 +308,19 @@ __device__ __forceinline__ u64 make_key(const KeyLayout L, u32 cell, u32 feat, u
     return k;
 }
 
+// the same two, straight-line (the streaming K1b: an exec-mask branch per record condition costs more than the few
+// instructions it skips)
+__device__ __forceinline__ u64 make_key_flat(const KeyLayout L, u32 cell, u32 feat, u32 umi, u32 meta) {
+    const u32 nn = (meta / META_UMI_NONNULL) & 1u, len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+    const u64 low = ((u64)nn << (L.umi_bits + L.len_bits)) | ((u64)(umi >> (32 - L.umi_bits)) << L.len_bits) | len;
+    return ((u64)cell << L.cell_shift) | ((u64)feat << L.feat_shift) | (low & (0ull - (u64)nn));
+}
+__device__ __forceinline__ bool umi_overflows_flat(const KeyLayout L, u32 umi, u32 meta) {
+    const u32 tail = L.umi_bits < 32 ? (1u << (32 - L.umi_bits)) - 1u : 0u;        // (scalar) the bits of umi the field cannot hold
+    const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+    return ((meta & META_UMI_TOOLONG) != 0) | (((meta & META_UMI_NONNULL) != 0) & ((len > L.umi_max_bytes) | ((umi & tail) != 0)));
+}
+
 // the rest of a wide key (everything below the group word) from a UMI of up to 32 bases in 64 bits (first base on top)
 __device__ __forceinline__ u64 make_val64(const KeyLayout L, u64 umi, u32 meta) {
     if (!(meta & META_UMI_NONNULL)) return 0;
@@ -1093,9 +1106,12 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
         Place q;
         q.avail = rank0 < p.n_draws ? (u32)(p.n_draws - rank0 < 1024 ? p.n_draws - rank0 : 1024) : 0u;
         q.sbit = (u32)rank0 & 31u;
-        const u64 last = p.n_draws ? (p.n_draws - 1) >> 5 : 0;             // last word of the stream that holds a decision
-        const u64 wi = (rank0 >> 5) + ((u32)lane & 15u);
-        words = p.dbits[(wi < last ? wi : last) & (p.draw_mask >> 5)];
+        // (word numbers in 32 bits: a stream of up to 2^37 decisions; the clamp to the last word that holds one is scalar)
+        const u64 last = p.n_draws ? (p.n_draws - 1) >> 5 : 0, first = rank0 >> 5;
+        const u32 room = first < last ? (u32)(last - first < 15 ? last - first : 15) : 0u;
+        const u32 off = (u32)lane & 15u;
+        const u32 wi = ((u32)(first < last ? first : last) + (off < room ? off : room)) & (u32)(p.draw_mask >> 5);
+        words = p.dbits[wi];
         return q;
     };
     // (asked for as VECTOR loads, the tile base through an opaque zero in its address: a load the compiler knows to be
@@ -1138,17 +1154,21 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
         }
         // ---- depth draw (E4/E5): ranks in record order; a record's decision comes from the lane that fetched its word ----
         u32 keep[K1S_IPT];
-        u32 pre = 0;                                                       // hits of the unit in front of item j
+        {
+            u64 hm[K1S_IPT]; u32 H = 0;
 #pragma unroll
-        for (int j = 0; j < K1S_IPT; ++j) {
-            const u64 hm = __ballot(cell[j] != 0);
-            const u32 rl = pre + rank_below(hm);                           // local hit rank (meaningful on hit lanes)
-            const u32 bpos = sbit + rl;                                    // < 32 + 256: words 0..8
-            keep[j] = ((u32)__builtin_amdgcn_ds_bpermute((int)((bpos >> 5) << 2), (int)dw) >> (bpos & 31u)) & 1u;    // (only read where cell[j] != 0)
-            const bool dry = (cell[j] != 0) & (rl >= avail);               // a hit beyond the stream: an error, the record is dropped
-            if (__ballot(dry)) { errs |= (u32)ERR_DRAWS_SHORT; cell[j] = dry ? 0u : cell[j]; }     // (uniform branch, never taken on a complete stream)
-            const u32 c = (u32)__popcll(hm);
-            pre += c; w_hit += c;
+            for (int j = 0; j < K1S_IPT; ++j) { hm[j] = __ballot(cell[j] != 0); H += (u32)__popcll(hm[j]); }
+            w_hit += H;
+            u32 pre = 0;                                                   // hits of the unit in front of item j
+#pragma unroll
+            for (int j = 0; j < K1S_IPT; ++j) {
+                const u32 rl = pre + rank_below(hm[j]);                    // local hit rank (meaningful on hit lanes)
+                const u32 bpos = sbit + rl;                                // < 32 + 256: words 0..8
+                keep[j] = ((u32)__builtin_amdgcn_ds_bpermute((int)((bpos >> 5) << 2), (int)dw) >> (bpos & 31u)) & 1u;    // (only read where cell[j] != 0)
+                if (H > avail) cell[j] = rl >= avail ? 0u : cell[j];       // (uniform, never on a complete stream) a hit beyond the stream: dropped
+                pre += (u32)__popcll(hm[j]);
+            }
+            if (H > avail) errs |= (u32)ERR_DRAWS_SHORT;
         }
         // ---- E8: gene lookup in LDS ----
         // straight-line: every lane reads the table (index 0 when it has no business there) and the result is selected — an
@@ -1186,8 +1206,8 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
             bool alive = (cell[j] != 0) & (keep[j] != 0);
             w_samp += (u32)__popcll(__ballot(alive));                                      // E6
             alive = alive & (feat[j] != 0) & ((meta[j] & META_HAS_UB) != 0);
-            if (__ballot(alive & umi_overflows(p.L, umi[j], meta[j]))) errs |= (u32)ERR_UMI_TOOLONG;      // (uniform branch, never taken on good data)
-            key[j] = alive ? make_key(p.L, cell[j], feat[j], umi[j], meta[j]) : 0;
+            if (__ballot(alive & umi_overflows_flat(p.L, umi[j], meta[j]))) errs |= (u32)ERR_UMI_TOOLONG;      // (uniform branch, never taken on good data)
+            key[j] = make_key_flat(p.L, cell[j], feat[j], umi[j], meta[j]);                // (stored where alive only)
             em[j] = __ballot(alive);
             n_keys += (u32)__popcll(em[j]);
         }
