@@ -270,7 +270,7 @@ static int multi_retire_chunk(fastf_multi* m) {
                 HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
                 HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)
             }
-            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(256), 0, mg.e->s_compute, (u32*)mg.d_mt.p, (u32*)mg.d_ring.p, base, hits, (u64)(mg.ring_len - 1),
+            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(MT_BITS_THREADS), 0, mg.e->s_compute, (u32*)mg.d_mt.p, (u32*)mg.d_ring.p, base, hits, (u64)(mg.ring_len - 1),
                                mg.e->threshold);
             HIP_OK(hipGetLastError());
         }

@@ -1260,7 +1260,7 @@ static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSourc
         // their decisions in the ring (on a stream of its own: one workgroup walks the stream block by block, about a
         // nanosecond per two draws — beside the record copies, not in front of them; K1 waits for both)
         if (e->draws_up < upto) {
-            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(256), 0, e->s_mt, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up,
+            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(MT_BITS_THREADS), 0, e->s_mt, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up,
                                (u64)(upto - e->draws_up), (u64)(e->ring_len - 1), e->threshold);
             HIP_OK(hipGetLastError());
             HIP_OK(hipEventRecord(e->ev_mt, e->s_mt));
@@ -1449,10 +1449,10 @@ extern "C" int fastf_debug_mt_fill(int device, uint32_t seed, uint64_t skip, con
 
 // test hook: the product form of the same kernel — the DECISIONS (draw < threshold) of the stream from init_genrand(seed)
 // advanced by `skip` draws, n_calls launches of counts[i] draws each, the first of them at absolute rank `first`, into a ring of
-// ring_bits bits (a power of two >= 32) that starts out as 0xFF bytes; the ring's words into out (ring_bits / 32 words)
+// ring_bits bits (a power of two >= 64) that starts out as 0xFF bytes; the ring's words into out (ring_bits / 32 words)
 extern "C" int fastf_debug_mt_fill_bits(int device, uint32_t seed, uint64_t skip, uint64_t first, const uint64_t* counts, uint32_t n_calls,
                                         uint64_t threshold, uint64_t ring_bits, uint32_t* out) FASTF_TRY {
-    if (ring_bits < 32 || (ring_bits & (ring_bits - 1))) return set_err("ring_bits must be a power of two >= 32");
+    if (ring_bits < 64 || (ring_bits & (ring_bits - 1))) return set_err("ring_bits must be a power of two >= 64");
     HIP_OK(hipSetDevice(device));
     fastf_mt_t mt; fastf_mt_seed(&mt, seed); fastf_mt_skip(&mt, skip);
     DevBuf st, buf;
@@ -1462,7 +1462,7 @@ extern "C" int fastf_debug_mt_fill_bits(int device, uint32_t seed, uint64_t skip
         if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess || hipMemset(buf.p, 0xFF, ring_bits / 8) != hipSuccess) { rc = set_err("copy failed"); break; }
         u64 at = first;
         for (u32 i = 0; i < n_calls; ++i) {
-            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ring_bits - 1, threshold);
+            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(MT_BITS_THREADS), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ring_bits - 1, threshold);
             at += counts[i];
         }
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }

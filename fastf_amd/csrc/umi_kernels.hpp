@@ -132,9 +132,9 @@ __global__ void clear_bits_kernel(u64* word, u64 mask) { atomicAnd(word, ~mask);
 // What K1b wants from a draw is ONE BIT — keep the read iff genrand_real1() <= rate, i.e. draw < threshold
 // (bam2db_ds.c:385-390, fastf_depth_threshold) — so that bit is what the product form (BITS) writes: the DECISION STREAM,
 // bit (r & 31) of word ((r & mask) >> 5) for absolute hit rank r.  K1b then reads 1/32 of the bytes per hit (configs[2]:
-// 0.72 GB of draws per 200 M records become 23 MB) and one word per lane and unit instead of four.  The bits of a block gather
-// in LDS (one ballot per wave and sweep, three LDS atomics) and go out as whole words; a word that straddles two blocks —
-// or two launches — is carried.  BITS = false writes the tempered words themselves to out[(first + i) & mask]
+// 0.72 GB of draws per 200 M records become 23 MB) and one word per lane and unit instead of four.  A wave's ballot is one
+// whole 64-bit word of the ring (see the kernel); a word that straddles two blocks — or two launches — is carried.  The ring
+// holds a multiple of 64 decisions.  BITS = false writes the tempered words themselves to out[(first + i) & mask]
 // (fastf_debug_mt_fill: the stream checked word for word against the reference's generator).
 // ------------------------------------------------------------------------------------
 constexpr u32 MT_N = 624, MT_M = 397;
@@ -146,105 +146,108 @@ __device__ __forceinline__ u32 mt_temper(u32 y) {
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     return y;
 }
-constexpr u32 MT_SEG_WORDS = 24;                             // decision words of one block: (31 + 624 + 31) / 32, and two of slack for a wave's deposit
-// the decisions of 64 consecutive stream positions (bit l of m: position o + l of the segment) into the segment's LDS words
-__device__ __forceinline__ void mt_deposit(u32* seg, u32 o, u64 m, int lane) {
-    const u32 wi = o >> 5, sh = o & 31u;
-    const u64 lo = m << sh;
-    const u32 hi = sh ? (u32)(m >> (64u - sh)) : 0u;
-    const u32 piece = lane == 0 ? (u32)lo : lane == 1 ? (u32)(lo >> 32) : hi;
-    if (lane < 3 && piece) (void)__hip_atomic_fetch_or(&seg[wi + (u32)lane], piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+// waves that hand out decisions beside the four that regenerate the state (BITS): 12 take one 64-bit ring word of a block each
+#ifndef FASTF_MT_EMIT_WAVES
+#define FASTF_MT_EMIT_WAVES 12
+#endif
+constexpr u32 MT_SWEEP_THREADS = 256, MT_EMIT_WAVES = FASTF_MT_EMIT_WAVES, MT_BITS_THREADS = MT_SWEEP_THREADS + MT_EMIT_WAVES * WAVE;
+static_assert(MT_EMIT_WAVES * WAVE >= MT_N + 63 && MT_BITS_THREADS <= 1024, "the emitting waves cover a block at any alignment");
 template <bool BITS>
-__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask, u64 threshold) {
+__global__ __launch_bounds__(BITS ? MT_BITS_THREADS : MT_SWEEP_THREADS) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask, u64 threshold) {
     // two copies of the state: a block is regenerated FROM one INTO the other, so a sweep never overwrites what it still
-    // reads: three barriers per block.  A word goes out the moment it is computed — no second pass over the block; only
-    // what is left of the block the kernel starts in is handed out by a loop of its own.
-    // BITS: two copies of the segment's decision words as well.  Segment g (the rest of the first block, then every block)
-    // gathers in sb[g & 1]; after its last barrier the whole words are stored and the partial last word is OR-ed into word 0
-    // of the other copy, which was cleared one barrier interval earlier (during sweep 2) — no barrier of its own.
+    // reads: three barriers per block.  The first 256 threads do that.
+    // BITS = false: a word goes out (tempered, to its rank's ring slot) the moment it is computed; only what is left of the
+    // block the kernel starts in is handed out by a loop of its own.
+    // BITS = true: the decisions of a block go out one block LATE and by OTHER WAVES — while the next block is being
+    // generated its source is complete and read-only, so the emitting waves take the block's words in RING order instead of
+    // state order: the lanes of emitting wave e look at ring positions (block's first rank rounded down to 64) + 64 e ..
+    // + 64 e + 63, the wave's ballot is one whole 64-bit word of the ring, and lane 0 stores it — eleven 8-byte stores per
+    // block, no atomics, and nothing added to the path of the four waves the three barriers wait for (tempering and
+    // packing inside those waves took the kernel from 1.7 to 0.7 G draws/s; profiles/r4_notes/mt_fill_decisions.txt).
+    // The word two consecutive blocks (or launches) share travels through LDS (s_carry, two slots by turns) and is stored
+    // by the block that completes it.
+    constexpr u32 THREADS = BITS ? MT_BITS_THREADS : MT_SWEEP_THREADS;
     __shared__ u32 buf[2][MT_N];
-    __shared__ u32 sb[2][MT_SEG_WORDS];
+    __shared__ u64 s_carry[2];
     const u32 tid = threadIdx.x;
     const int lane = lane_id();
-    const u32 kb = tid & ~63u;                               // stream position of this wave's lane 0 inside a sweep
-    const u64 wmask = mask >> 5;
-    for (u32 i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
-    // (word 0 of the first segment: the word the stream stands in, if the launch before left it partial)
-    if (BITS && tid < 2 * MT_SEG_WORDS) (&sb[0][0])[tid] = (tid == 0 && (first & 31u)) ? out[(first >> 5) & wmask] & ((1u << (first & 31u)) - 1u) : 0u;
+    const bool sweeper = tid < MT_SWEEP_THREADS;             // (wave-uniform)
+    const u64 wmask64 = mask >> 6;
+    u64* const out64 = reinterpret_cast<u64*>(out);
+    for (u32 i = tid; i < MT_N; i += THREADS) buf[0][i] = state[i];
+    // (slot 1 feeds segment 0: the word the stream stands in, if the launch before left it partial)
+    if (BITS && tid == 0) { s_carry[0] = 0; s_carry[1] = (first & 63u) ? out64[(first >> 6) & wmask64] & ((1ull << (first & 63u)) - 1ull) : 0ull; }
     u32 idx = state[MT_N];
     u32 cur = 0;                                             // buf[cur] holds the current block
-    u32 sc = 0;                                              // sb[sc] gathers the current segment
     __syncthreads();
-    // store the whole words of a finished segment [at, at + len), carry its partial last word (after the segment's last barrier)
-    auto flush = [&](const u64 at, const u32 len) {
-        const u32 s = (u32)at & 31u, full = (s + len) >> 5;
-        if (tid < full) out[((at >> 5) + tid) & wmask] = sb[sc][tid];
-        if (tid == full && ((s + len) & 31u) && sb[sc][full]) (void)__hip_atomic_fetch_or(&sb[sc ^ 1][0], sb[sc][full], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // an emitting wave's share of handing out src[k_lo .. k_lo + len) as the decisions of the ranks R0 .. R0 + len (sg numbers
+    // the segments of the launch), in three steps — read, temper and pack, store — one per phase of the block being generated
+    // meanwhile, each shorter than the sweep beside it: the barriers are paced by the sweeps
+    struct Emit { u32 w0, sp, end, word; u64 base, carry, m; bool in; };
+    auto emit_read = [&](Emit& e, const u32* src, const u32 k_lo, const u32 len, const u64 R0, const u32 sg) {
+        e.base = R0 & ~63ull;
+        e.sp = (u32)(R0 - e.base); e.end = e.sp + len;       // the segment's positions relative to base: [sp, end)
+        e.w0 = WAVE * ((tid - MT_SWEEP_THREADS) >> 6);       // first position of this wave's word
+        const u32 pos = e.w0 + (u32)lane;
+        e.in = pos >= e.sp && pos < e.end;
+        e.word = e.w0 < e.end ? src[k_lo + (e.in ? pos - e.sp : 0u)] : 0u;
+        e.carry = s_carry[(sg ^ 1u) & 1u];
+    };
+    auto emit_pack = [&](Emit& e) { e.m = __ballot(e.in && (u64)mt_temper(e.word) < threshold); };
+    auto emit_store = [&](const Emit& e, const u32 sg) {
+        if (e.w0 >= e.end || lane != 0) return;              // (a wave behind the segment has nothing to store)
+        const u64 v = e.m | (e.w0 < e.sp ? e.carry : 0ull);  // the segment's first word: the bits of the segment before it
+        if (e.w0 + 64u > e.end) s_carry[sg & 1u] = v;        // its last word, not full: the next segment (or the end of the launch) completes it
+        else out64[((e.base >> 6) + (e.w0 >> 6)) & wmask64] = v;
     };
     u64 done = 0;
+    u32 sg = 0;                                              // segments handed out so far
     if (idx < MT_N && count) {                               // the rest of the block the stream stands in
         const u32 take = (u32)(count < (u64)(MT_N - idx) ? count : (u64)(MT_N - idx));
         if (BITS) {
-            for (u32 i0 = 0; i0 < take; i0 += 256) {         // (uniform)
-                const u32 i = i0 + tid;
-                const u64 m = __ballot(i < take && (u64)mt_temper(buf[0][idx + (i < take ? i : 0u)]) < threshold);
-                mt_deposit(sb[0], ((u32)first & 31u) + i0 + kb, m, lane);
-            }
-            __syncthreads();
-            flush(first, take);
-            sc = 1;
+            if (!sweeper) { Emit e; emit_read(e, buf[0], idx, take, first, sg); emit_pack(e); emit_store(e, sg); }
+            ++sg;
         } else {
-            for (u32 i = tid; i < take; i += 256) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
+            for (u32 i = tid; i < take; i += THREADS) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
         }
         idx += take; done = take;
     }
+    bool have_prev = false; u32 prev_len = 0, prev_sg = 0; u64 prev_R0 = 0;    // BITS: the block generated last, still to be handed out
+    Emit em{};
     while (done < count) {                                   // (uniform) whole blocks; the last one may be handed out in part
         const u32* o = buf[cur]; u32* n = buf[cur ^ 1];
         const u64 left = count - done;                       // words of this block that go out: k < left
         const u64 at = first + done;
-        const u32 s = (u32)at & 31u;
         // sweep 1: k = 0..226   n[k] = o[k + 397] ^ mix(o[k], o[k + 1])
-        {
-            u32 v = 0;
-            if (tid < MT_N - MT_M) { v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; }
-            if (BITS) mt_deposit(sb[sc], s + kb, __ballot(tid < MT_N - MT_M && tid < left && (u64)mt_temper(v) < threshold), lane);
-            else if (tid < MT_N - MT_M && tid < left) out[(at + tid) & mask] = mt_temper(v);
-        }
+        if (tid < MT_N - MT_M) { const u32 v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; if (!BITS && tid < left) out[(at + tid) & mask] = mt_temper(v); }
+        if (BITS && !sweeper && have_prev) emit_read(em, o, 0, prev_len, prev_R0, prev_sg);
         __syncthreads();
         // sweep 2: k = 227..453  n[k] = n[k - 227] ^ mix(o[k], o[k + 1])
-        {
-            const u32 k2 = tid + (MT_N - MT_M);
-            u32 v = 0;
-            if (tid < MT_N - MT_M) { v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; }
-            if (BITS) {
-                mt_deposit(sb[sc], s + (MT_N - MT_M) + kb, __ballot(tid < MT_N - MT_M && k2 < left && (u64)mt_temper(v) < threshold), lane);
-                if (tid < MT_SEG_WORDS) sb[sc ^ 1][tid] = 0;   // the next segment's copy: its words were stored before this block's first barrier
-            } else if (tid < MT_N - MT_M && k2 < left) out[(at + k2) & mask] = mt_temper(v);
-        }
+        const u32 k2 = tid + (MT_N - MT_M);
+        if (tid < MT_N - MT_M) { const u32 v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; if (!BITS && k2 < left) out[(at + k2) & mask] = mt_temper(v); }
+        if (BITS && !sweeper && have_prev) emit_pack(em);
         __syncthreads();
         // sweep 3: k = 454..622 the same with n[k - 227] from sweep 2; k = 623: n[623] = n[396] ^ mix(o[623], n[0])
-        {
-            const u32 k3 = tid + 2 * (MT_N - MT_M);
-            u32 v = 0;
-            if (k3 < MT_N) {
-                v = k3 < MT_N - 1 ? n[k3 - (MT_N - MT_M)] ^ mt_mix(o[k3], o[k3 + 1]) : n[MT_M - 1] ^ mt_mix(o[MT_N - 1], n[0]);
-                n[k3] = v;
-            }
-            if (BITS) mt_deposit(sb[sc], s + 2 * (MT_N - MT_M) + kb, __ballot(k3 < MT_N && k3 < left && (u64)mt_temper(v) < threshold), lane);
-            else if (k3 < MT_N && k3 < left) out[(at + k3) & mask] = mt_temper(v);
+        const u32 k3 = tid + 2 * (MT_N - MT_M);
+        if (sweeper && k3 < MT_N) {
+            const u32 v = k3 < MT_N - 1 ? n[k3 - (MT_N - MT_M)] ^ mt_mix(o[k3], o[k3 + 1]) : n[MT_M - 1] ^ mt_mix(o[MT_N - 1], n[0]);
+            n[k3] = v;
+            if (!BITS && k3 < left) out[(at + k3) & mask] = mt_temper(v);
         }
+        if (BITS && !sweeper && have_prev) emit_store(em, prev_sg);
         __syncthreads();
         cur ^= 1;
         idx = (u32)(left < (u64)MT_N ? left : (u64)MT_N);
-        if (BITS) { flush(at, idx); sc ^= 1; }
+        if (BITS) { have_prev = true; prev_len = idx; prev_R0 = at; prev_sg = sg++; }
         done += idx;
     }
-    for (u32 i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
+    for (u32 i = tid; i < MT_N; i += THREADS) state[i] = buf[cur][i];
     if (tid == 0) state[MT_N] = idx;
     if (BITS) {
-        __syncthreads();                                     // the carry of the last segment
-        if (tid == 0 && ((first + count) & 31u) && count) out[((first + count) >> 5) & wmask] = sb[sc][0];
+        if (!sweeper && have_prev) { emit_read(em, buf[cur], 0, prev_len, prev_R0, prev_sg); emit_pack(em); emit_store(em, prev_sg); }   // the last block
+        __syncthreads();
+        // the word the launch ends in, if it is not full: the next launch reads it back and completes it
+        if (tid == 0 && count && ((first + count) & 63u)) out64[((first + count) >> 6) & wmask64] = s_carry[(sg - 1u) & 1u];
     }
 }
 

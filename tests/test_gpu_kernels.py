@@ -296,12 +296,14 @@ def test_device_mt19937_is_the_reference_stream(env, seed, skip, counts):
     (926, 25_000, 13, [3, 50_000, 0, 31, 1, 32, 33, 1_000_003], 0.5, 1 << 21),      # launches that start and end inside a word
     (0x39e, 624 * 1000 - 1, 4095, [1, 1, 624 * 3, 5, 59, 64], 0.123, 4096),         # the ring wraps inside the third launch
     (1, 623, 31, [2_000_000], 0.9, 1 << 21),
-    (7, 5, 1000, [40, 700, 3], 1.0, 1024),                                          # rate 1: the threshold is 2^32, every bit set
+    (7, 5, 1000, [40, 700, 3], 1.0, 1024),
+    (11, 0, 63, [1, 1, 62, 64, 65, 127, 1, 623, 625], 0.7, 1 << 13),                # words that take several launches to fill
+    (12, 300, 5, [5, 2, 1, 0, 3], 0.3, 64),                                         # a ring of one word                                          # rate 1: the threshold is 2^32, every bit set
 ])
 def test_device_decision_stream(env, seed, skip, first, counts, rate, ring_bits):
     """mt_fill_kernel<true> — what K1b reads: bit (r & 31) of ring word (r mod ring) >> 5 = draw (r - first) < threshold, for every
-    absolute rank r the launches cover; the bits gather per block in LDS, whole words are stored, the word a block or a launch
-    ends in is carried.  Ranks never written keep the 0xFF the hook fills the ring with, except the zero tail of the last word."""
+    absolute rank r the launches cover; a wave's ballot is a whole 64-bit word of the ring, the word a block or a launch ends in
+    is carried.  Ranks never written keep the 0xFF the hook fills the ring with, except the zero tail of the last word."""
     import ctypes as C
     torch, F, eng = env
     from fastf_amd import _lib
@@ -314,12 +316,12 @@ def test_device_decision_stream(env, seed, skip, first, counts, rate, ring_bits)
     assert L.fastf_debug_mt_fill_bits(0, seed, skip, first, cs.ctypes.data, len(counts), thr, ring_bits, out.ctypes.data) == 0, L.fastf_last_error()
     got = np.unpackbits(out.view(np.uint8), bitorder="little")
     want = (F.mt_draws(seed, skip, n).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
-    keep = min(n, ring_bits - 32)                      # the newest ranks; older ones may have been overwritten by the wrap
+    keep = min(n, ring_bits - 64)                      # the newest ranks; older ones may have been overwritten by the wrap
     r = np.arange(first + n - keep, first + n, dtype=np.uint64)
     np.testing.assert_array_equal(got[(r % np.uint64(ring_bits)).astype(np.int64)], want[n - keep:])
     end = first + n
-    if end % 32 and keep == n and n < ring_bits - 64:
-        tail = np.arange(end, (end // 32 + 1) * 32, dtype=np.uint64) % np.uint64(ring_bits)
-        assert not got[tail.astype(np.int64)].any()                                  # the rest of the last word: zeros
-        beyond = np.arange((end // 32 + 1) * 32, (end // 32 + 2) * 32, dtype=np.uint64) % np.uint64(ring_bits)
+    if end % 64 and keep == n and n < ring_bits - 128:
+        tail = np.arange(end, (end // 64 + 1) * 64, dtype=np.uint64) % np.uint64(ring_bits)
+        assert not got[tail.astype(np.int64)].any()                                  # the rest of the last 64-bit word: zeros
+        beyond = np.arange((end // 64 + 1) * 64, (end // 64 + 2) * 64, dtype=np.uint64) % np.uint64(ring_bits)
         assert got[beyond.astype(np.int64)].all()                                    # the word after it: untouched
