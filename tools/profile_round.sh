@@ -15,5 +15,8 @@ keys=$(grep '^{"metric"' $out/stats.log | tail -1 | python3 -c "import json,sys;
 recs=$(grep '^{"metric"' $out/stats.log | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['counters']['total'])")
 python3 tools/prof_summary.py $tag $out/stats $out/fetch $out/write $keys $recs > $out/summary.json
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) profiles/${tag}_rocprofv3_kernel_stats_raw.csv
+# the bench line of the PROFILED command itself: its HIP-event kernel times are the ones the rocprofv3 averages must agree with
+# (kernels run a few per cent slower under the tracer than in the plain run below)
+grep '^{"metric"' $out/stats.log | tail -1 > profiles/${tag}_bench_line_under_rocprofv3.json
 python3 bench.py --steps 100 --warmup 3 > profiles/${tag}_bench_line.json 2> $out/bench.err
 echo "profiles/${tag}_* written"
