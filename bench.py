@@ -233,7 +233,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: %d synthetic records, 10000 barcodes x 30000 genes, --cell 1.0 --depth 1.0 --seed 926, "
                                     "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (%s + the draw stream%s); the step ends at K3's segmented rows (rows_gather, which concatenates them where they are wanted — in the product it IS the device-to-host copy — is timed on its own line)" % ("cb array + blocked gx|umi|meta runs, the engine's staging layout" if blk is not None else "packed SoA",
-                                                                                           " as 32-bit draws, turned into decisions every step" if args.draw_words else " as K1b reads it: one keep/drop decision bit per CB hit, what mt_fill_kernel writes in the product; K1b's algorithmic bytes still count 4 bytes per hit (SURVEY 8d)"),
+                                                                                           " as 32-bit draws, turned into decisions every step" if args.draw_words else " as K1b reads it: one keep/drop decision bit per CB hit, what mt_fill_kernel + draw_bits_kernel leave in the ring in the product; K1b's algorithmic bytes still count 4 bytes per hit (SURVEY 8d)"),
                        "record_layout": "blocked" if blk is not None else "soa",
                        "records_per_gpu": n_local, "key_bits": eng.key_bits, "radix_passes_nominal": P_nom,
                        "radix_passes_executed": P_exe,

@@ -35,7 +35,7 @@ struct MultiDev {
     // the draw stream on the device: EVERY device continues the one MT19937 stream by the hits of EVERY chunk, in stream order
     // (mt_fill_kernel on its compute stream: a few hundred microseconds per chunk), into a ring of decisions addressed by absolute hit rank,
     // so the draws of its own chunks are there when its K1b runs and nothing about them crosses PCIe or waits for a host loop
-    DevBuf d_mt, d_ring; u64 ring_len = 0;
+    DevBuf d_mt, d_ring, d_mtwords; u64 ring_len = 0;
     u64* h_base[2] = {nullptr, nullptr};       // pinned: absolute hit-rank base of the chunk in that slot (copied beside the K1b launch)
     u64* h_cnt[2] = {nullptr, nullptr};        // pinned snapshot of the sub-engine's d_small behind that slot's K1a
     int next_slot = 0;
@@ -127,7 +127,7 @@ static void multi_destroy(fastf_engine* e) {
         if (md.ev_sent) (void)hipEventDestroy(md.ev_sent);
         if (md.h_info) (void)hipHostFree(md.h_info);
         multi_free_old_shards(md);
-        DevBuf* all[] = {&md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy, &md.d_mt, &md.d_ring};
+        DevBuf* all[] = {&md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy, &md.d_mt, &md.d_ring, &md.d_mtwords};
         for (DevBuf* b : all) b->release();
         if (md.e) fastf_engine_destroy(md.e);
     }
@@ -270,8 +270,7 @@ static int multi_retire_chunk(fastf_multi* m) {
                 HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
                 HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)
             }
-            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(MT_BITS_THREADS), 0, mg.e->s_compute, (u32*)mg.d_mt.p, (u32*)mg.d_ring.p, base, hits, (u64)(mg.ring_len - 1),
-                               mg.e->threshold);
+            if (launch_mt_decisions(mg.e->s_compute, (u32*)mg.d_mt.p, mg.d_mtwords, (u32*)mg.d_ring.p, base, hits, mg.ring_len - 1, mg.e->threshold)) return 1;
             HIP_OK(hipGetLastError());
         }
         if (hits) m->mt_uploaded = true;

@@ -139,6 +139,7 @@ struct fastf_engine {
     DevBuf d_ring; u64 ring_len = 0;     // the decision stream: ring_len bits (u32[ring_len / 32]), ring_len a power of two
     u32 ring_carry = 0;                  // host-packed decisions: the bits of the word draws_up stands in (below bit draws_up & 31)
     DevBuf d_dbits;                      // device-level calls that bring 32-bit draws: their decisions (draw_bits_kernel)
+    DevBuf d_mtwords;                    // the generator's words of one launch, between mt_fill_kernel and draw_bits_kernel
     DevBuf d_mt; bool mt_on_device = false;  // the engine-owned stream continues on the device (mt_fill_kernel): state words + read index
     u64 draws_up = 0;                    // absolute ranks below this are (being) uploaded
     u64 draws_valid = 0;                 // ranks below this carry a real draw (caller-supplied streams can run short)
@@ -552,7 +553,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
-    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release();
+    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp};
@@ -781,18 +782,32 @@ extern "C" int fastf_dev_count_hits_blocked(fastf_engine_t* e, const uint64_t* d
     return launch_probe_cells(e, (const u64*)d_cb_key, n, (u64*)d_hits_out, s, nullptr, nullptr, d_blocked);
 } FASTF_CATCH_INT
 
-static int launch_draw_bits(fastf_engine* e, const u32* d_draws, u64 n, u32* d_bits, hipStream_t s) {
+// draws[i] < threshold as bit (first + i) of a ring of decisions (ring_mask = bits - 1; ~0: a linear array that starts at bit 0)
+static int launch_draw_bits(u64 threshold, const u32* d_draws, u64 n, u32* d_bits, hipStream_t s, u64 first = 0, u64 ring_mask = ~0ull) {
     if (n == 0) return 0;
-    const u32 grid = (u32)std::min<u64>((n + 255) / 256, 8ull * g_cu_count);
-    hipLaunchKernelGGL(draw_bits_kernel, dim3(grid), dim3(256), 0, s, d_draws, n, e->threshold, d_bits);
+    const u32 grid = (u32)std::min<u64>((n + 255) / 256 + 1, 8ull * g_cu_count);
+    hipLaunchKernelGGL(draw_bits_kernel, dim3(grid), dim3(256), 0, s, d_draws, n, threshold, d_bits, first, ring_mask);
     HIP_OK(hipGetLastError());
     return 0;
+}
+// continue the MT19937 stream in d_mt by `count` draws and leave their DECISIONS at the ranks first .. first + count of the ring:
+// the generator writes words into `words` (grown to fit), draw_bits_kernel packs them behind it on the same stream
+static int launch_mt_decisions(hipStream_t s, u32* d_mt, DevBuf& words, u32* d_ring, u64 first, u64 count, u64 ring_mask, u64 threshold) {
+    if (count == 0) return 0;
+    if (words.bytes < count * 4) {
+        // (the launches that read the old buffer are queued on this stream: let them finish before it is freed)
+        if (words.p) HIP_OK(hipStreamSynchronize(s));
+        if (words.ensure(std::max<u64>(count * 4, 1u << 20))) return 1;
+    }
+    hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, s, d_mt, (u32*)words.p, 0ull, count, ~0ull);
+    HIP_OK(hipGetLastError());
+    return launch_draw_bits(threshold, (const u32*)words.p, count, d_ring, s, first, ring_mask);
 }
 extern "C" int fastf_dev_draw_bits(fastf_engine_t* e, const uint32_t* d_draws, uint64_t n_draws, uint32_t* d_bits_out, void* stream) FASTF_TRY {
     if (!e || (n_draws && (!d_draws || !d_bits_out))) return set_err("null argument");
     if (e->multi) return set_err("fastf_dev_draw_bits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
-    return launch_draw_bits(e, d_draws, n_draws, d_bits_out, (hipStream_t)stream);
+    return launch_draw_bits(e->threshold, d_draws, n_draws, d_bits_out, (hipStream_t)stream);
 } FASTF_CATCH_INT
 
 #define NO_WIDE(e, what) do { if ((e)->wide) return set_err(what ": this engine's keys are wider than 64 bits — the device-level calls take keys of at most 64 bits (the host-buffer API handles wide keys)"); } while (0)
@@ -900,8 +915,8 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
     if (!(flags & FASTF_PROBE_DRAW_BITS) && n && n_draws) {
         // 32-bit draws: K1b reads decisions — one pass over the draws on the caller's stream first (a caller that runs the same
         // stream again and again converts it once with fastf_dev_draw_bits and passes FASTF_PROBE_DRAW_BITS)
-        if (e->d_dbits.ensure(((n_draws + 31) / 32) * 4)) return 1;
-        if (launch_draw_bits(e, d_draws, n_draws, (u32*)e->d_dbits.p, (hipStream_t)stream)) return 1;
+        if (e->d_dbits.ensure(((n_draws + 63) / 64) * 8)) return 1;
+        if (launch_draw_bits(e->threshold, d_draws, n_draws, (u32*)e->d_dbits.p, (hipStream_t)stream)) return 1;
         d_draws = (const uint32_t*)e->d_dbits.p;
     }
     return launch_probe(e, (const u64*)d_cb_key, blocked ? nullptr : (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws,
@@ -1260,9 +1275,7 @@ static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSourc
         // their decisions in the ring (on a stream of its own: one workgroup walks the stream block by block, about a
         // nanosecond per two draws — beside the record copies, not in front of them; K1 waits for both)
         if (e->draws_up < upto) {
-            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(MT_BITS_THREADS), 0, e->s_mt, (u32*)e->d_mt.p, (u32*)e->d_ring.p, (u64)e->draws_up,
-                               (u64)(upto - e->draws_up), (u64)(e->ring_len - 1), e->threshold);
-            HIP_OK(hipGetLastError());
+            if (launch_mt_decisions(e->s_mt, (u32*)e->d_mt.p, e->d_mtwords, (u32*)e->d_ring.p, e->draws_up, upto - e->draws_up, e->ring_len - 1, e->threshold)) return 1;
             HIP_OK(hipEventRecord(e->ev_mt, e->s_mt));
             HIP_OK(hipStreamWaitEvent(e->s_compute, e->ev_mt, 0));
             e->draws_up = upto;
@@ -1437,7 +1450,7 @@ extern "C" int fastf_debug_mt_fill(int device, uint32_t seed, uint64_t skip, con
         if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess) { rc = set_err("copy failed"); break; }
         u64 at = 0;
         for (u32 i = 0; i < n_calls; ++i) {
-            hipLaunchKernelGGL(mt_fill_kernel<false>, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ~0ull, 0ull);
+            hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ~0ull);
             at += counts[i];
         }
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
@@ -1447,7 +1460,7 @@ extern "C" int fastf_debug_mt_fill(int device, uint32_t seed, uint64_t skip, con
     return rc;
 } FASTF_CATCH_INT
 
-// test hook: the product form of the same kernel — the DECISIONS (draw < threshold) of the stream from init_genrand(seed)
+// test hook: what the product does with that kernel (launch_mt_decisions) — the DECISIONS (draw < threshold) of the stream from init_genrand(seed)
 // advanced by `skip` draws, n_calls launches of counts[i] draws each, the first of them at absolute rank `first`, into a ring of
 // ring_bits bits (a power of two >= 64) that starts out as 0xFF bytes; the ring's words into out (ring_bits / 32 words)
 extern "C" int fastf_debug_mt_fill_bits(int device, uint32_t seed, uint64_t skip, uint64_t first, const uint64_t* counts, uint32_t n_calls,
@@ -1455,20 +1468,20 @@ extern "C" int fastf_debug_mt_fill_bits(int device, uint32_t seed, uint64_t skip
     if (ring_bits < 64 || (ring_bits & (ring_bits - 1))) return set_err("ring_bits must be a power of two >= 64");
     HIP_OK(hipSetDevice(device));
     fastf_mt_t mt; fastf_mt_seed(&mt, seed); fastf_mt_skip(&mt, skip);
-    DevBuf st, buf;
+    DevBuf st, buf, words;
     int rc = 0;
     do {
         if (st.ensure(sizeof mt) || buf.ensure(ring_bits / 8)) { rc = 1; break; }
         if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess || hipMemset(buf.p, 0xFF, ring_bits / 8) != hipSuccess) { rc = set_err("copy failed"); break; }
         u64 at = first;
         for (u32 i = 0; i < n_calls; ++i) {
-            hipLaunchKernelGGL(mt_fill_kernel<true>, dim3(1), dim3(MT_BITS_THREADS), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ring_bits - 1, threshold);
+            if (launch_mt_decisions((hipStream_t)0, (u32*)st.p, words, (u32*)buf.p, at, counts[i], ring_bits - 1, threshold)) { rc = 1; break; }
             at += counts[i];
         }
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
         if (hipMemcpy(out, buf.p, ring_bits / 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy back failed"); break; }
     } while (0);
-    st.release(); buf.release();
+    st.release(); buf.release(); words.release();
     return rc;
 } FASTF_CATCH_INT
 

@@ -125,17 +125,17 @@ __global__ void clear_bits_kernel(u64* word, u64 mask) { atomicAnd(word, ~mask);
 // MT19937 on the device (mt19937ar.c:105-140): the depth draws of the CB hits (bam2db_ds.c:385) are generated where they are
 // consumed — no host loop (about a nanosecond per draw on one core), no bytes per hit over PCIe.  One workgroup continues
 // the stream held in `state` (the 624 words + the read index, fastf_mt_t's layout: the host seeds and skips, rarely) by
-// `count` draws.  A block of 624 words is regenerated in three dependent sweeps — words 0..226 need old words only, 227..453
-// the new 0..226, 454..623 the new 227..396 (and word 623 the new word 0) — each sweep reading everything it needs before any
-// of it is overwritten.
+// `count` draws and writes the tempered values to out[(first + i) & mask].  A block of 624 words is regenerated in three
+// dependent sweeps — words 0..226 need old words only, 227..453 the new 0..226, 454..623 the new 227..396 (and word 623 the
+// new word 0) — each sweep reading everything it needs before any of it is overwritten.
 //
 // What K1b wants from a draw is ONE BIT — keep the read iff genrand_real1() <= rate, i.e. draw < threshold
-// (bam2db_ds.c:385-390, fastf_depth_threshold) — so that bit is what the product form (BITS) writes: the DECISION STREAM,
-// bit (r & 31) of word ((r & mask) >> 5) for absolute hit rank r.  K1b then reads 1/32 of the bytes per hit (configs[2]:
-// 0.72 GB of draws per 200 M records become 23 MB) and one word per lane and unit instead of four.  A wave's ballot is one
-// whole 64-bit word of the ring (see the kernel); a word that straddles two blocks — or two launches — is carried.  The ring
-// holds a multiple of 64 decisions.  BITS = false writes the tempered words themselves to out[(first + i) & mask]
-// (fastf_debug_mt_fill: the stream checked word for word against the reference's generator).
+// (bam2db_ds.c:385-390, fastf_depth_threshold) — and that bit is what it reads: the DECISION STREAM, bit (r & 31) of 32-bit
+// word ((r & mask) >> 5) for absolute hit rank r (configs[2]: 0.72 GB of draws per 200 M records become 23 MB, one word per
+// lane and unit instead of four).  The generator's four waves are a serial critical path (three barriers per 624 draws):
+// tempering, comparing and packing inside them, or beside them behind the same barriers, cost more than half its rate
+// (0.65–1.08 against 2.5 G draws/s, profiles/r4_notes/mt_fill_decisions.txt).  So the generator writes plain words into a
+// scratch buffer and draw_bits_kernel — as parallel as one likes — turns them into ring bits behind it on the same stream.
 // ------------------------------------------------------------------------------------
 constexpr u32 MT_N = 624, MT_M = 397;
 __device__ __forceinline__ u32 mt_mix(u32 hi, u32 lo) {
@@ -146,121 +146,69 @@ __device__ __forceinline__ u32 mt_temper(u32 y) {
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     return y;
 }
-// waves that hand out decisions beside the four that regenerate the state (BITS): 12 take one 64-bit ring word of a block each
-#ifndef FASTF_MT_EMIT_WAVES
-#define FASTF_MT_EMIT_WAVES 12
-#endif
-constexpr u32 MT_SWEEP_THREADS = 256, MT_EMIT_WAVES = FASTF_MT_EMIT_WAVES, MT_BITS_THREADS = MT_SWEEP_THREADS + MT_EMIT_WAVES * WAVE;
-static_assert(MT_EMIT_WAVES * WAVE >= MT_N + 63 && MT_BITS_THREADS <= 1024, "the emitting waves cover a block at any alignment");
-template <bool BITS>
-__global__ __launch_bounds__(BITS ? MT_BITS_THREADS : MT_SWEEP_THREADS) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask, u64 threshold) {
+__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
     // two copies of the state: a block is regenerated FROM one INTO the other, so a sweep never overwrites what it still
-    // reads: three barriers per block.  The first 256 threads do that.
-    // BITS = false: a word goes out (tempered, to its rank's ring slot) the moment it is computed; only what is left of the
-    // block the kernel starts in is handed out by a loop of its own.
-    // BITS = true: the decisions of a block go out one block LATE and by OTHER WAVES — while the next block is being
-    // generated its source is complete and read-only, so the emitting waves take the block's words in RING order instead of
-    // state order: the lanes of emitting wave e look at ring positions (block's first rank rounded down to 64) + 64 e ..
-    // + 64 e + 63, the wave's ballot is one whole 64-bit word of the ring, and lane 0 stores it — eleven 8-byte stores per
-    // block, no atomics, and nothing added to the path of the four waves the three barriers wait for (tempering and
-    // packing inside those waves took the kernel from 1.7 to 0.7 G draws/s; profiles/r4_notes/mt_fill_decisions.txt).
-    // The word two consecutive blocks (or launches) share travels through LDS (s_carry, two slots by turns) and is stored
-    // by the block that completes it.
-    constexpr u32 THREADS = BITS ? MT_BITS_THREADS : MT_SWEEP_THREADS;
+    // reads: three barriers per block.  A word goes out (tempered, to its rank's ring slot) the moment it is computed — no
+    // second pass over the block; only what is left of the block the kernel starts in is handed out by a loop of its own.
     __shared__ u32 buf[2][MT_N];
-    __shared__ u64 s_carry[2];
     const u32 tid = threadIdx.x;
-    const int lane = lane_id();
-    const bool sweeper = tid < MT_SWEEP_THREADS;             // (wave-uniform)
-    const u64 wmask64 = mask >> 6;
-    u64* const out64 = reinterpret_cast<u64*>(out);
-    for (u32 i = tid; i < MT_N; i += THREADS) buf[0][i] = state[i];
-    // (slot 1 feeds segment 0: the word the stream stands in, if the launch before left it partial)
-    if (BITS && tid == 0) { s_carry[0] = 0; s_carry[1] = (first & 63u) ? out64[(first >> 6) & wmask64] & ((1ull << (first & 63u)) - 1ull) : 0ull; }
+    for (u32 i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
     u32 idx = state[MT_N];
     u32 cur = 0;                                             // buf[cur] holds the current block
     __syncthreads();
-    // an emitting wave's share of handing out src[k_lo .. k_lo + len) as the decisions of the ranks R0 .. R0 + len (sg numbers
-    // the segments of the launch), in three steps — read, temper and pack, store — one per phase of the block being generated
-    // meanwhile, each shorter than the sweep beside it: the barriers are paced by the sweeps
-    struct Emit { u32 w0, sp, end, word; u64 base, carry, m; bool in; };
-    auto emit_read = [&](Emit& e, const u32* src, const u32 k_lo, const u32 len, const u64 R0, const u32 sg) {
-        e.base = R0 & ~63ull;
-        e.sp = (u32)(R0 - e.base); e.end = e.sp + len;       // the segment's positions relative to base: [sp, end)
-        e.w0 = WAVE * ((tid - MT_SWEEP_THREADS) >> 6);       // first position of this wave's word
-        const u32 pos = e.w0 + (u32)lane;
-        e.in = pos >= e.sp && pos < e.end;
-        e.word = e.w0 < e.end ? src[k_lo + (e.in ? pos - e.sp : 0u)] : 0u;
-        e.carry = s_carry[(sg ^ 1u) & 1u];
-    };
-    auto emit_pack = [&](Emit& e) { e.m = __ballot(e.in && (u64)mt_temper(e.word) < threshold); };
-    auto emit_store = [&](const Emit& e, const u32 sg) {
-        if (e.w0 >= e.end || lane != 0) return;              // (a wave behind the segment has nothing to store)
-        const u64 v = e.m | (e.w0 < e.sp ? e.carry : 0ull);  // the segment's first word: the bits of the segment before it
-        if (e.w0 + 64u > e.end) s_carry[sg & 1u] = v;        // its last word, not full: the next segment (or the end of the launch) completes it
-        else out64[((e.base >> 6) + (e.w0 >> 6)) & wmask64] = v;
-    };
     u64 done = 0;
-    u32 sg = 0;                                              // segments handed out so far
     if (idx < MT_N && count) {                               // the rest of the block the stream stands in
         const u32 take = (u32)(count < (u64)(MT_N - idx) ? count : (u64)(MT_N - idx));
-        if (BITS) {
-            if (!sweeper) { Emit e; emit_read(e, buf[0], idx, take, first, sg); emit_pack(e); emit_store(e, sg); }
-            ++sg;
-        } else {
-            for (u32 i = tid; i < take; i += THREADS) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
-        }
+        for (u32 i = tid; i < take; i += 256) out[(first + i) & mask] = mt_temper(buf[0][idx + i]);
         idx += take; done = take;
     }
-    bool have_prev = false; u32 prev_len = 0, prev_sg = 0; u64 prev_R0 = 0;    // BITS: the block generated last, still to be handed out
-    Emit em{};
     while (done < count) {                                   // (uniform) whole blocks; the last one may be handed out in part
         const u32* o = buf[cur]; u32* n = buf[cur ^ 1];
         const u64 left = count - done;                       // words of this block that go out: k < left
         const u64 at = first + done;
         // sweep 1: k = 0..226   n[k] = o[k + 397] ^ mix(o[k], o[k + 1])
-        if (tid < MT_N - MT_M) { const u32 v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; if (!BITS && tid < left) out[(at + tid) & mask] = mt_temper(v); }
-        if (BITS && !sweeper && have_prev) emit_read(em, o, 0, prev_len, prev_R0, prev_sg);
+        if (tid < MT_N - MT_M) { const u32 v = o[tid + MT_M] ^ mt_mix(o[tid], o[tid + 1]); n[tid] = v; if (tid < left) out[(at + tid) & mask] = mt_temper(v); }
         __syncthreads();
         // sweep 2: k = 227..453  n[k] = n[k - 227] ^ mix(o[k], o[k + 1])
         const u32 k2 = tid + (MT_N - MT_M);
-        if (tid < MT_N - MT_M) { const u32 v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; if (!BITS && k2 < left) out[(at + k2) & mask] = mt_temper(v); }
-        if (BITS && !sweeper && have_prev) emit_pack(em);
+        if (tid < MT_N - MT_M) { const u32 v = n[k2 - (MT_N - MT_M)] ^ mt_mix(o[k2], o[k2 + 1]); n[k2] = v; if (k2 < left) out[(at + k2) & mask] = mt_temper(v); }
         __syncthreads();
         // sweep 3: k = 454..622 the same with n[k - 227] from sweep 2; k = 623: n[623] = n[396] ^ mix(o[623], n[0])
         const u32 k3 = tid + 2 * (MT_N - MT_M);
-        if (sweeper && k3 < MT_N) {
+        if (k3 < MT_N) {
             const u32 v = k3 < MT_N - 1 ? n[k3 - (MT_N - MT_M)] ^ mt_mix(o[k3], o[k3 + 1]) : n[MT_M - 1] ^ mt_mix(o[MT_N - 1], n[0]);
             n[k3] = v;
-            if (!BITS && k3 < left) out[(at + k3) & mask] = mt_temper(v);
+            if (k3 < left) out[(at + k3) & mask] = mt_temper(v);
         }
-        if (BITS && !sweeper && have_prev) emit_store(em, prev_sg);
         __syncthreads();
         cur ^= 1;
         idx = (u32)(left < (u64)MT_N ? left : (u64)MT_N);
-        if (BITS) { have_prev = true; prev_len = idx; prev_R0 = at; prev_sg = sg++; }
         done += idx;
     }
-    for (u32 i = tid; i < MT_N; i += THREADS) state[i] = buf[cur][i];
+    for (u32 i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
     if (tid == 0) state[MT_N] = idx;
-    if (BITS) {
-        if (!sweeper && have_prev) { emit_read(em, buf[cur], 0, prev_len, prev_R0, prev_sg); emit_pack(em); emit_store(em, prev_sg); }   // the last block
-        __syncthreads();
-        // the word the launch ends in, if it is not full: the next launch reads it back and completes it
-        if (tid == 0 && count && ((first + count) & 63u)) out64[((first + count) >> 6) & wmask64] = s_carry[(sg - 1u) & 1u];
-    }
 }
 
-// caller-supplied draws (and the host's own stream, FASTF_HOST_DRAWS=1) as decisions: bits[i >> 5] bit (i & 31) = draws[i] <
-// threshold, i < n; the last word is zero-filled.  One wave per 64 draws and round.
-__global__ __launch_bounds__(256) void draw_bits_kernel(const u32* __restrict__ draws, u64 n, u64 threshold, u32* __restrict__ bits) {
+// draws -> decisions: bit (first + i) of the ring (ring_mask = its size in bits - 1, a power of two >= 64 — or ~0: a linear
+// array) = draws[i] < threshold, i < n.  A wave owns one 64-bit word of the ring per round: its ballot IS the word.  The word
+// `first` stands in keeps its bits below `first` (the launch before wrote them: same stream), the word the range ends in is
+// zero above the end (the next launch completes it).  Caller-supplied draws, the host's own stream (FASTF_HOST_DRAWS=1: packed
+// on the host instead) and mt_fill_kernel's words all become decisions here.
+__global__ __launch_bounds__(256) void draw_bits_kernel(const u32* __restrict__ draws, u64 n, u64 threshold, u32* __restrict__ bits, u64 first, u64 ring_mask) {
     const int lane = lane_id();
+    u64* const bits64 = reinterpret_cast<u64*>(bits);
+    const u64 wmask = ring_mask >> 6, w_first = first >> 6, end = first + n;
+    const u64 n_words = n ? ((end + 63) >> 6) - w_first : 0;
     const u64 waves = (u64)gridDim.x * (256 / WAVE), w0 = (u64)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-    for (u64 c = w0; c * WAVE < n; c += waves) {
-        const u64 i = c * WAVE + (u64)lane;
-        const u64 m = __ballot(i < n && (u64)draws[i < n ? i : 0] < threshold);
-        if (lane == 0) bits[2 * c] = (u32)m;
-        if (lane == 1 && c * WAVE + 32 < n) bits[2 * c + 1] = (u32)(m >> 32);
+    for (u64 c = w0; c < n_words; c += waves) {
+        const u64 r = ((w_first + c) << 6) + (u64)lane;      // this lane's rank
+        const bool in = r >= first && r < end;
+        const u64 m = __ballot(in && (u64)draws[in ? r - first : 0] < threshold);
+        if (lane == 0) {
+            u64* const w = bits64 + ((w_first + c) & wmask);
+            const u32 low = c == 0 ? (u32)(first & 63u) : 0u;                    // bits of this word that belong to earlier ranks
+            *w = low ? (*w & ((1ull << low) - 1ull)) | m : m;
+        }
     }
 }
 

@@ -310,7 +310,7 @@ int fastf_dev_count_hits_blocked(fastf_engine_t *e, const uint64_t *d_cb_key, ui
  * genrand_real1() <= rate (bam2db_ds.c:385-390), i.e. draw < the engine's integer threshold — so that is what it reads:
  * bit (i & 31) of word i >> 5 = draws[i] < threshold.  fastf_dev_probe_pack takes 32-bit draws and converts them on
  * every call (one extra pass over them); a caller that runs the same stream more than once converts it once with
- * fastf_dev_draw_bits (d_bits_out: (n_draws + 31) / 32 words, the tail of the last word zero) and passes the result
+ * fastf_dev_draw_bits (d_bits_out: 8-byte aligned, (n_draws + 63) / 64 * 8 bytes, the tail of the last 64 bits zero) and passes the result
  * as d_draws together with FASTF_PROBE_DRAW_BITS — n_draws and *d_draw_base keep counting draws. */
 #define FASTF_PROBE_DRAW_BITS 16u
 int fastf_dev_draw_bits(fastf_engine_t *e, const uint32_t *d_draws, uint64_t n_draws, uint32_t *d_bits_out, void *stream);

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out/r4
-timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -x -q > gpurun_out/r4/s24_tests.txt 2>&1; rc=$?; grep -q "Memory access fault" gpurun_out/r4/s24_tests.txt && rc=99
+timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_dist.py -x -q > gpurun_out/r4/s24_tests.txt 2>&1; rc=$?; grep -q "Memory access fault" gpurun_out/r4/s24_tests.txt && rc=99
 tail -3 gpurun_out/r4/s24_tests.txt
 [ $rc -ne 0 ] && exit $rc
 for v in main; do
