@@ -1,0 +1,7 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out/r4
+timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_kernels.py -x -q > gpurun_out/r4/s26_tests.txt 2>&1; rc=$?; grep -q "Memory access fault" gpurun_out/r4/s26_tests.txt && rc=99
+tail -3 gpurun_out/r4/s26_tests.txt
+[ $rc -ne 0 ] && exit $rc
+bash tools/ab_k.sh 4 main k1b_before
