@@ -265,7 +265,7 @@ static int multi_retire_chunk(fastf_multi* m) {
             HIP_OK(hipSetDevice(mg.dev));
             if (!m->mt_uploaded || !mg.d_mt.p) {
                 u64 r = 1024; while (r < 2 * cap) r <<= 1;
-                if (mg.d_mt.ensure(sizeof(fastf_mt_t)) || mg.d_ring.ensure(r / 8)) return 1;      // the decision stream: one bit per rank
+                if (mg.d_mt.ensure(sizeof(fastf_mt_t)) || mg.d_ring.ensure(r / 8) || mg.d_mtwords.ensure(cap * 4)) return 1;   // the decision stream: one bit per rank
                 mg.ring_len = r;
                 HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
                 HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)

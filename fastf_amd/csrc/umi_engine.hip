@@ -1416,7 +1416,9 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
         if (device_mt_wanted()) {
             static_assert(sizeof(fastf_mt_t) == (MT_N + 1) * 4, "fastf_mt_t: 624 state words + the read index");
             HIP_OK(hipStreamSynchronize(e->s_mt));                          // (idle already: every chunk that waited for it is retired)
-            if (e->d_mt.ensure(sizeof(fastf_mt_t))) return 1;
+            // (the generator's scratch for the most ranks one launch can be asked for — everything the ring holds — so that no
+            //  push stops to grow it)
+            if (e->d_mt.ensure(sizeof(fastf_mt_t)) || e->d_mtwords.ensure(e->ring_len * 4)) return 1;
             HIP_OK(hipMemcpy(e->d_mt.p, &e->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice));
             e->mt_on_device = true;
         }
