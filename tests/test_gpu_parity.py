@@ -483,6 +483,46 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
             os.environ.pop("FASTF_NO_STREAM_K1B", None)
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 256, 257, 511, 4095, 4096, 4097, 12 * 256 - 1, 12 * 256, 12 * 256 + 1, 24 * 256 + 3,
+                               16 * 4096 - 255, 16 * 4096 + 1])
+def test_streaming_k1b_record_counts_around_its_unit_tile_and_round_sizes(n):
+    """the hand-pipelined loop reads a unit's records one unit ahead, unconditionally — a unit that does not exist reads the last one
+    that does, a lane beyond the records its unit's last record: record counts around a unit (256), a tile (4096) and one round
+    of a 12-wave workgroup, blocked and SoA, every record a hit (the decision words of the last unit end the stream)"""
+    import torch
+    from fastf_amd.dist import HipStages, ShardedPass
+    case = Case(n=n, n_bar=64, n_gene=40, rate_depth=0.5, umi_pool=16, p_no_cb=0.0, p_unlisted_cb=0.0)
+    ora = case.oracle()
+    lists = case.lists()
+    cbk, gxk, umi, meta = case.packed(lists)
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+    d = [t(x) for x in (cbk, gxk, umi, meta)]
+    draws = t(F.mt_draws(case.seed, lists.mt_skip, ora["total"]))       # exactly as many draws as there can be hits
+    for form in ("blocked", "soa"):
+        eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12)
+        try:
+            st = HipStages(eng, dev)
+            sp = ShardedPass(st, case.n, dev)
+            blk = st.block(d[1], d[2], d[3], case.n) if form == "blocked" else None
+            assert (blk is not None) == (form == "blocked")
+            dr = sp.prepare_draws(draws)
+            for _ in range(2):
+                if blk is not None:
+                    sp.run(d[0], blk, None, None, case.n, dr)
+                else:
+                    sp.run(d[0], d[1], d[2], d[3], case.n, dr)
+            f, c, k = sp.local_coo()
+            hits, sampled, valid, err = sp.global_counters()
+            assert err == 0 and sp.st.segmented
+            assert (sampled, valid) == (ora["sampled"], ora["valid"])
+            np.testing.assert_array_equal(c, ora["cell"].astype(np.int64))
+            np.testing.assert_array_equal(f, ora["feature"].astype(np.int64))
+            np.testing.assert_array_equal(k, ora["count"].astype(np.int64))
+        finally:
+            eng.close()
+
+
 def test_finish_without_copy_returns_views_of_the_engines_rows():
     """Engine.finish(copy=False): what a C caller of fastf_engine_finish gets — arrays that live in the engine's row buffer"""
     case = Case(n=60_000, n_bar=300, n_gene=100, umi_pool=64, rate_depth=0.7)
