@@ -42,8 +42,15 @@ def _worker(rank, world, port, case_kw, steps, q):
         sp = ShardedPass(HipStages(eng, dev), max(b - a, 1), dev)
         assert sp.host_staged
         sl = [t(x[a:b].copy()) for x in (cbk, gxk, umi, meta)]
-        for _ in range(steps):                            # buffers are reused across steps, as in bench.py
-            sp.run(sl[0], sl[1], sl[2], sl[3], b - a, draws)
+        # buffers are reused across steps, as in bench.py: the first step from the SoA arrays and the 32-bit draws, the rest
+        # the way bench.py --gpus N runs them — blocked records, the decision bits made once
+        blk = sp.st.block(sl[1], sl[2], sl[3], b - a) if b > a else None
+        dr = sp.prepare_draws(draws)
+        for step in range(steps):
+            if step == 0 or blk is None:
+                sp.run(sl[0], sl[1], sl[2], sl[3], b - a, draws)
+            else:
+                sp.run(sl[0], blk, None, None, b - a, dr)
         f, c, k = sp.gather_coo()
         lf, lc, _ = sp.local_coo()
         owners_ok = bool((owner_of_cell(lc, world) == rank).all()) if len(lc) else True
