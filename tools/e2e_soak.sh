@@ -14,7 +14,7 @@ $R/build/gen_bam /dev/shm/gb/in.bam /dev/shm/gb/bar.tsv /dev/shm/gb/feat.tsv $N 
 python3 - "$R" $RUNS <<'PY'
 import hashlib, os, subprocess, sys, zlib
 R, runs = sys.argv[1], int(sys.argv[2])
-envs = [{}, {"FASTF_DEVICES": "0,0"}, {"FASTF_DEVICES": "0,0,0,0"}, {"FASTF_GPU_INFLATE": "0"}, {"FASTF_GPU_PARSE": "0"}, {"FASTF_BATCH_RECORDS": "1000000"}, {"FASTF_BAM_WINDOW": str(48 << 20)}, {"FASTF_HOST_THREADS": "7"}]
+envs = [{}, {"FASTF_DEVICES": "0,0"}, {"FASTF_DEVICES": "0,0,0,0"}, {"FASTF_GPU_INFLATE": "0"}, {"FASTF_GPU_PARSE": "0"}, {"FASTF_BATCH_RECORDS": "1000000"}, {"FASTF_BAM_WINDOW": str(48 << 20)}, {"FASTF_HOST_THREADS": "7"}, {"FASTF_HOST_DRAWS": "1"}]
 seen = {}
 for i in range(runs):
     e = envs[i % len(envs)] if i >= runs // 2 else {}
