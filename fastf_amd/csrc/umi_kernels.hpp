@@ -1946,7 +1946,12 @@ __global__ __launch_bounds__(K3_THREADS, 8) void reduce_windows_kernel(const Red
 // Groups longer than a window go to giant_groups_kernel as before.
 // ------------------------------------------------------------------------------------
 constexpr int K3H_THREADS = 512, K3H_WAVES = K3H_THREADS / WAVE, K3H_IPT = 4, K3H_TILE = K3H_THREADS * K3H_IPT, K3H_UNITS = K3H_TILE / WAVE;
-constexpr u32 K3H_TAB = 4096, K3H_WAVE_KEYS = K3H_IPT * WAVE;
+constexpr u32 K3H_TAB = 4096, K3H_WAVE_KEYS = K3H_IPT * WAVE;      // (slots of the 64-bit forms; the 32-bit form has K3H_TAB32)
+#ifndef FASTF_K3H_TAB32
+#define FASTF_K3H_TAB32 8192
+#endif
+constexpr u32 K3H_TAB32 = FASTF_K3H_TAB32, K3H_LO32 = K3H_TAB32 == 8192 ? 13u : 12u;   // slots of the 32-bit form and the key bits its slot number stands for
+static_assert(K3H_TAB32 == 4096 || K3H_TAB32 == 8192, "32-bit slots: (27 - lo) + 11 + 6 bits");
 static_assert(K3H_TILE == K3_TILE, "same chunk geometry as reduce_windows_kernel (k3_chunk_start, rows_gather_kernel)");
 static_assert(K3H_UNITS == 32 && K3H_TILE <= 2048, "32 head ballots per window; row ranks fit 11 bits");
 
@@ -1983,8 +1988,10 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
     typedef typename std::conditional<SLOT64, u64, u32>::type slot_t;
     __shared__ u64 s_hb[K3H_UNITS];        // head ballots of the 32 units of the window
     __shared__ u32 s_cnt[K3H_TILE];        // distinct counts by row; all-zero between windows
-    __shared__ u32 s_feat[K3H_TILE], s_cell[K3H_TILE];   // row identities
-    __shared__ slot_t s_tab[K3H_TAB];      // the set; all-zero between windows
+    constexpr u32 TAB = SLOT64 ? K3H_TAB : K3H_TAB32;
+    __shared__ slot_t s_tab[TAB];          // the set; all-zero between windows
+    // (the row identities go to memory straight from the head lanes: the 16 KB two arrays of them took are the set's now —
+    //  twice the slots, half the load, shorter probe chains; a wave waits for its longest chain)
     __shared__ u32 s_first;
     __shared__ u64 s_g0;
 
@@ -1993,7 +2000,7 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
     const u32 gshift = WIDE ? 0u : p.L.feat_shift, nn_shift = p.L.umi_bits + p.L.len_bits;
     const u32 G = gridDim.x, b = blockIdx.x;
     const u64 nom_start = k3_chunk_start(n, b, G), nom_end = k3_chunk_start(n, b + 1, G);
-    for (u32 i = tid; i < K3H_TAB; i += K3H_THREADS) s_tab[i] = 0;
+    for (u32 i = tid; i < TAB; i += K3H_THREADS) s_tab[i] = 0;
     for (u32 i = tid; i < K3H_TILE; i += K3H_THREADS) s_cnt[i] = 0;
 
     // ---- chunk start: the first head at or after the nominal start (a group that began earlier belongs to the chunk before) ----
@@ -2159,6 +2166,7 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
         // per unit j: sl[j] = the slot being tried, in the end the slot this key holds (~0: none); st bit j = the key counts as
         // distinct, bit 4 + j = it still has to be looked up
         u32 sl[K3H_IPT], row[K3H_IPT], st = 0;
+        const u64 row_base = region + rows_so_far;                         // the window's rows in the chunk's region
         {
             u32 stp[K3H_IPT]; slot_t wd[K3H_IPT], od[K3H_IPT];
             u32 Ru = R0;
@@ -2178,21 +2186,21 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
                 if constexpr (WIDE) {
                     const u64 x = k, hi = x >> 12;                         // x < 2^52 (UMIs of at most 24 bases)
                     const u32 f = (u32)hi * 0x9E3779B1u + (u32)(hi >> 32) * 0x85EBCA77u;
-                    sl[j] = ((u32)x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (K3H_TAB - 1);
+                    sl[j] = ((u32)x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (TAB - 1);
                     stp[j] = ((f >> 20) & 62u) | 1u;
                     wd[j] = hi | ((u64)r << 40) | (1ull << 51);            // hi: 40 bits, row rank: 11, probe number + 1: 6
                 } else if constexpr (SLOT64) {
                     const u64 x = k & ((1ull << gshift) - 1);
                     u32 hh = (u32)x * 0x9E3779B1u + (u32)(x >> 32) * 0x85EBCA77u + r * 0xC2B2AE3Du;
                     hh ^= hh >> 15;
-                    sl[j] = hh & (K3H_TAB - 1); stp[j] = ((hh >> 20) & 62u) | 1u;
+                    sl[j] = hh & (TAB - 1); stp[j] = ((hh >> 20) & 62u) | 1u;
                     wd[j] = (1ull << 63) | ((u64)r << 40) | x;
                 } else {
                     const u32 x = (u32)k & ((1u << gshift) - 1u);          // key bits below the group: NULL flag, UMI, length
-                    const u32 hi = x >> 12, f = __umul24(hi, 0x9E3779u);
-                    sl[j] = (x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (K3H_TAB - 1);
+                    const u32 hi = x >> K3H_LO32, f = __umul24(hi, 0x9E3779u);
+                    sl[j] = (x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (TAB - 1);
                     stp[j] = ((f >> 20) & 62u) | 1u;                       // odd: the walk visits every slot
-                    wd[j] = hi | (r << 15) | (1u << 26);
+                    wd[j] = hi | (r << 15) | (1u << 26);                   // hi: 27 - lo <= 15 bits, row rank: 11, probe number + 1: 6
                 }
                 Ru += (u32)__popcll(h);
             }
@@ -2211,7 +2219,7 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
                 u32 tries = 1;
 #pragma nounroll
                 while (go) {
-                    sl[j] = (sl[j] + stp[j]) & (K3H_TAB - 1);
+                    sl[j] = (sl[j] + stp[j]) & (TAB - 1);
                     if constexpr (WIDE) wd[j] += 1ull << 51;
                     else if constexpr (!SLOT64) wd[j] += 1u << 26;
                     od[j] = 0;
@@ -2236,8 +2244,8 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
                 const u32 r = row[j];
                 if (is_head) {
                     if (D) { k3h_add(s_cnt, r - 1u, D); k3h_add(s_cnt, r, 0u - D); }
-                    s_feat[r] = (WIDE ? (u32)key[j] : (u32)(key[j] >> p.L.feat_shift)) & p.feat_mask;
-                    s_cell[r] = (u32)(key[j] >> (WIDE ? p.wide_feat_bits : p.L.cell_shift));
+                    p.feature[row_base + r] = (WIDE ? (u32)key[j] : (u32)(key[j] >> p.L.feat_shift)) & p.feat_mask;
+                    p.cell[row_base + r] = (u32)(key[j] >> (WIDE ? p.wide_feat_bits : p.L.cell_shift));
                 }
                 const u32 heads = (u32)__popcll(h), tot = (u32)__popcll(dmj);
                 if (lane == 0 && tot) k3h_add(s_cnt, Ru + heads - 1u, tot);  // (Ru + heads >= 1: position 0 of the window is a head)
@@ -2245,16 +2253,12 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
             }
         }
         k3_barrier();
-        // ---- rows out (coalesced), the set and the counts back to all-zero ----
+        // ---- the rows' counts out (coalesced; their identities went out from the head lanes), the set and the counts back to all-zero ----
 #pragma unroll
         for (int j = 0; j < K3H_IPT; ++j) if (sl[j] != ~0u) s_tab[sl[j]] = 0;
-        {
-            const u64 row_base = region + rows_so_far;
-            for (u32 r = tid; r < n_rows; r += K3H_THREADS) {
-                p.count[row_base + r] = s_cnt[r];
-                p.feature[row_base + r] = s_feat[r]; p.cell[row_base + r] = s_cell[r];
-                s_cnt[r] = 0;
-            }
+        for (u32 r = tid; r < n_rows; r += K3H_THREADS) {
+            p.count[row_base + r] = s_cnt[r];
+            s_cnt[r] = 0;
         }
         rows_so_far += n_rows;
         cursor = base + cut;
