@@ -178,6 +178,7 @@ struct fastf_engine {
     DevBuf d_halfhits;                   // K1a: hits per 256-record unit (the streaming K1b's rank bases)
     DevBuf d_segkeys;                    // several shards: the streaming K1b's unsharded output (workgroup regions) in front of shard_partition_kernel
     DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
+    u32 giant_parity = 0;                        // which of the two giant-item counters the next group-only reduce counts up
     u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
     DevBuf d_scanblk;                    // chunk totals of a scan over more than 16 384 tiles
     // K3: row regions (one slot per key: a workgroup's rows go to the slots of its own chunk), rows per chunk and their bases
@@ -1078,7 +1079,10 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
         if (e->d_giant.ensure((size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64) + 64)) return 1;
         HIP_OK(hipMemsetAsync(e->d_giant.p, 0, e->d_giant.bytes, s));       // the list too: no slot of it is ever read unwritten
     }
-    u32* const giant_n = dedup == 2 ? (u32*)((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64)) : nullptr;
+    // the item counter: two of them by turns — giant_groups_kernel reads the one this launch counts up and clears the other
+    u32* const giant_cnt = dedup == 2 ? (u32*)((char*)e->d_giant.p + (size_t)GIANT_LIST_CAP * GIANT_ITEM_WORDS * sizeof(u64)) : nullptr;
+    const u32 parity = dedup == 2 ? (e->giant_parity ^= 1u) : 0u;
+    u32* const giant_n = giant_cnt ? giant_cnt + parity : nullptr;
     ReduceParams p{};
     p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
@@ -1095,10 +1099,11 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     else if (wide_vals) hipLaunchKernelGGL((reduce_hashed_kernel<true, true>), dim3(G), dim3(K3H_THREADS), 0, s, p);
     else if (e->L.feat_shift > 27) hipLaunchKernelGGL((reduce_hashed_kernel<true>), dim3(G), dim3(K3H_THREADS), 0, s, p);    // UMIs beyond 12 bases: 64-bit slots
     else hipLaunchKernelGGL((reduce_hashed_kernel<false>), dim3(G), dim3(K3H_THREADS), 0, s, p);
-    hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows, giant_n);
-    if (dedup == 2)
-        hipLaunchKernelGGL(giant_groups_kernel, dim3(g_cu_count), dim3(512), 0, s, wide_vals ? wide_vals : sorted, (const u64*)e->d_giant.p, (const u32*)(giant_n + 1), e->L,
-                           (u32*)e->d_rg_count.p, (u64*)e->d_small.p + SM_COUNTERS + 3);
+    if (dedup == 2)       // (its last workgroup scans the chunks' row counts: no span_scan launch of its own)
+        hipLaunchKernelGGL(giant_groups_kernel, dim3(g_cu_count + 1), dim3(512), 0, s, wide_vals ? wide_vals : sorted, (const u64*)e->d_giant.p, giant_cnt, parity, e->L,
+                           (u32*)e->d_rg_count.p, (u64*)e->d_small.p + SM_COUNTERS + 3, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows);
+    else
+        hipLaunchKernelGGL(span_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)e->d_spanrows.p, G, (u64*)e->d_spanbase.p, nrows);
     HIP_OK(hipGetLastError());
     if (!UMI_ROWS) t_end(e, s, &e->t_k3_ms, &e->t_k3_n);
     dbg_sync(s, "K3 reduce + span scan + giant groups");

@@ -2268,27 +2268,59 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
     if (tid == 0) p.span_rows[b] = rows_so_far;
 }
 
-// distinct non-NULL keys of one hash partition of a group longer than a window (work items left by DEDUP 2)
-__global__ __launch_bounds__(512) void giant_groups_kernel(const u64* __restrict__ keys, const u64* __restrict__ list, const u32* __restrict__ n_items,
-                                                           KeyLayout L, u32* __restrict__ count, u64* __restrict__ err) {
+// exclusive scan of the chunks' row counts (G <= 4096) -> row bases + the total; one workgroup of THREADS threads
+template <int THREADS>
+__device__ __forceinline__ void span_scan_body(const u32* __restrict__ span_rows, u32 G, u64* __restrict__ span_base, u64* __restrict__ total_out) {
+    constexpr u32 PER = 4096 / THREADS;
+    __shared__ u32 s_w[THREADS / WAVE];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    u32 v[PER]; u32 sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < PER; ++k) { const u32 i = threadIdx.x * PER + k; v[k] = i < G ? span_rows[i] : 0u; sum += v[k]; }
+    const u32 inc = wave_incl_scan32(sum, lane);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    u64 off = 0;
+    for (int i = 0; i < w; ++i) off += s_w[i];
+    u64 e = off + inc - sum;
+#pragma unroll
+    for (u32 k = 0; k < PER; ++k) { const u32 i = threadIdx.x * PER + k; if (i < G) span_base[i] = e; e += v[k]; }
+    if (threadIdx.x == THREADS - 1) { span_base[G] = e; if (total_out) *total_out = e; }
+}
+
+// distinct non-NULL keys of one hash partition of a group longer than a window (work items left by reduce_hashed_kernel).
+// The LAST workgroup of the grid does something else: the scan of the chunks' row counts (what span_scan_kernel does for the
+// other reduce kernel — one launch less behind the reduce) and the reset of the item counter the NEXT reduce will use
+// (items[0 / 1] by turns: this launch reads n_items[parity], which the reduce before it counted up).
+__global__ __launch_bounds__(512) void giant_groups_kernel(const u64* __restrict__ keys, const u64* __restrict__ list, u32* __restrict__ n_items, u32 parity,
+                                                           KeyLayout L, u32* __restrict__ count, u64* __restrict__ err,
+                                                           const u32* __restrict__ span_rows, u32 G, u64* __restrict__ span_base, u64* __restrict__ total_out) {
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 0) n_items[parity ^ 1u] = 0;
+        span_scan_body<512>(span_rows, G, span_base, total_out);
+        return;
+    }
     __shared__ u64 s_set[GIANT_TAB];
     __shared__ u32 s_cnt;
     // more items than the list holds: a group that straddled the end of the list left its slots unwritten, and the caller
     // sorts fully and reduces again anyway (ERR_RUN_TOO_LONG is up) — walk nothing
-    const u32 items = *n_items <= GIANT_LIST_CAP ? *n_items : 0u;
+    const u32 have = n_items[parity];
+    const u32 items = have <= GIANT_LIST_CAP ? have : 0u;
     const u32 nn_shift = L.umi_bits + L.len_bits;
-    for (u32 g = blockIdx.x; g < items; g += gridDim.x) {
+    for (u32 g = blockIdx.x; g < items; g += gridDim.x - 1) {
         const u64* it = list + (u64)g * GIANT_ITEM_WORDS;
         const u64 start = it[0], len = it[1], row = it[2];
         const u32 part = (u32)it[3], parts = (u32)(it[3] >> 32);
         for (u32 i = threadIdx.x; i < GIANT_TAB; i += 512) s_set[i] = 0;
         if (threadIdx.x == 0) s_cnt = 0;
+        u64 k[4], kn[4];                                                   // this round's keys and the next round's, asked for a round ahead
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const u64 i = (u64)u * 512 + threadIdx.x; kn[u] = i < len ? keys[start + i] : 0; }
         __syncthreads();
         u32 mine = 0; bool full = false;
         for (u64 i0 = 0; i0 < len; i0 += 4 * 512) {
-            u64 k[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const u64 i = i0 + (u64)u * 512 + threadIdx.x; k[u] = i < len ? keys[start + i] : 0; }
+            for (int u = 0; u < 4; ++u) { k[u] = kn[u]; const u64 i = i0 + 4 * 512 + (u64)u * 512 + threadIdx.x; kn[u] = i < len ? keys[start + i] : 0; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (!((k[u] >> nn_shift) & 1)) continue;                  // NULL umi (and the padding zeros): not counted
@@ -2366,25 +2398,11 @@ __global__ __launch_bounds__(UW_THREADS) void pair_copies_kernel(const u64* __re
         ncopy[r] = (u32)((r + 1 < rows ? hpos[r + 1] : n) - hpos[r]);
 }
 
-// row bases of the chunks (exclusive scan of span_rows, G <= 4096) and the total; the work-item counter of the giant
-// groups is handed over (frozen for giant_groups_kernel) and cleared for the next launch
+// row bases of the chunks (exclusive scan of span_rows, G <= 4096) and the total — behind reduce_windows_kernel; behind
+// reduce_hashed_kernel the last workgroup of giant_groups_kernel does it
 __global__ __launch_bounds__(1024) void span_scan_kernel(const u32* __restrict__ span_rows, u32 G, u64* __restrict__ span_base,
-                                                         u64* __restrict__ total_out, u32* __restrict__ giant_n = nullptr) {
-    if (giant_n && threadIdx.x == 0) { giant_n[1] = giant_n[0]; giant_n[0] = 0; }
-    __shared__ u32 s_w[16];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    u32 v[4]; u32 sum = 0;
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k) { const u32 i = threadIdx.x * 4 + k; v[k] = i < G ? span_rows[i] : 0u; sum += v[k]; }
-    const u32 inc = wave_incl_scan32(sum, lane);
-    if (lane == WAVE - 1) s_w[w] = inc;
-    __syncthreads();
-    u64 off = 0;
-    for (int i = 0; i < w; ++i) off += s_w[i];
-    u64 e = off + inc - sum;
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k) { const u32 i = threadIdx.x * 4 + k; if (i < G) span_base[i] = e; e += v[k]; }
-    if (threadIdx.x == 1023) { span_base[G] = e; if (total_out) *total_out = e; }
+                                                         u64* __restrict__ total_out) {
+    span_scan_body<1024>(span_rows, G, span_base, total_out);
 }
 
 // concatenation of the chunks' row regions: one workgroup per chunk.  The destinations may be device arrays or pinned
