@@ -57,7 +57,7 @@ def kernel_table(eng, N, H, K, Z):
     c = eng.cell_scratch_bytes
     names = {0: ("probe_cells (K1a)", (8 + c) * N), 4: ("filter_pack (K1b)", (16 + c) * N + 4 * H + 8 * K),
              3: ("tile_count (K2, per pass)", 8 * K), 1: ("scatter (K2, per pass)", 16 * K),
-             2: ("reduce_hashed+span_scan+giant_groups (K3)", 8 * K + 12 * Z),
+             2: ("reduce_hashed+giant_groups (K3; the span scan is the last workgroup of giant_groups)", 8 * K + 12 * Z),
              5: ("rows_gather (not part of the step: concatenates K3's row regions where the rows are wanted)", 24 * Z)}
     out = {}
     for which, (nm, b) in names.items():
@@ -200,7 +200,7 @@ def main():
     # their own, gfx950 corrections applied there); only a profile of this very workload counts
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    kernels_of = {"reduce_hashed+span_scan+giant_groups": ["reduce_hashed_kernel", "span_scan_kernel", "giant_groups_kernel"], "probe_cells": ["probe_cells_lds_kernel", "probe_cells_filtered_kernel", "probe_cells_kernel"],
+    kernels_of = {"reduce_hashed+giant_groups": ["reduce_hashed_kernel", "span_scan_kernel", "giant_groups_kernel"], "probe_cells": ["probe_cells_lds_kernel", "probe_cells_filtered_kernel", "probe_cells_kernel"],
                   "filter_pack": ["filter_pack_stream_kernel", "filter_pack_kernel"], "tile_count": ["tile_count_kernel"],
                   "scatter": ["scatter_kernel"], "reduce_windows+span_scan": ["reduce_hashed_kernel", "reduce_windows_kernel", "span_scan_kernel", "giant_groups_kernel"]}
     if os.path.exists(tpath):
