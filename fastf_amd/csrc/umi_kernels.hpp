@@ -1,15 +1,18 @@
 // umi_kernels.hpp — hand-written HIP kernels of the bam2db hot path for gfx950 (CDNA4).
 //
+//   mt_fill / draw_bits           the MT19937 draw stream (mt19937ar.c:105-140) continued on the device and packed to one
+//                                 keep/drop decision bit per CB hit (bam2db_ds.c:385-390)
 //   K1a probe_cells_kernel        CB probe, E2/E3 of the reference loop (bam2db_ds.c:366-380)
-//   K1b filter_pack_kernel        E4..E12 (:385-435): depth draw by hit rank, xf, GX probe,
+//   K1b filter_pack_kernel        E4..E12 (:385-435): depth decision by hit rank, xf, GX probe,
 //                                 UB, packed 64-bit (cell, feature, umi) key
-//   K1b filter_pack_stream_kernel the same per wave on 256-record units, keys into workgroup regions (+ shard_partition_kernel
-//                                 when the pass is sharded)
+//   K1b filter_pack_stream_kernel the same per wave on 256-record units (a hand-pipelined loop: a unit's inputs are requested
+//                                 during the unit before), keys into workgroup regions (+ shard_partition_kernel when the pass
+//                                 is sharded)
 //   K2  tile_count / row_scan / scatter: 64-bit LSD radix sort, 8-bit digits — stands in for SQLite's sorter
 //                                 behind GROUP BY (bam2db_ds.c:480-483); the matrix path sorts (cell, feature) only
-//   K3  reduce_windows / span_scan / giant_groups / rows_gather
+//   K3  reduce_hashed / giant_groups (+ the span scan) / rows_gather   [reduce_windows / span_scan for fully sorted keys]
 //                                 COUNT(DISTINCT umi) GROUP BY cell, feature: the keys read once, rows into per-workgroup
-//                                 regions, distinct UMIs of a group through a hash set in LDS
+//                                 regions, distinct UMIs of a group through an exact hash set in LDS
 //   K3u (same, UMI_ROWS=true)     COUNT(*) GROUP BY cell, feature, umi (-u, :539-542), fully sorted keys
 //
 // All of it is integer indexing: wave64 ballots/mbcnt for ranking, LDS for the
