@@ -51,21 +51,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def kernel_table(eng, N, H, K, Z):
-    """per-kernel HIP-event averages (ms) with each kernel's algorithmic bytes per launch (DESIGN.md section 4);
-    c = bytes per entry of the cell-index scratch between K1a and K1b (2 when n_cells <= 65535, else 4)"""
+def kernel_table(eng, N, H, K, Z, draw_bits, steps_timed):
+    """per-kernel HIP-event averages (ms) with the bytes each kernel has to MOVE per launch (DESIGN.md section 4);
+    c = bytes per entry of the cell-index scratch between K1a and K1b (2 when n_cells <= 65535, else 4).
+    K1b reads ONE BIT per CB hit when the draw stream is the decision stream (the product's form): its bytes are counted
+    that way, and SURVEY 8d's figure (4 bytes per hit) is kept beside it as bytes_8d — never as the fraction's numerator."""
     c = eng.cell_scratch_bytes
-    names = {0: ("probe_cells (K1a)", (8 + c) * N), 4: ("filter_pack (K1b)", (16 + c) * N + 4 * H + 8 * K),
-             3: ("tile_count (K2, per pass)", 8 * K), 1: ("scatter (K2, per pass)", 16 * K),
-             2: ("reduce_hashed+giant_groups (K3; the span scan is the last workgroup of giant_groups)", 8 * K + 12 * Z),
-             5: ("rows_gather (not part of the step: concatenates K3's row regions where the rows are wanted)", 24 * Z)}
+    draw_bytes = (H + 7) // 8 if draw_bits else 4 * H
+    names = {0: ("probe_cells (K1a)", (8 + c) * N, None), 4: ("filter_pack (K1b)", (16 + c) * N + draw_bytes + 8 * K, (16 + c) * N + 4 * H + 8 * K),
+             3: ("tile_count (K2, per pass; the first pass has none: K1b left its histograms)", 8 * K, None), 1: ("scatter (K2, per pass)", 16 * K, None),
+             2: ("reduce_hashed+giant_groups (K3; the span scan is the last workgroup of giant_groups)", 8 * K + 12 * Z, None),
+             5: ("rows_gather (not part of the step: concatenates K3's row regions where the rows are wanted)", 24 * Z, None)}
     out = {}
-    for which, (nm, b) in names.items():
+    for which, (nm, b, b8d) in names.items():
         ms, n = eng.get_timing(which)
         if n:
             avg = ms / n
-            out[nm] = {"avg_ms": avg, "launches_timed": int(n), "bytes_per_launch": b,
+            out[nm] = {"avg_ms": avg, "launches_timed": int(n), "launches_per_step": n / steps_timed, "bytes_per_launch": b,
                        "GBs": b / (avg * 1e-3) / 1e9, "frac": b / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if b8d is not None:
+                out[nm]["bytes_8d"] = b8d
     return out
 
 
@@ -185,16 +190,17 @@ def main():
 
     # ---- per-kernel HIP-event timing (events on the launch stream, a few extra steps after the timed region) ----
     eng.set_timing(True)
-    for _ in range(3):
+    STEPS_TIMED = 3
+    for _ in range(STEPS_TIMED):
         step()
         sp.st.rows_gather(sp.d_n, sp.feature, sp.cell, sp.count)      # concatenation of K3's row regions (timed as its own line)
     torch.cuda.synchronize()
     H_local = hits // G
-    ktab = kernel_table(eng, n_local, H_local, K_local, Z_local)
+    ktab = kernel_table(eng, n_local, H_local, K_local, Z_local, not args.draw_words, STEPS_TIMED)
     eng.set_timing(False)
     P_nom = (eng.key_bits + 7) // 8
     P_exe = eng.sort_passes(sp.st.skip_low)
-    per_step = {k: v["avg_ms"] * (P_exe if "per pass" in k else 1) for k, v in ktab.items()}
+    per_step = {k: v["avg_ms"] * v["launches_per_step"] for k, v in ktab.items() if not k.startswith("rows_gather")}
     dom = max(per_step, key=per_step.get)
     # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE in runs of
     # their own, gfx950 corrections applied there); only a profile of this very workload counts
@@ -218,12 +224,16 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         d = ktab[dom]
-        # algorithmic bytes of one step of the whole job: B = 24N + 4H + 8K(3+2P) + 12Z
-        def B_of(P):
-            return 24 * N_total + 4 * hits + 8 * K_job * (3 + 2 * P) + 12 * Z_job
+        # algorithmic bytes of one step of the whole job: B = 24N + 4H + 8K(3+2P) + 12Z — with the draw term at what
+        # the step really reads: one decision bit per hit (H / 8 bytes) unless --draw-words hands it the 32-bit draws
+        # (round 4 credited 4H = 0.36 GB of draws that no kernel read any more; B_8d keeps SURVEY's letter for comparison)
+        draw_b = (hits + 7) // 8 if not args.draw_words else 4 * hits
 
-        def Bread_of(P):
-            return 24 * N_total + 4 * hits + 8 * K_job * (2 + P)
+        def B_of(P, draws=None):
+            return 24 * N_total + (draw_b if draws is None else draws) + 8 * K_job * (3 + 2 * P) + 12 * Z_job
+
+        def Bread_of(P, draws=None):
+            return 24 * N_total + (draw_b if draws is None else draws) + 8 * K_job * (2 + P)
         gbs = lambda b: b / (ms_step * 1e-3) / 1e9 / G      # per GPU
         out = {
             "metric": "BAM records/sec -> deduped UMI matrix; achieved HBM GB/s vs roofline",
@@ -233,14 +243,14 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: %d synthetic records, 10000 barcodes x 30000 genes, --cell 1.0 --depth 1.0 --seed 926, "
                                     "uniform cells/genes, 10-bp UMIs" % N_total) if c2 else workload.describe(N_total), "scope": "device kernels, inputs resident in HBM (%s + the draw stream%s); the step ends at K3's segmented rows (rows_gather, which concatenates them where they are wanted — in the product it IS the device-to-host copy — is timed on its own line)" % ("cb array + blocked gx|umi|meta runs, the engine's staging layout" if blk is not None else "packed SoA",
-                                                                                           " as 32-bit draws, turned into decisions every step" if args.draw_words else " as K1b reads it: one keep/drop decision bit per CB hit, what mt_fill_kernel + draw_bits_kernel leave in the ring in the product; K1b's algorithmic bytes still count 4 bytes per hit (SURVEY 8d)"),
+                                                                                           " as 32-bit draws, turned into decisions every step" if args.draw_words else " as K1b reads it: one keep/drop decision bit per CB hit, what mt_fill_kernel + draw_bits_kernel leave in the ring in the product; every byte count here takes the draws at H/8 bytes, what is read (SURVEY 8d's 4 bytes per hit: bytes_8d / B_8d)"),
                        "record_layout": "blocked" if blk is not None else "soa",
                        "records_per_gpu": n_local, "key_bits": eng.key_bits, "radix_passes_nominal": P_nom,
                        "radix_passes_executed": P_exe,
                        "sharding": ("cell-hash, one all-to-all, %s" % ("3-stream pipeline" if sp.pipelined else "single stream")) if G > 1 else "single GPU",
                        "lookup_tables": eng.table_modes},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["frac"], "traffic": traffic, "bytes_per_launch": d["bytes_per_launch"],
+                         "frac": d["frac"], "traffic": traffic, "bytes_per_launch": d["bytes_per_launch"], "bytes_8d": d.get("bytes_8d"),
                          "avg_launch_ms": d["avg_ms"], "launches_timed": d["launches_timed"],
                          "share_of_step": per_step[dom] / sum(per_step.values())},
             "kernels": ktab,
@@ -251,7 +261,9 @@ def main():
                            "frac_of_peak_nominal": gbs(B_of(P_nom)) / HBM_PEAK_GBS,
                            "frac_of_peak": gbs(B_of(P_exe)) / HBM_PEAK_GBS,
                            "read_GBs_executed": gbs(Bread_of(P_exe)), "read_frac_of_peak": gbs(Bread_of(P_exe)) / HBM_PEAK_GBS,
-                           "read_frac_of_peak_nominal": gbs(Bread_of(P_nom)) / HBM_PEAK_GBS},
+                           "read_frac_of_peak_nominal": gbs(Bread_of(P_nom)) / HBM_PEAK_GBS,
+                           "draw_bytes_counted": draw_b,
+                           "B_8d_executed": B_of(P_exe, 4 * hits), "B_read_8d_executed": Bread_of(P_exe, 4 * hits)},
             "counters": {"total": N_total, "hits": hits, "sampled": sampled, "valid": valid,
                          "keys": K_job, "rows": Z_job, "device_error_bits": err},
         }

@@ -228,6 +228,15 @@ GI_FN int copy_match(Work& w, Out& o, uint32_t len, uint32_t dist) {
     len = GI_UNIFORM(len); dist = GI_UNIFORM(dist); o.op = GI_UNIFORM(o.op);   // wave-uniform by construction: scalar control flow below
     if (dist > o.op) return E_DIST;                        // (dist >= 1 by construction)
     if (o.over) return E_OVERRUN;
+#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI_NO_COPY)
+    // timing probe (wrong output): the token is decoded, its bytes are never copied — what the symbol loop costs on its own
+    o.op += len; o.flushed = o.op & ~63u;
+    return OK;
+#endif
+#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI_NEAR_ONLY)
+    // timing probe (wrong output): every far match reads the ring instead of memory — what the far sources' round trips cost
+    if (dist > RING_SAFE) dist = (dist & (RING_SAFE / 2 - 1)) + 64u;
+#endif
 #ifndef GI_HOST
     // The source left the ring, i.e. it went to memory at least 62 line stores ago.  Memory operations of a wave complete
     // in order, so with at most four of them still outstanding every older store has landed — in BAM payloads most matches

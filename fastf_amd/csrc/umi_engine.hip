@@ -179,7 +179,16 @@ struct fastf_engine {
     DevBuf d_segkeys;                    // several shards: the streaming K1b's unsharded output (workgroup regions) in front of shard_partition_kernel
     DevBuf d_segcount, d_segprefix, d_tileseg;   // segmented key buffer left by the streaming K1b: counts, prefix sums, first region of each sort tile
     u32 giant_parity = 0;                        // which of the two giant-item counters the next group-only reduce counts up
-    u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call
+    u32 seg_n = 0; u64 seg_stride = 0;           // valid for the key buffer of the last FASTF_PROBE_SEGMENTED call (seg_stride 0: regions of several launches, no common stride)
+    // per region of the streaming K1b: its first slot in the key store and the histogram of the sort's first digit (scatter_regions_kernel);
+    // d_segcount holds the key counts
+    DevBuf d_rgn_phys, d_rgn_hist, d_rgn_blk;
+    u32 rgn_hist_n = 0, rgn_hist_shift = 0;      // regions whose histograms are in place and unconsumed (0: none), and the digit they count
+    // the push path in stream mode (single shard, gene list in LDS, keys of at most 64 bits): every chunk is staged in the blocked
+    // layout and runs the streaming K1b; its regions are appended to the key store, which holds SLOTS (regions with gaps) until
+    // fastf_engine_finish sorts out of them
+    bool stream_mode = false, store_regions = false;
+    u64 slots_used = 0, slot_cap = 0; u32 rgn_n = 0, rgn_cap = 0;
     DevBuf d_scanblk;                    // chunk totals of a scan over more than 16 384 tiles
     // K3: row regions (one slot per key: a workgroup's rows go to the slots of its own chunk), rows per chunk and their bases
     DevBuf d_rg_feature, d_rg_cell, d_rg_count, d_rg_ukeys, d_spanrows, d_spanbase, d_giant;
@@ -531,6 +540,9 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
         lap("kernel attributes (code object loaded)");
         e->batch_cap = cfg->batch_records ? cfg->batch_records : (4ull << 20);
         e->key_cap = cfg->key_capacity;
+        // the push path stages blocked and runs the streaming K1b whenever the engine can (FASTF_PUSH_TILE_FORM=1: SoA staging and
+        // the tile form, as lists that keep the gene table in L2, wide keys and sharded engines use)
+        e->stream_mode = e->use_lds_genes && !e->wide && e->n_shards == 1 && !getenv("FASTF_NO_STREAM_K1B") && !getenv("FASTF_PUSH_TILE_FORM");
     } while (0);
     if (rc) { fastf_engine_destroy(e); return 1; }
     *out = e;
@@ -557,7 +569,8 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
-                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp};
+                     &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp,
+                     &e->d_rgn_phys, &e->d_rgn_hist, &e->d_rgn_blk};
     for (DevBuf* b : all) b->release();
     if (e->s_compute) (void)hipStreamDestroy(e->s_compute);
     if (e->s_copy) (void)hipStreamDestroy(e->s_copy);
@@ -815,19 +828,25 @@ extern "C" int fastf_dev_draw_bits(fastf_engine_t* e, const uint32_t* d_draws, u
 
 // the streaming K1b over `tiles` K1a tiles: workgroups (at most two per CU: 12 or 16 waves each) and the key slots of one
 // workgroup's region (every record of the units its waves walk: waves x rounds units)
+// (a workgroup fills K1S_SUB regions by turns, one unit each: a region holds every record of the units that go to it; and a
+//  wave should find about four units to walk — the loop is pipelined across units — before more workgroups are started: a short
+//  chunk of the push path then leaves few, well filled regions instead of many nearly empty ones)
 static void stream_geometry(const fastf_engine* e, u64 tiles, u32* grid, u64* region) {
     const u32 waves = (e->genes_blocks_per_cu >= 2 ? K1S_THREADS : K1S_THREADS_ROOMY) / WAVE;
     const u64 units = std::max<u64>(tiles, 1) * (K1_TILE / K1S_UNIT);
-    const u64 g = std::min<u64>((units + waves - 1) / waves, (u64)std::min<u32>(e->genes_blocks_per_cu, 2) * g_cu_count);
+    const u64 g = std::max<u64>(1, std::min<u64>((units + 4 * waves - 1) / (4 * waves), (u64)std::min<u32>(e->genes_blocks_per_cu, 2) * g_cu_count));
     const u64 rounds = (units + g * waves - 1) / (g * waves);
-    *grid = (u32)g; *region = rounds * waves * K1S_UNIT;
+    *grid = (u32)g; *region = ((rounds + K1S_SUB - 1) / K1S_SUB) * waves * K1S_UNIT;
 }
+// regions of several launches behind each other in one key store (the push path): where this launch's begin
+struct RegionAppend { u64 slot0; u32 rgn0; };
 
+static int grow_regions(fastf_engine* e, u32 need);
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* dbits, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
                         u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr,
-                        bool segmented = false, void* blk = nullptr) {
-    if (segmented) e->seg_n = 0;
+                        bool segmented = false, void* blk = nullptr, const RegionAppend* app = nullptr) {
+    if (segmented && !app) { e->seg_n = 0; e->rgn_hist_n = 0; }
     if (n == 0) return 0;
     // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order).
     // d_running: the scan leaves the running hit total of the earlier chunks at draw_base and adds this chunk's hits.
@@ -861,13 +880,22 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
         // streaming form: every wave on its own, keys into one private region per workgroup (see filter_pack_stream_kernel)
         u32 grid; u64 region;
         stream_geometry(e, tiles, &grid, &region);
+        const u32 n_rgn = grid * (u32)K1S_SUB, rgn0 = app ? app->rgn0 : 0u;
         if (stream_shards) {
-            if (e->d_segkeys.ensure((size_t)grid * region * sizeof(u64))) return 1;
+            if (e->d_segkeys.ensure((size_t)n_rgn * region * sizeof(u64))) return 1;
             p.keys = (u64*)e->d_segkeys.p;
-        } else if ((u64)grid * region > stride) return set_err("segmented key output needs %llu slots, the buffer has %llu (fastf_dev_probe_capacity)",
-                                                               (unsigned long long)((u64)grid * region), (unsigned long long)stride);
-        if (e->d_segcount.ensure(grid * sizeof(u64)) || e->d_segprefix.ensure((grid + 1) * sizeof(u64))) return 1;
-        StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p};
+        } else if ((u64)n_rgn * region > stride) return set_err("segmented key output needs %llu slots, the buffer has %llu (fastf_dev_probe_capacity)",
+                                                                (unsigned long long)((u64)n_rgn * region), (unsigned long long)stride);
+        if (app) {                                       // the push path has grown the tables (their contents stay)
+            if (e->rgn_cap < rgn0 + n_rgn) return set_err("internal error: region tables too small");
+        } else {
+            if (e->rgn_n) return set_err("device-level K1 on an engine that holds pushed chunks: fastf_engine_reset first");
+            if (grow_regions(e, n_rgn)) return 1;
+        }
+        if (e->d_segprefix.ensure(((size_t)n_rgn + 1) * sizeof(u64))) return 1;
+        StreamParams sp{(const u32*)e->d_halfhits.p, region, (u64*)e->d_segcount.p + rgn0,
+                        stream_shards ? nullptr : (u32*)e->d_rgn_hist.p + (size_t)rgn0 * RADIX, (u64*)e->d_rgn_phys.p + rgn0,
+                        app ? app->slot0 : 0ull, e->skip_bits};
         // compile-time: roomy (one workgroup per CU: 128 VGPRs), width of the cell scratch, form of the gene image
         const int variant = (e->genes_blocks_per_cu >= 2 ? 0 : 4) | (e->cell16 ? 2 : 0) | (e->lds_genes.direct ? 1 : 0);
 #define FPS(R, C, D) do { if (blk) hipLaunchKernelGGL((filter_pack_stream_kernel<R, C, D, true>), dim3(grid), dim3(R ? K1S_THREADS_ROOMY : K1S_THREADS), e->lds_genes.bytes, s, p, sp); \
@@ -880,11 +908,15 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
         }
 #undef FPS
         if (stream_shards) {
-            hipLaunchKernelGGL(shard_partition_kernel, dim3(grid), dim3(SP_THREADS), 0, s, (const u64*)e->d_segkeys.p, (const u64*)e->d_segcount.p,
+            hipLaunchKernelGGL(shard_partition_kernel, dim3(n_rgn), dim3(SP_THREADS), 0, s, (const u64*)e->d_segkeys.p, (const u64*)e->d_segcount.p,
                                region, e->L.cell_shift, e->n_shards, keys, stride, key_counts, counters + 3);
+        } else if (app) {
+            // (the prefix sums are of no use here — the first sort pass walks the regions — the running key count is)
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p + rgn0, n_rgn, (u64*)e->d_segprefix.p, key_counts, true);
         } else {
-            hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p, grid, (u64*)e->d_segprefix.p, key_counts);
-            e->seg_n = grid; e->seg_stride = region;
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, (const u64*)e->d_segcount.p, n_rgn, (u64*)e->d_segprefix.p, key_counts, false);
+            e->seg_n = n_rgn; e->seg_stride = region;
+            e->rgn_hist_n = n_rgn; e->rgn_hist_shift = e->skip_bits;
         }
     } else if (e->use_lds_genes) {
         const u32 grid = std::min<u32>(tiles, e->genes_blocks_per_cu * g_cu_count);
@@ -933,7 +965,7 @@ extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uin
     if (!(e->n_shards == 1 && e->use_lds_genes) || getenv("FASTF_NO_STREAM_K1B")) return 0;
     u32 grid; u64 region;
     stream_geometry(e, (n + K1_TILE - 1) / K1_TILE, &grid, &region);
-    *key_slots = (u64)grid * region;
+    *key_slots = (u64)grid * K1S_SUB * region;
     return 0;
 } FASTF_CATCH_INT
 
@@ -977,6 +1009,7 @@ static int set_scatter_lds_limit() {
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)scatter_kernel<-1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes_vals(SORT_IPT)) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)scatter_regions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_smem_bytes()) != hipSuccess) return 1;
     return 0;
 }
 
@@ -995,19 +1028,41 @@ static int launch_sort(fastf_engine* e, u64* keys, u64* tmp, const u64* d_n, u64
     const u32 T = (u32)((max_n + (u64)ipt * SORT_THREADS - 1) / ((u64)ipt * SORT_THREADS));
     u32* bintot = (u32*)e->d_binbase.p; u32* cnt = (u32*)e->d_cnt.p;
     SegMap seg{nullptr, nullptr, 0, 0};
+    bool walk = false;
     if (segmented_input) {
-        // the keys are the segmented output of the streaming K1b: the first pass reads through the region map
+        // the keys lie in the regions the streaming K1b left (or fastf_dev_set_regions named)
         if (!e->seg_n) return set_err("FASTF_SORT_SEGMENTED without a preceding FASTF_PROBE_SEGMENTED probe_pack");
         if (passes == 0) return set_err("segmented keys need at least one sort pass");
-        seg = SegMap{(const u64*)e->d_segprefix.p, (const TileSeg*)e->d_tileseg.p, e->seg_n, e->seg_stride};
-        hipLaunchKernelGGL(seg_tiles_kernel, dim3(std::min<u32>((T + 255) / 256, 1024)), dim3(256), 0, s, seg.prefix, seg.n_seg,
-                           seg.stride, ipt * SORT_THREADS, (TileSeg*)e->d_tileseg.p);
+        // K1b left a histogram of this very digit per region: the first pass walks the regions, nothing is counted
+        static const bool no_walk = getenv("FASTF_NO_REGION_WALK") != nullptr;
+        walk = e->rgn_hist_n == e->seg_n && e->rgn_hist_shift == low_bit && !no_walk && !vals;
+        if (!walk) {
+            // otherwise (another digit grid, regions without histograms): count per tile, reading through the region map
+            if (!e->seg_stride) return set_err("internal error: regions without a common stride need their histograms");
+            seg = SegMap{(const u64*)e->d_segprefix.p, (const TileSeg*)e->d_tileseg.p, e->seg_n, e->seg_stride};
+            hipLaunchKernelGGL(seg_tiles_kernel, dim3(std::min<u32>((T + 255) / 256, 1024)), dim3(256), 0, s, seg.prefix, seg.n_seg,
+                               seg.stride, ipt * SORT_THREADS, (TileSeg*)e->d_tileseg.p);
+        }
     }
     const SegMap none{nullptr, nullptr, 0, 0};
     for (u32 q = 0; q < passes; ++q) {
         const u64* src = (q & 1) ? tmp : keys;
         u64* dst = (q & 1) ? keys : tmp;
         const u32 shift = low_bit + 8 * q;
+        if (q == 0 && walk) {
+            const u32 R = e->seg_n, n_blk = (R + RGN_BLK - 1) / RGN_BLK;
+            if (e->d_rgn_blk.ensure((size_t)n_blk * RADIX * sizeof(u32))) return 1;
+            hipLaunchKernelGGL(rgn_scan_blocks_kernel, dim3(n_blk), dim3(RADIX), 0, s, (u32*)e->d_rgn_hist.p, R, (u32*)e->d_rgn_blk.p);
+            hipLaunchKernelGGL(rgn_scan_fix_kernel, dim3(n_blk), dim3(RADIX), 0, s, (u32*)e->d_rgn_hist.p, R, (const u32*)e->d_rgn_blk.p, n_blk, bintot);
+            t_begin(e, s);
+            hipLaunchKernelGGL(scatter_regions_kernel, dim3(tile_grid(R)), dim3(SORT_THREADS), scatter_smem_bytes(ipt), s, src, dst,
+                               (const u64*)e->d_rgn_phys.p, (const u64*)e->d_segcount.p, (const u32*)e->d_rgn_hist.p, (const u32*)bintot, R, ipt, shift,
+                               max_n >= (24ull << 20));
+            t_end(e, s, &e->t_scatter_ms, &e->t_scatter_n);
+            e->rgn_hist_n = 0;                           // (the histograms are offsets now: consumed)
+            dbg_sync(s, "K2 sort pass (region walk)");
+            continue;
+        }
         t_begin(e, s);
         if (q == 0 && seg.prefix) hipLaunchKernelGGL(tile_count_kernel<true>, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt, seg);
         else hipLaunchKernelGGL(tile_count_kernel<false>, dim3(tile_grid(T)), dim3(SORT_THREADS), 0, s, src, d_n, shift, cnt, ipt, none);
@@ -1032,7 +1087,7 @@ extern "C" int fastf_dev_set_regions(fastf_engine_t* e, const uint64_t* d_counts
     if (e->d_segprefix.ensure(((size_t)n_regions + 1) * sizeof(u64))) return 1;
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const u64*)d_counts, (u32)n_regions, (u64*)e->d_segprefix.p, (u64*)d_n_out);
     HIP_OK(hipGetLastError());
-    e->seg_n = n_regions; e->seg_stride = stride;
+    e->seg_n = n_regions; e->seg_stride = stride; e->rgn_hist_n = 0;
     return 0;
 } FASTF_CATCH_INT
 
@@ -1204,7 +1259,9 @@ static const char* err_bits_text(u64 bits) {
     return buf;
 }
 
-static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4 + 4); }     // (+ 4: umi_ext of engines with umi_max_bases > 16)
+// SoA: cb | gx | umi | meta (+ 4: umi_ext of engines with umi_max_bases > 16); blocked: cb | one run of 4608 or 5120 bytes per 256
+// records (8 + 20 bytes per record at most, and the last run whole)
+static size_t stage_bytes(u64 cap) { return (size_t)cap * (8 + 8 + 4 + 4 + 4) + 8192; }
 
 // Streaming push path.
 //   chunk i:  [host staging, pageable input only]  ->  H2D on s_copy  ->  K1a + scan + K1b on s_compute
@@ -1241,11 +1298,52 @@ static int retire_all(fastf_engine* e) {
     return retire_slot(e, e->slot[first ^ 1]);
 }
 
+// stream mode: the key store holds SLOTS (the regions of the chunks, with gaps): room for `need` of them
+static int grow_slots(fastf_engine* e, u64 need) {
+    if (need <= e->slot_cap && e->d_keys.p) return 0;
+    if (retire_all(e)) return 1;
+    HIP_OK(hipStreamSynchronize(e->s_compute));
+    const u64 ncap = std::max<u64>(need, std::max<u64>(e->slot_cap * 2, 1u << 22));
+    void* np = nullptr;
+    HIP_OK(hipMalloc(&np, ncap * sizeof(u64)));
+    if (e->d_keys.p && e->slots_used) HIP_OK(hipMemcpy(np, e->d_keys.p, e->slots_used * sizeof(u64), hipMemcpyDeviceToDevice));
+    e->d_keys.release();
+    e->d_keys.p = np; e->d_keys.bytes = ncap * sizeof(u64);
+    e->slot_cap = ncap;
+    return 0;
+}
+// ... and the tables of its regions (first slot, key count, histogram of the first sort digit): room for `need` regions
+static int grow_regions(fastf_engine* e, u32 need) {
+    if (need <= e->rgn_cap && e->d_rgn_hist.p) return 0;
+    if (retire_all(e)) return 1;
+    HIP_OK(hipStreamSynchronize(e->s_compute));
+    const u32 ncap = std::max<u32>(need, std::max<u32>(e->rgn_cap * 2, 8192u));
+    DevBuf* bufs[3] = {&e->d_segcount, &e->d_rgn_phys, &e->d_rgn_hist};
+    const size_t per[3] = {sizeof(u64), sizeof(u64), RADIX * sizeof(u32)};
+    for (int i = 0; i < 3; ++i) {
+        void* np = nullptr;
+        HIP_OK(hipMalloc(&np, (size_t)ncap * per[i]));
+        if (bufs[i]->p && e->rgn_n) HIP_OK(hipMemcpy(np, bufs[i]->p, (size_t)e->rgn_n * per[i], hipMemcpyDeviceToDevice));
+        bufs[i]->release();
+        bufs[i]->p = np; bufs[i]->bytes = (size_t)ncap * per[i];
+    }
+    e->rgn_cap = ncap;
+    return 0;
+}
+
 static int grow_keys(fastf_engine* e, u64 need) {
-    if (need <= e->key_cap && e->d_keys.p) return 0;
+    if (need <= e->key_cap && (e->stream_mode ? e->d_tmp.p : e->d_keys.p)) return 0;
     if (retire_all(e)) return 1;           // the copy below needs the exact key count and a quiet key store
     HIP_OK(hipStreamSynchronize(e->s_compute));
     u64 ncap = std::max<u64>(need, std::max<u64>(e->key_cap * 2, 1u << 20));
+    if (e->stream_mode) {
+        // the keys themselves live in the slot store (grow_slots); this is the bound on their NUMBER, which sizes what
+        // fastf_engine_finish works in
+        e->key_cap = ncap;
+        if (e->d_tmp.ensure(ncap * sizeof(u64)) || e->d_feature.ensure(ncap * 4) || e->d_cell.ensure(ncap * 4) || e->d_count.ensure(ncap * 4)) return 1;
+        if (e->d_rg_feature.ensure(ncap * 4) || e->d_rg_cell.ensure(ncap * 4) || e->d_rg_count.ensure(ncap * 4)) return 1;
+        return reserve_workspace(e, 0, ncap);
+    }
     void* np = nullptr;
     HIP_OK(hipMalloc(&np, ncap * sizeof(u64)));
     if (e->d_keys.p && e->keys_so_far)
@@ -1334,6 +1432,13 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     if (grow_keys(e, keys_ub + n)) return 1;
     const u64 cap = e->batch_cap;
     char* ds = (char*)sl.d_stage.p;
+    // stream mode: this chunk's regions behind those of the chunks before
+    u32 s_grid = 0; u64 s_region = 0, s_slots = 0;
+    if (e->stream_mode) {
+        stream_geometry(e, (n + K1_TILE - 1) / K1_TILE, &s_grid, &s_region);
+        s_slots = (u64)s_grid * K1S_SUB * s_region;
+        if (grow_slots(e, e->slots_used + s_slots) || grow_regions(e, e->rgn_n + s_grid * (u32)K1S_SUB)) return 1;
+    }
     const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_ext = cap * 24;
     const void *s_cb = b->cb_key + off, *s_gx = b->gx_key + off, *s_umi = b->umi + off, *s_meta = b->meta + off;
     const void *s_ext = (e->long_umi && b->umi_ext) ? b->umi_ext + off : nullptr;
@@ -1356,9 +1461,29 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     hipStream_t sc = e->s_copy, sk = e->s_compute;
     // (hipMemcpyDefault: a "pinned" batch may also be DEVICE memory — the records the device-side BAM front end packed)
     HIP_OK(hipMemcpyAsync(ds, s_cb, n * 8, hipMemcpyDefault, sc));
+    char* const blk = ds + cap * 8;                                     // stream mode: the blocked runs behind the cb keys
+    if (e->stream_mode) {
+        // The batch lands in the BLOCKED layout (umi_kernels.hpp: per 256 records one run gx | umi | meta | cell scratch): three
+        // pitched copies — a row is one unit's slice of an array, the destination pitch the run — and three plain ones for the
+        // records of a last, partial unit.  Same rate as plain copies (tools/h2d_2d_probe.hip).
+        const u32 run = blk_run_bytes(e->cell16);
+        const u64 full = n / BLK_RECS, tail = n % BLK_RECS;
+        if (full) {
+            HIP_OK(hipMemcpy2DAsync(blk + BLK_GX, run, s_gx, BLK_RECS * 8, BLK_RECS * 8, full, hipMemcpyDefault, sc));
+            HIP_OK(hipMemcpy2DAsync(blk + BLK_UMI, run, s_umi, BLK_RECS * 4, BLK_RECS * 4, full, hipMemcpyDefault, sc));
+            HIP_OK(hipMemcpy2DAsync(blk + BLK_META, run, s_meta, BLK_RECS * 4, BLK_RECS * 4, full, hipMemcpyDefault, sc));
+        }
+        if (tail) {
+            char* const last = blk + full * run;
+            HIP_OK(hipMemcpyAsync(last + BLK_GX, (const char*)s_gx + full * BLK_RECS * 8, tail * 8, hipMemcpyDefault, sc));
+            HIP_OK(hipMemcpyAsync(last + BLK_UMI, (const char*)s_umi + full * BLK_RECS * 4, tail * 4, hipMemcpyDefault, sc));
+            HIP_OK(hipMemcpyAsync(last + BLK_META, (const char*)s_meta + full * BLK_RECS * 4, tail * 4, hipMemcpyDefault, sc));
+        }
+    } else {
     HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyDefault, sc));
     HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyDefault, sc));
     HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyDefault, sc));
+    }
     if (e->long_umi) {                                                  // bases 17.. (zeros when the batch has none)
         if (s_ext) HIP_OK(hipMemcpyAsync(ds + o_ext, s_ext, n * 4, hipMemcpyDefault, sc));
         else HIP_OK(hipMemsetAsync(ds + o_ext, 0, n * 4, sc));
@@ -1369,6 +1494,16 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     HIP_OK(hipEventRecord(sl.ev_copy, sc));
     HIP_OK(hipStreamWaitEvent(sk, sl.ev_copy, 0));
     u64* small = (u64*)e->d_small.p;
+    if (e->stream_mode) {
+        // K1a writes the cell indices into the runs' scratch slices, the streaming K1b reads the runs and appends this chunk's
+        // regions (keys, counts, first-digit histograms) to the store: what bench.py's resident pass runs, chunk by chunk
+        const RegionAppend app{e->slots_used, e->rgn_n};
+        if (launch_probe(e, (const u64*)ds, nullptr, nullptr, nullptr, n, (const u32*)e->d_ring.p, std::min(e->draws_up, e->draws_valid),
+                         small + SM_DRAWBASE, (u64*)e->d_keys.p + e->slots_used, s_slots, small + SM_KEYCOUNT, small + SM_COUNTERS, false, sk,
+                         e->ring_len - 1, small + SM_RUNNING, true, blk, &app))
+            return 1;
+        e->slots_used += s_slots; e->rgn_n += s_grid * (u32)K1S_SUB; e->store_regions = true;
+    } else
     if (launch_probe(e, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), n,
                      (const u32*)e->d_ring.p, std::min(e->draws_up, e->draws_valid), small + SM_DRAWBASE, (u64*)e->d_keys.p, e->key_cap,
                      small + SM_KEYCOUNT, small + SM_COUNTERS, false, sk, e->ring_len - 1, small + SM_RUNNING))
@@ -1383,6 +1518,30 @@ static int push_chunk(fastf_engine* e, const fastf_batch_t* b, size_t off, size_
     return 0;
 }
 
+// stream mode, a push AFTER fastf_engine_finish (no reset in between: the job goes on): the sort passes have rewritten the store,
+// so the keys so far become regions again — runs of 64 K keys of the sorted (or last permuted) array, their histograms counted
+// by a kernel of its own (rare: nothing on the hot path does this)
+static int rebase_store(fastf_engine* e) {
+    const u64 n = e->n_sorted;
+    HIP_OK(hipStreamSynchronize(e->s_compute));
+    if (e->store_regions && n)                           // one pass only: the keys in the store are still the regions, the array is d_tmp's
+        HIP_OK(hipMemcpy(e->d_keys.p, e->d_tmp.p, n * sizeof(u64), hipMemcpyDeviceToDevice));
+    constexpr u64 RUN = 1u << 16;
+    const u32 R = (u32)((n + RUN - 1) / RUN);
+    e->rgn_n = 0; e->slots_used = 0; e->store_regions = false; e->rgn_hist_n = 0;
+    if (R == 0) return 0;
+    if (grow_regions(e, R)) return 1;
+    std::vector<u64> phys(R), cnt(R);
+    for (u32 i = 0; i < R; ++i) { phys[i] = (u64)i * RUN; cnt[i] = std::min<u64>(RUN, n - phys[i]); }
+    HIP_OK(hipMemcpy(e->d_rgn_phys.p, phys.data(), R * sizeof(u64), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(e->d_segcount.p, cnt.data(), R * sizeof(u64), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rgn_hist_kernel, dim3(std::min<u32>(R, 8 * g_cu_count)), dim3(256), 0, e->s_compute, (const u64*)e->d_keys.p, (const u64*)e->d_rgn_phys.p,
+                       (const u64*)e->d_segcount.p, R, e->skip_bits, (u32*)e->d_rgn_hist.p);
+    HIP_OK(hipGetLastError());
+    e->rgn_n = R; e->slots_used = n; e->store_regions = true;
+    return 0;
+}
+
 static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32_t* draws, size_t n_draws, bool pinned) {
     if (!e || !batch) return set_err("null argument");
     if (e->multi) {
@@ -1392,6 +1551,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
     if (e->n_shards != 1) return set_err("fastf_engine_push drives a single shard; use the fastf_dev_* calls for sharded runs");
     HIP_OK(hipSetDevice(e->device));
     if (batch->n == 0) return 0;
+    if (e->stream_mode && e->finished && rebase_store(e)) return 1;
     if (!e->d_ring.p) {
         u64 r = 1024; while (r < 4 * e->batch_cap) r <<= 1;            // three chunks of ranks can be live at once
         if (e->d_ring.ensure(r / 8)) return 1;                         // one bit per rank
@@ -1555,6 +1715,15 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
                                                  e->sorted_in_tmp ? (u64*)e->d_vtmp.p : (u64*)e->d_vals.p))
                     return 1;
             } else {
+            if (e->stream_mode && e->store_regions) {
+                // the keys lie in the regions the chunks' K1b left, each with the histogram of the first digit: the first pass
+                // walks the regions (no counting pass), the later ones see contiguous buffers
+                e->seg_n = e->rgn_n; e->seg_stride = 0; e->rgn_hist_n = e->rgn_n; e->rgn_hist_shift = e->skip_bits;
+                if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
+                                &e->sorted_in_tmp, s, true))
+                    return 1;
+                if (sort_passes(e->L.total_bits, e->skip_bits) >= 2) e->store_regions = false;   // the second pass wrote the store from its front
+            } else
             if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
                             &e->sorted_in_tmp, s))
                 return 1;
@@ -1580,7 +1749,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             HIP_OK(hipMemcpyAsync(small + SM_COUNTERS + 3, &keep, sizeof(u64), hipMemcpyHostToDevice, s));
             if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, &in_other, s)) return 1;
             if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
-            e->fully_sorted = true;
+            e->fully_sorted = true; e->store_regions = false;
             const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
             if (launch_reduce_regions<false>(e, sorted, small + SM_KEYCOUNT, n, small + SM_NNZ, 0, s)) return 1;
             HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
@@ -1723,7 +1892,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
             int in_other = 0;
             if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, &in_other, s)) return 1;
             if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
-            e->fully_sorted = true;
+            e->fully_sorted = true; e->store_regions = false;
         }
         const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
         if (launch_reduce<true>(e, sorted, small + SM_KEYCOUNT, n, nullptr, nullptr, (u32*)e->d_ncopy.p,
@@ -1776,6 +1945,7 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) FASTF_TRY {
     e->inflight_records = 0;
     e->total_records = e->hits_so_far = e->keys_so_far = e->c_sampled = e->c_valid = 0;
     e->finished = false; e->h_nnz = 0;
+    e->slots_used = 0; e->rgn_n = 0; e->store_regions = false; e->rgn_hist_n = 0; e->seg_n = 0;
     e->lent_rows = nullptr; e->lent_cap = 0; e->rows_at = nullptr; e->rows_stride = 0;     // a loan lasts for one finish
     e->draws_up = e->draws_valid = 0;
     e->mt_live = false;                  // the engine-owned stream goes on after the last draw a hit consumed

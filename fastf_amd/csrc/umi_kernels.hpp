@@ -954,10 +954,21 @@ static_assert(K1_TILE % K1S_UNIT == 0 && K1_TILE / K1S_UNIT == 16, "16 units per
 constexpr int K1S_THREADS = FASTF_K1S_THREADS, K1S_THREADS_ROOMY = 1024;
 static_assert(K1S_THREADS % (4 * WAVE) == 0 && K1S_THREADS <= 1024, "whole waves on every SIMD");
 
+// Every workgroup owns K1S_SUB regions of the key buffer and fills them by turns, one unit into the one, the next into the
+// other (the loop body exists twice anyway: the register sets of the hand-pipelined loop): region 2 b + s, region_stride slots
+// each.  Twice the regions of half the size make the first sort pass — which walks REGIONS, not tiles — a full round of
+// workgroups at four per CU.  Per region the kernel also leaves the histogram of the sort's first digit (the 8 key bits from
+// hist_shift up; LDS atomics on the keys it has in registers anyway): rgn_hist[256 r + d], and with it the first pass needs no
+// counting pass over the keys (scatter_regions_kernel; round 4 read all keys once more for that: tile_count_kernel<true>).
+constexpr int K1S_SUB = 2, K1S_BINS = 256;
 struct StreamParams {
     const u32* half_hits;          // [16 * n_tiles]
-    u64 region_stride;             // keys per workgroup region
-    u64* seg_count;                // [gridDim.x] out
+    u64 region_stride;             // key slots per region
+    u64* seg_count;                // [K1S_SUB * gridDim.x] out: keys per region
+    u32* rgn_hist;                 // [K1S_SUB * gridDim.x][256] out, or nullptr: no histogram wanted (sharded passes)
+    u64* rgn_phys;                 // [K1S_SUB * gridDim.x] out (with rgn_hist): first slot of each region, counted from slot0
+    u64 slot0;                     //   the slot number p.keys stands at in the caller's key store
+    u32 hist_shift;
 };
 
 // sum over the lanes 0..15 of one 16-lane row (DPP row shifts, no LDS traffic); the total is returned to every lane
@@ -976,7 +987,8 @@ template <bool ROOMY, bool C16, bool DIRECT, bool BLOCKED = false>
 __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 : 2 * K1S_THREADS / (4 * WAVE)) void filter_pack_stream_kernel(const PackParams p, const StreamParams sp) {
     constexpr int THREADS = ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, WAVES = THREADS / WAVE;
     __shared__ u64 s_tot[3];
-    __shared__ u32 s_cursor, s_err;
+    __shared__ u32 s_cursor[K1S_SUB], s_err;
+    __shared__ u32 s_hist[K1S_SUB * K1S_BINS];                             // first sort digit of the keys of each region
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the gene image
     const int tid = threadIdx.x, lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                // scalar: the unit's addresses are scalar base + lane
@@ -990,11 +1002,14 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
         for (u32 i = tid; i < (p.genes.bytes + 15u) / 16u; i += THREADS) dst[i] = src[i];
     }
     if (tid < 3) s_tot[tid] = 0;
-    if (tid == 0) { s_cursor = 0; s_err = 0; }
+    if (tid < K1S_SUB) s_cursor[tid] = 0;
+    if (tid == 0) s_err = 0;
+    for (int i = tid; i < K1S_SUB * K1S_BINS; i += THREADS) s_hist[i] = 0;
     __syncthreads();
 
     constexpr bool NT = FASTF_NT_K1B != 0;
-    u64* const region = p.keys + (u64)blockIdx.x * sp.region_stride;
+    u64* const region0 = p.keys + (u64)blockIdx.x * K1S_SUB * sp.region_stride;
+    const bool hs_hi = sp.hist_shift >= 32u;                               // (uniform) the digit lies in the key's upper word
     const u64 draw_off = p.draw_base ? *p.draw_base : 0;
     u32 w_hit = 0, w_samp = 0, w_valid = 0, errs = 0;                      // wave-uniform running counts
     // the workgroup's waves take consecutive units per round (unit u: tile u >> 4, place u & 15 in it): the same locality as
@@ -1088,7 +1103,8 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
     }
     // one unit: `cur` holds it, `nxt` receives the unit after it.  The loop below runs the body twice per turn with the two
     // register sets exchanged — a copy at the end of the body would have to wait for the loads it copies
-    auto one_unit = [&](UnitRegs& cur, UnitRegs& nxt) {
+    auto one_unit = [&](UnitRegs& cur, UnitRegs& nxt, auto sub_c) {
+        constexpr int SUB = decltype(sub_c)::value;                        // which of the workgroup's regions this unit's keys go to
         u32 (&cell)[K1S_IPT] = cur.cell; u32 (&umi)[K1S_IPT] = cur.umi; u32 (&meta)[K1S_IPT] = cur.meta;
         const u32 dw = cur.dw, avail = cur.avail, sbit = cur.sbit, nvalid = cur.nvalid;
         const u32 un = u + ustep;                                          // the unit after this one
@@ -1168,13 +1184,20 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
         w_valid += n_keys;                                                                 // E12
         if (n_keys) {
             u32 pos0 = 0;
-            if (lane == 0) pos0 = atomicAdd(&s_cursor, n_keys);
+            if (lane == 0) pos0 = atomicAdd(&s_cursor[SUB], n_keys);
             pos0 = (u32)__builtin_amdgcn_readfirstlane((int)pos0);
-            if ((u64)pos0 + n_keys > sp.region_stride) errs |= (u32)ERR_KEYS_FULL;         // cannot happen: the region holds every record of the workgroup
+            if ((u64)pos0 + n_keys > sp.region_stride) errs |= (u32)ERR_KEYS_FULL;         // cannot happen: the region holds every record that goes to it
             else {
+                u64* const region = region0 + (u64)SUB * sp.region_stride;
 #pragma unroll
                 for (int j = 0; j < K1S_IPT; ++j) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(em[j])) region[pos0 + rank_below(em[j])] = key[j];   // (32-bit index off the region's scalar base)
+                    if (__builtin_amdgcn_inverse_ballot_w64(em[j])) {
+                        region[pos0 + rank_below(em[j])] = key[j];                         // (32-bit index off the region's scalar base)
+                        // the sort's first digit of the key, counted per region (scatter_regions_kernel); always: a sharded pass
+                        // has no use for it, and a test in the loop would cost it a scalar register it does not have
+                        const u32 dg = hs_hi ? (u32)(key[j] >> 32) >> (sp.hist_shift - 32u) : __builtin_amdgcn_alignbit((u32)(key[j] >> 32), (u32)key[j], sp.hist_shift);
+                        (void)__hip_atomic_fetch_add(&s_hist[SUB * K1S_BINS + (dg & (K1S_BINS - 1))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     pos0 += (u32)__popcll(em[j]);
                 }
             }
@@ -1182,9 +1205,9 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
         u = un;
     };
     while (u < n_units) {
-        one_unit(ra, rb);
+        one_unit(ra, rb, std::integral_constant<int, 0>{});
         if (u >= n_units) break;
-        one_unit(rb, ra);
+        one_unit(rb, ra, std::integral_constant<int, 1>{});
     }
     if (lane == 0) {
         if (w_hit) atomicAdd(&s_tot[0], (u64)w_hit);
@@ -1198,9 +1221,18 @@ __global__ __launch_bounds__(ROOMY ? K1S_THREADS_ROOMY : K1S_THREADS, ROOMY ? 4 
         if (lane == 0 && e) atomicOr(&s_err, e);
     }
     __syncthreads();
-    if (tid < 3 && s_tot[tid]) atomicAdd(&p.counters[tid], s_tot[tid]);
-    if (tid == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
-    if (tid == 4) sp.seg_count[blockIdx.x] = s_cursor;
+    // (the thread index from the wave number and the lane: `tid` itself would have to live through the loop in a register the
+    //  loop does not have — it went to scratch memory)
+    const int te = w * WAVE + lane;
+    if (te < 3 && s_tot[te]) atomicAdd(&p.counters[te], s_tot[te]);
+    if (te == 3 && s_err) atomicOr(&p.counters[3], (u64)s_err);
+    if (te >= 64 && te < 64 + K1S_SUB) {
+        const u32 r = blockIdx.x * K1S_SUB + (u32)(te - 64);
+        sp.seg_count[r] = s_cursor[te - 64];
+        if (sp.rgn_hist) sp.rgn_phys[r] = sp.slot0 + (u64)r * sp.region_stride;
+    }
+    if (sp.rgn_hist)                                                       // one contiguous 2 KB run per workgroup
+        for (int i = te; i < K1S_SUB * K1S_BINS; i += THREADS) sp.rgn_hist[(u64)blockIdx.x * (K1S_SUB * K1S_BINS) + i] = s_hist[i];
 }
 
 // SoA on the device -> blocked runs (callers that hold device-resident SoA and want the blocked K1 path; the push path lands
@@ -1275,8 +1307,9 @@ struct TileSeg { u64 delta1, hi1, delta2, hi2; };
 struct SegMap { const u64* prefix; const TileSeg* tile_seg; u32 n_seg; u64 stride; };   // prefix == nullptr: contiguous buffer
 
 // prefix[b] = keys in the regions before b, prefix[n_seg] = total, also stored to *n_out (the key count the sort reads)
+// add: *n_out grows by the total instead (the push path: regions of one chunk behind those of the chunks before)
 __global__ __launch_bounds__(1024) void seg_scan_kernel(const u64* __restrict__ seg_count, u32 n_seg, u64* __restrict__ prefix,
-                                                        u64* __restrict__ n_out) {
+                                                        u64* __restrict__ n_out, bool add = false) {
     __shared__ u64 s_w[16];
     __shared__ u64 s_carry;
     const int lane = lane_id(), w = threadIdx.x >> 6;
@@ -1297,7 +1330,7 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(const u64* __restrict__ 
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { prefix[n_seg] = s_carry; *n_out = s_carry; }
+    if (threadIdx.x == 0) { prefix[n_seg] = s_carry; *n_out = add ? *n_out + s_carry : s_carry; }
 }
 
 // largest b with prefix[b] <= idx and a non-empty region (idx < total)
@@ -1481,12 +1514,14 @@ __device__ __forceinline__ u32 digit_of(u64 key, u32 rshift) {
 // bounds check (only the last tile of a pass is partial).
 // VALS: every key carries a 64-bit value (vin -> vout) that moves with it (keys wider than 64 bits: the group is sorted, the
 // rest of the key rides along); the values take a second tile-sized LDS array behind everything else
+// g_off (threads < 256): where in bin `tid` this tile's keys of that digit begin — asked for by the caller ahead of the call,
+// needed only after the ranking.  Returns (threads < 256) the tile's number of keys with digit `tid`.
 template <int SHIFT, bool FULL, bool SEG, bool VALS = false>
-__device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
-                                             u32 T, u32 tile, const u32* __restrict__ off, const u32* __restrict__ bin_tot,
-                                             const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, const int tid,
-                                             const bool streams, u64* stamps = nullptr,
-                                             const u64* __restrict__ vin = nullptr, u64* __restrict__ vout = nullptr) {
+__device__ __forceinline__ u32 scatter_tile(const u64* __restrict__ in, u64* __restrict__ out, u64 base, u32 n_valid,
+                                            u32 tile, const u32 g_off, const u32* __restrict__ bin_tot,
+                                            const int ipt, unsigned char* smem, const u32 rshift, const SegMap seg, const int tid,
+                                            const bool streams, u64* stamps = nullptr,
+                                            const u64* __restrict__ vin = nullptr, u64* __restrict__ vout = nullptr) {
 #ifdef FASTF_STAMPS
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1502,8 +1537,6 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     const int lane = tid & (WAVE - 1), w = tid >> 6;       // (tid comes in opaque, see scatter_kernel)
 
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS) s_whist[i] = 0;
-    // this tile's global bin offsets: issued now, needed only after the ranking
-    const u32 g_off = tid < RADIX ? off[(u64)tid * row_stride(T) + tile] : 0u;
     const u32 g_tot = tid < RADIX ? bin_tot[tid] : 0u;     // keys of the whole pass with digit tid → bin base by a scan below
 
     // wave-striped load: wave w owns [w*IPT*64, (w+1)*IPT*64) of the tile
@@ -1615,6 +1648,7 @@ __device__ __forceinline__ void scatter_tile(const u64* __restrict__ in, u64* __
     STAMP(6);
 #endif
 #undef STAMP
+    return run;
 }
 
 // SEG: the input is the segmented key buffer of the streaming K1b (first pass only; its own instantiation, so that the
@@ -1646,10 +1680,89 @@ __global__ __launch_bounds__(SORT_THREADS, VALS ? 4 : 8) void scatter_kernel(con
         // the loop and stays live across it (75 VGPRs, three workgroups per CU, instead of 47 and four).
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
+        // this tile's global bin offsets: issued now, needed only after the ranking
+        const u32 g_off = tid < RADIX ? off[(u64)tid * row_stride(T) + tile] : 0u;
         // (no barrier between tiles: whatever a tile reads last from LDS is rewritten only after two barriers of the next)
-        if (n_valid == tile_keys) scatter_tile<SHIFT, true, SEG, VALS>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps, vin, vout);
-        else scatter_tile<SHIFT, false, SEG, VALS>(in, out, base, n_valid, T, tile, off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps, vin, vout);
+        if (n_valid == tile_keys) (void)scatter_tile<SHIFT, true, SEG, VALS>(in, out, base, n_valid, tile, g_off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps, vin, vout);
+        else (void)scatter_tile<SHIFT, false, SEG, VALS>(in, out, base, n_valid, tile, g_off, bin_tot, (int)ipt, smem, rshift, seg, tid, streams, stamps, vin, vout);
         if constexpr (VALS) __syncthreads();                 // the value array is read last and rewritten before the next tile's second barrier
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The FIRST pass of a sort over the regions the streaming K1b left (filter_pack_stream_kernel): no counting pass.  K1b kept a
+// histogram of this pass's digit per region (rgn_hist[r][256]); two small kernels turn those into exclusive offsets over the
+// regions, per digit, and the bin totals — region-major, so a workgroup flushes and fetches one contiguous KB — and
+// scatter_regions_kernel has every workgroup WALK a region tile by tile, carrying the count of each digit it has sent out so
+// far: a tile's place in a bin is the region's offset plus what the tiles of the region in front of it put there.  The order
+// of the keys inside a bin is region by region, tile by tile: as good as any other for the first pass of an LSD sort.
+// Round 4 read all keys once more to count them per tile (tile_count_kernel<true>, 0.074 ms of the 2.1 ms step on configs[2]).
+// ------------------------------------------------------------------------------------
+constexpr u32 RGN_BLK = 64;            // regions per workgroup of the offset scan
+static_assert(K1S_BINS == RADIX, "K1b's region histograms are histograms of a sort digit");
+// per block of RGN_BLK regions: exclusive offsets inside the block (in place), the block's totals per digit
+__global__ __launch_bounds__(RADIX) void rgn_scan_blocks_kernel(u32* __restrict__ hist, u32 R, u32* __restrict__ blk_sum) {
+    const u32 d = threadIdx.x, r0 = blockIdx.x * RGN_BLK, r1 = r0 + RGN_BLK < R ? r0 + RGN_BLK : R;
+    u32 acc = 0;
+    for (u32 r = r0; r < r1; r += 8) {                       // eight loads in flight, then the running sum
+        u32 v[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) v[k] = r + k < r1 ? hist[(u64)(r + k) * RADIX + d] : 0u;
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) { if (r + k < r1) hist[(u64)(r + k) * RADIX + d] = acc; acc += v[k]; }
+    }
+    blk_sum[(u64)blockIdx.x * RADIX + d] = acc;
+}
+// the blocks in front added in; workgroup 0 also leaves the totals per digit (the bin sizes of the pass)
+__global__ __launch_bounds__(RADIX) void rgn_scan_fix_kernel(u32* __restrict__ hist, u32 R, const u32* __restrict__ blk_sum, u32 n_blk,
+                                                             u32* __restrict__ bin_tot) {
+    const u32 d = threadIdx.x, w = blockIdx.x;
+    u32 off = 0, tot = 0;
+    for (u32 i = 0; i < n_blk; ++i) { const u32 v = blk_sum[(u64)i * RADIX + d]; off += i < w ? v : 0u; tot += v; }
+    if (w == 0) bin_tot[d] = tot;
+    if (off == 0) return;
+    const u32 r0 = w * RGN_BLK, r1 = r0 + RGN_BLK < R ? r0 + RGN_BLK : R;
+    for (u32 r = r0; r < r1; ++r) hist[(u64)r * RADIX + d] += off;
+}
+// region r: rgn_count[r] keys from keys + rgn_phys[r]; hist_excl[r][d]: keys with digit d in the regions in front of r
+__global__ __launch_bounds__(SORT_THREADS, 8) void scatter_regions_kernel(const u64* __restrict__ keys, u64* __restrict__ out,
+                                                                           const u64* __restrict__ rgn_phys, const u64* __restrict__ rgn_count,
+                                                                           const u32* __restrict__ hist_excl, const u32* __restrict__ bin_tot,
+                                                                           u32 R, u32 ipt, u32 rshift, bool streams) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 tile_keys = ipt * SORT_THREADS;
+    const SegMap none{nullptr, nullptr, 0, 0};
+    // neighbouring regions write neighbouring runs of every bin: a contiguous range of regions per XCD, as for the tiles
+    for (u32 i = blockIdx.x >> 3;; i += gridDim.x >> 3) {
+        const u32 r = xcd_tile(R, i);
+        if (r >= R) return;                                  // block-uniform
+        const u64 cnt = rgn_count[r];
+        const u64* const in = keys + rgn_phys[r];
+        u32 acc = threadIdx.x < RADIX ? hist_excl[(u64)r * RADIX + threadIdx.x] : 0u;
+        for (u64 base = 0; base < cnt; base += tile_keys) {
+            const u32 n_valid = (u32)(cnt - base < (u64)tile_keys ? cnt - base : (u64)tile_keys);
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));                    // (see scatter_kernel: keeps the tile body's addresses out of the loop's live set)
+            u32 run;
+            if (n_valid == tile_keys) run = scatter_tile<-1, true, false>(in, out, base, n_valid, r, acc, bin_tot, (int)ipt, smem, rshift, none, tid, streams);
+            else run = scatter_tile<-1, false, false>(in, out, base, n_valid, r, acc, bin_tot, (int)ipt, smem, rshift, none, tid, streams);
+            acc += run;
+        }
+    }
+}
+// histograms of regions whose keys are already in memory (an engine that is pushed to again after a finish: rare)
+__global__ __launch_bounds__(256) void rgn_hist_kernel(const u64* __restrict__ keys, const u64* __restrict__ rgn_phys, const u64* __restrict__ rgn_count,
+                                                       u32 R, u32 shift, u32* __restrict__ hist) {
+    __shared__ u32 s_h[RADIX];
+    for (u32 r = blockIdx.x; r < R; r += gridDim.x) {
+        s_h[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 cnt = rgn_count[r];
+        const u64* const in = keys + rgn_phys[r];
+        for (u64 i = threadIdx.x; i < cnt; i += 256) atomicAdd(&s_h[(u32)(in[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        hist[(u64)r * RADIX + threadIdx.x] = s_h[threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -2151,9 +2264,12 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
                 __syncthreads();
                 const u32 at = __builtin_amdgcn_readfirstlane(s_first);
                 if (at + parts > GIANT_LIST_CAP) { if (tid == 0) atomicOr(p.err, ERR_RUN_TOO_LONG); }
-                else if ((u32)tid < parts) {
-                    u64* it = p.giant_list + (u64)(at + tid) * GIANT_ITEM_WORDS;
-                    it[0] = base; it[1] = len; it[2] = row; it[3] = (u64)tid | ((u64)parts << 32);
+                else {
+                    // (strided: the wide path takes groups of up to 4 M reads = 2731 items, more than the workgroup has threads — ADVICE r4)
+                    for (u32 t = (u32)tid; t < parts; t += K3H_THREADS) {
+                        u64* it = p.giant_list + (u64)(at + t) * GIANT_ITEM_WORDS;
+                        it[0] = base; it[1] = len; it[2] = row; it[3] = (u64)t | ((u64)parts << 32);
+                    }
                 }
                 __syncthreads();                                           // s_first is reused by the next search
             }

@@ -313,6 +313,9 @@ WIDE_CASES = {
     # LDS tables, deep groups: windows full of one group (giant_groups_kernel on the values), all duplicates, NULL UMIs only
     "huge groups": (dict(n=400_000, n_bar=3, n_gene=2, umi_len=12, data_seed=11), 12, None),
     "one group, all duplicates": (dict(n=100_000, n_bar=1, n_gene=1, umi_pool=1), 12, None),
+    # one (cell, feature) group of a million reads: 652 hash partitions, more work items than reduce_hashed_kernel has threads
+    # (items 512.. were never written)
+    "one group of a million reads": (dict(n=1_000_000, n_bar=1, n_gene=1, umi_len=12, data_seed=13), 12, None),
     "one group, NULL UMIs": (dict(n=30_000, n_bar=1, n_gene=1, umi_pool=3, p_n_umi=0.9), 12, None),
     "mixed": (dict(n=250_000, n_bar=3000, n_gene=1500, rate_cell=0.5, rate_depth=0.5, umi_pool=64, p_no_cb=0.05, p_unlisted_cb=0.05,
                    p_bad_xf=0.15, p_n_umi=0.02, p_multi_gene=0.05, p_no_ub=0.02), 16, None),
