@@ -11,9 +11,10 @@
 // The window is cut into slices that run H2D -> kernel -> D2H on alternating streams, so the three stages of
 // neighbouring slices overlap.
 #include "gpu_inflate.hpp"
+#include "gpu_inflate2.hpp"
 #include "gpu_records.hpp"
 
-struct GiBlock { u64 coff; u32 clen, isize; u64 uoff; };          // offsets into the slice's compressed / inflated bytes
+struct GiBlock { u64 coff; u32 clen, isize; u64 uoff; u64 toff; };   // offsets into the slice's compressed / inflated bytes / token lists
 
 #ifndef FASTF_GI_MINBLOCKS
 #define FASTF_GI_MINBLOCKS 5      // waves per SIMD: 96 VGPRs instead of 109, twenty blocks per CU as the LDS allows (25.6 -> 26.0 GB/s)
@@ -29,6 +30,95 @@ __global__ __launch_bounds__(64, FASTF_GI_MINBLOCKS) void bgzf_inflate_kernel(co
     if (gi_lane0()) status[b] = (uint8_t)rc;
 }
 
+// ---- the two-kernel inflate (round 5; gpu_inflate2.hpp has the why) ----
+// Phase 1: ONE LANE per BGZF block, GI2_LPW blocks per wave (their working sets side by side in LDS: 580 bytes each).  A lane
+// decodes its block's tokens, stores the literals where they belong and lists the matches as 4-byte tokens.
+#ifndef FASTF_GI2_LPW
+#define FASTF_GI2_LPW 64
+#endif
+constexpr int GI2_LPW = FASTF_GI2_LPW;
+static_assert(GI2_LPW >= 1 && GI2_LPW <= 64 && sizeof(gi2::Work) * GI2_LPW <= 40 * 1024, "blocks per wave: four waves' working sets share a CU's LDS");
+constexpr size_t GI2_LDS_BYTES = sizeof(gi2::Work) * GI2_LPW;
+__global__ __launch_bounds__(GI2_LPW) void bgzf_decode_kernel(const GiBlock* __restrict__ blk, u32 n_blk, const uint8_t* __restrict__ comp,
+                                                               uint8_t* __restrict__ out, u32* __restrict__ tokens, u32* __restrict__ tok_count,
+                                                               uint8_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gi2_smem[];
+    gi2::Work* const ws = reinterpret_cast<gi2::Work*>(gi2_smem);
+    const u32 b = blockIdx.x * (u32)GI2_LPW + threadIdx.x;
+    if (b >= n_blk) return;
+    const GiBlock k = blk[b];
+    int rc = 0; u32 nt = 0;
+    if (k.isize) rc = gi2::inflate_tokens(ws[threadIdx.x], comp + k.coff, k.clen, out + k.uoff, k.isize, tokens + k.toff, &nt);
+    status[b] = (uint8_t)rc;
+    tok_count[b] = rc ? 0u : nt;
+}
+// Phase 2: one WAVE per block resolves its matches, 64 tokens at a time.  A wave scan over (literals + length) gives every
+// match its place.  A match may copy once the bytes it READS are final: the literals are (phase 1), everything in front of the
+// batch is, so what it has to wait for are the matches of its own batch whose output overlaps its source — a contiguous run of
+// lanes (the outputs lie in order), found once per batch by two binary searches over the lanes' positions and kept as a 64-bit
+// mask: ready = none of those lanes is still pending.  Rounds per batch = the depth of the batch's dependency chains (a field
+// copied from the record before, which copied it from the one before: two to four on BAM payloads), not the number of matches
+// that have a near source (the first form of this kernel waited for "everything below the first pending match": a round per
+// such match, 35 ms for a 2.3 GB window).  Inside a round every ready lane copies 16 bytes per step — sixteen loads issued
+// back to back, then sixteen stores, and no wait between the steps: one memory round trip per 16 bytes, not per 4.  A match that overlaps its own output
+// (distance < length) repeats its first `distance` bytes and reads only those.  The sources are read past the CU's L1 (this
+// wave stored some of them a round ago: gi_coherent_load8) after the stores before have been acknowledged.
+__global__ __launch_bounds__(256) void bgzf_resolve_kernel(const GiBlock* __restrict__ blk, u32 n_blk, uint8_t* __restrict__ out,
+                                                           const u32* __restrict__ tokens, const u32* __restrict__ tok_count,
+                                                           const uint8_t* __restrict__ status) {
+    const int lane = lane_id();
+    const u32 b = blockIdx.x * 4u + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (b >= n_blk) return;
+    if (status[b]) return;                                             // (declined in phase 1: the host inflates it)
+    const GiBlock k = blk[b];
+    const u32 n_tok = tok_count[b];
+    uint8_t* const o = out + k.uoff;
+    const u32* const tk = tokens + k.toff;
+    const u64 below_me = lane ? (~0ull >> (64 - lane)) : 0ull;
+    u32 pos = 0;                                                       // (uniform) output position in front of this batch
+    for (u32 t0 = 0; t0 < n_tok; t0 += 64) {
+        const u32 t = t0 + (u32)lane < n_tok ? tk[t0 + (u32)lane] : gi2::TOK_SKIP;
+        const bool skip = (t & gi2::TOK_SKIP) != 0;
+        const u32 lit = skip ? t >> 16 : t >> 24, len = skip ? 0u : ((t >> 16) & 255u) + 3u, dist = (t & 0x7FFFu) + 1u;
+        const u32 incl = wave_incl_scan32(lit + len, lane);
+        const u32 dend = pos + incl, dst = dend - len, src = dst - dist;   // (phase 1 checked: dist <= dst, dst + len <= isize)
+        pos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 rd_end = src + (len < dist ? len : dist);            // the bytes this match reads: [src, rd_end)
+        // lanes whose output overlaps them: those with dend > src and dst < rd_end (both arrays ascend with the lane)
+        u32 i0 = 0, i1 = 0;
+#pragma unroll
+        for (u32 s_ = 32; s_ >= 1; s_ >>= 1) {
+            const u32 e = (u32)__shfl((int)dend, (int)(i0 + s_ - 1u), WAVE), d = (u32)__shfl((int)dst, (int)(i1 + s_ - 1u), WAVE);
+            if (e <= src) i0 += s_;
+            if (d < rd_end) i1 += s_;
+        }
+        const u64 upto1 = i1 >= 64u ? ~0ull : ((1ull << i1) - 1ull), upto0 = (1ull << i0) - 1ull;     // (i0 <= 63)
+        u64 pending = __ballot(len != 0);
+        const u64 deps = upto1 & ~upto0 & below_me;
+        while (pending) {
+            const bool ready = ((pending >> lane) & 1ull) && (pending & deps) == 0ull;   // (the first pending match always is)
+            const u64 rm = __ballot(ready);
+            const u32 maxlen = (u32)__builtin_amdgcn_readfirstlane((int)wave_max32(ready ? len : 0u));
+            u32 m = 0;                                                 // position inside the (possibly repeating) source
+            for (u32 kk = 0; kk < maxlen; kk += 16) {
+                uint8_t v[16];
+#pragma unroll
+                for (u32 u = 0; u < 16; ++u) {
+                    const bool act = ready && kk + u < len;
+                    v[u] = act ? gi_coherent_load8(o + src + m) : (uint8_t)0;
+                    m = m + 1u == dist ? 0u : m + 1u;
+                }
+#pragma unroll
+                for (u32 u = 0; u < 16; ++u) if (ready && kk + u < len) o[dst + kk + u] = v[u];
+                // (no wait between the steps of a match: it reads [src, src + min(len, dist)) only, which lies in front of its
+                //  own output and was final when the round began)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the round's stores have landed before the next round reads them
+            pending &= ~rm;
+        }
+    }
+}
+
 struct fastf_gpuinf {
     int device = 0;
     static constexpr int NS = 3;                                   // slices in flight
@@ -36,6 +126,8 @@ struct fastf_gpuinf {
     GiBlock* h_blk[NS] = {nullptr, nullptr, nullptr}; size_t h_blk_cap[NS] = {0, 0, 0};
     uint8_t* h_status[NS] = {nullptr, nullptr, nullptr};
     DevBuf d_comp[NS], d_out[NS], d_blk[NS], d_status[NS];
+    DevBuf d_tok[NS], d_tokn[NS];                                  // two-kernel inflate: the blocks' token lists and their lengths
+    bool wave_kernel = false;                                      // FASTF_GI_KERNEL=wave: round 4's one-wavefront-per-block kernel
     hipEvent_t ev0 = nullptr, ev_done[NS] = {nullptr, nullptr, nullptr};
     size_t first[NS + 1] = {0, 0, 0, 0}; size_t pending_n = 0; int pending_slices = 0;
     u64 n_blocks = 0, n_declined = 0;
@@ -55,6 +147,10 @@ extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) FASTF_TRY {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     fastf_gpuinf* g = new fastf_gpuinf();
     g->device = device;
+    { const char* kv = getenv("FASTF_GI_KERNEL"); g->wave_kernel = kv && !strcmp(kv, "wave"); }
+    if (!g->wave_kernel && hipFuncSetAttribute((const void*)bgzf_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GI2_LDS_BYTES) != hipSuccess) {
+        delete g; set_err("cannot raise the dynamic LDS limit of bgzf_decode_kernel to %zu bytes", GI2_LDS_BYTES); return nullptr;
+    }
     bool ok = hipEventCreate(&g->ev0) == hipSuccess;
     for (int i = 0; i < fastf_gpuinf::NS && ok; ++i)
         ok = hipStreamCreateWithFlags(&g->s[i], hipStreamNonBlocking) == hipSuccess && hipEventCreate(&g->ev_done[i]) == hipSuccess;
@@ -72,6 +168,7 @@ extern "C" void fastf_gpuinf_destroy(fastf_gpuinf_t* g) FASTF_TRY {
         if (g->h_status[i]) (void)hipHostFree(g->h_status[i]);
         if (g->h_crc[i]) (void)hipHostFree(g->h_crc[i]);
         g->d_comp[i].release(); g->d_out[i].release(); g->d_blk[i].release(); g->d_status[i].release(); g->d_crc[i].release();
+        g->d_tok[i].release(); g->d_tokn[i].release();
     }
     if (g->s_parse) { (void)hipStreamSynchronize(g->s_parse); (void)hipStreamDestroy(g->s_parse); }
     if (g->h_result) (void)hipHostFree(g->h_result);
@@ -164,9 +261,11 @@ extern "C" int fastf_gpuinf_reserve(fastf_gpuinf_t* g, size_t window_bytes, size
     for (int q = 0; q < fastf_gpuinf::NS; ++q) {
         if (gpuinf_slice_host(g, q, n_blocks)) return 1;
         const size_t cap = g->h_blk_cap[q];
-        if (g->d_comp[q].ensure(comp_bytes + 128) || g->d_blk[q].ensure(cap * sizeof(GiBlock)) || g->d_status[q].ensure(cap) ||
+        if (g->d_comp[q].ensure(comp_bytes + 1024) || g->d_blk[q].ensure(cap * sizeof(GiBlock)) || g->d_status[q].ensure(cap) ||
             g->d_crc[q].ensure(cap * sizeof(GrCrcBlock)))
             return 1;
+        // token lists of a slice (a third to a half of a window): at most a token per three bytes (gi2::token_cap)
+        if (!g->wave_kernel && (g->d_tok[q].ensure((window_bytes / 2 / 3 + window_bytes / 2 / 256 + 4 * cap) * sizeof(u32)) || g->d_tokn[q].ensure(cap * sizeof(u32)))) return 1;
     }
     return 0;
 } FASTF_CATCH_INT
@@ -202,17 +301,29 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
         for (size_t i = a; i < b; ++i) u1 = std::max<u64>(u1, blk[i].uoff + blk[i].isize);
         const size_t cbytes = (size_t)(c1 - c0) + 64, ubytes = (size_t)(u1 - u0);
         if (gpuinf_slice_host(g, q, nb)) return 1;
-        for (size_t i = a; i < b; ++i) g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0};
-        if (g->d_comp[q].ensure(cbytes) || (!keep && g->d_out[q].ensure(std::max<size_t>(ubytes, 64))) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
+        u64 n_tok_cap = 0;
+        for (size_t i = a; i < b; ++i) {
+            g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0, n_tok_cap};
+            n_tok_cap += gi2::token_cap(blk[i].isize);
+        }
+        if (g->d_comp[q].ensure(cbytes + 512) || (!keep && g->d_out[q].ensure(std::max<size_t>(ubytes, 64))) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
             g->d_status[q].ensure(nb))
             return 1;
+        if (!g->wave_kernel && (g->d_tok[q].ensure((size_t)n_tok_cap * sizeof(u32)) || g->d_tokn[q].ensure(nb * sizeof(u32)))) return 1;
         uint8_t* const d_dst = keep ? (uint8_t*)g->d_win[keep_parity].p + u0 : (uint8_t*)g->d_out[q].p;     // block i lands at d_dst + (uoff - u0)
         hipStream_t s = g->s[q];
         if (q) HIP_OK(hipStreamWaitEvent(s, g->ev0, 0));
         HIP_OK(hipMemcpyAsync(g->d_comp[q].p, comp + c0, cbytes, hipMemcpyHostToDevice, s));
         HIP_OK(hipMemcpyAsync(g->d_blk[q].p, g->h_blk[q], nb * sizeof(GiBlock), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((u32)nb), dim3(64), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
-                           (const uint8_t*)g->d_comp[q].p, d_dst, (uint8_t*)g->d_status[q].p);
+        if (g->wave_kernel)
+            hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((u32)nb), dim3(64), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
+                               (const uint8_t*)g->d_comp[q].p, d_dst, (uint8_t*)g->d_status[q].p);
+        else {
+            hipLaunchKernelGGL(bgzf_decode_kernel, dim3((u32)((nb + GI2_LPW - 1) / GI2_LPW)), dim3(GI2_LPW), GI2_LDS_BYTES, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
+                               (const uint8_t*)g->d_comp[q].p, d_dst, (u32*)g->d_tok[q].p, (u32*)g->d_tokn[q].p, (uint8_t*)g->d_status[q].p);
+            hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((u32)((nb + 3) / 4)), dim3(256), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb, d_dst,
+                               (const u32*)g->d_tok[q].p, (const u32*)g->d_tokn[q].p, (const uint8_t*)g->d_status[q].p);
+        }
         HIP_OK(hipGetLastError());
         if (keep) {
             for (size_t i = a; i < b; ++i) g->h_crc[q][i - a] = GrCrcBlock{blk[i].uoff - u0, blk[i].isize, crc[i]};

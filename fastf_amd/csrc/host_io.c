@@ -249,6 +249,9 @@ struct fastf_bam {
     void *pin_a, *pin_b; size_t pin_len;              /* what the device's init thread pins before it reports ready */
     uint8_t *gstatus; size_t gstatus_cap; double t_gpu; uint64_t n_gpu_windows;
     double gpu_share;                                 /* fraction of a window's blocks the device takes (hybrid inflate) */
+    /* the device's time for its share as a line a + b * blocks (ms), from the last two windows whose shares differed: the
+     * two-kernel inflate decodes every block it is given side by side, so most of its time does not grow with its share */
+    double md_a, md_b, md_ms; size_t md_n; int md_have;
     double gpu_share_max;                             /* its upper bound (FASTF_GPU_INFLATE_MAX); the init thread pins the window buffers that far */
     unsigned char *gcomp; size_t gcomp_cap;           /* pinned copy of the window's compressed bytes (the file mapping cannot be pinned) */
     /* device-side parse (gpu_records.hpp): the device's share of a window is inflated in KEEP mode — the bytes stay in the
@@ -796,10 +799,27 @@ static int fill_next(fastf_bam_t *b)
               if (pv && pv[0] == '2')
                   fprintf(stderr, "[bam] %.3f window %llu: %zu blocks, %zu on the device in %.1f ms, %zu on the host in %.1f ms, staged+queued in %.1f ms, whole window %.1f ms (%.1f ms of page mapping and block walk before), share %.2f\n",
                           now_s() - b->t_open, (unsigned long long)b->n_gpu_windows, b->nblk, n_dev, dev_ms, b->nblk - n_dev, t_host * 1e3, (t_sub - t0) * 1e3, (now_s() - t0) * 1e3, (t0 - t_entry) * 1e3, b->gpu_share); }
-            if (b->gpu_wanted != 2 && dev_ms > 0 && t_host > 0 && n_dev < b->nblk) {
-                /* next window: shares in proportion to the two rates (blocks per second) */
-                const double r_dev = (double)n_dev / (dev_ms * 1e-3), r_host = (double)(b->nblk - n_dev) / t_host;
-                double want = r_dev / (r_dev + r_host);
+            if (b->gpu_wanted != 2 && dev_ms > 0 && t_host > 0 && n_dev < b->nblk && !getenv("FASTF_GPU_INFLATE_PIN")) {   /* (_PIN: diagnostic runs keep the share they were given) */
+                /* next window: the share at which both sides finish together.  The host's side is a rate (blocks per ms); the
+                 * device's is a line a + b n fitted through this window and the last one that had a different share — with one
+                 * point only, a line through the origin (the shares then go in proportion to the two rates, round 4's rule) and
+                 * a step upward so that the next window gives the second point. */
+                const double r_host = (double)(b->nblk - n_dev) / (t_host * 1e3), N = (double)b->nblk;
+                double a_ = 0, b_ = dev_ms / (double)n_dev;
+                if (b->md_have && (double)(n_dev > b->md_n ? n_dev - b->md_n : b->md_n - n_dev) > 0.04 * (double)n_dev) {
+                    b_ = (dev_ms - b->md_ms) / ((double)n_dev - (double)b->md_n);
+                    if (b_ < 0) b_ = 0;
+                    if (b_ > dev_ms / (double)n_dev) b_ = dev_ms / (double)n_dev;
+                    a_ = dev_ms - b_ * (double)n_dev;
+                    b->md_a = a_; b->md_b = b_;
+                } else if (b->md_have > 1) { a_ = b->md_a; b_ = b->md_b; }
+                double want = (N / r_host - a_) / (b_ + 1.0 / r_host) / N;
+                if (b->md_have < 2 && want < b->gpu_share + 0.08) want = b->gpu_share + 0.08;      /* (the probe) */
+                if (!b->md_have || (double)(n_dev > b->md_n ? n_dev - b->md_n : b->md_n - n_dev) > 0.04 * (double)n_dev) {
+                    b->md_have = b->md_have ? 2 : 1; b->md_n = n_dev; b->md_ms = dev_ms;
+                }
+                if (want < 0.05) want = 0.05;
+                if (want > 1.0) want = 1.0;
                 /* (a run has a dozen shared windows: three quarters of the way per window, not half) */
                 b->gpu_share = 0.25 * b->gpu_share + 0.75 * want;
                 if (b->gpu_share < 0.05) b->gpu_share = 0.05;
@@ -966,6 +986,17 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
     /* device inflate wants many blocks per launch (the chip holds 5 120 of them at once): 128 MiB windows, about 8 000
      * blocks, of which the device takes its share, unless told otherwise */
     b->ccap = w ? (size_t)strtoull(w, NULL, 0) : ((size_t)(b->gpu_wanted ? 128 : 32) << 20);
+    if (!w && b->gpu_wanted) {
+        /* The two-kernel device inflate decodes every block of a window side by side — 65 536 of them fit the chip — and a
+         * window costs it about the same 15 ms whether it holds 8 000 blocks or 35 000: a large file is read in windows of a
+         * sixth of its size, up to 512 MiB (profiles/r5_notes/e2e_windows_lane_decoder.txt: 445 -> 640-730 blocks per ms). */
+        struct stat st0;
+        if (fstat(fileno(fp), &st0) == 0 && S_ISREG(st0.st_mode)) {
+            size_t want = ((size_t)st0.st_size / 6) & ~(((size_t)1 << 20) - 1);
+            if (want > ((size_t)512 << 20)) want = (size_t)512 << 20;
+            if (want > b->ccap) b->ccap = want;
+        }
+    }
     if (b->ccap < (1 << 17)) b->ccap = 1 << 17;
     {   /* regular files are mapped (FASTF_BAM_MMAP=0: read() into a buffer, as for anything that cannot be mapped) */
         const char *mm = getenv("FASTF_BAM_MMAP");

@@ -342,7 +342,8 @@ class Engine:
                                            stream))
 
     def dev_draw_bits(self, d_draws, n_draws, d_bits_out, stream=0):
-        """bit i of d_bits_out (u32 words, (n_draws + 31) // 32 of them) = d_draws[i] < this engine's keep threshold"""
+        """bit i of d_bits_out = d_draws[i] < this engine's keep threshold.  The kernel stores whole 64-bit words: d_bits_out must
+        be 8-byte aligned and hold ((n_draws + 63) // 64) * 8 bytes = ((n_draws + 63) // 64) * 2 u32 words (include/fastf_amd.h)"""
         check(self._L.fastf_dev_draw_bits(self._h, d_draws, n_draws, d_bits_out, stream))
 
     def probe_capacity(self, n) -> int:

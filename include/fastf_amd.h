@@ -279,11 +279,13 @@ int fastf_dev_probe_pack(fastf_engine_t *e,
                          uint64_t *d_keys_out, uint64_t shard_stride,
                          uint64_t *d_key_counts, uint64_t *d_counters, uint32_t flags, void *stream);
 #define FASTF_PROBE_REUSE_HITS 1u  /* fastf_dev_count_hits(e, d_cb_key, n, …) was the previous call on this stream */
-/* Streaming form of K1b (single shard, gene list in LDS): every wave filters and packs on its own and writes into a
- * private region of d_keys_out per workgroup — no barrier and no global atomic in the loop.  The key buffer is then
- * SEGMENTED (regions with gaps): d_key_counts[0] is SET to the number of keys, the buffer must hold
- * fastf_dev_probe_capacity() slots, and the next fastf_dev_sort over it must carry FASTF_SORT_SEGMENTED (its first
- * pass reads through the region map the engine keeps; the sorted result is contiguous as always). */
+/* Streaming form of K1b (single shard, gene list in LDS): every wave filters and packs on its own and writes into
+ * private regions of d_keys_out (two per workgroup, filled by turns) — no barrier and no global atomic in the loop.  The
+ * key buffer is then SEGMENTED (regions with gaps): d_key_counts[0] is SET to the number of keys, the buffer must hold
+ * fastf_dev_probe_capacity() slots, and the next fastf_dev_sort over it must carry FASTF_SORT_SEGMENTED.  The kernel also
+ * leaves, per region, the histogram of the first digit of the FASTF_SORT_SKIP_LOW sort: such a sort's first pass walks the
+ * regions and counts nothing (scatter_regions_kernel); a sort on another digit grid counts per tile through the region map
+ * the engine keeps.  The sorted result is contiguous as always.  One sort per probe_pack: the histograms are used up. */
 #define FASTF_PROBE_SEGMENTED 2u
 /* key slots a FASTF_PROBE_SEGMENTED call over n records needs in d_keys_out (a little more than n);
  * 0 = this engine cannot run the streaming form (several shards, or a gene list that does not fit LDS) */
@@ -293,8 +295,11 @@ int fastf_dev_probe_capacity(const fastf_engine_t *e, uint64_t n, uint64_t *key_
  *     gx u64[256] | umi u32[256] | meta u32[256] | cell scratch (u16[256], or u32[256] when n_cells > 65535)
  * of 4608 (5120) bytes; the cb keys stay an array of their own.  K1a writes a unit's scratch slice, the streaming K1b reads a
  * unit as ONE stream instead of four distant ones (the same 18 bytes per record move 18 % faster that way:
- * tools/hbm_probe_streams.hip).  fastf_batch_t is untouched: a host batch reaches this layout through pitched copies
- * (three hipMemcpy2DAsync per chunk), device-resident SoA through fastf_dev_block_records.
+ * tools/hbm_probe_streams.hip).  fastf_batch_t is untouched: fastf_engine_push / _push_pinned land every chunk of a batch in
+ * this layout themselves — three hipMemcpy2DAsync per chunk (a row = one unit's slice of gx / umi / meta, destination pitch =
+ * the run) plus three plain copies for a last partial unit, umi_engine.hip push_chunk — and run the same K1a + streaming K1b
+ * on it as the device-level calls below; engines whose gene list stays in L2, keys wider than 64 bits and sharded engines
+ * stage SoA and run the tile form of K1b.  Device-resident SoA gets here through fastf_dev_block_records.
  * fastf_dev_block_bytes: size of the buffer for n records; 0 = this engine cannot run the streaming K1b (gene list not in
  * LDS, FASTF_NO_STREAM_K1B): use the SoA form. */
 int fastf_dev_block_bytes(const fastf_engine_t *e, uint64_t n, uint64_t *bytes);
@@ -307,7 +312,8 @@ int fastf_dev_block_records(fastf_engine_t *e, const uint64_t *d_gx_key, const u
 int fastf_dev_count_hits_blocked(fastf_engine_t *e, const uint64_t *d_cb_key, uint64_t n, void *d_blocked,
                                  uint64_t *d_hits_out, void *stream);
 /* The decision stream.  All K1b wants from the draw of a CB hit is one bit — the read is kept iff
- * genrand_real1() <= rate (bam2db_ds.c:385-390), i.e. draw < the engine's integer threshold — so that is what it reads:
+ * genrand_real1() < rate (the reference drops on `>=`, bam2db_ds.c:385-390), i.e. draw < the engine's integer threshold
+ * (fastf_draw_threshold) — so that is what it reads:
  * bit (i & 31) of word i >> 5 = draws[i] < threshold.  fastf_dev_probe_pack takes 32-bit draws and converts them on
  * every call (one extra pass over them); a caller that runs the same stream more than once converts it once with
  * fastf_dev_draw_bits (d_bits_out: 8-byte aligned, (n_draws + 63) / 64 * 8 bytes, the tail of the last 64 bits zero) and passes the result

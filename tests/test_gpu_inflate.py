@@ -1,5 +1,5 @@
-"""BGZF inflate on the device (gpu_frontend.hpp / gpu_inflate.hpp: one wavefront per block) against zlib, and the BAM
-reader with FASTF_GPU_INFLATE on against the host-only reader."""
+"""BGZF inflate on the device (gpu_frontend.hpp: gpu_inflate2.hpp's lane-per-block decoder + the match resolver, and
+gpu_inflate.hpp's one wavefront per block) against zlib, and the BAM reader with FASTF_GPU_INFLATE on against the host-only reader."""
 import ctypes as C
 import zlib
 
@@ -19,8 +19,15 @@ class Blk(C.Structure):
     _fields_ = [("coff", C.c_uint64), ("clen", C.c_uint32), ("isize", C.c_uint32), ("uoff", C.c_uint64)]
 
 
-def test_device_inflate_matches_zlib():
+@pytest.mark.parametrize("kernel", ["lanes", "wave"])
+def test_device_inflate_matches_zlib(kernel, monkeypatch):
+    """both device decoders: the two-kernel form (one lane per block decodes to literals + match tokens, one wave per block
+    resolves the matches: gpu_inflate2.hpp) and round 4's one wavefront per block (FASTF_GI_KERNEL=wave)"""
     import torch  # noqa: F401
+    if kernel == "wave":
+        monkeypatch.setenv("FASTF_GI_KERNEL", "wave")
+    else:
+        monkeypatch.delenv("FASTF_GI_KERNEL", raising=False)
     L = _lib.lib()
     L.fastf_gpuinf_create.restype = C.c_void_p; L.fastf_gpuinf_create.argtypes = [C.c_int]
     L.fastf_gpuinf_destroy.argtypes = [C.c_void_p]

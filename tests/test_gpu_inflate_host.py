@@ -78,3 +78,72 @@ def test_host_build_rejects_malformed_input_without_crashing(gi):
         c = bytearray(comp); i = int(rng.integers(0, len(c))); c[i] ^= 1 << int(rng.integers(0, 8))
         rc, out = gi(bytes(c), len(data))
         assert rc != 0 or len(out) == len(data)
+
+
+# ---- the lane-per-block decoder of the two-kernel device inflate (gpu_inflate2.hpp): plain single-threaded C++, the same source
+#      the device runs per lane; tools/gi2_host.cpp decodes to literals + match tokens and applies the tokens one by one ----
+@pytest.fixture(scope="module")
+def gi2():
+    so = os.path.join(ROOT, "build", "libgi2_host.so")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "fastf_amd", "csrc"), so])
+    L = C.CDLL(so)
+    L.gi2_host_inflate.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+
+    def inflate(comp, n):
+        out = C.create_string_buffer(max(n, 1)); nt = C.c_uint32()
+        rc = L.gi2_host_inflate(comp, len(comp), out, n, C.byref(nt))
+        return rc, out.raw[:n], nt.value
+    return inflate
+
+
+def test_token_decoder_matches_zlib(gi2):
+    rng = np.random.default_rng(3)
+    n = 0
+    for data in sample_payloads(rng, 40):
+        for comp in raw_streams(data):
+            rc, out, nt = gi2(comp, len(data))
+            assert rc == 0 and out == data
+            assert nt <= len(data) // 3 + len(data) // 256 + 4
+            n += 1
+    assert n > 1000
+
+
+def test_token_decoder_edge_shapes(gi2):
+    """a block of 65 536 literals (a literal run that needs two step-over tokens if a stored block ends it), long literal runs in
+    front of a match, an overlapping match of every short distance, stored blocks between compressed ones"""
+    rng = np.random.default_rng(9)
+    lit = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()
+    co = zlib.compressobj(0, zlib.DEFLATED, -15)                     # stored blocks only
+    rc, out, nt = gi2(co.compress(lit) + co.flush(), len(lit)); assert rc == 0 and out == lit
+    co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)   # literals only, one Huffman block
+    rc, out, nt = gi2(co.compress(lit) + co.flush(), len(lit)); assert rc == 0 and out == lit and nt <= 2       # (zlib stores what does not compress: step-over tokens at most)
+    for d in (1, 2, 3, 5, 63, 64, 65, 257, 258, 259):
+        data = (rng.integers(0, 256, d, dtype=np.uint8).tobytes() * (70000 // d + 1))[:65000]
+        for lvl in (1, 6, 9):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15)
+            rc, out, nt = gi2(co.compress(data) + co.flush(), len(data)); assert rc == 0 and out == data
+    # 300..60000 incompressible bytes, then a repeat of them (a long literal run in front of matches), then a stored block
+    for n in (300, 5000, 30000):
+        head = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        data = head + head[:n // 2] + b"xyz" * 100
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush(zlib.Z_FULL_FLUSH)
+        co0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+        tail = rng.integers(0, 256, 1000, dtype=np.uint8).tobytes()
+        comp += co0.compress(tail) + co0.flush()
+        rc, out, nt = gi2(comp, len(data) + len(tail)); assert rc == 0 and out == data + tail
+
+
+def test_token_decoder_rejects_malformed_input_without_crashing(gi2):
+    rng = np.random.default_rng(4)
+    data = sample_payloads(rng, 0)[8]
+    comp = zlib.compress(data, 6)[2:-4]
+    assert gi2(comp[:len(comp) // 2], len(data))[0] != 0
+    assert gi2(comp, len(data) - 1)[0] != 0 and gi2(comp, len(data) + 1)[0] != 0
+    for _ in range(600):
+        c = bytearray(comp); i = int(rng.integers(0, len(c))); c[i] ^= 1 << int(rng.integers(0, 8))
+        rc, out, nt = gi2(bytes(c), len(data))
+        assert rc != 0 or len(out) == len(data)
+    for _ in range(200):                                              # garbage
+        g = rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8).tobytes()
+        gi2(g, int(rng.integers(0, 65537)))

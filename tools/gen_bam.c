@@ -1,7 +1,10 @@
 /* gen_bam.c — fast synthetic BAM generator for end-to-end benchmarks (test tooling, not product).
- *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len] [threads] [repeat]
+ *   gen_bam <out.bam> <barcodes.tsv> <features.tsv> <n_records> [seed] [umi_len] [seq_len] [threads] [repeat] [bodies]
  * repeat > 1 writes the n_records-record body (the 64 pieces: whole BGZF blocks, no record straddles a piece) that many
  * times behind the one header: a file of n_records x repeat records for the price of generating n_records.
+ * bodies > 1 generates that many DIFFERENT bodies, one after the other, each from its own seed (and each written `repeat`
+ * times): n_records x bodies distinct records — the matrix, the depth of its groups and the output files are those of a
+ * file of that size, which a repeated body's are not.
  * The record stream is cut into 64 pieces, each with its own generator state and its own run of BGZF blocks, so the
  * file is the same for every thread count.
  * seq_len > 0 gives records the size and content mix of a Cell Ranger BAM: mapped reads with one CIGAR word, seq_len
@@ -53,7 +56,7 @@ static void put(const void *p, size_t n)
 
 enum { PIECES = 64 };
 static piece_t *g_piece[PIECES + 1];
-static size_t g_n, g_nb, g_ng; static char **g_bar, **g_gen; static uint64_t g_seed; static int g_ul, g_sl; static int g_next;
+static size_t g_n, g_nb, g_ng, g_name0; static char **g_bar, **g_gen; static uint64_t g_seed; static int g_ul, g_sl; static int g_next;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static void gen_piece(int pc);
 static void *worker(void *vp)
@@ -68,12 +71,13 @@ static void *worker(void *vp)
 
 int main(int argc, char **argv)
 {
-    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len] [seq_len] [threads] [repeat]\n"); return 1; }
+    if (argc < 5) { fprintf(stderr, "usage: gen_bam out.bam barcodes features n [seed] [umi_len] [seq_len] [threads] [repeat] [bodies]\n"); return 1; }
     g_bar = read_col1(argv[2], &g_nb); g_gen = read_col1(argv[3], &g_ng);
     g_n = strtoull(argv[4], NULL, 10); g_seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 1; g_ul = argc > 6 ? atoi(argv[6]) : 10;
     g_sl = argc > 7 ? atoi(argv[7]) : 0; if (g_sl > 150) g_sl = 150; if (g_sl > 0) g_level = 6;
     int nt = argc > 8 ? atoi(argv[8]) : 1; if (nt < 1) nt = 1; if (nt > 64) nt = 64;
     int repeat = argc > 9 ? atoi(argv[9]) : 1; if (repeat < 1) repeat = 1;
+    int bodies = argc > 10 ? atoi(argv[10]) : 1; if (bodies < 1) bodies = 1;
     out = fopen(argv[1], "wb"); if (!out) { perror(argv[1]); return 1; }
     for (int i = 0; i <= PIECES; i++) { g_piece[i] = calloc(1, sizeof(piece_t)); if (!g_piece[i]) { perror("calloc"); return 1; } }
     /* the header is a block run of its own (piece PIECES, written first) */
@@ -83,12 +87,17 @@ int main(int argc, char **argv)
     if (g_sl > 0) { nref = 1; put(&nref, 4); int32_t ln = 5, lref = 248956422; put(&ln, 4); put("chr1", 5); put(&lref, 4); }   /* mapped reads name refID 0 */
     else put(&nref, 4);
     if (blen) flush_block();
-    pthread_t th[64];
-    for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, worker, NULL);
-    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
     fwrite(g_piece[PIECES]->out, 1, g_piece[PIECES]->olen, out);
-    for (int r = 0; r < repeat; r++)
-        for (int i = 0; i < PIECES; i++) fwrite(g_piece[i]->out, 1, g_piece[i]->olen, out);
+    const uint64_t seed0 = g_seed;
+    for (int b = 0; b < bodies; b++) {
+        g_seed = seed0 + 7919ull * (uint64_t)b; g_name0 = g_n * (size_t)b; g_next = 0;
+        for (int i = 0; i < PIECES; i++) { P = g_piece[i]; P->olen = 0; blen = 0; }
+        pthread_t th[64];
+        for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, worker, NULL);
+        for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+        for (int r = 0; r < repeat; r++)
+            for (int i = 0; i < PIECES; i++) fwrite(g_piece[i]->out, 1, g_piece[i]->olen, out);
+    }
     static const unsigned char eof[28] = {0x1f,0x8b,8,4,0,0,0,0,0,0xff,6,0,'B','C',2,0,0x1b,0,3,0,0,0,0,0,0,0,0,0};
     fwrite(eof, 1, 28, out); fclose(out);
     return 0;
@@ -102,7 +111,7 @@ static void gen_piece(int pc)
     s[0] = seed * 0x9E3779B97F4A7C15ull + 1; s[1] = seed ^ 0xD1B54A32D192ED03ull; for (int i = 0; i < 8; i++) rnd();
     unsigned char rec[1024];
     for (size_t i = n0; i < n1; i++) {
-        unsigned char *p = rec + 4; int32_t m1 = -1, z = 0; char name[24]; int nl = snprintf(name, sizeof name, "r%zu", i) + 1;
+        unsigned char *p = rec + 4; int32_t m1 = -1, z = 0; char name[24]; int nl = snprintf(name, sizeof name, "r%zu", g_name0 + i) + 1;
         memcpy(p, &m1, 4); memcpy(p + 4, &m1, 4); p[8] = (unsigned char)nl; p[9] = 0; uint16_t bin = 4680, nc = 0, fl = 4;
         memcpy(p + 10, &bin, 2); memcpy(p + 12, &nc, 2); memcpy(p + 14, &fl, 2); memcpy(p + 16, &z, 4);
         memcpy(p + 20, &m1, 4); memcpy(p + 24, &m1, 4); memcpy(p + 28, &z, 4);
