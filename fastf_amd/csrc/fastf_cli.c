@@ -41,6 +41,7 @@ int main(int argc, const char **argv)
             int rc = commands[i].fn(argc - 1, argv + 1);
             /* every output is closed by now; skip the ~0.2 s the HIP runtime spends unloading at exit */
             fflush(NULL);
+            if (!fastf_process_is_exiting_) return rc;       /* FASTF_FULL_TEARDOWN: an ordinary exit (a profiler writes its output from exit handlers) */
             _exit(rc);
         }
     fprintf(stderr, "\x1b[31mError:\x1b[0m unknown command `%s`\n", argv[1]);

@@ -30,6 +30,11 @@ __global__ __launch_bounds__(64, FASTF_GI_MINBLOCKS) void bgzf_inflate_kernel(co
     if (gi_lane0()) status[b] = (uint8_t)rc;
 }
 
+// an aligned dword past the CU's L1 (agent scope: this wave's own stores of a round ago are in L2, not necessarily in its L1)
+__device__ __forceinline__ u32 gi_l2_load32(const uint8_t* p) {
+    return __hip_atomic_load(reinterpret_cast<const u32*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- the two-kernel inflate (round 5; gpu_inflate2.hpp has the why) ----
 // Phase 1: ONE LANE per BGZF block, GI2_LPW blocks per wave (their working sets side by side in LDS: 580 bytes each).  A lane
 // decodes its block's tokens, stores the literals where they belong and lists the matches as 4-byte tokens.
@@ -59,9 +64,11 @@ __global__ __launch_bounds__(GI2_LPW) void bgzf_decode_kernel(const GiBlock* __r
 // mask: ready = none of those lanes is still pending.  Rounds per batch = the depth of the batch's dependency chains (a field
 // copied from the record before, which copied it from the one before: two to four on BAM payloads), not the number of matches
 // that have a near source (the first form of this kernel waited for "everything below the first pending match": a round per
-// such match, 35 ms for a 2.3 GB window).  Inside a round every ready lane copies 16 bytes per step — sixteen loads issued
-// back to back, then sixteen stores, and no wait between the steps: one memory round trip per 16 bytes, not per 4.  A match that overlaps its own output
-// (distance < length) repeats its first `distance` bytes and reads only those.  The sources are read past the CU's L1 (this
+// such match, 35 ms for a 2.3 GB window).  Inside a round every ready lane copies 16 bytes per step AS DWORDS — five aligned
+// loads shifted into place, four unaligned stores: what bounds this kernel is the number of memory requests a CU can issue
+// (a lane per match means a cache line per lane: 64 requests per instruction), and a byte per request was 10 ms per 21 000
+// blocks — with no wait between a match's steps.  A match that overlaps its own output (distance < length) repeats its first
+// `distance` bytes and reads only those.  The sources are read past the CU's L1 (this
 // wave stored some of them a round ago: gi_coherent_load8) after the stores before have been acknowledged.
 __global__ __launch_bounds__(256) void bgzf_resolve_kernel(const GiBlock* __restrict__ blk, u32 n_blk, uint8_t* __restrict__ out,
                                                            const u32* __restrict__ tokens, const u32* __restrict__ tok_count,
@@ -95,21 +102,79 @@ __global__ __launch_bounds__(256) void bgzf_resolve_kernel(const GiBlock* __rest
         const u64 upto1 = i1 >= 64u ? ~0ull : ((1ull << i1) - 1ull), upto0 = (1ull << i0) - 1ull;     // (i0 <= 63)
         u64 pending = __ballot(len != 0);
         const u64 deps = upto1 & ~upto0 & below_me;
+        // how a match copies: 0 = its source lies wholly in front of its output (distance >= length: nearly all) — 16 bytes per
+        // step as four dwords; 1 = it repeats its last 1..3 bytes (a run of one quality value: distance < 4 <= length) — the
+        // pattern is built once, in registers; 2 = it repeats a longer stretch (4 <= distance < length: rare) — byte by byte
+        const u32 mode = dist >= len ? 0u : (dist < 4u ? 1u : 2u);
         while (pending) {
             const bool ready = ((pending >> lane) & 1ull) && (pending & deps) == 0ull;   // (the first pending match always is)
             const u64 rm = __ballot(ready);
             const u32 maxlen = (u32)__builtin_amdgcn_readfirstlane((int)wave_max32(ready ? len : 0u));
-            u32 m = 0;                                                 // position inside the (possibly repeating) source
-            for (u32 kk = 0; kk < maxlen; kk += 16) {
-                uint8_t v[16];
-#pragma unroll
-                for (u32 u = 0; u < 16; ++u) {
-                    const bool act = ready && kk + u < len;
-                    v[u] = act ? gi_coherent_load8(o + src + m) : (uint8_t)0;
-                    m = m + 1u == dist ? 0u : m + 1u;
+            const uint8_t* const sp = o + src;
+            uint8_t* const dp = o + dst;
+            // the pattern of a mode-1 match as three dwords (bytes 0..11 of its output; byte j = source byte j mod distance)
+            u32 pat0 = 0, pat1 = 0, pat2 = 0;
+            if (__ballot(ready && mode == 1u)) {
+                if (ready && mode == 1u) {
+                    const u32 sh = (u32)(reinterpret_cast<uintptr_t>(sp) & 3u);
+                    const u32 w0 = gi_l2_load32(sp - sh), w1 = gi_l2_load32(sp - sh + 4);
+                    const u32 v = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                    const u32 b0 = v & 255u, b1 = dist > 1u ? (v >> 8) & 255u : b0, b2 = dist > 2u ? (v >> 16) & 255u : (dist > 1u ? b0 : b0);
+                    // distance 1: b0 b0 b0 ..; 2: b0 b1 b0 b1 ..; 3: b0 b1 b2 b0 ..
+                    const u32 c0 = b0, c1 = b1, c2 = dist == 2u ? b0 : b2;        // bytes 0, 1, 2 of the sequence
+                    const u32 c3 = dist == 3u ? b0 : (dist == 2u ? b1 : b0);
+                    pat0 = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+                    if (dist == 3u) { pat1 = b1 | (b2 << 8) | (b0 << 16) | (b1 << 24); pat2 = b2 | (b0 << 8) | (b1 << 16) | (b2 << 24); }
+                    else { pat1 = pat0; pat2 = pat0; }
                 }
+            }
+            u32 m = 0;                                                 // mode 2: position inside the repeating source
+            for (u32 kk = 0; kk < maxlen; kk += 16) {
+                const bool act = ready && kk < len;
+                const u32 n = act ? (len - kk < 16u ? len - kk : 16u) : 0u;       // bytes of this step
+                u32 d0 = pat0, d1 = pat1, d2 = pat2, d3 = pat0;        // (mode 1: four dwords of the sequence, rotated below)
+                if (__ballot(act && mode == 0u)) {
+                    // five aligned dwords around [sp + kk, sp + kk + 16), shifted into place (the buffer is readable a few
+                    // bytes past the block: the window buffers carry slack)
+                    const u32 sh = (u32)(reinterpret_cast<uintptr_t>(sp + kk) & 3u);
+                    const uint8_t* const a = sp + kk - sh;
+                    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
+                    if (act && mode == 0u) {
+                        w0 = gi_l2_load32(a); w1 = gi_l2_load32(a + 4);
+                        if (sh + n > 8u) w2 = gi_l2_load32(a + 8);
+                        if (sh + n > 12u) w3 = gi_l2_load32(a + 12);
+                        if (sh + n > 16u) w4 = gi_l2_load32(a + 16);
+                        d0 = __builtin_amdgcn_alignbyte(w1, w0, sh); d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                        d2 = __builtin_amdgcn_alignbyte(w3, w2, sh); d3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+                    }
+                }
+                if (act && mode != 2u) {
+                    uint8_t* const q = dp + kk;
+                    // whole dwords (unaligned stores: the hardware splits them), then the last 1..3 bytes
+                    if (n >= 4u) __builtin_memcpy(q, &d0, 4);
+                    if (n >= 8u) __builtin_memcpy(q + 4, &d1, 4);
+                    if (n >= 12u) __builtin_memcpy(q + 8, &d2, 4);
+                    if (n >= 16u) __builtin_memcpy(q + 12, &d3, 4);
+                    const u32 full = n & ~3u, tail = n & 3u;
+                    const u32 dt = full == 0u ? d0 : full == 4u ? d1 : full == 8u ? d2 : d3;
+                    if (tail >= 1u) q[full] = (uint8_t)dt;
+                    if (tail >= 2u) q[full + 1u] = (uint8_t)(dt >> 8);
+                    if (tail >= 3u) q[full + 2u] = (uint8_t)(dt >> 16);
+                }
+                if (mode == 1u) {                                      // the next step's sequence begins 16 bytes on: 16 mod 3 = 1 dword further
+                    const u32 t_ = pat0; pat0 = pat1; pat1 = pat2; pat2 = t_;
+                }
+                if (__ballot(act && mode == 2u)) {
+                    uint8_t v[16];
 #pragma unroll
-                for (u32 u = 0; u < 16; ++u) if (ready && kk + u < len) o[dst + kk + u] = v[u];
+                    for (u32 u = 0; u < 16; ++u) {
+                        const bool a2 = act && mode == 2u && u < n;
+                        v[u] = a2 ? gi_coherent_load8(sp + m) : (uint8_t)0;
+                        m = m + 1u == dist ? 0u : m + 1u;
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < 16; ++u) if (act && mode == 2u && u < n) dp[kk + u] = v[u];
+                }
                 // (no wait between the steps of a match: it reads [src, src + min(len, dist)) only, which lies in front of its
                 //  own output and was final when the round began)
             }
@@ -306,7 +371,7 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
             g->h_blk[q][i - a] = GiBlock{blk[i].coff - c0, blk[i].clen, blk[i].isize, blk[i].uoff - u0, n_tok_cap};
             n_tok_cap += gi2::token_cap(blk[i].isize);
         }
-        if (g->d_comp[q].ensure(cbytes + 512) || (!keep && g->d_out[q].ensure(std::max<size_t>(ubytes, 64))) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
+        if (g->d_comp[q].ensure(cbytes + 512) || (!keep && g->d_out[q].ensure(std::max<size_t>(ubytes, 64) + 64)) || g->d_blk[q].ensure(nb * sizeof(GiBlock)) ||
             g->d_status[q].ensure(nb))
             return 1;
         if (!g->wave_kernel && (g->d_tok[q].ensure((size_t)n_tok_cap * sizeof(u32)) || g->d_tokn[q].ensure(nb * sizeof(u32)))) return 1;
