@@ -44,6 +44,9 @@ __device__ __forceinline__ u32 gi_l2_load32(const uint8_t* p) {
 constexpr int GI2_LPW = FASTF_GI2_LPW;
 static_assert(GI2_LPW >= 1 && GI2_LPW <= 64 && sizeof(gi2::Work) * GI2_LPW <= 40 * 1024, "blocks per wave: four waves' working sets share a CU's LDS");
 constexpr size_t GI2_LDS_BYTES = sizeof(gi2::Work) * GI2_LPW;
+#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI2_STAMPS)
+__device__ unsigned long long gi2_stamp_acc[8];
+#endif
 __global__ __launch_bounds__(GI2_LPW) void bgzf_decode_kernel(const GiBlock* __restrict__ blk, u32 n_blk, const uint8_t* __restrict__ comp,
                                                                uint8_t* __restrict__ out, u32* __restrict__ tokens, u32* __restrict__ tok_count,
                                                                uint8_t* __restrict__ status) {
@@ -53,10 +56,21 @@ __global__ __launch_bounds__(GI2_LPW) void bgzf_decode_kernel(const GiBlock* __r
     if (b >= n_blk) return;
     const GiBlock k = blk[b];
     int rc = 0; u32 nt = 0;
+#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI2_STAMPS)
+    uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k.isize) rc = gi2::inflate_tokens(ws[threadIdx.x], comp + k.coff, k.clen, out + k.uoff, k.isize, tokens + k.toff, &nt, st);
+    if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&gi2_stamp_acc[i], (unsigned long long)st[i]);
+#else
     if (k.isize) rc = gi2::inflate_tokens(ws[threadIdx.x], comp + k.coff, k.clen, out + k.uoff, k.isize, tokens + k.toff, &nt);
+#endif
     status[b] = (uint8_t)rc;
     tok_count[b] = rc ? 0u : nt;
 }
+#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI2_STAMPS)
+extern "C" int fastf_debug_gi2_stamps(unsigned long long out[8]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gi2_stamp_acc), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 // Phase 2: one WAVE per block resolves its matches, 64 tokens at a time.  A wave scan over (literals + length) gives every
 // match its place.  A match may copy once the bytes it READS are final: the literals are (phase 1), everything in front of the
 // batch is, so what it has to wait for are the matches of its own batch whose output overlaps its source — a contiguous run of
@@ -378,6 +392,10 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
         uint8_t* const d_dst = keep ? (uint8_t*)g->d_win[keep_parity].p + u0 : (uint8_t*)g->d_out[q].p;     // block i lands at d_dst + (uoff - u0)
         hipStream_t s = g->s[q];
         if (q) HIP_OK(hipStreamWaitEvent(s, g->ev0, 0));
+        // (the lane decoder reading the compressed bytes straight out of the caller's pinned buffer — no copy, 32 bytes per lane
+        //  over PCIe an epoch ahead of their use — was measured and loses: 420-470 against 610-740 blocks per ms end to end,
+        //  profiles/r5_notes/e2e_windows_lane_decoder.txt)
+        const uint8_t* d_src = (const uint8_t*)g->d_comp[q].p;
         HIP_OK(hipMemcpyAsync(g->d_comp[q].p, comp + c0, cbytes, hipMemcpyHostToDevice, s));
         HIP_OK(hipMemcpyAsync(g->d_blk[q].p, g->h_blk[q], nb * sizeof(GiBlock), hipMemcpyHostToDevice, s));
         if (g->wave_kernel)
@@ -385,7 +403,7 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
                                (const uint8_t*)g->d_comp[q].p, d_dst, (uint8_t*)g->d_status[q].p);
         else {
             hipLaunchKernelGGL(bgzf_decode_kernel, dim3((u32)((nb + GI2_LPW - 1) / GI2_LPW)), dim3(GI2_LPW), GI2_LDS_BYTES, s, (const GiBlock*)g->d_blk[q].p, (u32)nb,
-                               (const uint8_t*)g->d_comp[q].p, d_dst, (u32*)g->d_tok[q].p, (u32*)g->d_tokn[q].p, (uint8_t*)g->d_status[q].p);
+                               d_src, d_dst, (u32*)g->d_tok[q].p, (u32*)g->d_tokn[q].p, (uint8_t*)g->d_status[q].p);
             hipLaunchKernelGGL(bgzf_resolve_kernel, dim3((u32)((nb + 3) / 4)), dim3(256), 0, s, (const GiBlock*)g->d_blk[q].p, (u32)nb, d_dst,
                                (const u32*)g->d_tok[q].p, (const u32*)g->d_tokn[q].p, (const uint8_t*)g->d_status[q].p);
         }

@@ -46,6 +46,17 @@
 #define GI2_UNROLL
 #endif
 
+// timing probe (experiment builds): cycles of a wave per section of the symbol loop, summed into gi2_stamp_acc[] by one lane
+#if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI2_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define GI2_STAMP(k) do { const uint64_t t__ = __builtin_amdgcn_s_memtime(); st_acc[k] += t__ - st_last; st_last = t__; } while (0)
+#define GI2_STAMP_DECL uint64_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_last = __builtin_amdgcn_s_memtime()
+#define GI2_STAMP_OUT(dst) do { for (int k__ = 0; k__ < 8; ++k__) (dst)[k__] = st_acc[k__]; } while (0)
+#else
+#define GI2_STAMP(k) do { } while (0)
+#define GI2_STAMP_DECL do { } while (0)
+#define GI2_STAMP_OUT(dst) do { } while (0)
+#endif
+
 namespace gi2 {
 
 enum { OK = 0, E_BTYPE = 1, E_STORED = 2, E_LENS = 3, E_CODE = 4, E_DIST = 5, E_OVERRUN = 6, E_INPUT = 7, E_SIZE = 8, E_TOKENS = 9 };
@@ -176,7 +187,8 @@ GI2_FN uint32_t rev32(uint32_t c) {                          // all 32 bits in r
 // A canonical Huffman code as fifteen words, v[l - 1] for code length l:
 //     (first code of length l + number of codes of length l) << (15 - l)    in bits 16..31   (<= 32768: the END of the codes of
 //                                                                            length <= l on the 15-bit left-aligned code line)
-//     number of symbols of length <= l                                        in bits 0..15
+//     l                                                                       in bits 12..15
+//     number of symbols of length <= l (at most 288)                          in bits 0..11
 // The ends never decrease with l, so a 15-bit left-aligned code c has length 1 + #{l : c >= end(l)}, the codes of its length
 // begin at the last end it has passed, and the symbols in front of them are that word's low half.
 struct Canon { uint32_t v[15]; };
@@ -198,7 +210,7 @@ GI2_UNROLL
         first = (first + prev) << 1;                       // first code of length l
         w.offs[l] = (uint16_t)cum;
         cum += n;
-        c.v[l - 1] = (((first + n) << (15 - l)) << 16) | cum;
+        c.v[l - 1] = (((first + n) << (15 - l)) << 16) | ((uint32_t)l << 12) | cum;
         prev = n;
     }
     if (bad || (left > 0 && n_codes > 1)) return E_LENS;
@@ -220,11 +232,24 @@ template <bool LIT>
 GI2_FN int decode(Bits& b, const Canon& c, const Work& w) {
     const uint32_t code = rev32((uint32_t)b.buf) >> 17;    // the next 15 stream bits, first bit on top
     const uint32_t key = (code << 16) | 0xFFFFu;           // (>= a word iff the code has reached that word's end)
-    uint32_t l = 1, sel = 0;
+    // the last of the fifteen ascending words the key has reached: it carries where its length's codes begin, the symbols in
+    // front, and its own number (n: the code's length is n + 1).  Fifteen INDEPENDENT compare-and-selects and a tree of maxima:
+    // a wave has its SIMD to itself, so what a token-step costs is the length of its dependent chains, not its instruction
+    // count — a running count over fifteen compares (a chain of adds) and a four-level binary search (a chain of compares)
+    // were both measured slower (profiles/r5_notes/inflate_two_kernels.txt).
+    uint32_t cnd[15];
 GI2_UNROLL
-    for (int i = 0; i < 15; ++i) { const bool ge = key >= c.v[i]; l += ge ? 1u : 0u; sel = ge ? c.v[i] : sel; }
+    for (int i = 0; i < 15; ++i) cnd[i] = key >= c.v[i] ? c.v[i] : 0u;
+#define GI2_MAX3(a, b, d) ((a) > (b) ? ((a) > (d) ? (a) : (d)) : ((b) > (d) ? (b) : (d)))
+    const uint32_t m0 = GI2_MAX3(cnd[0], cnd[1], cnd[2]), m1 = GI2_MAX3(cnd[3], cnd[4], cnd[5]), m2 = GI2_MAX3(cnd[6], cnd[7], cnd[8]),
+                   m3 = GI2_MAX3(cnd[9], cnd[10], cnd[11]), m4 = GI2_MAX3(cnd[12], cnd[13], cnd[14]);
+    const uint32_t u0 = GI2_MAX3(m0, m1, m2), u1 = m3 > m4 ? m3 : m4;
+    const uint32_t sel = u0 > u1 ? u0 : u1;
+#undef GI2_MAX3
+    const uint32_t n = (sel >> 12) & 15u;
+    const uint32_t l = n + 1u;
     if (l > 15u) return -1;                                // beyond the end of the last length: not a code of this set
-    const uint32_t idx = ((code - (sel >> 16)) >> (15u - l)) + (sel & 0xFFFFu);
+    const uint32_t idx = ((code - (sel >> 16)) >> (15u - l)) + (sel & 0xFFFu);
     drop(b, l);
     if (LIT) return (int)(w.lit_lo[idx] | (((w.lit_hi[idx >> 5] >> (idx & 31u)) & 1u) << 8));
     return (int)w.dist_sorted[idx];
@@ -283,7 +308,10 @@ GI2_FN int put_match(Work& w, Out& o, uint32_t len, uint32_t dist) {
 // One BGZF block: out must hold `isize` bytes; literals are written to their places in out, the bytes of the matches are
 // LEFT OUT — tok[0 .. *n_tok) says where they are and where they come from (resolve() below, bgzf_resolve_kernel on the device).
 // tok must hold token_cap(isize) entries.
-GI2_FN int inflate_tokens(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t isize, uint32_t* tok, uint32_t* n_tok) {
+GI2_FN int inflate_tokens(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t isize, uint32_t* tok, uint32_t* n_tok,
+                          uint64_t* stamps_out = nullptr) {
+    GI2_STAMP_DECL;
+    (void)stamps_out;
     const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     Bits b;
     uint32_t lead = bits_open(b, in, in_len);
@@ -353,15 +381,20 @@ GI2_FN int inflate_tokens(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* 
             // (from here on w.lens is dead: its space holds the epochs' staged literals and tokens)
             // the symbols: at most two refills per token (>= 33 bits after each: code <= 15 + extra <= 13 bits)
             uint32_t step = 0;
+            GI2_STAMP(0);                                                  // (0: headers and code construction)
             while (!err) {
                 if (b.pos > b.n_words) { err = E_INPUT; break; }           // a stream that runs on past its block
                 if ((++step & (EPOCH - 1u)) == 0) { epoch_take(b); flush_staged(w, o); epoch_ask(b); }   // all of the wave's memory traffic, every EPOCH tokens
+                GI2_STAMP(1);                                              // (1: loop head + epochs)
                 refill(b);
+                GI2_STAMP(2);                                              // (2: refill)
                 const int sym = decode<true>(b, cl, w);
+                GI2_STAMP(3);                                              // (3: literal/length symbol)
                 if (sym < 256) {
                     if (sym < 0) { err = E_CODE; break; }
                     if (o.op >= o.cap) { err = E_OVERRUN; break; }
                     put_literal(w, o, (uint32_t)sym);
+                    GI2_STAMP(4);                                          // (4: literal staged)
                     continue;
                 }
                 if (sym == 256) break;
@@ -374,11 +407,15 @@ GI2_FN int inflate_tokens(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* 
                 if (ds < 0 || ds >= 30) { err = E_CODE; break; }
                 dist_code((uint32_t)ds, db, de);
                 const uint32_t dist = db + take(b, (int)de);
+                GI2_STAMP(5);                                              // (5: length extra bits, distance symbol, its extra bits)
                 err = put_match(w, o, len, dist);
+                GI2_STAMP(6);                                              // (6: token staged)
             }
         } else err = E_BTYPE;
     }
     flush_staged(w, o);
+    GI2_STAMP(7);
+    GI2_STAMP_OUT(stamps_out);
     *n_tok = o.n_tok;
     if (err) return err;
     if (o.op != isize) return E_SIZE;

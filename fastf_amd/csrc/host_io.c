@@ -988,12 +988,12 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
     b->ccap = w ? (size_t)strtoull(w, NULL, 0) : ((size_t)(b->gpu_wanted ? 128 : 32) << 20);
     if (!w && b->gpu_wanted) {
         /* The two-kernel device inflate decodes every block of a window side by side — 65 536 of them fit the chip — and a
-         * window costs it about the same 15 ms whether it holds 8 000 blocks or 35 000: a large file is read in windows of a
-         * sixth of its size, up to 512 MiB (profiles/r5_notes/e2e_windows_lane_decoder.txt: 445 -> 640-730 blocks per ms). */
+         * window costs it about the same 15 ms whether it holds 8 000 blocks or 50 000: a large file is read in windows of a
+         * sixth of its size, up to 768 MiB (profiles/r5_notes/e2e_windows_lane_decoder.txt: 445 -> 610-780 blocks per ms). */
         struct stat st0;
         if (fstat(fileno(fp), &st0) == 0 && S_ISREG(st0.st_mode)) {
             size_t want = ((size_t)st0.st_size / 6) & ~(((size_t)1 << 20) - 1);
-            if (want > ((size_t)512 << 20)) want = (size_t)512 << 20;
+            if (want > ((size_t)768 << 20)) want = (size_t)768 << 20;
             if (want > b->ccap) b->ccap = want;
         }
     }

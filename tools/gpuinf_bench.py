@@ -37,3 +37,13 @@ cbuf = pin
 for rep in range(4):
     t = time.perf_counter(); rc = L.fastf_gpuinf_run(g, cbuf, desc, n, out_p, status); dt = time.perf_counter() - t
     print("run %d: rc %d, %d blocks, %.1f MB in, %.1f MB out, %.1f ms -> %.1f GB/s inflated; declined %d" % (rep, rc, n, pos / 1e6, uoff / 1e6, dt * 1e3, uoff / dt / 1e9, sum(1 for s in status if s)))
+
+if hasattr(L, "fastf_debug_gi2_stamps"):                      # experiment build with FASTF_X_GI2_STAMPS: cycles per section of the symbol loop
+    try:
+        st = (C.c_ulonglong * 8)()
+        if L.fastf_debug_gi2_stamps(st) == 0:
+            tot = float(sum(st)) or 1.0
+            names = ["headers+construction", "loop head+epochs", "refill", "lit/len symbol", "literal staged", "len extra+dist symbol+extra", "token staged", "final flush"]
+            print("symbol-loop stamps (share of one lane-0 wave clock, all waves summed): " + "; ".join("%s %.1f%%" % (n, 100.0 * v / tot) for n, v in zip(names, st)))
+    except Exception as ex:
+        print("stamps:", ex)

@@ -16,4 +16,4 @@ f=$(find $O/s8_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $
 import csv
 for r in csv.DictReader(open('$f')):
     print('   %-44s calls %5s total %8.2f ms avg %8.3f ms' % (r['Name'][:44], r['Calls'], float(r['TotalDurationNs'])/1e6, float(r['AverageNs'])/1e6))"
-rm -rf $O/s8_prof /dev/shm/gb
+t=$(find $O/s8_prof -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && cp $t $O/s8_cli_kernel_trace.csv; rm -rf $O/s8_prof /dev/shm/gb
