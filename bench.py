@@ -181,6 +181,38 @@ def main():
 
     err = eng.dev_error_bits()
     hits, sampled, valid, _ = sp.global_counters()
+
+    # ---- the step WITH its draw generation (N = 1): the job's draws — one per CB hit — made inside the clock by the device's own
+    #      MT19937 (fastf_dev_mt_decisions: sub-streams seated by jump-ahead, generated side by side), then the same step ----
+    with_draws = None
+    K_ref = int(sp.d_n.item())
+    if world == 1 and not args.draw_words:
+        n_gen_steps = max(3, min(args.steps, 20))
+        bits = stages.mt_decisions(workload.SEED, lists.mt_skip, hits)         # (first call: polynomials up, buffers sized)
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        for _ in range(n_gen_steps):
+            bits = stages.mt_decisions(workload.SEED, lists.mt_skip, hits, out=bits)
+        torch.cuda.synchronize()
+        t_gen_only = (time.perf_counter() - tg0) / n_gen_steps
+
+        def step_gen():
+            b = stages.mt_decisions(workload.SEED, lists.mt_skip, hits, out=bits)
+            if blk is not None:
+                sp.run(cb, blk, None, None, n_local, b)
+            else:
+                sp.run(cb, gx, umi, meta, n_local, b)
+        step_gen(); torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        for _ in range(n_gen_steps):
+            step_gen()
+        torch.cuda.synchronize()
+        t_with = (time.perf_counter() - tg0) / n_gen_steps
+        h2, s2, v2, _ = sp.global_counters()
+        with_draws = {"ms_per_step": t_with * 1e3, "records_per_s": N_total / t_with, "steps": n_gen_steps,
+                      "draw_generation_ms": t_gen_only * 1e3, "draws_per_step": hits, "draws_per_s": hits / t_gen_only,
+                      "same_counters_as_the_resident_stream": (h2, s2, v2) == (hits, sampled, valid) and int(sp.d_n.item()) == K_ref,
+                      "scope": "fastf_dev_mt_decisions (host seeds and skips the stream, the device seats 624 x 512-draw sub-streams by jump-ahead and generates them side by side, draw_bits packs the decisions; the call synchronises) + the step above"}
     K_local = int(sp.d_n.item())
     Z_local = int(sp.nnz.item())
     tot = torch.tensor([K_local, Z_local], dtype=torch.int64, device=dev)
@@ -264,6 +296,7 @@ def main():
                            "read_frac_of_peak_nominal": gbs(Bread_of(P_nom)) / HBM_PEAK_GBS,
                            "draw_bytes_counted": draw_b,
                            "B_8d_executed": B_of(P_exe, 4 * hits), "B_read_8d_executed": Bread_of(P_exe, 4 * hits)},
+            "step_with_draw_generation": with_draws,
             "counters": {"total": N_total, "hits": hits, "sampled": sampled, "valid": valid,
                          "keys": K_job, "rows": Z_job, "device_error_bits": err},
         }

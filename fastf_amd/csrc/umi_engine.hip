@@ -22,6 +22,7 @@
 extern "C" {
 #include "fastf_amd.h"
 #include "host_io.h"
+#include "mt_jump.h"
 }
 
 using namespace fastf;
@@ -141,6 +142,8 @@ struct fastf_engine {
     DevBuf d_dbits;                      // device-level calls that bring 32-bit draws: their decisions (draw_bits_kernel)
     DevBuf d_mtwords;                    // the generator's words of one launch, between mt_fill_kernel and draw_bits_kernel
     DevBuf d_mt; bool mt_on_device = false;  // the engine-owned stream continues on the device (mt_fill_kernel): state words + read index
+    u32 mt_dev_idx = MT_N;                   // ... and where in its block that stream stands, as the host knows it (the parallel generator starts at a block boundary)
+    DevBuf d_mtsub, d_mtpoly, d_mtseat;      // parallel generator (jump-ahead): the sub-streams' states; the jump polynomials; the state fastf_dev_mt_decisions seats
     u64 draws_up = 0;                    // absolute ranks below this are (being) uploaded
     u64 draws_valid = 0;                 // ranks below this carry a real draw (caller-supplied streams can run short)
     // staging: chunks in flight, double buffered
@@ -566,7 +569,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
-    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release();
+    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release(); e->d_mtsub.release(); e->d_mtpoly.release(); e->d_mtseat.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp,
@@ -817,6 +820,80 @@ static int launch_mt_decisions(hipStream_t s, u32* d_mt, DevBuf& words, u32* d_r
     HIP_OK(hipGetLastError());
     return launch_draw_bits(threshold, (const u32*)words.p, count, d_ring, s, first, ring_mask);
 }
+// where a stream that stood at read index idx of its block stands after n more draws
+static u32 mt_idx_after(u32 idx, u64 n) {
+    if (n == 0) return idx;
+    if (idx + n <= MT_N) return (u32)(idx + n);
+    return (u32)((idx + n - 1) % MT_N) + 1u;
+}
+// The same as launch_mt_decisions, by MANY workgroups (mt_jump_kernel / mt_fill_multi_kernel: jump-ahead).  *idx: the read index of
+// the stream in d_mt as the host knows it (the jumps start at a block boundary: the rest of the block the stream stands in is
+// handed out by the one-workgroup kernel first); updated.  Calls below MT_PAR_MIN draws take the one-workgroup kernel: seating
+// the sub-streams costs a handful of launches.
+constexpr u64 MT_PAR_MIN = 4ull * MT_SUB_DRAWS;
+static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u32* idx, DevBuf& words, u32* d_ring, u64 first, u64 count,
+                                   u64 ring_mask, u64 threshold) {
+    if (count == 0) return 0;
+    static const bool no_par = getenv("FASTF_MT_SERIAL") != nullptr;
+    const u64 head = *idx < MT_N ? std::min<u64>(count, MT_N - *idx) : 0;          // to the next block boundary
+    if (count < MT_PAR_MIN || no_par || count - head > ((u64)MT_SUB_DRAWS << FASTF_MT_JUMP_LEVELS)) {
+        if (launch_mt_decisions(s, d_mt, words, d_ring, first, count, ring_mask, threshold)) return 1;
+        *idx = mt_idx_after(*idx, count);
+        return 0;
+    }
+    if (words.bytes < count * 4) {
+        if (words.p) HIP_OK(hipStreamSynchronize(s));
+        if (words.ensure(std::max<u64>(count * 4, 1u << 20))) return 1;
+    }
+    if (!e->d_mtpoly.p) {                                      // the polynomials: constants of the generator (mt_jump.c), once per engine
+        static_assert(MT_POLY_WORDS == FASTF_MT_POLY_WORDS && MT_SUB_DRAWS == FASTF_MT_SUB_DRAWS, "kernel and table agree");
+        if (e->d_mtpoly.ensure((size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64))) return 1;
+        HIP_OK(hipMemcpy(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64), hipMemcpyHostToDevice));
+        HIP_OK(hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_SEQ_WORDS * sizeof(u32))));
+    }
+    u32* const w = (u32*)words.p;
+    if (head) {                                                // the rest of the block the stream stands in
+        hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, s, d_mt, w, 0ull, head, ~0ull);
+    }
+    const u64 body = count - head;
+    const u32 S = (u32)((body + MT_SUB_DRAWS - 1) / MT_SUB_DRAWS);
+    if (e->d_mtsub.bytes < (size_t)S * MT_STATE_WORDS * 4) {
+        if (e->d_mtsub.p) HIP_OK(hipStreamSynchronize(s));
+        if (e->d_mtsub.ensure((size_t)std::max<u32>(S, 64) * MT_STATE_WORDS * 4)) return 1;
+    }
+    u32* const sub = (u32*)e->d_mtsub.p;
+    HIP_OK(hipMemcpyAsync(sub, d_mt, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
+    u32 levels = 0;
+    while ((1u << levels) < S) ++levels;
+    for (u32 l = levels; l-- > 0;) {                           // sub-streams 2^l apart from those 2^(l+1) apart
+        const u32 stride = 1u << l, grid = (S + 2 * stride - 1) / (2 * stride);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(grid), dim3(1024), MT_SEQ_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p + (size_t)l * MT_POLY_WORDS, stride, S);
+    }
+    hipLaunchKernelGGL(mt_fill_multi_kernel, dim3(S), dim3(256), 0, s, sub, w + head, 0ull, body, ~0ull);
+    HIP_OK(hipMemcpyAsync(d_mt, sub + (size_t)(S - 1) * MT_STATE_WORDS, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipGetLastError());
+    *idx = mt_idx_after(MT_N, body - (u64)(S - 1) * MT_SUB_DRAWS);
+    return launch_draw_bits(threshold, (const u32*)w, count, d_ring, s, first, ring_mask);
+}
+
+// The decisions of `n_draws` draws of the stream init_genrand(seed) + skip, from the device's own generator (the parallel
+// one for large counts), as a linear array of bits — what a resident pass hands to fastf_dev_probe_pack with
+// FASTF_PROBE_DRAW_BITS (bench.py: the step with its draw generation inside the clock; tests).
+extern "C" int fastf_dev_mt_decisions(fastf_engine_t* e, uint32_t seed, uint64_t skip, uint64_t n_draws, uint32_t* d_bits_out, void* stream) FASTF_TRY {
+    if (!e || (n_draws && !d_bits_out)) return set_err("null argument");
+    if (e->multi) return set_err("fastf_dev_mt_decisions: device-level calls take a single-device engine");
+    HIP_OK(hipSetDevice(e->device));
+    fastf_mt_t mt; fastf_mt_seed(&mt, seed); fastf_mt_skip(&mt, skip);
+    // (the seated state goes into the first slot of the sub-stream array's tail: a buffer the engine keeps)
+    if (e->d_mtseat.ensure(sizeof mt)) return 1;
+    HIP_OK(hipMemcpyAsync(e->d_mtseat.p, &mt, sizeof mt, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));                    // (mt is on this stack)
+    u32 idx = (u32)mt.idx;
+    if (launch_mt_decisions_par(e, (hipStream_t)stream, (u32*)e->d_mtseat.p, &idx, e->d_mtwords, d_bits_out, 0, n_draws, ~0ull, e->threshold)) return 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return set_err("the generator kernels failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+} FASTF_CATCH_INT
+
 extern "C" int fastf_dev_draw_bits(fastf_engine_t* e, const uint32_t* d_draws, uint64_t n_draws, uint32_t* d_bits_out, void* stream) FASTF_TRY {
     if (!e || (n_draws && (!d_draws || !d_bits_out))) return set_err("null argument");
     if (e->multi) return set_err("fastf_dev_draw_bits: device-level calls take a single-device engine");
@@ -1378,7 +1455,7 @@ static int upload_draws(fastf_engine* e, fastf_engine::Slot& sl, const DrawSourc
         // their decisions in the ring (on a stream of its own: one workgroup walks the stream block by block, about a
         // nanosecond per two draws — beside the record copies, not in front of them; K1 waits for both)
         if (e->draws_up < upto) {
-            if (launch_mt_decisions(e->s_mt, (u32*)e->d_mt.p, e->d_mtwords, (u32*)e->d_ring.p, e->draws_up, upto - e->draws_up, e->ring_len - 1, e->threshold)) return 1;
+            if (launch_mt_decisions_par(e, e->s_mt, (u32*)e->d_mt.p, &e->mt_dev_idx, e->d_mtwords, (u32*)e->d_ring.p, e->draws_up, upto - e->draws_up, e->ring_len - 1, e->threshold)) return 1;
             HIP_OK(hipEventRecord(e->ev_mt, e->s_mt));
             HIP_OK(hipStreamWaitEvent(e->s_compute, e->ev_mt, 0));
             e->draws_up = upto;
@@ -1585,6 +1662,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
             //  push stops to grow it)
             if (e->d_mt.ensure(sizeof(fastf_mt_t)) || e->d_mtwords.ensure(e->ring_len * 4)) return 1;
             HIP_OK(hipMemcpy(e->d_mt.p, &e->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice));
+            e->mt_dev_idx = (u32)e->mt.idx;
             e->mt_on_device = true;
         }
     }

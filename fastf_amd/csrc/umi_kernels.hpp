@@ -149,11 +149,10 @@ __device__ __forceinline__ u32 mt_temper(u32 y) {
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     return y;
 }
-__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
+__device__ __forceinline__ void mt_fill_body(u32 (&buf)[2][MT_N], u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
     // two copies of the state: a block is regenerated FROM one INTO the other, so a sweep never overwrites what it still
     // reads: three barriers per block.  A word goes out (tempered, to its rank's ring slot) the moment it is computed — no
     // second pass over the block; only what is left of the block the kernel starts in is handed out by a loop of its own.
-    __shared__ u32 buf[2][MT_N];
     const u32 tid = threadIdx.x;
     for (u32 i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
     u32 idx = state[MT_N];
@@ -190,6 +189,68 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u
     }
     for (u32 i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
     if (tid == 0) state[MT_N] = idx;
+}
+__global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
+    __shared__ u32 buf[2][MT_N];
+    mt_fill_body(buf, state, out, first, count, mask);
+}
+
+// ------------------------------------------------------------------------------------
+// The same stream from MANY workgroups: jump-ahead (mt_jump.c has the algebra).  The stream's state is linear over GF(2), so
+// the state J draws on is g(F) applied to the state now, with g = x^J mod the characteristic polynomial — a constant of the
+// generator, no seed in it.  Sub-stream j of a call starts J = 624 x 512 draws behind sub-stream j - 1:
+//   mt_jump_kernel        one workgroup per jump: the source array (a block boundary: all 624 words handed out) is continued
+//                         as a flat word sequence X_{t+624} = X_{t+397} ^ mix(X_t, X_{t+1}) for 19 937 words more, in LDS (83 KB;
+//                         sweeps of 227 words, a barrier each), and the array J words on is the XOR of the windows X[k .. k+623]
+//                         over the set coefficients k of g: thread i XORs X[k + i], the polynomial's bits walk in scalar registers.
+//                         Level l of a call seats the sub-streams 2^l apart from those 2^(l+1) apart (polynomial l of the table
+//                         the library carries): log2(S) launches for S sub-streams.
+//   mt_fill_multi_kernel  workgroup j continues sub-stream j by its share of the call's draws (mt_fill_body above).
+// 90 M draws (one configs[2] job): 283 sub-streams, nine jump launches, one fill launch.
+// ------------------------------------------------------------------------------------
+constexpr u32 MT_SUB_DRAWS = 624u * 512u, MT_POLY_WORDS = 312, MT_DEG = 19937, MT_STATE_WORDS = MT_N + 1;
+constexpr u32 MT_JUMP_SWEEPS = 88, MT_SEQ_WORDS = MT_N + MT_JUMP_SWEEPS * (MT_N - MT_M);   // 20 600 words >= 624 + 19 936: every window of the convolution
+static_assert(MT_SEQ_WORDS >= MT_N + MT_DEG, "the sequence covers the windows of every coefficient");
+__global__ __launch_bounds__(1024) void mt_jump_kernel(u32* __restrict__ states, const u64* __restrict__ poly, u32 stride, u32 n_sub) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mtj_smem[];
+    u32* const X = reinterpret_cast<u32*>(mtj_smem);
+    const u32 src = blockIdx.x * 2u * stride, dst = src + stride;
+    if (dst >= n_sub) return;                                  // (block-uniform)
+    const u32 tid = threadIdx.x;
+    const u32* const a = states + (u64)src * MT_STATE_WORDS;
+    for (u32 i = tid; i < MT_N; i += 1024) X[i] = a[i];
+    __syncthreads();
+    // the sequence: words t + 624 for t in [base, base + 227) need nothing beyond X[base + 623]
+    for (u32 sw = 0; sw < MT_JUMP_SWEEPS; ++sw) {
+        if (tid < MT_N - MT_M) { const u32 t = sw * (MT_N - MT_M) + tid; X[t + MT_N] = X[t + MT_M] ^ mt_mix(X[t], X[t + 1]); }
+        __syncthreads();
+    }
+    // W_J[i] = XOR over the set coefficients k of X[k + i]
+    if (tid < MT_N) {
+        u32 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        for (u32 w = 0; w < MT_POLY_WORDS; ++w) {
+            u64 bits = uniform64(poly[w]);
+            const u32* const xw = X + (w << 6) + tid;
+            while (bits) {                                     // (uniform: the bits are the same for every thread; four reads in flight)
+                const u32 k0 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+                const u32 k1 = bits ? (u32)__builtin_ctzll(bits) : k0; const bool h1 = bits != 0; bits &= bits - (h1 ? 1ull : 0ull);
+                const u32 k2 = bits ? (u32)__builtin_ctzll(bits) : k0; const bool h2 = bits != 0; bits &= bits - (h2 ? 1ull : 0ull);
+                const u32 k3 = bits ? (u32)__builtin_ctzll(bits) : k0; const bool h3 = bits != 0; bits &= bits - (h3 ? 1ull : 0ull);
+                const u32 x0 = xw[k0], x1 = xw[k1], x2 = xw[k2], x3 = xw[k3];
+                acc0 ^= x0; acc1 ^= h1 ? x1 : 0u; acc2 ^= h2 ? x2 : 0u; acc3 ^= h3 ? x3 : 0u;
+            }
+        }
+        states[(u64)dst * MT_STATE_WORDS + tid] = acc0 ^ acc1 ^ acc2 ^ acc3;
+    }
+    if (tid == 0) states[(u64)dst * MT_STATE_WORDS + MT_N] = MT_N;   // a block boundary: the next draw regenerates
+}
+// sub-stream j: draws [j * MT_SUB_DRAWS, ...) of the call's `count`, to out[(first + that) & mask]
+__global__ __launch_bounds__(256) void mt_fill_multi_kernel(u32* __restrict__ states, u32* __restrict__ out, u64 first, u64 count, u64 mask) {
+    __shared__ u32 buf[2][MT_N];
+    const u64 off = (u64)blockIdx.x * MT_SUB_DRAWS;
+    if (off >= count) return;
+    const u64 n = count - off < (u64)MT_SUB_DRAWS ? count - off : (u64)MT_SUB_DRAWS;
+    mt_fill_body(buf, states + (u64)blockIdx.x * MT_STATE_WORDS, out, first + off, n, mask);
 }
 
 // draws -> decisions: bit (first + i) of the ring (ring_mask = its size in bits - 1, a power of two >= 64 — or ~0: a linear

@@ -110,6 +110,13 @@ class HipStages:
         self.eng.dev_draw_bits(draws.data_ptr(), n, words.data_ptr(), self._s())
         return DrawBits(words, n)
 
+    def mt_decisions(self, seed, skip, n, out=None):
+        """DrawBits of n draws of init_genrand(seed) + skip made by the device's generator (fastf_dev_mt_decisions); `out`: the
+        DrawBits of an earlier call of at least that size, written again"""
+        words = out.words if out is not None else torch.zeros((n + 63) // 64 * 2 + 2, dtype=torch.int32, device=self.device)
+        self.eng.dev_mt_decisions(seed, skip, n, words.data_ptr(), self._s())
+        return DrawBits(words, n)
+
     def probe_pack(self, cb, gx, umi, meta, n, draws, draw_base, keys_out, stride, key_counts, counters, reuse_hits=False):
         """draws: a tensor of 32-bit draws (converted on every call) or the DrawBits made from one"""
         self.segmented = self.eng.n_shards == 1 and self.eng.probe_capacity(n) > 0 and stride >= self.eng.probe_capacity(n)

@@ -346,6 +346,11 @@ class Engine:
         be 8-byte aligned and hold ((n_draws + 63) // 64) * 8 bytes = ((n_draws + 63) // 64) * 2 u32 words (include/fastf_amd.h)"""
         check(self._L.fastf_dev_draw_bits(self._h, d_draws, n_draws, d_bits_out, stream))
 
+    def dev_mt_decisions(self, seed, skip, n_draws, d_bits_out, stream=0):
+        """the decisions of n_draws draws of init_genrand(seed) + skip from the device's own generator (parallel for large
+        counts: jump-ahead), bit i of d_bits_out; same size rule as dev_draw_bits"""
+        check(self._L.fastf_dev_mt_decisions(self._h, seed, skip, n_draws, d_bits_out, stream))
+
     def probe_capacity(self, n) -> int:
         """key slots a segmented probe_pack over n records needs; 0 = the streaming form is not available"""
         v = C.c_uint64()

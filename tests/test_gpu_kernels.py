@@ -325,3 +325,43 @@ def test_device_decision_stream(env, seed, skip, first, counts, rate, ring_bits)
         assert not got[tail.astype(np.int64)].any()                                  # the rest of the last 64-bit word: zeros
         beyond = np.arange((end // 64 + 1) * 64, (end // 64 + 2) * 64, dtype=np.uint64) % np.uint64(ring_bits)
         assert got[beyond.astype(np.int64)].all()                                    # the word after it: untouched
+
+
+J_SUB = 624 * 512                                      # draws per sub-stream of the parallel generator (mt_jump.h)
+
+
+@pytest.mark.parametrize("seed,skip,n,rate", [
+    (926, 0, 5 * J_SUB + 1234, 0.5),                   # a stream that starts at a block boundary (seeded: the first draw regenerates)
+    (926, 100, 4 * J_SUB, 0.3),                        # ... in the middle of a block: the rest of it goes out first; the smallest parallel call
+    (7, 7, 4 * J_SUB + 1, 0.7),
+    (5489, 624 * 3 + 5, 20_000_000, 0.5),              # 63 sub-streams, six levels of jumps
+    (1, 623, 9 * J_SUB - 623, 1.0),                    # ends exactly on a sub-stream boundary
+])
+def test_parallel_mt_decisions_are_the_reference_stream(env, seed, skip, n, rate):
+    """fastf_dev_mt_decisions: the MT19937 stream (mt19937ar.c:105-140) from many workgroups at once — sub-streams 624 x 512 draws
+    apart, seated by jump-ahead (mt_jump_kernel: the state J draws on is g(F) applied to the state now, g = x^J mod the
+    characteristic polynomial) and generated side by side — must be the stream one generator produces, decision for decision"""
+    torch, F, eng0 = env
+    from fastf_amd import _lib
+    from helpers import Case
+    L = _lib.lib()
+    case = Case(n=10, n_bar=20, n_gene=10, rate_depth=rate)
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=rate, seed=926)
+    try:
+        thr = int(L.fastf_draw_threshold(rate))
+        words = torch.full(((max(n, 4 * J_SUB + 99) + 63) // 64 * 2 + 2,), -1, dtype=torch.int32, device="cuda")
+        eng.dev_mt_decisions(seed, skip, n, words.data_ptr())
+        torch.cuda.synchronize()
+        got = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+        want = (F.mt_draws(seed, skip, n).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
+        np.testing.assert_array_equal(got[:n], want)
+        assert not got[n:(n + 63) // 64 * 64].any()    # the tail of the last 64-bit word is zero
+        # a second call on the same engine (the polynomials and the sub-stream states are in place) from another position
+        eng.dev_mt_decisions(seed + 1, skip + 17, 4 * J_SUB + 99, words.data_ptr())
+        torch.cuda.synchronize()
+        got = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+        want = (F.mt_draws(seed + 1, skip + 17, 4 * J_SUB + 99).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
+        np.testing.assert_array_equal(got[:4 * J_SUB + 99], want)
+    finally:
+        eng.close()

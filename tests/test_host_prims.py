@@ -203,3 +203,35 @@ def test_pack_umi_long_matches_the_codec_up_to_28_bases():
     u, e = C.c_uint32(), C.c_uint32()
     assert L.fastf_pack_umi_long(b"ACGTNACGTACGTACGTACG", 20, C.byref(u), C.byref(e)) & 4 == 0 and (u.value, e.value) == (0, 0)
     assert L.fastf_pack_umi_long(b"A" * 29, 29, C.byref(u), C.byref(e)) & 8
+
+
+def test_mt_jump_polynomials_are_the_generator_advanced():
+    """mt_jump.c: x^J mod the characteristic polynomial of MT19937 (Berlekamp-Massey on its own output, then squarings), applied
+    to a block-boundary array as a convolution with the generated sequence, must give the array fastf_mt_skip reaches by
+    generating J draws — for the table the library carries (strides of 624 x 512 x 2^l draws) and for polynomials computed here"""
+    import ctypes as C
+    L = _lib.lib()
+    NW, J = 312, 624 * 512
+    L.fastf_mt_jump_table.restype = C.POINTER(C.c_uint64)
+    L.fastf_mt_jump_polys.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+    L.fastf_mt_jump_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    table = np.ctypeslib.as_array(L.fastf_mt_jump_table(), shape=(12 * NW,)).copy()
+    fresh = np.zeros(3 * NW, np.uint64)
+    assert L.fastf_mt_jump_polys(J, 3, fresh.ctypes.data) == 0
+    np.testing.assert_array_equal(fresh, table[:3 * NW])                 # the build tool's table is what the code computes
+    odd = np.zeros(2 * NW, np.uint64)
+    assert L.fastf_mt_jump_polys(624 * 33, 2, odd.ctypes.data) == 0      # another stride (odd part 39 * 33 > 624: square-and-multiply)
+
+    def array_after(seed, blocks):
+        from fastf_amd.engine import MT
+        mt = MT(); L.fastf_mt_seed(C.byref(mt), seed); L.fastf_mt_skip(C.byref(mt), 624 * blocks)
+        return np.array(mt.s[:], dtype=np.uint32), mt
+
+    for seed in (926, 1):
+        a, mt = array_after(seed, 5)
+        for poly, stride in ((table[:NW], J), (table[NW:2 * NW], 2 * J), (table[5 * NW:6 * NW], 32 * J), (odd[:NW], 624 * 33), (odd[NW:], 624 * 66)):
+            out = np.zeros(624, np.uint32)
+            L.fastf_mt_jump_apply(a.ctypes.data, np.ascontiguousarray(poly).ctypes.data, out.ctypes.data)
+            want, _ = array_after(seed, 5 + stride // 624)
+            np.testing.assert_array_equal(out[1:], want[1:])
+            assert (int(out[0]) ^ int(want[0])) >> 31 == 0                # word 0 lends only its top bit
