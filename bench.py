@@ -432,22 +432,29 @@ def e2e_leg(job, sizes):
         # the third file is the configs[2]-sized one: the Cell-Ranger-shaped body written `rep` times behind one header
         # (every record ten times: ten times the keys, the same distinct UMIs — the same matrix as the 20 M-record file)
         big_rep = max(1, int(os.environ.get("FASTF_E2E_BIG_REPEAT", "10")))
-        cases = [("skinny", sizes[0], 0, 1), ("cell_ranger_shaped", sizes[1], 91, 1)]
+        cases = [("skinny", sizes[0], 0, 1, 1), ("cell_ranger_shaped", sizes[1], 91, 1, 1)]
         if big_rep > 1 and not os.environ.get("FASTF_E2E_NO_BIG"):
-            cases.append(("cell_ranger_shaped_%dM" % (sizes[1] * big_rep // 1_000_000), sizes[1], 91, big_rep))
-        for label, n_gen, seq_len, rep in cases:
-            n = n_gen * rep
+            # the configs[2]-sized file twice: ten DIFFERENT bodies from ten seeds (200 M distinct records: the matrix, the depth of
+            # its groups and the output files are those of a file of that size) — the line of record — and, for continuity with
+            # round 4, the one body written ten times (the matrix of the 20 M-record file, every group ten times deeper)
+            cases.append(("cell_ranger_shaped_%dM" % (sizes[1] * big_rep // 1_000_000), sizes[1], 91, 1, big_rep))
+            if not os.environ.get("FASTF_E2E_NO_REPEATED"):
+                cases.append(("cell_ranger_shaped_%dM_repeated_body" % (sizes[1] * big_rep // 1_000_000), sizes[1], 91, big_rep, 1))
+        for label, n_gen, seq_len, rep, bodies in cases:
+            n = n_gen * rep * bodies
             bam = os.path.join(td, "in.bam")
             t0 = time.perf_counter()
-            subprocess.check_call([gen, bam, os.path.join(td, "bar.tsv"), os.path.join(td, "feat.tsv"), str(n_gen), "7", "12", str(seq_len), str(threads), str(rep)])
+            subprocess.check_call([gen, bam, os.path.join(td, "bar.tsv"), os.path.join(td, "feat.tsv"), str(n_gen), "7", "12", str(seq_len), str(threads), str(rep), str(bodies)])
             t_gen = time.perf_counter() - t0
-            out[label] = {"records": n, "bam_bytes": os.path.getsize(bam), "bam_generated_in_s": t_gen}
+            out[label] = {"records": n, "bam_bytes": os.path.getsize(bam), "bam_generated_in_s": t_gen, "records_distinct": rep == 1}
             if rep > 1:
                 out[label]["built_as"] = "the %d-record body written %d times behind one header" % (n_gen, rep)
+            if bodies > 1:
+                out[label]["built_as"] = "%d bodies of %d records from %d seeds behind one header" % (bodies, n_gen, bodies)
             # the same file with the BGZF inflate on the host's threads only, and shared with the device (the CLI's default)
             for variant, extra in (("host_inflate", {"FASTF_GPU_INFLATE": "0"}), ("hybrid_inflate", {"FASTF_GPU_INFLATE": "1"})):
                 best = None
-                for _rep in range(2 if rep == 1 else 1):
+                for _rep in range(2 if rep * bodies == 1 else 1):
                     od = os.path.join(td, "out"); os.makedirs(od, exist_ok=True)
                     for f in os.listdir(od):
                         os.unlink(os.path.join(od, f))
@@ -467,6 +474,7 @@ def e2e_leg(job, sizes):
                     # BAM, the pinned slab and the GPU context of the exiting process) is reported next to it, not in it
                     done = (closed[-1] - w0) if closed else wall
                     md5 = subprocess.run("zcat %s/matrix.mtx.gz | md5sum" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()[0]
+                    dims = subprocess.run("zcat %s/matrix.mtx.gz | grep -v '^%%' -m 1" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()
                     # the clock a user lives with: process start -> process exit.  "outputs closed" (SURVEY 8d's end-to-end
                     # scope) is kept beside it
                     # the three pieces of the run (bam2db()'s own clock, FASTF_PROFILE): until the device takes work, the steady
@@ -478,6 +486,7 @@ def e2e_leg(job, sizes):
                     if best is None or wall < best["seconds"]:
                         best = {"value": n / wall, "unit": "records/s", "seconds": wall, "scope": "process start -> process exit",
                                 "seconds_to_outputs_closed": done, "records_per_s_to_outputs_closed": n / done, "matrix_md5": md5,
+                                "matrix_rows": int(dims[2]) if len(dims) == 3 else None,
                                 "start_up_s": ph.get("decoder_saw_engine_s"), "records_decoded_during_start_up": ph.get("records_before"),
                                 "steady_state_records_per_s": (ph["steady_records"] / ph["steady_s"]) if ph.get("steady_s") else None,
                                 "steady_state_s": ph.get("steady_s"), "finish_and_write_s": (ph["outputs_closed_s"] - ph["last_record_s"]) if ph else None,

@@ -67,9 +67,9 @@ __global__ __launch_bounds__(GI2_LPW) void bgzf_decode_kernel(const GiBlock* __r
     tok_count[b] = rc ? 0u : nt;
 }
 #if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI2_STAMPS)
-extern "C" int fastf_debug_gi2_stamps(unsigned long long out[8]) {
+extern "C" int fastf_debug_gi2_stamps(unsigned long long out[8]) FASTF_TRY {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(gi2_stamp_acc), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
+} FASTF_CATCH_INT
 #endif
 // Phase 2: one WAVE per block resolves its matches, 64 tokens at a time.  A wave scan over (literals + length) gives every
 // match its place.  A match may copy once the bytes it READS are final: the literals are (phase 1), everything in front of the
