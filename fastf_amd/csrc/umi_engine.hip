@@ -849,7 +849,7 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
         static_assert(MT_POLY_WORDS == FASTF_MT_POLY_WORDS && MT_SUB_DRAWS == FASTF_MT_SUB_DRAWS, "kernel and table agree");
         if (e->d_mtpoly.ensure((size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64))) return 1;
         HIP_OK(hipMemcpy(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64), hipMemcpyHostToDevice));
-        HIP_OK(hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_SEQ_WORDS * sizeof(u32))));
+        HIP_OK(hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_JUMP_LDS_WORDS * sizeof(u32))));
     }
     u32* const w = (u32*)words.p;
     if (head) {                                                // the rest of the block the stream stands in
@@ -867,7 +867,7 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
     while ((1u << levels) < S) ++levels;
     for (u32 l = levels; l-- > 0;) {                           // sub-streams 2^l apart from those 2^(l+1) apart
         const u32 stride = 1u << l, grid = (S + 2 * stride - 1) / (2 * stride);
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(grid), dim3(1024), MT_SEQ_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p + (size_t)l * MT_POLY_WORDS, stride, S);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(grid), dim3(1024), MT_JUMP_LDS_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p + (size_t)l * MT_POLY_WORDS, stride, S);
     }
     hipLaunchKernelGGL(mt_fill_multi_kernel, dim3(S), dim3(256), 0, s, sub, w + head, 0ull, body, ~0ull);
     HIP_OK(hipMemcpyAsync(d_mt, sub + (size_t)(S - 1) * MT_STATE_WORDS, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u
 // ------------------------------------------------------------------------------------
 constexpr u32 MT_SUB_DRAWS = 624u * 512u, MT_POLY_WORDS = 312, MT_DEG = 19937, MT_STATE_WORDS = MT_N + 1;
 constexpr u32 MT_JUMP_SWEEPS = 88, MT_SEQ_WORDS = MT_N + MT_JUMP_SWEEPS * (MT_N - MT_M);   // 20 600 words >= 624 + 19 936: every window of the convolution
-static_assert(MT_SEQ_WORDS >= MT_N + MT_DEG, "the sequence covers the windows of every coefficient");
+static_assert(MT_SEQ_WORDS >= MT_N + MT_DEG + 16, "the sequence covers the windows of every coefficient (and the sixteen outputs beyond 624 a lane reads along)");
+constexpr u32 MT_JUMP_LDS_WORDS = MT_SEQ_WORDS + 16 * 640;      // + the sixteen waves' partial arrays
 __global__ __launch_bounds__(1024) void mt_jump_kernel(u32* __restrict__ states, const u64* __restrict__ poly, u32 stride, u32 n_sub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mtj_smem[];
     u32* const X = reinterpret_cast<u32*>(mtj_smem);
@@ -225,22 +226,34 @@ __global__ __launch_bounds__(1024) void mt_jump_kernel(u32* __restrict__ states,
         if (tid < MT_N - MT_M) { const u32 t = sw * (MT_N - MT_M) + tid; X[t + MT_N] = X[t + MT_M] ^ mt_mix(X[t], X[t + 1]); }
         __syncthreads();
     }
-    // W_J[i] = XOR over the set coefficients k of X[k + i]
-    if (tid < MT_N) {
-        u32 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-        for (u32 w = 0; w < MT_POLY_WORDS; ++w) {
-            u64 bits = uniform64(poly[w]);
-            const u32* const xw = X + (w << 6) + tid;
-            while (bits) {                                     // (uniform: the bits are the same for every thread; four reads in flight)
-                const u32 k0 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
-                const u32 k1 = bits ? (u32)__builtin_ctzll(bits) : k0; const bool h1 = bits != 0; bits &= bits - (h1 ? 1ull : 0ull);
-                const u32 k2 = bits ? (u32)__builtin_ctzll(bits) : k0; const bool h2 = bits != 0; bits &= bits - (h2 ? 1ull : 0ull);
-                const u32 k3 = bits ? (u32)__builtin_ctzll(bits) : k0; const bool h3 = bits != 0; bits &= bits - (h3 ? 1ull : 0ull);
-                const u32 x0 = xw[k0], x1 = xw[k1], x2 = xw[k2], x3 = xw[k3];
-                acc0 ^= x0; acc1 ^= h1 ? x1 : 0u; acc2 ^= h2 ? x2 : 0u; acc3 ^= h3 ? x3 : 0u;
+    // W_J[i] = XOR over the set coefficients k of X[k + i].  All sixteen waves work: wave w takes the polynomial's words w, w + 16,
+    // ... (a sixteenth of the coefficients), every lane ten of the 624 outputs (i = lane + 64 q), and the sixteen partial arrays
+    // meet in LDS.  (One output per thread — 624 threads, each walking all 10 000 coefficients — took 0.53 ms a jump: ten waves
+    // waiting on one LDS read stream each; profiles/r5_notes/mt_jump.txt.)
+    u32* const part = X + MT_SEQ_WORDS;                            // [16][640]
+    {
+        const u32 lane = tid & 63u, w = tid >> 6;
+        u32 acc[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) acc[q] = 0;
+        for (u32 pw = w; pw < MT_POLY_WORDS; pw += 16) {
+            u64 bits = uniform64(poly[pw]);
+            const u32* const xw = X + (pw << 6) + lane;
+            while (bits) {                                         // (uniform inside the wave)
+                const u32 k = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) acc[q] ^= xw[k + 64 * q];     // (outputs 624..639 read on into the sequence: never stored)
             }
         }
-        states[(u64)dst * MT_STATE_WORDS + tid] = acc0 ^ acc1 ^ acc2 ^ acc3;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) part[w * 640u + lane + 64u * q] = acc[q];
+    }
+    __syncthreads();
+    if (tid < MT_N) {
+        u32 v = 0;
+#pragma unroll
+        for (u32 w = 0; w < 16; ++w) v ^= part[w * 640u + tid];
+        states[(u64)dst * MT_STATE_WORDS + tid] = v;
     }
     if (tid == 0) states[(u64)dst * MT_STATE_WORDS + MT_N] = MT_N;   // a block boundary: the next draw regenerates
 }

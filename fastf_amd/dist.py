@@ -288,7 +288,7 @@ class ShardedPass:
         steps must pass `inputs_ready`, an event recorded on its stream after the writes: K1 waits for it.  Without it
         the inputs must be ready when the first step starts and stay untouched afterwards (bench.py: resident inputs)."""
         G, st = self.G, self.st
-        self._last_inputs = (cb, gx, umi, meta, n, draws)
+        self._last_inputs = (cb, gx, umi, meta, n, draws, inputs_ready)       # (a step repeated by ensure_exact() waits for the same event)
         self._fixed_step = False
         if G > 1 and self.fixed and self.cap is not None:
             self._run_fixed(cb, gx, umi, meta, n, draws, inputs_ready)
@@ -386,7 +386,10 @@ class ShardedPass:
             rows = self._k1_fixed(cb, gx, umi, meta, n, draws)
             self._all_to_all_single(recv_rows.view(-1), rows.view(-1))
         counts = recv_rows[:, cap].contiguous()
-        self._overflow = (counts > cap).any() | (rows[:, cap] > cap).any()
+        # (the headers this rank RECEIVED: every count of the job is some receiver's header, and ensure_exact() takes the maximum
+        #  over the ranks — reading the sender's own rows here as well raced the K1 stage of the step after next, which
+        #  rewrites that slot on its own stream: ADVICE r4)
+        self._overflow = (counts > cap).any()
         self.d_n = self._d_n_buf
         st.set_regions(counts.clamp(max=cap), G, cap + 1, self.d_n)
         self.n_recv = G * cap                           # the host knows a bound only; the device reads the count at d_n
@@ -441,7 +444,13 @@ class ShardedPass:
 
     def ensure_exact(self):
         """If the group-only sort met runs beyond its cap, finish the sort and reduce again (every key is still in
-        the buffers, permuted).  Costs one synchronisation; called before results are read."""
+        the buffers, permuted).  Costs one synchronisation; called before results are read.
+
+        COLLECTIVE when G > 1: after a fixed-capacity step the ranks agree on whether a count outgrew its row (one
+        all_reduce), so every rank must call it — and with it gather_rows(), local_coo() and global_counters(), which
+        call it first — at the same point of the job, whether or not it wants the rows itself.  Only the LAST step can be
+        repeated: a caller that runs several steps before reading checks after each one (bench.py reads after every step's
+        warm-up and once at the end of identical steps)."""
         if self._verified:
             return
         if self._fixed_step:
