@@ -583,3 +583,31 @@ def test_rows_on_loan_in_the_callers_pinned_memory():
     finally:
         eng.close()
         pb.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n=300_000, n_bar=2000, n_gene=900, rate_cell=0.7, rate_depth=0.6, umi_pool=512, p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.01),
+    dict(n=90_000, n_bar=30, n_gene=20, umi_pool=64),                       # deep groups: one sort pass is not all there is
+])
+def test_push_after_finish_continues_the_job(kw):
+    """finish() in the middle of a job, then more pushes and another finish (no reset): the second result is the whole job's.
+    In stream mode the sort passes of the first finish have rewritten the key store, so the keys so far become regions again
+    (rebase_store: runs of 64 K keys, their first-digit histograms counted by a kernel of their own) before the new chunks'
+    regions are appended behind them"""
+    case = Case(**kw)
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed)
+    try:
+        packed = case.packed(lists)
+        a, b = case.n // 3, 2 * case.n // 3
+        eng.push(*(x[:a] for x in packed))
+        first = eng.finish()
+        assert first["total"] == a
+        eng.push(*(x[a:b] for x in packed))
+        eng.finish(); eng.umi_rows()                                        # (a full sort in between as well)
+        eng.push(*(x[b:] for x in packed))
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+    finally:
+        eng.close()
