@@ -18,7 +18,7 @@ for s in "$@"; do
 import re, sys
 w = []
 for l in sys.stdin:
-    m = re.match(r'\[bam\] ([0-9.]+) window (\d+): (\d+) blocks, (\d+) on the device in ([0-9.]+) ms, (\d+) on the host in ([0-9.]+) ms', l)
+    m = re.match(r'\[bam\] ([0-9.]+) window (\d+): (\d+) blocks, (\d+) on the device in ([0-9.]+) ms(?: \(queued a window ago\))?, (\d+) on the host in ([0-9.]+) ms', l)
     if m: w.append((float(m.group(1)), int(m.group(3)), int(m.group(4)), float(m.group(5)), float(m.group(7))))
     if l.startswith('[bam2db] lists'): tot = l.split('total so far')[1].strip()
     if 'device side ready' in l: ready = l.split()[1]
