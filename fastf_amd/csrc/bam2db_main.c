@@ -288,7 +288,7 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
     if (umi_bases) cfg.umi_max_bases = umi_bases;
     else if (ul) cfg.umi_max_bases = (uint32_t)atoi(ul);
     else cfg.umi_max_bases = (group_bits + 36 <= 64 || group_bits + 27 > 64) ? 16 : 12;
-    const int may_rerun = !ul && cfg.umi_max_bases < 24;
+    const int may_rerun = !ul && cfg.umi_max_bases < 32;
     cfg.batch_records = cap;
     tt = now_s();
     if (fastf_engine_create(&cfg, &eng)) { fprintf(stderr, "\x1b[31mError:\x1b[0m %s\n", fastf_last_error()); goto done; }
@@ -419,7 +419,7 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
     int longer_umis = 0;
     int rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, 0, &longer_umis);
     while (longer_umis) {
-        const uint32_t next = longer_umis < 16 ? 16 : 24;
+        const uint32_t next = longer_umis < 16 ? 16 : 32;
         fprintf(stderr, "Note: UMIs longer than %d bases in %s: running again with room for %u (keys wider than 64 bits)\n", longer_umis, bam_file, next);
         longer_umis = 0;
         rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, next, &longer_umis);

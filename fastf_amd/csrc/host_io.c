@@ -761,7 +761,7 @@ static void early_queue_next(fastf_bam_t *b, size_t next_start, int cur_h, int c
     if (b->scout_asked != next_start + 1 || !scout_take_early(b, next_start)) return;
     if (!b->early.eof) scout_ask(b, next_start + b->early.pos, b->ccap);
     if (b->early.nblk < 256 || NX_RESERVE + b->early.utotal > b->ncap) return;      /* (a window the buffers must grow for: the ordinary way) */
-    size_t n_dev = (size_t)(b->gpu_share * (double)b->early.nblk);
+    size_t n_dev = b->gpu_wanted == 2 ? b->early.nblk : (size_t)(b->gpu_share * (double)b->early.nblk);
     if (n_dev > b->early.nblk) n_dev = b->early.nblk;
     if (!n_dev) return;
     int h, p;
@@ -911,7 +911,7 @@ static int fill_next(fastf_bam_t *b)
         }
         const double t_host = now_s() - t_sub;
         /* two windows in flight: the NEXT window's device share is queued now, before this one's is waited for */
-        if (keep && b->gpu_wanted == 1 && b->map && !b->file_eof) early_queue_next(b, b->map_pos + pos, keep_handle, keep_parity);
+        if (keep && b->gpu_wanted && b->map && !b->file_eof) early_queue_next(b, b->map_pos + pos, keep_handle, keep_parity);
         const double t_wait0 = now_s();
         if (n_dev) {
             double dev_ms = 0;

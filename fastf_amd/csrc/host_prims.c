@@ -191,7 +191,7 @@ uint32_t fastf_pack_umi_long(const char *ub, size_t len, uint32_t *umi_out, uint
 {
     uint32_t meta = FASTF_META_HAS_UB;
     *umi_out = 0; *ext_out = 0;
-    if (len > 28) return meta | FASTF_META_UMI_TOOLONG;      /* (7 blob bytes: what the 3-bit length field holds) */
+    if (len > 32) return meta | FASTF_META_UMI_TOOLONG;      /* (8 blob bytes: two 32-bit words of bases) */
     uint64_t packed = 0; uint32_t bad = 0;
     for (size_t i = 0; i < len; i++) {
         const uint32_t code = k_base_code[(unsigned char)ub[i]];

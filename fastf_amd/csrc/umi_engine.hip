@@ -199,6 +199,10 @@ struct fastf_engine {
     // keys wider than 64 bits (cell bits + feature bits + UMI field > 64): the sort key is the GROUP (cell << feat_bits |
     // feature, group_bits wide), the rest of the key (NULL flag, UMI, length: feat_shift bits) travels beside it as a value
     bool wide = false, long_umi = false; u32 group_bits = 0;
+    // umi_max_bases > 24: the rest of the key is more than the 52 bits reduce_hashed_kernel<true, true> holds exactly — its top
+    // sub_bits (the UMI's first bases, umi_kernels.hpp make_val_sub) sit in the sorted word below the feature (group_bits counts
+    // them), K3 emits a row per (cell, feature, sub-group) split into two 32-bit halves at row_split, merge_sub_rows sums them
+    u32 sub_bits = 0, row_split = 0;
     DevBuf d_vals, d_vtmp;
     // timing
     bool timing = false;
@@ -456,7 +460,7 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     lap("device count");
     if (he != hipSuccess || ndev == 0)
         return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
-    if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 24) return set_err("umi_max_bases must be 1..24");
+    if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 32) return set_err("umi_max_bases must be 1..32");
     {   // keys wider than 64 bits run on the single-device engine (the group word is sorted, the rest rides along)
         const u32 tb = bits_for(cfg->n_cells) + bits_for(cfg->n_features) + 1 + 2 * cfg->umi_max_bases + bits_for((cfg->umi_max_bases + 3) / 4);
         if ((tb > 64 || cfg->umi_max_bases > 16) && (cfg->n_devices > 1 || cfg->n_shards > 1))
@@ -484,12 +488,20 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     e->L.umi_bits = 2 * cfg->umi_max_bases;
     e->L.umi_max_bytes = (cfg->umi_max_bases + 3) / 4;
     e->L.len_bits = bits_for(e->L.umi_max_bytes);
+    if (cfg->umi_max_bases > 24) {                       // 25..32 bases: one layout, the value = flag | low 51 bits of [bases: 64][blob bytes: 4]
+        e->sub_bits = WIDE_SUB_BITS; e->L.umi_max_bytes = 8; e->L.len_bits = WIDE_SUB_LEN_BITS; e->L.umi_bits = WIDE_SUB_VAL_BITS - WIDE_SUB_LEN_BITS;
+    }
     e->L.feat_shift = 1 + e->L.umi_bits + e->L.len_bits;
     e->L.cell_shift = e->L.feat_shift + e->feat_bits;
     e->L.total_bits = e->L.cell_shift + e->cell_bits;
     e->wide = e->L.total_bits > 64 || cfg->umi_max_bases > 16 || getenv("FASTF_FORCE_WIDE_KEYS") != nullptr;
     e->long_umi = cfg->umi_max_bases > 16;               // batches carry bases 17.. in fastf_batch_t.umi_ext
-    e->group_bits = e->cell_bits + e->feat_bits;
+    e->group_bits = e->cell_bits + e->feat_bits + e->sub_bits;
+    e->row_split = e->sub_bits ? std::min<u32>(32u, e->feat_bits + e->sub_bits) : e->feat_bits;
+    if (e->group_bits > 64) {
+        const u32 gb = e->group_bits; delete e;
+        return set_err("umi_max_bases > 24 with %u bits of (cell, feature): the sorted word would need %u bits (> 64)", gb - WIDE_SUB_BITS, gb);
+    }
     e->threshold = cfg->draw_threshold;
     {   // Matrix path: only (cell, feature) is sorted — every bit below feat_shift may stay unsorted, K3 (reduce_hashed_kernel)
         // finds the distinct UMIs of a group through its window set.  The digit grid is anchored at the TOP of the key, so
@@ -944,7 +956,7 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.blk = (const unsigned char*)blk;
     if (e->wide) {                                      // wide keys: group word into keys[], the rest into d_vals[] (tile form, one shard)
         if (segmented || blk || e->n_shards != 1 || keys != (u64*)e->d_keys.p) return set_err("internal error: wide keys go through the engine's own key store");
-        p.vals = (u64*)e->d_vals.p; p.wide_feat_bits = e->feat_bits;
+        p.vals = (u64*)e->d_vals.p; p.wide_feat_bits = e->feat_bits; p.wide_sub_bits = e->sub_bits;
         p.umi_ext = e->cur_umi_ext;
     }
     // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
@@ -1216,7 +1228,7 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     const u32 parity = dedup == 2 ? (e->giant_parity ^= 1u) : 0u;
     u32* const giant_n = giant_cnt ? giant_cnt + parity : nullptr;
     ReduceParams p{};
-    p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << e->feat_bits) - 1);
+    p.keys = sorted; p.n_ptr = d_n; p.L = e->L; p.feat_mask = (u32)((1ull << (wide_vals ? e->row_split : e->feat_bits)) - 1);
     p.err = (u64*)e->d_small.p + SM_COUNTERS + 3;
     p.feature = (u32*)e->d_rg_feature.p; p.cell = (u32*)e->d_rg_cell.p; p.count = (u32*)e->d_rg_count.p; p.ukeys = (u64*)e->d_rg_ukeys.p;
     p.span_rows = (u32*)e->d_spanrows.p;
@@ -1224,7 +1236,7 @@ static int launch_reduce_regions(fastf_engine* e, const u64* sorted, const u64* 
     // groups beyond giant_max send the caller to the full sort; wide keys have no full-sort path, and giant_groups_kernel takes
     // any length (one work item per ~1536 keys, GIANT_LIST_CAP items per launch): 4 M reads of one gene in one cell
     p.giant_max = wide_vals ? (1u << 22) : GIANT_MAX;
-    p.vals = wide_vals; p.wide_feat_bits = e->feat_bits;
+    p.vals = wide_vals; p.wide_feat_bits = e->row_split;       // (the rows' two halves: (cell, feature) but for engines with sub-groups)
     t_begin(e, s);
     if (UMI_ROWS) hipLaunchKernelGGL((reduce_windows_kernel<true>), dim3(G), dim3(K3_THREADS), 0, s, p);
     else if (dedup == 0) hipLaunchKernelGGL((reduce_windows_kernel<false>), dim3(G), dim3(K3_THREADS), 0, s, p);
@@ -1330,7 +1342,7 @@ static const char* err_bits_text(u64 bits) {
     snprintf(buf, sizeof buf, "device error bits 0x%llx:%s%s%s%s%s", (unsigned long long)bits,
              (bits & 1) ? " (unknown bit 0);" : "",
              (bits & ERR_DRAWS_SHORT) ? " draw stream shorter than CB hits;" : "",
-             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it: up to 24, with fastf_batch_t.umi_ext from 17 on);" : "",
+             (bits & ERR_UMI_TOOLONG) ? " UMI longer than umi_max_bases (raise it: up to 32, with fastf_batch_t.umi_ext from 17 on);" : "",
              (bits & ERR_KEYS_FULL) ? " key store full;" : "",
              (bits & ERR_RUN_TOO_LONG) ? " unsorted run longer than the group-only path handles: sort fully (drop FASTF_SORT_SKIP_LOW);" : "");
     return buf;
@@ -1763,6 +1775,22 @@ extern "C" int fastf_pinned_register(void* p, size_t bytes) FASTF_TRY {
 } FASTF_CATCH_INT
 extern "C" void fastf_pinned_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
 
+// Engines with sub-groups (umi_max_bases > 24): K3's rows are one per (cell, feature, first bases of the UMI), the sorted word split
+// into two halves at row_split, ascending.  One row per (cell, feature), the counts summed: UMIs of different sub-groups differ.
+static u64 merge_sub_rows(fastf_engine* e, u64 nnz) {
+    u32 *h_f = e->rows_at, *h_c = e->rows_at + e->rows_stride, *h_k = e->rows_at + 2 * e->rows_stride;
+    const u32 fmask = (u32)((1ull << e->feat_bits) - 1);
+    u64 out = 0, prev = ~0ull;
+    for (u64 i = 0; i < nnz; ++i) {
+        const u64 g = ((((u64)h_c[i]) << e->row_split) | h_f[i]) >> e->sub_bits;          // cell << feat_bits | feature
+        if (g == prev) { h_k[out - 1] += h_k[i]; continue; }
+        prev = g;
+        h_f[out] = (u32)g & fmask; h_c[out] = (u32)(g >> e->feat_bits); h_k[out] = h_k[i];
+        ++out;
+    }
+    return out;
+}
+
 extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) FASTF_TRY {
     if (!e || !coo) return set_err("null argument");
     if (e->multi) return multi_finish(e, coo, counters);
@@ -1873,7 +1901,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             HIP_OK(hipStreamSynchronize(s));
         }
         lap("rows on the host");
-        e->h_nnz = nnz;
+        e->h_nnz = e->sub_bits ? merge_sub_rows(e, nnz) : nnz;
         e->n_sorted = n;
         e->finished = true;
     }
@@ -1940,6 +1968,14 @@ static int umi_rows_wide(fastf_engine* e, fastf_umi_rows_t* rows) {
     const u32 fmask = (u32)((1ull << e->feat_bits) - 1);
     const u64 umask = e->L.umi_bits >= 64 ? ~0ull : ((1ull << e->L.umi_bits) - 1);
     for (u64 i = 0; i < nrows; ++i) {
+        if (e->sub_bits) {           // (cell, feature, the UMI's first bases) in the sorted word: rows in blob order as they are
+            e->h_ufeature[i] = (u32)(uk[i] >> e->sub_bits) & fmask;
+            e->h_ucell[i] = (u32)(uk[i] >> (e->feat_bits + e->sub_bits));
+            e->h_unonnull[i] = (uint8_t)((uv[i] >> WIDE_SUB_VAL_BITS) & 1);
+            const u64 bases = ((uk[i] & ((1ull << e->sub_bits) - 1)) << (WIDE_SUB_VAL_BITS - WIDE_SUB_LEN_BITS)) | ((uv[i] & ((1ull << WIDE_SUB_VAL_BITS) - 1)) >> WIDE_SUB_LEN_BITS);
+            e->h_uumi[i] = (u32)(bases >> 32);
+            continue;
+        }
         e->h_ufeature[i] = (u32)uk[i] & fmask;
         e->h_ucell[i] = (u32)(uk[i] >> e->feat_bits);
         e->h_unonnull[i] = (uint8_t)((uv[i] >> (e->L.umi_bits + e->L.len_bits)) & 1);

@@ -53,7 +53,7 @@ constexpr u64 ERR_RUN_TOO_LONG = 16;       // group-only sort: a (cell, feature)
 
 // meta bits (mirror of fastf_amd.h)
 constexpr u32 META_XF_OK = 1, META_HAS_UB = 2, META_UMI_NONNULL = 4, META_UMI_TOOLONG = 8;
-constexpr u32 META_LEN_SHIFT = 4, META_LEN_MASK = 0x70;
+constexpr u32 META_LEN_SHIFT = 4, META_LEN_MASK = 0xF0;
 
 // ------------------------------------------------------------------------------------
 // small helpers
@@ -354,6 +354,21 @@ __device__ __forceinline__ u64 make_val64(const KeyLayout L, u64 umi, u32 meta) 
     if (!(meta & META_UMI_NONNULL)) return 0;
     const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
     return (1ULL << (L.umi_bits + L.len_bits)) | ((umi >> (64 - L.umi_bits)) << L.len_bits) | len;
+}
+// UMIs of up to 32 bases (engines with umi_max_bases > 24).  The rest of the key, [bases: 64 bits][blob bytes: 4 bits] under the
+// non-NULL flag, is 69 bits and the reduce holds 52 exactly: the low 51 under the flag are the value, the top WIDE_SUB_BITS (the
+// first bases) go into the sorted word below the feature — keys that differ there are different UMIs whatever the rest, so the
+// distinct count of a (cell, feature) is the sum over its sub-groups (summed on the host: umi_engine.hip merge_sub_rows)
+constexpr u32 WIDE_SUB_BITS = 17, WIDE_SUB_VAL_BITS = 51, WIDE_SUB_LEN_BITS = 4;
+__device__ __forceinline__ u64 make_val_sub(u64 umi, u32 meta, u32* sub) {
+    *sub = 0;
+    if (!(meta & META_UMI_NONNULL)) return 0;
+    const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
+    *sub = (u32)(umi >> (WIDE_SUB_VAL_BITS - WIDE_SUB_LEN_BITS));
+    return (1ULL << WIDE_SUB_VAL_BITS) | (((umi << WIDE_SUB_LEN_BITS) | len) & ((1ULL << WIDE_SUB_VAL_BITS) - 1));
+}
+__device__ __forceinline__ bool umi_overflows_sub(u32 meta) {
+    return (meta & META_UMI_TOOLONG) || ((meta & META_UMI_NONNULL) && ((meta & META_LEN_MASK) >> META_LEN_SHIFT) > 8u);
 }
 __device__ __forceinline__ bool umi_overflows64(const KeyLayout L, u64 umi, u32 meta) {
     if (meta & META_UMI_TOOLONG) return true;
@@ -776,6 +791,7 @@ struct PackParams {
     // keys wider than 64 bits (tile form, one shard): keys[] takes the GROUP (cell << wide_feat_bits | feature) and vals[]
     // the rest of the key — NULL flag, UMI, length, laid out as the low feat_shift bits of a narrow key; vals == nullptr: narrow
     u64* vals; u32 wide_feat_bits;
+    u32 wide_sub_bits;             // 0, or WIDE_SUB_BITS (umi_max_bases > 24): keys[] = (group << wide_sub_bits) | the UMI's first bases (make_val_sub)
     const u32* umi_ext;            // wide keys, umi_max_bases > 16: bases 17.. of every UMI (nullptr: none)
     u64* key_counts;               // [n_shards], appended
     u64* counters;                 // {hits, sampled, valid, err}
@@ -927,12 +943,14 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
             const u64 idx = base + (u64)j * K1B_THREADS + tid;
             umi_w = ((u64)umi[j] << 32) | ((p.umi_ext && alive && idx < p.n) ? p.umi_ext[idx] : 0u);
         }
-        if (alive && (p.vals ? umi_overflows64(p.L, umi_w, meta[j]) : umi_overflows(p.L, umi[j], meta[j]))) errs |= (u32)ERR_UMI_TOOLONG;
+        if (alive && (p.vals ? (p.wide_sub_bits ? umi_overflows_sub(meta[j]) : umi_overflows64(p.L, umi_w, meta[j])) : umi_overflows(p.L, umi[j], meta[j])))
+            errs |= (u32)ERR_UMI_TOOLONG;
         if (alive) {
             n_valid++;                                               // E12 :435
             // (wide keys: the low part only here — cell and feature go into the group word at the store below)
-            key[j] = p.vals ? make_val64(p.L, umi_w, meta[j]) : make_key(p.L, cell[j], feat[j], umi[j], meta[j]);
             shard[j] = p.n_shards > 1 ? shard_of(cell[j], p.n_shards) : 0;
+            if (p.vals && p.wide_sub_bits) key[j] = make_val_sub(umi_w, meta[j], &shard[j]);      // (one shard: shard[] carries the sub-group)
+            else key[j] = p.vals ? make_val64(p.L, umi_w, meta[j]) : make_key(p.L, cell[j], feat[j], umi[j], meta[j]);
         }
         emit[j] = alive;
         // order inside a shard list is irrelevant: the keys are sorted next
@@ -973,11 +991,11 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
 #pragma unroll
     for (int j = 0; j < K1B_IPT; ++j) {
         if (emit[j]) {
-            const u64 b = s_shard_base[shard[j]];
+            const u64 b = s_shard_base[p.vals ? 0u : shard[j]];
             if (b != ~0ULL) {
                 if (p.vals) {                                            // wide key: group and rest side by side
                     p.vals[b + pos[j]] = key[j];
-                    p.keys[b + pos[j]] = ((u64)cell[j] << p.wide_feat_bits) | feat[j];
+                    p.keys[b + pos[j]] = ((((u64)cell[j] << p.wide_feat_bits) | feat[j]) << p.wide_sub_bits) | (p.wide_sub_bits ? shard[j] : 0u);
                 } else p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];
             }
         }

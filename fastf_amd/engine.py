@@ -86,7 +86,7 @@ class Lists:
 
 
 def pack_records(lists: Lists, flags, xf, cb, gx, ub, long_umis=False):
-    """String-level records → packed SoA via the product's own packer (host_io.c).  long_umis: UMIs of up to 28 bases, a
+    """String-level records → packed SoA via the product's own packer (host_io.c).  long_umis: UMIs of up to 32 bases, a
     fifth array (bases 17..) is returned behind the four"""
     L = _lib.lib()
     if long_umis:

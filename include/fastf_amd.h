@@ -105,16 +105,16 @@ int fastf_sample_cells(size_t n_cells, float rate_cell, unsigned int seed,
 /* 2-bit UMI codec — bam2db_ds.c:5-51 (+ size rule :419).  Packs up to 16 bases
  * MSB-first into a left-aligned u32.  Returns meta bits (FASTF_META_*). */
 uint32_t fastf_pack_umi(const char *ub, size_t len, uint32_t *umi_out);
-/* The same for UMIs of up to 28 bases: bases 1..16 into *umi_out, bases 17..28 left-aligned into *ext_out (the reference
- * encodes a UMI of any length, bam2db_ds.c:417-419; an engine created with umi_max_bases 17..24 takes these) */
+/* The same for UMIs of up to 32 bases: bases 1..16 into *umi_out, bases 17..32 left-aligned into *ext_out (the reference
+ * encodes a UMI of any length, bam2db_ds.c:417-419; an engine created with umi_max_bases 17..32 takes these) */
 uint32_t fastf_pack_umi_long(const char *ub, size_t len, uint32_t *umi_out, uint32_t *ext_out);
 
 #define FASTF_META_XF_OK      0x01u   /* xf present and in {25,17}   (bam2db_ds.c:397)  */
 #define FASTF_META_HAS_UB     0x02u   /* UB tag present              (bam2db_ds.c:412)  */
 #define FASTF_META_UMI_NONNULL 0x04u  /* every base in ACGT          (bam2db_ds.c:36-41)*/
-#define FASTF_META_UMI_TOOLONG 0x08u  /* > 16 bases (fastf_pack_umi) / > 28 (_long): not representable, the engine errors */
-#define FASTF_META_LEN_SHIFT  4       /* bits 4..6: blob byte length (len+3)/4, 0..7     */
-#define FASTF_META_LEN_MASK   0x70u
+#define FASTF_META_UMI_TOOLONG 0x08u  /* > 16 bases (fastf_pack_umi) / > 32 (_long): not representable, the engine errors */
+#define FASTF_META_LEN_SHIFT  4       /* bits 4..7: blob byte length (len+3)/4, 0..8     */
+#define FASTF_META_LEN_MASK   0xF0u
 
 /* Exact string → 64-bit key packer.  Two strings get the same key iff they are
  * equal (for every string registered with _add and every string later passed to
@@ -145,10 +145,13 @@ typedef struct fastf_engine_config {
     const uint64_t *feature_keys;  /* key of feature_index i+1                             */
     uint32_t        n_features;
     uint64_t        draw_threshold;/* fastf_draw_threshold(rate_depth), 0..2^32            */
-    uint32_t        umi_max_bases; /* 1..24; widths of the packed sort key follow from it.  A key of more than 64 bits (many
+    uint32_t        umi_max_bases; /* 1..32; widths of the packed sort key follow from it.  A key of more than 64 bits (many
                                       barcodes x many features x long UMIs; always from 17 bases on, which also need
                                       fastf_batch_t.umi_ext) runs on the single-device engine: it sorts the (cell, feature)
-                                      word and carries the rest of the key beside it */
+                                      word and carries the rest of the key beside it.  From 25 bases on the rest of the key
+                                      is itself more than the 52 bits the reduce holds exactly: its top 17 bits (the UMI's
+                                      first bases) join the sorted word, the matrix rows of one (cell, feature) are summed
+                                      on the host */
     uint32_t        mt_seed;       /* engine-owned draw stream: init_genrand(seed) …       */
     uint64_t        mt_skip;       /* … advanced by the draws SampleInt consumed           */
     uint32_t        n_shards;      /* cell-hash shards (1 = single GPU)                    */
@@ -174,7 +177,7 @@ typedef struct fastf_batch {
     const uint32_t *umi;      /* fastf_pack_umi()                             */
     const uint32_t *meta;     /* FASTF_META_*                                 */
     size_t          n;
-    const uint32_t *umi_ext;  /* NULL, or bases 17..28 of every UMI (fastf_pack_umi_long) for an engine with umi_max_bases > 16 */
+    const uint32_t *umi_ext;  /* NULL, or bases 17..32 of every UMI (fastf_pack_umi_long) for an engine with umi_max_bases > 16 */
 } fastf_batch_t;
 
 typedef struct fastf_coo {

@@ -92,10 +92,11 @@ def test_cli_runs_again_when_the_umis_are_longer_than_the_64_bit_key_holds(tmp_p
     assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
 
 
-def test_cli_with_20_base_umis(tmp_path):
-    """small lists (16-base UMIs fit the 64-bit key: the first run), 20-base UMIs in the file: bam2db() runs again with room
-    for 24 bases; matrix and -u rows are the oracle's (decode_DNA(..., 10) prints the first ten bases, bam2db_ds.c:629)"""
-    case = Case(n=60_000, n_bar=400, n_gene=150, rate_cell=0.8, rate_depth=0.7, umi_len=20, umi_pool=512, p_n_umi=0.02, p_bad_xf=0.1, data_seed=35)
+@pytest.mark.parametrize("umi_len", [20, 30])
+def test_cli_with_20_and_30_base_umis(tmp_path, umi_len):
+    """small lists (16-base UMIs fit the 64-bit key: the first run), 20- or 30-base UMIs in the file: bam2db() runs again with room
+    for 32 bases; matrix and -u rows are the oracle's (decode_DNA(..., 10) prints the first ten bases, bam2db_ds.c:629)"""
+    case = Case(n=60_000, n_bar=400, n_gene=150, rate_cell=0.8, rate_depth=0.7, umi_len=umi_len, umi_pool=512, p_n_umi=0.02, p_bad_xf=0.1, data_seed=35)
     bam, b, f = _write_inputs(tmp_path, case)
     out = tmp_path / "out"; out.mkdir()
     case.label = str(bam).encode()
@@ -103,7 +104,7 @@ def test_cli_with_20_base_umis(tmp_path):
     r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out), "-c", "0.8", "-r", "0.7", "-u"],
                        capture_output=True, text=True, env=dict(os.environ, FASTF_BATCH_RECORDS="25000"))
     assert r.returncode == 0, r.stderr
-    assert "room for 24" in r.stderr
+    assert "room for 32" in r.stderr
     assert _read_gz(out / "matrix.mtx.gz") == ora["matrix"]
     assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
 

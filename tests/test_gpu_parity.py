@@ -372,7 +372,8 @@ def test_umis_of_17_to_24_bases_match_oracle(umi_len, kw):
 def test_mixed_umi_lengths_0_to_28_with_room_for_24():
     """lengths 0..28 in one run against an engine with room for 24 bases: the blob byte length and the zero padding decide
     equality (ACGT x 5 and ACGT x 5 + A: 5 and 6 bytes, different blobs; 21 and 24 bases of the same prefix padded with A: the
-    same 6-byte blob); 25..28 bases (7 bytes) do not fit and must raise the error bit, not a wrong count"""
+    same 6-byte blob); 25..28 bases (7 bytes) do not fit THIS engine and must raise the error bit, not a wrong count (an engine
+    with room for 32 takes them: test_mixed_umi_lengths_0_to_32)"""
     from fastf_amd import synth
     from oracle import oracle as O
     rng = np.random.default_rng(4)
@@ -392,9 +393,51 @@ def test_mixed_umi_lengths_0_to_28_with_room_for_24():
         res = eng.finish()
         assert_matches_oracle(res, ora)
         assert eng.format_umi_rows(eng.umi_rows()) == ora["umi"]
-        # a 25-base UMI (7 blob bytes) is beyond this engine: refused loudly
+        # a 25-base UMI (7 blob bytes) is beyond an engine created for 24: refused loudly
         eng.reset()
         ub2 = ub.copy(); ub2[0] = b"A" * 25
+        flags2 = flags.copy(); flags2[0] |= 1 | 2 | 4 | 8; xf2 = xf.copy(); xf2[0] = 25
+        cb2 = synth.as_cstr(cb).copy(); cb2[0] = bar[0]; gx2 = synth.as_cstr(gx).copy(); gx2[0] = genes[0]
+        c, g, u, m, e = F.pack_records(lists, flags2, xf2, cb2, gx2, synth.as_cstr(ub2), long_umis=True)
+        eng.push(c, g, u, m, umi_ext=e)
+        with pytest.raises(F.FastfError) as ei:
+            eng.finish()
+        assert "umi_max_bases" in str(ei.value)
+    finally:
+        eng.close()
+
+
+def test_mixed_umi_lengths_0_to_32():
+    """the reference binds a UMI of any length (bam2db_ds.c:417-419); an engine with room for 32 bases takes every blob of up to 8
+    bytes exactly: 28 bases and the same 28 + "A" are 7- and 8-byte blobs (different), 29 and 32 bases of one prefix padded with A
+    the same 8-byte blob, 32 x A the all-zero 8-byte blob (counted: it is not NULL), UMIs that share their first 8 bases (one
+    sub-group of the sorted word) and UMIs that differ there (several matrix rows on the device, summed on the host); N anywhere:
+    NULL; 33 bases: refused loudly"""
+    from fastf_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(14)
+    n = 60_000
+    bt, ft, bar, genes = synth.make_lists(40, 30, seed=5)
+    flags, xf, cb, gx, _ = synth.make_records(n, bar, genes, seed=6)
+    p28 = b"ACGTTGCAACGTTGCAGGATCCTTAGGA"
+    pool = [b"", b"ACGT", b"ACGTACGTACGTACGT", b"ACGTACGTACGTACGTA", b"ACGTACGTACGTACGTACGTAAAA", p28, p28 + b"A", p28 + b"AAAA", p28 + b"C", p28 + b"CAAA",
+            p28 + b"CAAT", b"A" * 32, b"A" * 31, b"A" * 28, b"A" * 25, b"T" * 32, b"T" * 31 + b"N", b"T" * 29, b"N" + b"C" * 30,
+            b"ACGTTGCAGGGGGGGGGGGGGGGGGGGGGGGGG"[:32], b"ACGTTGCATTTTTTTTTTTTTTTTTTTTTTTTT"[:32], b"ACGTTGCA" + b"C" * 17, b"GCGTTGCA" + b"C" * 17, b"GCGTTGCA" + b"C" * 18]
+    pool += [bytes(rng.choice(list(b"ACGT"), size=int(l))) for l in rng.integers(25, 33, size=200)]
+    ub = np.array([pool[i] for i in rng.integers(0, len(pool), size=n)], dtype="S40")
+    lists = F.Lists(bt, ft, 1.0, 926)
+    ora = O.run_bam2db(bt, ft, flags, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub), 1.0, 1.0, 926, b"x.bam", True)
+    eng = F.Engine.from_lists(lists, umi_max_bases=32)
+    try:
+        c, g, u, m, e = F.pack_records(lists, flags, xf, synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub), long_umis=True)
+        for a in range(0, n, 25_000):                            # several pushes: the sub-groups of one (cell, feature) meet in the sort
+            eng.push(c[a:a + 25_000], g[a:a + 25_000], u[a:a + 25_000], m[a:a + 25_000], umi_ext=e[a:a + 25_000])
+        res = eng.finish()
+        assert_matches_oracle(res, ora)
+        assert eng.format_umi_rows(eng.umi_rows()) == ora["umi"]
+        # 33 bases (9 blob bytes) are beyond what a batch carries: refused loudly
+        eng.reset()
+        ub2 = ub.copy(); ub2[0] = b"A" * 33
         flags2 = flags.copy(); flags2[0] |= 1 | 2 | 4 | 8; xf2 = xf.copy(); xf2[0] = 25
         cb2 = synth.as_cstr(cb).copy(); cb2[0] = bar[0]; gx2 = synth.as_cstr(gx).copy(); gx2[0] = genes[0]
         c, g, u, m, e = F.pack_records(lists, flags2, xf2, cb2, gx2, synth.as_cstr(ub2), long_umis=True)

@@ -189,7 +189,7 @@ def test_cli_with_device_parse_equals_oracle_bytes(tmp_path, umicopies):
 def test_cli_with_two_windows_in_flight_equals_oracle_bytes(tmp_path):
     """FASTF_BAM_EARLY=1 (host_io.c: early_queue_next): the next window's device share is queued on a second context while this
     window's is still running.  Same bytes as the oracle, and the trace says windows really were queued a window ahead."""
-    case = Case(n=600_000, n_bar=800, n_gene=300, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=3.0,
+    case = Case(n=1_200_000, n_bar=800, n_gene=300, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=3.0,
                 p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.005)
     bam = tmp_path / "in.bam"
     synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub, shape=lambda i: (91, 1, 0, i * 37 % 900))
@@ -198,7 +198,7 @@ def test_cli_with_two_windows_in_flight_equals_oracle_bytes(tmp_path):
     out = tmp_path / "out"; out.mkdir()
     case.label = str(bam).encode()
     ora = case.oracle()
-    env = dict(os.environ, FASTF_GPU_INFLATE="2", FASTF_BAM_EARLY="1", FASTF_BAM_WINDOW=str(6 << 20), FASTF_BATCH_RECORDS="50000",
+    env = dict(os.environ, FASTF_GPU_INFLATE="2", FASTF_BAM_EARLY="1", FASTF_BAM_WINDOW=str(2 << 20), FASTF_BATCH_RECORDS="50000",
                FASTF_BAM_PROFILE="2")
     r = subprocess.run([_lib.cli_path(), "bam2db", "-b", str(bam), "-a", str(b), "-f", str(f), "-o", str(out),
                         "-c", "0.5", "-r", "0.5", "-u"], capture_output=True, text=True, env=env)

@@ -177,9 +177,9 @@ class _FakeEngine:
     _L = _lib.lib()
 
 
-def test_pack_umi_long_matches_the_codec_up_to_28_bases():
-    """fastf_pack_umi_long: bases 1..16 in the first word, 17..28 left-aligned in the second — together the zero-padded
-    2-bit blob of encode_DNA (bam2db_ds.c:22-51) for lengths up to 28; N anywhere makes it NULL; 29 bases: too long"""
+def test_pack_umi_long_matches_the_codec_up_to_32_bases():
+    """fastf_pack_umi_long: bases 1..16 in the first word, 17..32 left-aligned in the second — together the zero-padded
+    2-bit blob of encode_DNA (bam2db_ds.c:22-51) for lengths up to 32; N anywhere makes it NULL; 33 bases: too long"""
     import ctypes as C
     from fastf_amd import _lib
     L = _lib.lib()
@@ -187,7 +187,7 @@ def test_pack_umi_long_matches_the_codec_up_to_28_bases():
     L.fastf_pack_umi_long.restype = C.c_uint32
     rng = np.random.default_rng(8)
     code = {"A": 0, "C": 1, "G": 2, "T": 3}
-    for ln in list(range(0, 29)) * 4:
+    for ln in list(range(0, 33)) * 4:
         sq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=ln))
         u, e = C.c_uint32(), C.c_uint32()
         m = L.fastf_pack_umi_long(sq.encode(), ln, C.byref(u), C.byref(e))
@@ -196,13 +196,13 @@ def test_pack_umi_long_matches_the_codec_up_to_28_bases():
             want = (want << 2) | code[ch]
         want <<= 64 - 2 * ln if ln else 0
         assert (u.value << 32 | e.value) == want and (m & 2) and (m & 4) and not (m & 8)
-        assert (m >> 4) & 7 == (ln + 3) // 4
+        assert (m >> 4) & 15 == (ln + 3) // 4
         if ln <= 16:                                          # the short packer agrees on what it can hold
             u2 = C.c_uint32()
             assert L.fastf_pack_umi(sq.encode(), ln, C.byref(u2)) == m and u2.value == u.value and e.value == 0
     u, e = C.c_uint32(), C.c_uint32()
     assert L.fastf_pack_umi_long(b"ACGTNACGTACGTACGTACG", 20, C.byref(u), C.byref(e)) & 4 == 0 and (u.value, e.value) == (0, 0)
-    assert L.fastf_pack_umi_long(b"A" * 29, 29, C.byref(u), C.byref(e)) & 8
+    assert L.fastf_pack_umi_long(b"A" * 33, 33, C.byref(u), C.byref(e)) & 8
 
 
 def test_mt_jump_polynomials_are_the_generator_advanced():
