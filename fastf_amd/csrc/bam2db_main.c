@@ -414,8 +414,8 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file, c
 {
     (void)db_file;                      /* no SQLite in this engine */
     /* the reference takes a UMI of any length (bam2db_ds.c:417-419).  The first run assumes what keeps the key within 64 bits
-     * where it can (12 or 16 bases); a file with longer UMIs is run again with room for 16, then 24 bases — keys wider than 64
-     * bits, and from 17 bases on a fifth array beside the packed records.  Beyond 24 bases: an error. */
+     * where it can (12 or 16 bases); a file with longer UMIs is run again with room for 16, then 32 bases — keys wider than 64
+     * bits, and from 17 bases on a fifth array beside the packed records.  Beyond 32 bases: an error. */
     int longer_umis = 0;
     int rc = bam2db_run(bam_file, path_out, barcodes_file, features_file, rate_cell, rate_depth, seed, 0, &longer_umis);
     while (longer_umis) {

@@ -216,7 +216,7 @@ typedef struct { size_t coff; uint32_t clen, isize; size_t uoff; } bgzf_blk;
 struct fastf_bam {
     FILE *fp;
     int n_threads;
-    uint32_t *umi_ext;                           /* fastf_bam_set_umi_ext: where bases 17..28 of the next batch's UMIs go (NULL: UMIs of at most 16 bases) */
+    uint32_t *umi_ext;                           /* fastf_bam_set_umi_ext: where bases 17..32 of the next batch's UMIs go (NULL: UMIs of at most 16 bases) */
     int file_eof;
     unsigned char *cbuf; size_t ccap, clen;      /* compressed window (whole blocks + a partial tail) */
     unsigned char *map; size_t map_len, map_pos; unsigned char *cbuf_own;   /* the file mapped read-only: windows are views, nothing is copied */
@@ -1309,7 +1309,7 @@ static int64_t aux_int(const unsigned char *p)
 }
 
 /* one record's aux block → packed fields; first occurrence of a tag wins (bam_aux_get) */
-/* ext: NULL, or where bases 17..28 of the UMI go (readers of engines with umi_max_bases > 16: fastf_bam_set_umi_ext) */
+/* ext: NULL, or where bases 17..32 of the UMI go (readers of engines with umi_max_bases > 16: fastf_bam_set_umi_ext) */
 static void pack_record(const unsigned char *aux, const unsigned char *end,
                         const fastf_keydict_t *cells, const fastf_keydict_t *feats,
                         uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta,
@@ -1986,7 +1986,7 @@ void fastf_pack_records_ext(const fastf_keydict_t *cells, const fastf_keydict_t 
                             uint64_t *cb_key, uint64_t *gx_key, uint32_t *umi, uint32_t *meta, uint32_t *umi_ext)
 {
     fastf_pack_records(cells, feats, n, flags, xf, cb, cb_stride, gx, gx_stride, ub, ub_stride, cb_key, gx_key, umi, meta);
-    for (size_t i = 0; i < n; i++) {                              /* the UMIs again, with room for 28 bases */
+    for (size_t i = 0; i < n; i++) {                              /* the UMIs again, with room for 32 bases */
         umi_ext[i] = 0;
         if (flags[i] & 8) {
             const char *s = ub + i * ub_stride;

@@ -90,7 +90,7 @@ long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fa
 int  fastf_bam_enable_device_parse(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats);
 /* as fastf_bam_read_batch; a batch either fills the host arrays (*on_device = 0) or lies packed in device memory already
  * (*on_device = 1, dev: valid until the second next call) */
-/* the next fastf_bam_read_batch / _dev call packs UMIs of up to 28 bases: bases 1..16 into umi[i] as always, bases 17..28 into
+/* the next fastf_bam_read_batch / _dev call packs UMIs of up to 32 bases: bases 1..16 into umi[i] as always, bases 17..32 into
  * umi_ext[i] (same index).  NULL (the default): fastf_pack_umi, 16 bases at most.  Host-packed batches only. */
 void fastf_bam_set_umi_ext(fastf_bam_t *b, uint32_t *umi_ext);
 long fastf_bam_read_batch_dev(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,

@@ -2395,7 +2395,7 @@ __global__ __launch_bounds__(K3H_THREADS, WIDE ? 4 : (SLOT64 ? 6 : FASTF_K3H_MIN
                 const bool probe = dist && !single;
                 st |= (dist ? 1u : 0u) << j; st |= (probe ? 16u : 0u) << j;
                 if constexpr (WIDE) {
-                    const u64 x = k, hi = x >> 12;                         // x < 2^52 (UMIs of at most 24 bases)
+                    const u64 x = k, hi = x >> 12;                         // x < 2^52 (24 bases; longer UMIs: make_val_sub keeps 52 bits here)
                     const u32 f = (u32)hi * 0x9E3779B1u + (u32)(hi >> 32) * 0x85EBCA77u;
                     sl[j] = ((u32)x ^ (f >> 8) ^ __umul24(r, 0x9E5u)) & (TAB - 1);
                     stp[j] = ((f >> 20) & 62u) | 1u;
