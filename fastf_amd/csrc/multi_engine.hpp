@@ -20,6 +20,9 @@
 //            when devices alias — the one-GPU rehearsal — or FASTF_EXCHANGE=peer), then K2 + K3 locally on every
 //            device, rows back, and a merge of the G row lists by cell (each cell lives on exactly one device).
 // Nothing but the keys crosses devices; the three counters are added up on the host.
+// Keys wider than 64 bits: K1b (tile form) writes the group word and the rest of the key into two arrays per
+// destination, both cross in the same exchange and land in the RECEIVER's own wide key store — from there on the sub-engine
+// does what the single-device engine does (finish_queue on every device, then fastf_engine_finish / _umi_rows collect).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -40,7 +43,7 @@ struct MultiDev {
     u64* h_cnt[2] = {nullptr, nullptr};        // pinned snapshot of the sub-engine's d_small behind that slot's K1a
     int next_slot = 0;
     u64* h_info = nullptr;                     // pinned mirror of the sub-engine's d_small (finish)
-    DevBuf d_shard; u64 stride = 0;            // keys by destination: [G][stride]
+    DevBuf d_shard; u64 stride = 0;            // keys by destination: [G][stride] (wide keys: the values behind them, another [G][stride])
     std::vector<void*> old_shards;             // replaced while work was queued: freed when the streams are idle
     u64 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // keys per destination, exact as of the last read-back
     u64 keys_exact = 0, recs_since = 0;        // most keys in one destination as of the last snapshot; records counted since
@@ -70,6 +73,7 @@ struct fastf_multi {
     bool device_mt = false, mt_uploaded = false;                 // the stream continues on the devices (else: on the host, FASTF_HOST_DRAWS=1)
     u64 hits = 0, total_records = 0, c_sampled = 0, c_valid = 0;
     bool finished = false, aliased = false;
+    bool keycount_lent = false;                                  // wide keys: the sub-engines' key-count words hold what they received (multi_finish_wide)
     int use_rccl = 0; RcclApi rccl; std::vector<ncclComm_t> comms;
     std::vector<u32> feature, cell, count;                       // merged rows
     std::vector<u32> ufeature, ucell, uumi, ncopy; std::vector<uint8_t> unonnull;
@@ -103,6 +107,7 @@ static int multi_load_rccl(fastf_multi* m) {
 
 static void multi_free_old_shards(MultiDev& md);
 static int multi_retire_all(fastf_multi* m);
+static int multi_return_keycount(fastf_multi* m);
 static void multi_destroy(fastf_engine* e) {
     fastf_multi* m = e->multi;
     if (!m) return;
@@ -185,7 +190,10 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
         fastf_engine_config_t sub = *cfg;
         sub.n_devices = 0; sub.devices = nullptr;
         sub.n_shards = G; sub.shard_rank = g; sub.device = md.dev;
-        if (fastf_engine_create(&sub, &md.e)) return 1;
+        g_wide_shard_ok = true;
+        const int crc = fastf_engine_create(&sub, &md.e);
+        g_wide_shard_ok = false;
+        if (crc) return 1;
         HIP_OK(hipSetDevice(md.dev));
         HIP_OK(hipHostMalloc((void**)&md.h_info, SM_WORDS * sizeof(u64), hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) {
@@ -210,6 +218,7 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
     e->L = m->d[0].e->L; e->cell_bits = m->d[0].e->cell_bits; e->feat_bits = m->d[0].e->feat_bits;
     e->skip_bits = m->d[0].e->skip_bits; e->n_cells = cfg->n_cells; e->n_features = cfg->n_features;
     e->use_lds_cells = m->d[0].e->use_lds_cells; e->use_lds_genes = m->d[0].e->use_lds_genes; e->lds_genes = m->d[0].e->lds_genes;
+    e->wide = m->d[0].e->wide; e->long_umi = m->d[0].e->long_umi; e->sub_bits = m->d[0].e->sub_bits; e->group_bits = m->d[0].e->group_bits;
     return 0;
 }
 
@@ -219,14 +228,15 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
 static int multi_grow_shards(fastf_multi* m, MultiDev& md, u64 need) {
     if (need <= md.stride && md.d_shard.p) return 0;
     const u64 ns = std::max<u64>(need, std::max<u64>(md.stride * 2, 1u << 20));
+    const u32 rows = md.e->wide ? 2 * m->G : m->G;             // (wide keys: row G + h holds the values of row h)
     void* np = nullptr;
-    HIP_OK(hipMalloc(&np, (size_t)m->G * ns * sizeof(u64)));
+    HIP_OK(hipMalloc(&np, (size_t)rows * ns * sizeof(u64)));
     if (md.d_shard.p) {
-        for (u32 h = 0; h < m->G; ++h)
+        for (u32 h = 0; h < rows; ++h)
             HIP_OK(hipMemcpyAsync((u64*)np + (u64)h * ns, (u64*)md.d_shard.p + (u64)h * md.stride, md.stride * sizeof(u64), hipMemcpyDeviceToDevice, md.e->s_compute));
         md.old_shards.push_back(md.d_shard.p);
     }
-    md.d_shard.p = np; md.d_shard.bytes = (size_t)m->G * ns * sizeof(u64);
+    md.d_shard.p = np; md.d_shard.bytes = (size_t)rows * ns * sizeof(u64);
     md.stride = ns;
     return 0;
 }
@@ -242,7 +252,7 @@ static int multi_retire_chunk(fastf_multi* m) {
     MultiDev& md = m->d[c.dev];
     fastf_engine* se = md.e;
     const u64 cap = m->cap;
-    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_ext = cap * 24;
     HIP_OK(hipSetDevice(md.dev));
     HIP_OK(hipEventSynchronize(md.ev_cnt[c.slot]));
     const u64* snap = md.h_cnt[c.slot];
@@ -256,6 +266,9 @@ static int multi_retire_chunk(fastf_multi* m) {
     // exactly this chunk's draws, in stream order (the chunks are retired in stream order)
     u64* small = (u64*)se->d_small.p;
     char* ds = (char*)md.d_stage[c.slot].p;
+    // wide keys: the values of destination h behind the keys of all destinations; UMIs beyond 16 bases: the chunk's fifth array
+    u64* const wide_vals = se->wide ? (u64*)md.d_shard.p + (u64)m->G * md.stride : nullptr;
+    const u32* const wide_ext = se->long_umi ? (const u32*)(ds + o_ext) : nullptr;
     if (m->device_mt) {
         // every device moves the stream on by this chunk's hits (its own copy of the state, its own ring); the owner of the
         // chunk then runs K1b against its ring, hit ranks counted from the stream's start
@@ -282,7 +295,8 @@ static int multi_retire_chunk(fastf_multi* m) {
         HIP_OK(hipMemcpyAsync(small + SM_DRAWBASE, md.h_base[c.slot], sizeof(u64), hipMemcpyHostToDevice, se->s_compute));
         if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), c.n,
                          (const u32*)md.d_ring.p, base + hits, small + SM_DRAWBASE, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
-                         small + SM_COUNTERS, true, se->s_compute, md.ring_len ? md.ring_len - 1 : ~0ull))
+                         small + SM_COUNTERS, true, se->s_compute, md.ring_len ? md.ring_len - 1 : ~0ull, nullptr, false, nullptr, nullptr,
+                         wide_vals, wide_ext))
             return 1;
     } else {
     if (md.d_draws[c.slot].ensure(std::max<u64>(cap, 1) * 4)) return 1;
@@ -302,7 +316,7 @@ static int multi_retire_chunk(fastf_multi* m) {
     if (hits) HIP_OK(hipMemcpyAsync(md.d_draws[c.slot].p, md.h_draws[c.slot], ((hits + 31) / 32) * 4, hipMemcpyHostToDevice, se->s_compute));
     if (launch_probe(se, (const u64*)ds, (const u64*)(ds + o_gx), (const u32*)(ds + o_umi), (const u32*)(ds + o_meta), c.n,
                      (const u32*)md.d_draws[c.slot].p, hits, nullptr, (u64*)md.d_shard.p, md.stride, small + SM_KEYCOUNT,
-                     small + SM_COUNTERS, true, se->s_compute))
+                     small + SM_COUNTERS, true, se->s_compute, ~0ull, nullptr, false, nullptr, nullptr, wide_vals, wide_ext))
         return 1;
     }
     HIP_OK(hipEventRecord(md.ev_k1b[c.slot], se->s_compute));
@@ -316,7 +330,7 @@ static int multi_enqueue_chunk(fastf_multi* m, const fastf_batch_t* b, size_t of
     MultiDev& md = m->d[dev];
     fastf_engine* se = md.e;
     const u64 cap = m->cap;
-    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20;
+    const size_t o_gx = cap * 8, o_umi = cap * 16, o_meta = cap * 20, o_ext = cap * 24;
     // K1a of this chunk overwrites the device's K1 scratch (cell indices, tile bases): K1b of the chunk this device took
     // before must be queued first, i.e. that chunk — and, for the stream order of the draws, every older one — retired
     for (;;) {
@@ -332,11 +346,13 @@ static int multi_enqueue_chunk(fastf_multi* m, const fastf_batch_t* b, size_t of
     // the slot is refilled behind the K1b that read it (two chunks of this device ago)
     if (md.k1b_queued[slot]) HIP_OK(hipStreamWaitEvent(se->s_copy, md.ev_k1b[slot], 0));
     const void *s_cb = b->cb_key + off, *s_gx = b->gx_key + off, *s_umi = b->umi + off, *s_meta = b->meta + off;
+    const void *s_ext = (se->long_umi && b->umi_ext) ? b->umi_ext + off : nullptr;      // bases 17.. (engines with umi_max_bases > 16)
     if (!pinned) {
         if (!md.h_stage[slot]) HIP_OK(hipHostMalloc(&md.h_stage[slot], stage_bytes(cap), hipHostMallocDefault));
         else HIP_OK(hipEventSynchronize(md.ev_in[slot]));   // the copy that last read this staging buffer has left it
         char* hs = (char*)md.h_stage[slot];
         memcpy(hs, s_cb, n * 8); memcpy(hs + o_gx, s_gx, n * 8); memcpy(hs + o_umi, s_umi, n * 4); memcpy(hs + o_meta, s_meta, n * 4);
+        if (s_ext) { memcpy(hs + o_ext, s_ext, n * 4); s_ext = hs + o_ext; }
         s_cb = hs; s_gx = hs + o_gx; s_umi = hs + o_umi; s_meta = hs + o_meta;
     }
     char* ds = (char*)md.d_stage[slot].p;
@@ -346,6 +362,10 @@ static int multi_enqueue_chunk(fastf_multi* m, const fastf_batch_t* b, size_t of
     HIP_OK(hipMemcpyAsync(ds + o_gx, s_gx, n * 8, hipMemcpyDefault, se->s_copy));
     HIP_OK(hipMemcpyAsync(ds + o_umi, s_umi, n * 4, hipMemcpyDefault, se->s_copy));
     HIP_OK(hipMemcpyAsync(ds + o_meta, s_meta, n * 4, hipMemcpyDefault, se->s_copy));
+    if (se->long_umi) {
+        if (s_ext) HIP_OK(hipMemcpyAsync(ds + o_ext, s_ext, n * 4, hipMemcpyDefault, se->s_copy));
+        else HIP_OK(hipMemsetAsync(ds + o_ext, 0, n * 4, se->s_copy));                 // (a batch without the fifth array: no UMI beyond 16 bases)
+    }
     HIP_OK(hipEventRecord(md.ev_in[slot], se->s_copy));
     HIP_OK(hipStreamWaitEvent(se->s_compute, md.ev_in[slot], 0));
     u64* small = (u64*)se->d_small.p;
@@ -367,6 +387,7 @@ static int multi_retire_all(fastf_multi* m) {
 
 static int multi_push(fastf_engine* e, const fastf_batch_t* b, bool pinned) {
     fastf_multi* m = e->multi;
+    if (multi_return_keycount(m)) return 1;
     for (size_t off = 0; off < b->n;) {
         const size_t n = std::min<size_t>(b->n - off, m->cap);
         if (multi_enqueue_chunk(m, b, off, n, pinned)) return 1;
@@ -401,6 +422,7 @@ static void multi_merge_by_cell(u32 G, const std::vector<const u32*>& cell, cons
 
 static int multi_exchange(fastf_multi* m) {
     const u32 G = m->G;
+    const bool wide = m->d[0].e->wide;
     if (multi_retire_all(m)) return 1;
     // exact key counts
     for (u32 g = 0; g < G; ++g) {
@@ -421,8 +443,13 @@ static int multi_exchange(fastf_multi* m) {
         for (u32 g = 0; g < G; ++g) { at[h][g] = r; r += m->d[g].cnt[h]; }
         mh.n_recv = r;
         HIP_OK(hipSetDevice(mh.dev));
-        if (mh.d_recv.ensure(std::max<u64>(r, 1) * 8) || mh.d_tmp.ensure(std::max<u64>(r, 1) * 8)) return 1;
+        if (wide) { if (grow_keys(mh.e, std::max<u64>(r, 1))) return 1; }      // the receiver's own wide store (keys, values, sort and row buffers)
+        else if (mh.d_recv.ensure(std::max<u64>(r, 1) * 8) || mh.d_tmp.ensure(std::max<u64>(r, 1) * 8)) return 1;
     }
+    // where device h receives (wide keys: two arrays, same offsets) and where device g's values for destination h lie
+    auto recv_keys = [&](u32 h) { return wide ? (u64*)m->d[h].e->d_keys.p : (u64*)m->d[h].d_recv.p; };
+    auto recv_vals = [&](u32 h) { return (u64*)m->d[h].e->d_vals.p; };
+    auto send_vals = [&](u32 g, u32 h) { return (const u64*)m->d[g].d_shard.p + (u64)(G + h) * m->d[g].stride; };
     if (m->use_rccl) {
         // the single all-to-all of the path: one group of G x G send/recv pairs, each device's calls on its own stream
         NCCL_OK(m, m->rccl.GroupStart());
@@ -430,7 +457,9 @@ static int multi_exchange(fastf_multi* m) {
             MultiDev& mg = m->d[g];
             for (u32 h = 0; h < G; ++h) {
                 if (mg.cnt[h]) NCCL_OK_IN_GROUP(m, m->rccl.Send((const u64*)mg.d_shard.p + (u64)h * mg.stride, mg.cnt[h], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
-                if (m->d[h].cnt[g]) NCCL_OK_IN_GROUP(m, m->rccl.Recv((u64*)mg.d_recv.p + at[g][h], m->d[h].cnt[g], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+                if (m->d[h].cnt[g]) NCCL_OK_IN_GROUP(m, m->rccl.Recv(recv_keys(g) + at[g][h], m->d[h].cnt[g], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+                if (wide && mg.cnt[h]) NCCL_OK_IN_GROUP(m, m->rccl.Send(send_vals(g, h), mg.cnt[h], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
+                if (wide && m->d[h].cnt[g]) NCCL_OK_IN_GROUP(m, m->rccl.Recv(recv_vals(g) + at[g][h], m->d[h].cnt[g], ncclUint64, (int)h, m->comms[g], mg.e->s_compute));
             }
         }
         NCCL_OK(m, m->rccl.GroupEnd());
@@ -442,9 +471,13 @@ static int multi_exchange(fastf_multi* m) {
                 if (!mg.cnt[h]) continue;
                 MultiDev& mh = m->d[h];
                 const u64* src = (const u64*)mg.d_shard.p + (u64)h * mg.stride;
-                u64* dst = (u64*)mh.d_recv.p + at[h][g];
+                u64* dst = recv_keys(h) + at[h][g];
                 if (mh.dev == mg.dev) HIP_OK(hipMemcpyAsync(dst, src, mg.cnt[h] * 8, hipMemcpyDeviceToDevice, mg.e->s_compute));
                 else HIP_OK(hipMemcpyPeerAsync(dst, mh.dev, src, mg.dev, mg.cnt[h] * 8, mg.e->s_compute));
+                if (wide) {
+                    if (mh.dev == mg.dev) HIP_OK(hipMemcpyAsync(recv_vals(h) + at[h][g], send_vals(g, h), mg.cnt[h] * 8, hipMemcpyDeviceToDevice, mg.e->s_compute));
+                    else HIP_OK(hipMemcpyPeerAsync(recv_vals(h) + at[h][g], mh.dev, send_vals(g, h), mg.dev, mg.cnt[h] * 8, mg.e->s_compute));
+                }
             }
             HIP_OK(hipEventRecord(mg.ev_sent, mg.e->s_compute));
         }
@@ -489,11 +522,49 @@ static int multi_sort_reduce(fastf_multi* m, u32 low_bit, bool resort) {
     return 0;
 }
 
+// Keys wider than 64 bits: every device has received into its sub-engine's own store.  The sort and the reduce are queued on all
+// devices (finish_queue), then each sub-engine's fastf_engine_finish waits for its own and brings its rows to the host.
+static int multi_finish_wide(fastf_multi* m) {
+    const u32 G = m->G;
+    for (u32 h = 0; h < G; ++h) {
+        MultiDev& mh = m->d[h];
+        fastf_engine* se = mh.e;
+        HIP_OK(hipSetDevice(mh.dev));
+        se->keys_so_far = mh.n_recv; se->finished = false; se->finish_queued = false; se->fully_sorted = false;
+        // (the count the sub-engine's sort reads: its own key count word — K1b's count for destination 0 until now, put back below)
+        mh.h_info[SM_KEYCOUNT] = mh.n_recv;
+        HIP_OK(hipMemcpyAsync((u64*)se->d_small.p + SM_KEYCOUNT, mh.h_info + SM_KEYCOUNT, sizeof(u64), hipMemcpyHostToDevice, se->s_compute));
+        if (finish_queue(se)) return 1;
+    }
+    for (u32 h = 0; h < G; ++h) {
+        MultiDev& mh = m->d[h];
+        fastf_coo_t part;
+        if (fastf_engine_finish(mh.e, &part, nullptr)) return 1;
+        mh.f.assign(part.feature, part.feature + part.nnz); mh.c.assign(part.cell, part.cell + part.nnz); mh.k.assign(part.count, part.count + part.nnz);
+    }
+    m->keycount_lent = true;           // (-u rows read the same word; the next push puts K1b's count back: multi_return_keycount)
+    return 0;
+}
+
+// a push after a wide finish: K1b goes on counting keys for destination 0 in the word the sub-engine's sort was lent
+static int multi_return_keycount(fastf_multi* m) {
+    if (!m->keycount_lent) return 0;
+    for (MultiDev& md : m->d) {
+        HIP_OK(hipSetDevice(md.dev));
+        md.h_info[SM_KEYCOUNT] = md.cnt[0];
+        HIP_OK(hipMemcpyAsync((u64*)md.e->d_small.p + SM_KEYCOUNT, md.h_info + SM_KEYCOUNT, sizeof(u64), hipMemcpyHostToDevice, md.e->s_compute));
+        HIP_OK(hipStreamSynchronize(md.e->s_compute));
+    }
+    m->keycount_lent = false;
+    return 0;
+}
+
 static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3]) {
     fastf_multi* m = e->multi;
     const u32 G = m->G;
     if (!m->finished) {
         if (multi_exchange(m)) return 1;
+        if (m->d[0].e->wide) { if (multi_finish_wide(m)) return 1; } else {
         const u32 skip = m->d[0].e->skip_bits;
         if (multi_sort_reduce(m, skip, false)) return 1;
         bool too_long = false;
@@ -518,6 +589,7 @@ static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3])
                 HIP_OK(hipMemcpy(mh.k.data(), mh.d_k.p, nnz * 4, hipMemcpyDeviceToHost));
             }
         }
+        }
         u64 total = 0;
         std::vector<const u32*> cells(G); std::vector<u64> ns(G);
         for (u32 h = 0; h < G; ++h) { cells[h] = m->d[h].c.data(); ns[h] = m->d[h].c.size(); total += ns[h]; }
@@ -541,6 +613,24 @@ static int multi_umi_rows(fastf_engine* e, fastf_umi_rows_t* rows) {
     fastf_multi* m = e->multi;
     if (!m->finished) return set_err("call fastf_engine_finish first");
     const u32 G = m->G;
+    if (m->d[0].e->wide) {                                // every sub-engine's own -u rows (umi_rows_wide), merged by cell
+        std::vector<fastf_umi_rows_t> part(G);
+        for (u32 h = 0; h < G; ++h) if (fastf_engine_umi_rows(m->d[h].e, &part[h])) return 1;
+        u64 total = 0;
+        std::vector<const u32*> cells(G); std::vector<u64> ns(G);
+        for (u32 h = 0; h < G; ++h) { cells[h] = part[h].cell; ns[h] = part[h].n; total += ns[h]; }
+        m->ufeature.resize(total); m->ucell.resize(total); m->uumi.resize(total); m->unonnull.resize(total); m->ncopy.resize(total);
+        u64 w = 0;
+        multi_merge_by_cell(G, cells, ns, [&](u32 g, u64 a, u64 b) {
+            const fastf_umi_rows_t& r = part[g];
+            for (u64 i = a; i < b; ++i, ++w) {
+                m->ufeature[w] = r.feature[i]; m->ucell[w] = r.cell[i]; m->unonnull[w] = r.nonnull[i]; m->uumi[w] = r.umi[i]; m->ncopy[w] = r.n_copy[i];
+            }
+        });
+        rows->feature = m->ufeature.data(); rows->cell = m->ucell.data(); rows->n_copy = m->ncopy.data();
+        rows->umi = m->uumi.data(); rows->nonnull = m->unonnull.data(); rows->n = total;
+        return 0;
+    }
     for (u32 h = 0; h < G; ++h) {                         // -u rows are ordered by blob: every shard needs the full sort
         MultiDev& mh = m->d[h];
         fastf_engine* se = mh.e;
@@ -620,7 +710,7 @@ static int multi_reset(fastf_engine* e, bool reseed, u32 seed, u64 skip) {
     }
     m->chunks = 0;
     m->hits = m->total_records = m->c_sampled = m->c_valid = 0;
-    m->finished = false;
+    m->finished = false; m->keycount_lent = false;
     return 0;
 }
 

@@ -203,6 +203,7 @@ struct fastf_engine {
     // sub_bits (the UMI's first bases, umi_kernels.hpp make_val_sub) sit in the sorted word below the feature (group_bits counts
     // them), K3 emits a row per (cell, feature, sub-group) split into two 32-bit halves at row_split, merge_sub_rows sums them
     u32 sub_bits = 0, row_split = 0;
+    bool finish_queued = false;        // finish_queue() ran for the keys in the store; fastf_engine_finish waits and collects
     DevBuf d_vals, d_vtmp;
     // timing
     bool timing = false;
@@ -220,6 +221,7 @@ enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 6
 
 static int set_scatter_lds_limit();
 static u32 g_cu_count = 256;
+static thread_local bool g_wide_shard_ok = false;      // set by multi_create around the creation of its sub-engines (n_shards = G, possibly wide)
 // multi-device engine (multi_engine.hpp, included at the end of this file)
 static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e);
 static void multi_destroy(fastf_engine* e);
@@ -463,9 +465,11 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 32) return set_err("umi_max_bases must be 1..32");
     {   // keys wider than 64 bits run on the single-device engine (the group word is sorted, the rest rides along)
         const u32 tb = bits_for(cfg->n_cells) + bits_for(cfg->n_features) + 1 + 2 * cfg->umi_max_bases + bits_for((cfg->umi_max_bases + 3) / 4);
-        if ((tb > 64 || cfg->umi_max_bases > 16) && (cfg->n_devices > 1 || cfg->n_shards > 1))
-            return set_err("packed key needs %u bits (> 64): the sharded and multi-device engines take keys of at most 64 bits "
-                           "(lower umi_max_bases, or run the single-device engine)", tb);
+        // (the multi-device engine takes them: its sub-engines sort what they receive in their own wide store; a sharded engine
+        // driven through the fastf_dev_* calls does not)
+        if ((tb > 64 || cfg->umi_max_bases > 16) && cfg->n_devices <= 1 && cfg->n_shards > 1 && !g_wide_shard_ok)
+            return set_err("packed key needs %u bits (> 64): a sharded engine driven through the fastf_dev_* calls takes keys of at most 64 bits "
+                           "(lower umi_max_bases, or run the single-device or the multi-device engine)", tb);
     }
     if (cfg->n_devices > 1 || (cfg->n_devices == 1 && getenv("FASTF_FORCE_MULTI"))) {
         fastf_engine* me = new fastf_engine();
@@ -934,7 +938,8 @@ static int grow_regions(fastf_engine* e, u32 need);
 static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32* umi, const u32* meta, u64 n,
                         const u32* dbits, u64 n_draws, const u64* draw_base, u64* keys, u64 stride, u64* key_counts,
                         u64* counters, bool reuse_hits, hipStream_t s, u64 draw_mask = ~0ull, u64* d_running = nullptr,
-                        bool segmented = false, void* blk = nullptr, const RegionAppend* app = nullptr) {
+                        bool segmented = false, void* blk = nullptr, const RegionAppend* app = nullptr,
+                        u64* wide_vals = nullptr, const u32* wide_ext = nullptr) {
     if (segmented && !app) { e->seg_n = 0; e->rgn_hist_n = 0; }
     if (n == 0) return 0;
     // K1a, unless the caller states that fastf_dev_count_hits just ran on these very records (same stream order).
@@ -954,15 +959,18 @@ static int launch_probe(fastf_engine* e, const u64* cb, const u64* gx, const u32
     p.n_tiles = tiles;
     p.genes = e->lds_genes;
     p.blk = (const unsigned char*)blk;
-    if (e->wide) {                                      // wide keys: group word into keys[], the rest into d_vals[] (tile form, one shard)
-        if (segmented || blk || e->n_shards != 1 || keys != (u64*)e->d_keys.p) return set_err("internal error: wide keys go through the engine's own key store");
-        p.vals = (u64*)e->d_vals.p; p.wide_feat_bits = e->feat_bits; p.wide_sub_bits = e->sub_bits;
-        p.umi_ext = e->cur_umi_ext;
+    if (e->wide) {
+        // wide keys (tile form): group word into keys[], the rest into vals[] — the engine's own store (one shard), or
+        // wide_vals[n_shards][stride] beside keys[n_shards][stride] (the multi-device engine's per-destination buffers)
+        if (segmented || blk) return set_err("internal error: wide keys take the tile form");
+        if (!wide_vals && (e->n_shards != 1 || keys != (u64*)e->d_keys.p)) return set_err("internal error: wide keys go through the engine's own key store");
+        p.vals = wide_vals ? wide_vals : (u64*)e->d_vals.p; p.wide_feat_bits = e->feat_bits; p.wide_sub_bits = e->sub_bits;
+        p.umi_ext = wide_vals ? wide_ext : e->cur_umi_ext;
     }
     // several shards: the streaming kernel writes unsharded into a scratch buffer of workgroup regions, shard_partition_kernel
     // deals the keys to the per-destination buffers (same interface as the tile form: keys[G][stride], key_counts[G] += ...)
     const bool no_stream = getenv("FASTF_NO_STREAM_K1B") != nullptr;
-    const bool stream_shards = !segmented && e->n_shards > 1 && e->n_shards <= (u32)MAX_SHARDS && e->use_lds_genes && !no_stream;
+    const bool stream_shards = !segmented && !e->wide && e->n_shards > 1 && e->n_shards <= (u32)MAX_SHARDS && e->use_lds_genes && !no_stream;
     if (blk && !(segmented || stream_shards)) return set_err("FASTF_PROBE_BLOCKED needs the streaming K1b (fastf_dev_block_bytes returns 0 otherwise)");
     t_begin(e, s);
     if (segmented || stream_shards) {
@@ -1791,6 +1799,54 @@ static u64 merge_sub_rows(fastf_engine* e, u64 nnz) {
     return out;
 }
 
+// The device work of fastf_engine_finish up to the read-back of the counters, queued and not waited for (the multi-device
+// engine queues it on every device before it waits for any)
+static int finish_queue(fastf_engine* e) {
+    hipStream_t s = e->s_compute;
+    u64* small = (u64*)e->d_small.p;
+    const u64 n = e->keys_so_far;
+    if (n) {
+        if (e->d_tmp.ensure(e->key_cap * sizeof(u64))) return 1;
+        if (e->d_feature.ensure(n * 4) || e->d_cell.ensure(n * 4) || e->d_count.ensure(n * 4)) return 1;
+        // the matrix only needs equal keys to be neighbours inside a (cell, feature) group: the lowest digit
+        // passes are skipped and K3 resolves the short unsorted runs (fastf_engine_umi_rows sorts fully)
+        if (e->wide) {
+            // keys wider than 64 bits: the group words are sorted (the rest of each key moves with its group word), K3 finds
+            // the distinct rest-of-keys of a group in its window set
+            if (e->d_vtmp.ensure(e->key_cap * sizeof(u64))) return 1;
+            if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->group_bits, 0, &e->sorted_in_tmp, s, false,
+                            (u64*)e->d_vals.p, (u64*)e->d_vtmp.p))
+                return 1;
+            e->fully_sorted = false;
+            if (launch_reduce_regions<false>(e, e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p, small + SM_KEYCOUNT, n, small + SM_NNZ, 0, s,
+                                             e->sorted_in_tmp ? (u64*)e->d_vtmp.p : (u64*)e->d_vals.p))
+                return 1;
+        } else {
+        if (e->stream_mode && e->store_regions) {
+            // the keys lie in the regions the chunks' K1b left, each with the histogram of the first digit: the first pass
+            // walks the regions (no counting pass), the later ones see contiguous buffers
+            e->seg_n = e->rgn_n; e->seg_stride = 0; e->rgn_hist_n = e->rgn_n; e->rgn_hist_shift = e->skip_bits;
+            if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
+                            &e->sorted_in_tmp, s, true))
+                return 1;
+            if (sort_passes(e->L.total_bits, e->skip_bits) >= 2) e->store_regions = false;   // the second pass wrote the store from its front
+        } else
+        if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
+                        &e->sorted_in_tmp, s))
+            return 1;
+        e->fully_sorted = e->skip_bits == 0;
+        const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
+        // the rows stay in K3's regions until the host buffer is known to be large enough (the gather below)
+        if (launch_reduce_regions<false>(e, sorted, small + SM_KEYCOUNT, n, small + SM_NNZ, e->skip_bits, s)) return 1;
+        }
+    } else {
+        HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
+    }
+    HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
+    e->finish_queued = true;
+    return 0;
+}
+
 extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t counters[3]) FASTF_TRY {
     if (!e || !coo) return set_err("null argument");
     if (e->multi) return multi_finish(e, coo, counters);
@@ -1804,44 +1860,8 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
     u64* small = (u64*)e->d_small.p;
     const u64 n = e->keys_so_far;
     if (!e->finished) {
-        if (n) {
-            if (e->d_tmp.ensure(e->key_cap * sizeof(u64))) return 1;
-            if (e->d_feature.ensure(n * 4) || e->d_cell.ensure(n * 4) || e->d_count.ensure(n * 4)) return 1;
-            // the matrix only needs equal keys to be neighbours inside a (cell, feature) group: the lowest digit
-            // passes are skipped and K3 resolves the short unsorted runs (fastf_engine_umi_rows sorts fully)
-            if (e->wide) {
-                // keys wider than 64 bits: the group words are sorted (the rest of each key moves with its group word), K3 finds
-                // the distinct rest-of-keys of a group in its window set
-                if (e->d_vtmp.ensure(e->key_cap * sizeof(u64))) return 1;
-                if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->group_bits, 0, &e->sorted_in_tmp, s, false,
-                                (u64*)e->d_vals.p, (u64*)e->d_vtmp.p))
-                    return 1;
-                e->fully_sorted = false;
-                if (launch_reduce_regions<false>(e, e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p, small + SM_KEYCOUNT, n, small + SM_NNZ, 0, s,
-                                                 e->sorted_in_tmp ? (u64*)e->d_vtmp.p : (u64*)e->d_vals.p))
-                    return 1;
-            } else {
-            if (e->stream_mode && e->store_regions) {
-                // the keys lie in the regions the chunks' K1b left, each with the histogram of the first digit: the first pass
-                // walks the regions (no counting pass), the later ones see contiguous buffers
-                e->seg_n = e->rgn_n; e->seg_stride = 0; e->rgn_hist_n = e->rgn_n; e->rgn_hist_shift = e->skip_bits;
-                if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
-                                &e->sorted_in_tmp, s, true))
-                    return 1;
-                if (sort_passes(e->L.total_bits, e->skip_bits) >= 2) e->store_regions = false;   // the second pass wrote the store from its front
-            } else
-            if (launch_sort(e, (u64*)e->d_keys.p, (u64*)e->d_tmp.p, small + SM_KEYCOUNT, n, e->L.total_bits, e->skip_bits,
-                            &e->sorted_in_tmp, s))
-                return 1;
-            e->fully_sorted = e->skip_bits == 0;
-            const u64* sorted = e->sorted_in_tmp ? (u64*)e->d_tmp.p : (u64*)e->d_keys.p;
-            // the rows stay in K3's regions until the host buffer is known to be large enough (the gather below)
-            if (launch_reduce_regions<false>(e, sorted, small + SM_KEYCOUNT, n, small + SM_NNZ, e->skip_bits, s)) return 1;
-            }
-        } else {
-            HIP_OK(hipMemsetAsync(small + SM_NNZ, 0, sizeof(u64), s));
-        }
-        HIP_OK(hipMemcpyAsync(e->h_small, small, SM_WORDS * sizeof(u64), hipMemcpyDeviceToHost, s));
+        if (!e->finish_queued && finish_queue(e)) return 1;
+        e->finish_queued = false;
         HIP_OK(hipStreamSynchronize(s));
         if (n && e->wide && (e->h_small[SM_COUNTERS + 3] & ERR_RUN_TOO_LONG))
             return set_err("a (cell, feature) group of more than 4 M reads (or more than 6 M reads in groups beyond 2048) with keys wider than 64 bits: not supported");
@@ -2058,7 +2078,7 @@ extern "C" int fastf_engine_reset(fastf_engine_t* e) FASTF_TRY {
     for (auto& sl : e->slot) sl.busy = false;
     e->inflight_records = 0;
     e->total_records = e->hits_so_far = e->keys_so_far = e->c_sampled = e->c_valid = 0;
-    e->finished = false; e->h_nnz = 0;
+    e->finished = false; e->finish_queued = false; e->h_nnz = 0;
     e->slots_used = 0; e->rgn_n = 0; e->store_regions = false; e->rgn_hist_n = 0; e->seg_n = 0;
     e->lent_rows = nullptr; e->lent_cap = 0; e->rows_at = nullptr; e->rows_stride = 0;     // a loan lasts for one finish
     e->draws_up = e->draws_valid = 0;

@@ -360,12 +360,15 @@ __device__ __forceinline__ u64 make_val64(const KeyLayout L, u64 umi, u32 meta) 
 // first bases) go into the sorted word below the feature — keys that differ there are different UMIs whatever the rest, so the
 // distinct count of a (cell, feature) is the sum over its sub-groups (summed on the host: umi_engine.hip merge_sub_rows)
 constexpr u32 WIDE_SUB_BITS = 17, WIDE_SUB_VAL_BITS = 51, WIDE_SUB_LEN_BITS = 4;
-__device__ __forceinline__ u64 make_val_sub(u64 umi, u32 meta, u32* sub) {
-    *sub = 0;
+__device__ __forceinline__ u64 make_val_sub(u64 umi, u32 meta) {
     if (!(meta & META_UMI_NONNULL)) return 0;
     const u32 len = (meta & META_LEN_MASK) >> META_LEN_SHIFT;
-    *sub = (u32)(umi >> (WIDE_SUB_VAL_BITS - WIDE_SUB_LEN_BITS));
     return (1ULL << WIDE_SUB_VAL_BITS) | (((umi << WIDE_SUB_LEN_BITS) | len) & ((1ULL << WIDE_SUB_VAL_BITS) - 1));
+}
+// the sub-group: bits 68..52 of [bases][blob bytes] = the top WIDE_SUB_BITS of the bases = of their first 32-bit word
+__device__ __forceinline__ u32 wide_sub_of(u32 umi_first_word, u32 meta) {
+    static_assert(WIDE_SUB_VAL_BITS - WIDE_SUB_LEN_BITS + WIDE_SUB_BITS == 64, "the sub-group and the value's bases make up the 64 bits of bases");
+    return (meta & META_UMI_NONNULL) ? umi_first_word >> (32 - WIDE_SUB_BITS) : 0u;
 }
 __device__ __forceinline__ bool umi_overflows_sub(u32 meta) {
     return (meta & META_UMI_TOOLONG) || ((meta & META_UMI_NONNULL) && ((meta & META_LEN_MASK) >> META_LEN_SHIFT) > 8u);
@@ -788,7 +791,7 @@ struct PackParams {
     KeyLayout L;
     u32 n_shards;
     u64* keys; u64 shard_stride;   // keys + s*shard_stride
-    // keys wider than 64 bits (tile form, one shard): keys[] takes the GROUP (cell << wide_feat_bits | feature) and vals[]
+    // keys wider than 64 bits (tile form): keys[] takes the GROUP (cell << wide_feat_bits | feature) and vals[]
     // the rest of the key — NULL flag, UMI, length, laid out as the low feat_shift bits of a narrow key; vals == nullptr: narrow
     u64* vals; u32 wide_feat_bits;
     u32 wide_sub_bits;             // 0, or WIDE_SUB_BITS (umi_max_bases > 24): keys[] = (group << wide_sub_bits) | the UMI's first bases (make_val_sub)
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
             n_valid++;                                               // E12 :435
             // (wide keys: the low part only here — cell and feature go into the group word at the store below)
             shard[j] = p.n_shards > 1 ? shard_of(cell[j], p.n_shards) : 0;
-            if (p.vals && p.wide_sub_bits) key[j] = make_val_sub(umi_w, meta[j], &shard[j]);      // (one shard: shard[] carries the sub-group)
+            if (p.vals && p.wide_sub_bits) key[j] = make_val_sub(umi_w, meta[j]);                  // (the sub-group: at the store below)
             else key[j] = p.vals ? make_val64(p.L, umi_w, meta[j]) : make_key(p.L, cell[j], feat[j], umi[j], meta[j]);
         }
         emit[j] = alive;
@@ -991,11 +994,13 @@ __global__ __launch_bounds__(K1B_THREADS, ROOMY ? 4 : (LDS_GENES ? FASTF_K1B_MIN
 #pragma unroll
     for (int j = 0; j < K1B_IPT; ++j) {
         if (emit[j]) {
-            const u64 b = s_shard_base[p.vals ? 0u : shard[j]];
+            const u64 b = s_shard_base[shard[j]];
             if (b != ~0ULL) {
                 if (p.vals) {                                            // wide key: group and rest side by side
-                    p.vals[b + pos[j]] = key[j];
-                    p.keys[b + pos[j]] = ((((u64)cell[j] << p.wide_feat_bits) | feat[j]) << p.wide_sub_bits) | (p.wide_sub_bits ? shard[j] : 0u);
+                    const u32 sub = p.wide_sub_bits ? wide_sub_of(umi[j], meta[j]) : 0u;
+                    const u64 at = (u64)shard[j] * p.shard_stride + b + pos[j];
+                    p.vals[at] = key[j];
+                    p.keys[at] = ((((u64)cell[j] << p.wide_feat_bits) | feat[j]) << p.wide_sub_bits) | sub;
                 } else p.keys[(u64)shard[j] * p.shard_stride + b + pos[j]] = key[j];
             }
         }

@@ -49,6 +49,47 @@ def test_multi_device_engine_matches_oracle(name, G):
         eng.close()
 
 
+WIDE = {
+    # 210 k barcodes x 70 k genes x 16-base UMIs: 71 key bits
+    "71 bits": (dict(n=150_000, n_bar=210_000, n_gene=70_000, rate_depth=0.9, umi_len=16, umi_pool=4096, p_n_umi=0.01), 16),
+    "20 bases": (dict(n=200_000, n_bar=2000, n_gene=900, rate_cell=0.7, rate_depth=0.8, umi_len=20, dup_factor=3.0, p_no_cb=0.03,
+                      p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.02), 24),
+    "30 bases": (dict(n=120_000, n_bar=300, n_gene=100, umi_len=30, umi_pool=256, rate_depth=0.7, p_n_umi=0.05), 32),
+}
+
+
+@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("name", list(WIDE))
+def test_multi_device_wide_keys_match_oracle(name, G):
+    """keys wider than 64 bits and UMIs beyond 16 bases through the multi-device engine: K1b writes the group word and the rest of
+    the key per destination, both cross in the one exchange into the receiver's own wide store, every device sorts and reduces
+    what it owns (hashtable.c:70-115, bam2db_ds.c:417-419: any list size, any UMI length)"""
+    kw, umi_max = WIDE[name]
+    case = Case(**kw)
+    ora = case.oracle()
+    lists = case.lists()
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=umi_max, batch_records=23_000, devices=[0] * G)
+    try:
+        assert eng.key_bits > 64 or umi_max > 16
+        if umi_max > 16:
+            cb, gx, umi, meta, ext = case.packed_long(lists)
+            assert ext.any()
+        else:
+            cb, gx, umi, meta = case.packed(lists); ext = None
+        cuts = [0, 1, 50_000, case.n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng.push(cb[a:b], gx[a:b], umi[a:b], meta[a:b], umi_ext=None if ext is None else ext[a:b])
+        res = eng.finish()
+        assert_matches_oracle(res, ora, eng, case, lists, eng.umi_rows())
+        counts = eng.device_records(G)
+        assert len(counts) == G and all(c > 0 for c in counts)
+        eng.reset(); eng.reseed(case.seed, lists.mt_skip)                      # the same job again on the same handle
+        eng.push(cb, gx, umi, meta, umi_ext=ext)
+        assert_matches_oracle(eng.finish(), ora)
+    finally:
+        eng.close()
+
+
 def test_multi_device_empty_and_tiny():
     case = Case(n=10, n_bar=4, n_gene=3)
     lists = case.lists()
@@ -90,8 +131,10 @@ def test_rccl_exchange_call_sequence_on_one_device(monkeypatch):
         eng.close()
 
 
-def test_cli_with_fastf_devices(tmp_path):
-    case = Case(n=90_000, n_bar=600, n_gene=250, rate_cell=0.5, rate_depth=0.5, umi_len=12, dup_factor=3.0,
+@pytest.mark.parametrize("umi_len", [12, 22])
+def test_cli_with_fastf_devices(tmp_path, umi_len):
+    """(22 bases: the first run's 64-bit keys overflow, bam2db() runs again with room for 32 — wide keys on every device)"""
+    case = Case(n=90_000, n_bar=600, n_gene=250, rate_cell=0.5, rate_depth=0.5, umi_len=umi_len, dup_factor=3.0,
                 p_no_cb=0.05, p_unlisted_cb=0.05, p_bad_xf=0.15, p_n_umi=0.005)
     bam = tmp_path / "in.bam"
     synth.write_bam(str(bam), case.flags, case.xf, case.cb, case.gx, case.ub)

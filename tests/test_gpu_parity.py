@@ -449,8 +449,9 @@ def test_mixed_umi_lengths_0_to_32():
         eng.close()
 
 
-def test_wide_keys_are_refused_where_they_cannot_go():
-    """sharded and multi-device engines take keys of at most 64 bits: a clear refusal, not a wrong matrix"""
+def test_wide_keys_are_refused_by_the_device_level_calls_only():
+    """a sharded engine driven through the fastf_dev_* calls takes keys of at most 64 bits: a clear refusal, not a wrong matrix
+    (the multi-device engine takes them: tests/test_gpu_multi.py::test_multi_device_wide_keys_match_oracle)"""
     case = Case(n=10, n_bar=70_000, n_gene=70_000)
     lists = case.lists()
     with pytest.raises(F.FastfError) as ei:
