@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
     "fastf_engine_finish", "fastf_engine_lend_rows", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes", "fastf_engine_cell_scratch_bytes",
-    "fastf_dev_count_hits", "fastf_dev_count_hits_blocked", "fastf_dev_block_bytes", "fastf_dev_block_records", "fastf_dev_set_regions", "fastf_dev_draw_bits", "fastf_dev_mt_decisions", "fastf_dev_probe_pack", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce", "fastf_dev_rows_gather", "fastf_engine_device_records",
+    "fastf_dev_count_hits", "fastf_dev_count_hits_blocked", "fastf_dev_block_bytes", "fastf_dev_block_records", "fastf_dev_set_regions", "fastf_dev_draw_bits", "fastf_dev_mt_decisions", "fastf_dev_probe_pack", "fastf_dev_probe_pack_wide", "fastf_dev_adopt_wide", "fastf_engine_is_wide", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce", "fastf_dev_rows_gather", "fastf_engine_device_records",
     "fastf_dev_umi_rows", "fastf_dev_reserve", "fastf_dev_error_bits",
     "fastf_dev_clear_error_bits", "fastf_kernel_names",
     # crb / extract
@@ -169,6 +169,10 @@ def lib():
     if hasattr(L, "fastf_dev_mt_decisions"):
         L.fastf_dev_mt_decisions.argtypes = [vp, u32, u64, u64, vp, vp]
     L.fastf_dev_probe_pack.argtypes = [vp, vp, vp, vp, vp, u64, vp, u64, vp, vp, u64, vp, vp, u32, vp]
+    if hasattr(L, "fastf_dev_probe_pack_wide"):
+        L.fastf_dev_probe_pack_wide.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, u32, vp]
+        L.fastf_dev_adopt_wide.argtypes = [vp, vp, vp, u64, vp]
+        L.fastf_engine_is_wide.argtypes = [vp]
     L.fastf_dev_sort.argtypes = [vp, vp, vp, vp, u64, u32, u32, C.POINTER(C.c_int), vp]
     L.fastf_dev_reduce.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, u32, vp]
     L.fastf_dev_rows_gather.argtypes = [vp, vp, vp, vp, vp, vp]

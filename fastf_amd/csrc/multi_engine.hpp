@@ -190,10 +190,7 @@ static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e) {
         fastf_engine_config_t sub = *cfg;
         sub.n_devices = 0; sub.devices = nullptr;
         sub.n_shards = G; sub.shard_rank = g; sub.device = md.dev;
-        g_wide_shard_ok = true;
-        const int crc = fastf_engine_create(&sub, &md.e);
-        g_wide_shard_ok = false;
-        if (crc) return 1;
+        if (fastf_engine_create(&sub, &md.e)) return 1;
         HIP_OK(hipSetDevice(md.dev));
         HIP_OK(hipHostMalloc((void**)&md.h_info, SM_WORDS * sizeof(u64), hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) {

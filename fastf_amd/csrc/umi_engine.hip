@@ -221,7 +221,6 @@ enum { SM_KEYCOUNT = 0, SM_COUNTERS = 32, SM_NNZ = 64, SM_NROWS_U = 65, SM_N = 6
 
 static int set_scatter_lds_limit();
 static u32 g_cu_count = 256;
-static thread_local bool g_wide_shard_ok = false;      // set by multi_create around the creation of its sub-engines (n_shards = G, possibly wide)
 // multi-device engine (multi_engine.hpp, included at the end of this file)
 static int multi_create(const fastf_engine_config_t* cfg, fastf_engine* e);
 static void multi_destroy(fastf_engine* e);
@@ -463,14 +462,6 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
     if (he != hipSuccess || ndev == 0)
         return set_err("no HIP device available (%s): the engine has no CPU fallback", hipGetErrorString(he));
     if (cfg->umi_max_bases < 1 || cfg->umi_max_bases > 32) return set_err("umi_max_bases must be 1..32");
-    {   // keys wider than 64 bits run on the single-device engine (the group word is sorted, the rest rides along)
-        const u32 tb = bits_for(cfg->n_cells) + bits_for(cfg->n_features) + 1 + 2 * cfg->umi_max_bases + bits_for((cfg->umi_max_bases + 3) / 4);
-        // (the multi-device engine takes them: its sub-engines sort what they receive in their own wide store; a sharded engine
-        // driven through the fastf_dev_* calls does not)
-        if ((tb > 64 || cfg->umi_max_bases > 16) && cfg->n_devices <= 1 && cfg->n_shards > 1 && !g_wide_shard_ok)
-            return set_err("packed key needs %u bits (> 64): a sharded engine driven through the fastf_dev_* calls takes keys of at most 64 bits "
-                           "(lower umi_max_bases, or run the single-device or the multi-device engine)", tb);
-    }
     if (cfg->n_devices > 1 || (cfg->n_devices == 1 && getenv("FASTF_FORCE_MULTI"))) {
         fastf_engine* me = new fastf_engine();
         if (multi_create(cfg, me)) { multi_destroy(me); delete me; return 1; }
@@ -917,7 +908,7 @@ extern "C" int fastf_dev_draw_bits(fastf_engine_t* e, const uint32_t* d_draws, u
     return launch_draw_bits(e->threshold, d_draws, n_draws, d_bits_out, (hipStream_t)stream);
 } FASTF_CATCH_INT
 
-#define NO_WIDE(e, what) do { if ((e)->wide) return set_err(what ": this engine's keys are wider than 64 bits — the device-level calls take keys of at most 64 bits (the host-buffer API handles wide keys)"); } while (0)
+#define NO_WIDE(e, what) do { if ((e)->wide) return set_err(what ": this engine's keys are wider than 64 bits — this call moves one 64 bits word per key (fastf_dev_probe_pack_wide / fastf_dev_adopt_wide + fastf_engine_finish and the host-buffer API take wide keys)"); } while (0)
 
 // the streaming K1b over `tiles` K1a tiles: workgroups (at most two per CU: 12 or 16 waves each) and the key slots of one
 // workgroup's region (every record of the units its waves walk: waves x rounds units)
@@ -1053,6 +1044,31 @@ extern "C" int fastf_dev_probe_pack(fastf_engine_t* e, const uint64_t* d_cb_key,
                         (const u64*)d_draw_base, (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters,
                         (flags & FASTF_PROBE_REUSE_HITS) != 0, (hipStream_t)stream, ~0ull, nullptr, seg,
                         blocked ? const_cast<uint64_t*>(d_gx_key) : nullptr);
+} FASTF_CATCH_INT
+
+extern "C" int fastf_engine_is_wide(const fastf_engine_t* e) { return e && !e->multi && e->wide ? 1 : 0; }
+
+extern "C" int fastf_dev_probe_pack_wide(fastf_engine_t* e, const uint64_t* d_cb_key, const uint64_t* d_gx_key, const uint32_t* d_umi,
+                                         const uint32_t* d_meta, const uint32_t* d_umi_ext, uint64_t n,
+                                         const uint32_t* d_draws, uint64_t n_draws, const uint64_t* d_draw_base,
+                                         uint64_t* d_keys_out, uint64_t* d_vals_out, uint64_t shard_stride, uint64_t* d_key_counts,
+                                         uint64_t* d_counters, uint32_t flags, void* stream) FASTF_TRY {
+    if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_probe_pack_wide: device-level calls take a single-device engine");
+    if (!e->wide) return set_err("fastf_dev_probe_pack_wide: this engine's keys fit 64 bits (fastf_dev_probe_pack)");
+    if (flags & (FASTF_PROBE_SEGMENTED | FASTF_PROBE_BLOCKED)) return set_err("fastf_dev_probe_pack_wide: wide keys take the tile form (no SEGMENTED / BLOCKED)");
+    if (!d_keys_out || !d_vals_out) return set_err("null key or value output");
+    if (e->long_umi && !d_umi_ext && n) return set_err("this engine was created with umi_max_bases > 16: d_umi_ext (bases 17.. of every UMI, zeros where none) is needed");
+    HIP_OK(hipSetDevice(e->device));
+    if (n && n_draws && !d_draws) return set_err("null d_draws");
+    if (!(flags & FASTF_PROBE_DRAW_BITS) && n && n_draws) {
+        if (e->d_dbits.ensure(((n_draws + 63) / 64) * 8)) return 1;
+        if (launch_draw_bits(e->threshold, d_draws, n_draws, (u32*)e->d_dbits.p, (hipStream_t)stream)) return 1;
+        d_draws = (const uint32_t*)e->d_dbits.p;
+    }
+    return launch_probe(e, (const u64*)d_cb_key, (const u64*)d_gx_key, d_umi, d_meta, n, d_draws, n_draws, (const u64*)d_draw_base,
+                        (u64*)d_keys_out, shard_stride, (u64*)d_key_counts, (u64*)d_counters, (flags & FASTF_PROBE_REUSE_HITS) != 0,
+                        (hipStream_t)stream, ~0ull, nullptr, false, nullptr, nullptr, (u64*)d_vals_out, d_umi_ext);
 } FASTF_CATCH_INT
 
 extern "C" int fastf_dev_probe_capacity(const fastf_engine_t* e, uint64_t n, uint64_t* key_slots) FASTF_TRY {
@@ -2066,6 +2082,25 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
 extern "C" int fastf_engine_device_records(const fastf_engine_t* e, uint64_t* records, uint32_t n) FASTF_TRY {
     if (!e || !records) return set_err("null argument");
     return multi_device_records(e, records, n);
+} FASTF_CATCH_INT
+
+extern "C" int fastf_dev_adopt_wide(fastf_engine_t* e, const uint64_t* d_keys, const uint64_t* d_vals, uint64_t n, void* stream) FASTF_TRY {
+    if (!e) return set_err("null engine");
+    if (e->multi) return set_err("fastf_dev_adopt_wide: device-level calls take a single-device engine");
+    if (!e->wide) return set_err("fastf_dev_adopt_wide: this engine's keys fit 64 bits");
+    if (n && (!d_keys || !d_vals)) return set_err("null keys or values");
+    HIP_OK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (grow_keys(e, std::max<u64>(n, 1))) return 1;
+    if (n) {
+        HIP_OK(hipMemcpyAsync(e->d_keys.p, d_keys, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync(e->d_vals.p, d_vals, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    }
+    const u64 cnt = n;
+    HIP_OK(hipMemcpyAsync((u64*)e->d_small.p + SM_KEYCOUNT, &cnt, sizeof(u64), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));                       // (fastf_engine_finish works on the engine's own stream; cnt is a local)
+    e->keys_so_far = n; e->finished = false; e->finish_queued = false; e->fully_sorted = false; e->sorted_in_tmp = 0;
+    return 0;
 } FASTF_CATCH_INT
 
 extern "C" int fastf_engine_reset(fastf_engine_t* e) FASTF_TRY {

@@ -19,6 +19,13 @@ runs K1 on it; a key belongs to shard hash(cell_index) mod G, so all UMIs of a
   5. COO rows stay on their shard (gather_coo() merges them); the three counters are summed over ranks on demand
      (global_counters(): one all_reduce, outside the data path).
 
+Keys wider than 64 bits (a raw whitelist x 36 k genes x 12-base UMIs needs 66; UMIs beyond 16 bases always): stages with
+``wide`` set run the same five steps with the key in two words (``_run_wide``): K1 writes the group word and the rest of the key
+into two buffers per destination, the exact protocol exchanges both (the counts, then two all_to_all_single with splits), the
+receiver hands the pairs to its engine (``reduce_wide``: sort on the group word with the values riding along, reduce, rows).  No
+fixed-capacity form and no pipelining there: the path exists so that no input the single-GPU engine takes is refused by the
+sharded one; its throughput is not the headline's.
+
 With more than one shard on GPUs the pass is software-pipelined over three HIP streams: the K1 stage of step i+1
 (hit count, draw-rank base, probe/filter/pack, count exchange) on one, the key exchange of step i on another, sort and
 reduce on the caller's stream — K1 and the sort are HBM-bound, the exchange is xGMI-bound, so the exchange overlaps
@@ -78,6 +85,26 @@ class HipStages:
 
     def _s(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def wide(self):
+        return self.eng.wide
+
+    def probe_pack_wide(self, cb, gx, umi, meta, ext, n, draws, draw_base, keys_out, vals_out, stride, key_counts, counters, reuse_hits=False):
+        """K1 of an engine whose keys are wider than 64 bits: group words into keys_out[shard], the rest of each key into
+        vals_out[shard] (fastf_dev_probe_pack_wide); ext: bases 17.. of the UMIs or None"""
+        bits = isinstance(draws, DrawBits)
+        self.eng.dev_probe_pack_wide(cb.data_ptr(), gx.data_ptr(), umi.data_ptr(), meta.data_ptr(), 0 if ext is None else ext.data_ptr(), n,
+                                     draws.words.data_ptr() if bits else draws.data_ptr(), draws.n_draws if bits else draws.numel(),
+                                     keys_out.data_ptr(), vals_out.data_ptr(), stride, key_counts.data_ptr(), counters.data_ptr(), self._s(),
+                                     d_draw_base=draw_base.data_ptr(), reuse_hits=reuse_hits, draw_bits=bits)
+
+    def reduce_wide(self, keys, vals, n):
+        """the n pairs this shard owns -> its rows (feature, cell, count) on the host, ascending (cell, feature):
+        fastf_dev_adopt_wide + fastf_engine_finish (K2 on the group word, K3 on the values)"""
+        self.eng.dev_adopt_wide(keys.data_ptr(), vals.data_ptr(), n, self._s())
+        r = self.eng.finish()
+        return r["feature"].astype(np.int64), r["cell"].astype(np.int64), r["count"].astype(np.int64)
 
     def block(self, gx, umi, meta, n):
         """the records' gx / umi / meta in the engine's BLOCKED layout (one contiguous run per 256-record unit, with the
@@ -280,7 +307,44 @@ class ShardedPass:
         to run() in place of `draws`"""
         return self.st.draw_bits(draws) if hasattr(self.st, "draw_bits") else draws
 
-    def run(self, cb, gx, umi, meta, n, draws, inputs_ready=None):
+    def _run_wide(self, cb, gx, umi, meta, n, draws, umi_ext):
+        """one pass with keys wider than 64 bits (module docstring): exact protocol, the caller's stream, two words per key"""
+        G, st = self.G, self.st
+        if umi is None:
+            raise ValueError("keys wider than 64 bits take SoA records (cb, gx, umi, meta [, umi_ext]), not the blocked layout")
+        if getattr(self, "_wide_vals", None) is None:
+            self._wide_vals = torch.empty((G, self.stride), dtype=torch.int64, device=self.dev)
+            self._wide_recv_v = torch.empty(self.recv_cap, dtype=torch.int64, device=self.dev)
+        self._use_slot(0)
+        self.recv = self._recv_slots[0]
+        self._small.zero_()
+        st.count_hits(cb, n, self.hits)
+        if G > 1:
+            self._all_gather(self.all_hits, self.hits)
+            self.draw_base.copy_(self.all_hits[:self.rank].sum().reshape(1))
+        st.probe_pack_wide(cb, gx, umi, meta, umi_ext, n, draws, self.draw_base, self.keys_out, self._wide_vals, self.stride,
+                           self.key_counts, self.counters, reuse_hits=True)
+        if G > 1:
+            self._all_to_all_single(self.recv_counts, self.key_counts)
+            both = torch.cat([self.key_counts, self.recv_counts]).tolist()
+            send, recv = both[:G], both[G:]
+            if max(send) > self.stride:
+                raise RuntimeError("a destination buffer overflowed (%d keys, room for %d)" % (max(send), self.stride))
+            self.n_recv = int(sum(recv))
+            pack = lambda buf: torch.cat([buf[g, :send[g]] for g in range(G)]) if sum(send) else self.recv[:0]
+            self._all_to_all_single(self.recv[:self.n_recv], pack(self.keys_out), recv, send)
+            self._all_to_all_single(self._wide_recv_v[:self.n_recv], pack(self._wide_vals), recv, send)
+            keys, vals = self.recv, self._wide_recv_v
+        else:
+            self.n_recv = int(self.key_counts[0].item())
+            keys, vals = self.keys_out.view(-1), self._wide_vals.view(-1)
+        self._wide_rows = st.reduce_wide(keys, vals, self.n_recv)
+        self._counters_reduced = False
+        self._verified = True
+        self._fixed_step = False
+        self._gathered = True
+
+    def run(self, cb, gx, umi, meta, n, draws, inputs_ready=None, umi_ext=None):
         """One pass over this rank's slice.  `draws` is the job-wide draw stream (resident), or prepare_draws() of it.
 
         Pipelined mode runs K1 on its own stream so that it overlaps the previous step's sort on the caller's stream;
@@ -288,6 +352,11 @@ class ShardedPass:
         steps must pass `inputs_ready`, an event recorded on its stream after the writes: K1 waits for it.  Without it
         the inputs must be ready when the first step starts and stay untouched afterwards (bench.py: resident inputs)."""
         G, st = self.G, self.st
+        self._wide_rows = None
+        if getattr(st, "wide", False):
+            if inputs_ready is not None:
+                inputs_ready.wait()
+            return self._run_wide(cb, gx, umi, meta, n, draws, umi_ext)
         self._last_inputs = (cb, gx, umi, meta, n, draws, inputs_ready)       # (a step repeated by ensure_exact() waits for the same event)
         self._fixed_step = False
         if G > 1 and self.fixed and self.cap is not None:
@@ -480,6 +549,8 @@ class ShardedPass:
             self._gathered = True
 
     def local_coo(self):
+        if getattr(self, "_wide_rows", None) is not None:
+            return self._wide_rows
         self.gather_rows()
         z = int(self.nnz.item())
         return (self.feature[:z].cpu().numpy().astype(np.int64), self.cell[:z].cpu().numpy().astype(np.int64),

@@ -341,6 +341,23 @@ class Engine:
                                            (1 if reuse_hits else 0) | (2 if segmented else 0) | (8 if blocked else 0) | (16 if draw_bits else 0),
                                            stream))
 
+    @property
+    def wide(self) -> bool:
+        """keys wider than 64 bits (or UMIs beyond 16 bases): the group word and the rest of the key travel in two words"""
+        return bool(self._L.fastf_engine_is_wide(self._h))
+
+    def dev_probe_pack_wide(self, d_cb, d_gx, d_umi, d_meta, d_umi_ext, n, d_draws, n_draws, d_keys, d_vals, shard_stride,
+                            d_key_counts, d_counters, stream=0, d_draw_base=None, reuse_hits=False, draw_bits=False):
+        """dev_probe_pack for an engine whose keys are wider than 64 bits: group words into d_keys[shard][..], the rest of each key
+        into d_vals[shard][..]; d_umi_ext: bases 17.. of the UMIs (0 / None: none)"""
+        check(self._L.fastf_dev_probe_pack_wide(self._h, d_cb, d_gx, d_umi, d_meta, d_umi_ext or None, n, d_draws, n_draws, d_draw_base,
+                                                d_keys, d_vals, shard_stride, d_key_counts, d_counters,
+                                                (1 if reuse_hits else 0) | (16 if draw_bits else 0), stream))
+
+    def dev_adopt_wide(self, d_keys, d_vals, n, stream=0):
+        """the n (group word, rest of key) pairs this shard owns into the engine's own store: finish() / umi_rows() follow"""
+        check(self._L.fastf_dev_adopt_wide(self._h, d_keys, d_vals, n, stream))
+
     def dev_draw_bits(self, d_draws, n_draws, d_bits_out, stream=0):
         """bit i of d_bits_out = d_draws[i] < this engine's keep threshold.  The kernel stores whole 64-bit words: d_bits_out must
         be 8-byte aligned and hold ((n_draws + 63) // 64) * 8 bytes = ((n_draws + 63) // 64) * 2 u32 words (include/fastf_amd.h)"""

@@ -329,6 +329,24 @@ int fastf_dev_draw_bits(fastf_engine_t *e, const uint32_t *d_draws, uint64_t n_d
  * jump-ahead (mt_jump.c) and generated side by side.  Synchronises the stream. */
 int fastf_dev_mt_decisions(fastf_engine_t *e, uint32_t seed, uint64_t skip, uint64_t n_draws, uint32_t *d_bits_out, void *stream);
 
+/* Keys wider than 64 bits on a SHARDED engine (n_shards > 1; one process per GPU: fastf_amd/dist.py).  The calls above take
+ * 64-bit keys; an engine whose keys are wider (fastf_engine_is_wide: many barcodes x many features x long UMIs, or
+ * umi_max_bases > 16) runs the same E1-E12 chain (bam2db_ds.c:360-438) with the key in two words:
+ *   fastf_dev_probe_pack_wide   as fastf_dev_probe_pack (tile form; flags FASTF_PROBE_REUSE_HITS / _DRAW_BITS), the group word of
+ *                               every surviving record into d_keys_out[shard][..], the rest of its key into d_vals_out[shard][..]
+ *                               (same slot), d_umi_ext = bases 17.. of the UMIs or NULL;
+ *   [the caller exchanges both arrays: keys and values of shard s to rank s]
+ *   fastf_dev_adopt_wide        the n pairs this shard owns into the engine's own key store (synchronises the stream);
+ *                               fastf_engine_finish / fastf_engine_umi_rows then give this shard's rows (hashtable.c:70-115 and
+ *                               bam2db_ds.c:417-419 take any list size and UMI length; the GROUP BY of :480-483 never joins cells). */
+int fastf_engine_is_wide(const fastf_engine_t *e);
+int fastf_dev_probe_pack_wide(fastf_engine_t *e, const uint64_t *d_cb_key, const uint64_t *d_gx_key, const uint32_t *d_umi,
+                              const uint32_t *d_meta, const uint32_t *d_umi_ext, uint64_t n,
+                              const uint32_t *d_draws, uint64_t n_draws, const uint64_t *d_draw_base,
+                              uint64_t *d_keys_out, uint64_t *d_vals_out, uint64_t shard_stride, uint64_t *d_key_counts,
+                              uint64_t *d_counters, uint32_t flags, void *stream);
+int fastf_dev_adopt_wide(fastf_engine_t *e, const uint64_t *d_keys, const uint64_t *d_vals, uint64_t n, void *stream);
+
 /* K2: LSD radix sort of the low `key_bits` bits of n keys (n read from *d_n on the
  * device, at most max_n).  d_keys and d_tmp are ping-pong buffers of max_n keys;
  * *sorted_in_tmp tells where the result landed. */

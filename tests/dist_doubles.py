@@ -83,3 +83,60 @@ class NumpyStages:
         count[:z] = torch.from_numpy(cnt.astype(np.int32))
         nnz[0] = z
         return keys
+
+
+class NumpyWideStages(NumpyStages):
+    """the same chain with the key in two words (fastf_amd.dist: keys wider than 64 bits): group word = cell << feature_bits |
+    feature, value = NULL flag | UMI of up to 24 bases | blob bytes — what fastf_dev_probe_pack_wide / _adopt_wide + finish do"""
+    wide = True
+
+    def __init__(self, cell_keys, feature_keys, threshold, umi_max_bases=24):
+        assert 16 < umi_max_bases <= 24
+        super().__init__(cell_keys, feature_keys, threshold, umi_max_bases)
+
+    def probe_pack(self, *a, **k):
+        raise AssertionError("wide stages take probe_pack_wide")
+
+    def probe_pack_wide(self, cb, gx, umi, meta, ext, n, draws, draw_base, keys_out, vals_out, stride, key_counts, counters, reuse_hits=False):
+        cell = self._cells_of(cb, n)
+        hit = cell != 0
+        rank = np.cumsum(hit) - 1 + int(draw_base[0])
+        d = draws.numpy().view(np.uint32)
+        keep = hit.copy()
+        keep[hit] = d[rank[hit]].astype(np.uint64) < np.uint64(self.T) if self.T < (1 << 32) else True
+        m = meta[:n].numpy().view(np.uint32)
+        g = gx[:n].numpy().view(np.uint64)
+        feat = np.array([self.feats.get(int(x), 0) for x in g], dtype=np.int64)
+        valid = keep & ((m & META_XF_OK) != 0) & (feat != 0) & ((m & META_HAS_UB) != 0)
+        u = umi[:n].numpy().view(np.uint32).astype(np.uint64) << np.uint64(32)
+        if ext is not None:
+            u |= ext[:n].numpy().view(np.uint32).astype(np.uint64)
+        nonnull = (m & META_NONNULL) != 0
+        ln = ((m >> 4) & 15).astype(np.uint64)
+        key = (cell.astype(np.uint64) << np.uint64(self.feat_bits)) | feat.astype(np.uint64)
+        val = (np.uint64(1) << np.uint64(self.umi_bits + self.len_bits)) | ((u >> np.uint64(64 - self.umi_bits)) << np.uint64(self.len_bits)) | ln
+        val = np.where(nonnull, val, np.uint64(0))
+        G = keys_out.shape[0]
+        own = owner_of_cell(cell, G) if G > 1 else np.zeros(n, dtype=np.int64)
+        for s in range(G):
+            sel = valid & (own == s)
+            ks, vs = key[sel], val[sel]
+            c = int(key_counts[s])
+            room = max(0, min(len(ks), stride - c))
+            keys_out[s, c:c + room] = torch.from_numpy(ks[:room].view(np.int64))
+            vals_out[s, c:c + room] = torch.from_numpy(vs[:room].view(np.int64))
+            key_counts[s] = c + len(ks)
+        counters[0] += int(hit.sum()); counters[1] += int(keep.sum()); counters[2] += int(valid.sum())
+
+    def reduce_wide(self, keys, vals, n):
+        k = keys[:n].numpy().view(np.uint64)
+        v = vals[:n].numpy().view(np.uint64)
+        order = np.lexsort((v, k))
+        k, v = k[order], v[order]
+        ug = np.unique(k)
+        new = np.ones(n, dtype=bool)
+        new[1:] = (k[1:] != k[:-1]) | (v[1:] != v[:-1])
+        dist_nn = new & (v != 0)                          # a distinct non-NULL (group, value) pair
+        cnt = np.zeros(len(ug), dtype=np.int64)
+        np.add.at(cnt, np.searchsorted(ug, k[dist_nn]), 1)
+        return ((ug & np.uint64((1 << self.feat_bits) - 1)).astype(np.int64), (ug >> np.uint64(self.feat_bits)).astype(np.int64), cnt)

@@ -24,22 +24,29 @@ def _worker(rank, world, port, case_kw, q, mode="steps"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from dist_doubles import NumpyStages
+        from dist_doubles import NumpyStages, NumpyWideStages
         case = Case(**case_kw)
         lists = case.lists()
-        cbk, gxk, umi, meta = case.packed(lists)
+        if mode == "wide":
+            cbk, gxk, umi, meta, ext = case.packed_long(lists)
+        else:
+            cbk, gxk, umi, meta = case.packed(lists)
         n = case.n
         # contiguous slices of the record stream, deliberately uneven
         cuts = [0] + [int(n * (i + 1) / world * (0.8 if i % 2 == 0 and i + 1 < world else 1.0)) for i in range(world)]
         cuts[-1] = n
         a, b = cuts[rank], cuts[rank + 1]
         draws = torch.from_numpy(F.mt_draws(case.seed, lists.mt_skip, n).view(np.int32))
-        st = NumpyStages(lists.cell_keys, lists.feature_keys, F.draw_threshold(case.rate_depth))
+        st = (NumpyWideStages if mode == "wide" else NumpyStages)(lists.cell_keys, lists.feature_keys, F.draw_threshold(case.rate_depth))
         sp = ShardedPass(st, max(b - a, 1), torch.device("cpu"))
         t = lambda x: torch.from_numpy(x[a:b].copy().view(np.int64) if x.dtype == np.uint64 else x[a:b].copy().view(np.int32))
         d = (t(cbk), t(gxk), t(umi), t(meta))
         info = {}
-        if mode == "overflow":
+        if mode == "wide":
+            for _ in range(2):                                        # (a second step on the same buffers)
+                sp.run(*d, b - a, draws, umi_ext=t(ext))
+            f, c, k = sp.gather_coo()
+        elif mode == "overflow":
             os.environ["FASTF_DIST_CAP_SLACK"] = "0"
             # the capacity of the fixed-size rows is learned from a step over a tenth of the slice; the full slice then
             # outgrows it: ensure_exact() (behind every result) must notice and repeat the step the exact way
@@ -70,12 +77,14 @@ def _worker(rank, world, port, case_kw, q, mode="steps"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "steps"), (3, "steps"), (2, "overflow")])
+@pytest.mark.parametrize("world,mode", [(2, "steps"), (3, "steps"), (2, "overflow"), (2, "wide"), (3, "wide")])
 def test_sharded_pass_over_gloo(world, mode):
     """the first step learns the per-destination key counts the exact way; every later step is the fixed-capacity form:
     TWO collectives (hit counts, keys), nothing on the host that waits for the device — and the oracle's rows"""
     case_kw = dict(n=6000, n_bar=60, n_gene=25, rate_cell=0.7, rate_depth=0.6, umi_pool=40,
                    p_no_cb=0.05, p_unlisted_cb=0.1, p_bad_xf=0.1, p_n_umi=0.05, p_no_ub=0.02)
+    if mode == "wide":                       # 20-base UMIs: the key travels as (group word, value) through two exchanges
+        case_kw["umi_len"] = 20
     ora = Case(**case_kw).oracle()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -91,7 +100,7 @@ def test_sharded_pass_over_gloo(world, mode):
         assert owners_ok
         if mode == "steps":
             assert info["fixed"] and info["collectives_per_step"] == [2, 2, 2], info
-        else:
+        elif mode == "overflow":
             assert info["fixed_then_redone"] and info["redone_exactly"] and info["cap_grew"], info
         np.testing.assert_array_equal(f, ora["feature"].astype(np.int64))
         np.testing.assert_array_equal(c, ora["cell"].astype(np.int64))

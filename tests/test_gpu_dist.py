@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_kw, steps, q):
+def _worker(rank, world, port, case_kw, steps, q, umi_max=12):
     import torch
     import torch.distributed as dist
     import fastf_amd as F
@@ -30,18 +30,34 @@ def _worker(rank, world, port, case_kw, steps, q):
         torch.cuda.set_device(dev)
         case = Case(**case_kw)
         lists = case.lists()
-        cbk, gxk, umi, meta = case.packed(lists)
+        ext = None
+        if umi_max > 16:
+            cbk, gxk, umi, meta, ext = case.packed_long(lists)
+        else:
+            cbk, gxk, umi, meta = case.packed(lists)
         n = case.n
         cuts = [n * i // world for i in range(world + 1)]
         cuts[1] = int(cuts[1] * 0.7)                      # uneven slices
         a, b = cuts[rank], cuts[rank + 1]
         t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
         draws = t(F.mt_draws(case.seed, lists.mt_skip, n))
-        eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, n_shards=world, shard_rank=rank, device=0)
+        eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, n_shards=world, shard_rank=rank, device=0,
+                                  umi_max_bases=umi_max)
         eng.reserve(b - a, n)
         sp = ShardedPass(HipStages(eng, dev), max(b - a, 1), dev)
         assert sp.host_staged
         sl = [t(x[a:b].copy()) for x in (cbk, gxk, umi, meta)]
+        if eng.wide:
+            # keys wider than 64 bits: (group word, value) pairs through the exchange, the receiver's engine sorts and reduces them
+            dr = sp.prepare_draws(draws)
+            for step in range(steps):
+                sp.run(sl[0], sl[1], sl[2], sl[3], b - a, draws if step == 0 else dr, umi_ext=None if ext is None else t(ext[a:b].copy()))
+            f, c, k = sp.gather_coo()
+            lf, lc, _ = sp.local_coo()
+            owners_ok = bool((owner_of_cell(lc, world) == rank).all()) if len(lc) else True
+            q.put((rank, f, c, k, sp.global_counters(), owners_ok, 0))
+            eng.close()
+            return
         # buffers are reused across steps, as in bench.py: the first step from the SoA arrays and the 32-bit draws, the rest
         # the way bench.py --gpus N runs them — blocked records, the decision bits made once
         blk = sp.st.block(sl[1], sl[2], sl[3], b - a) if b > a else None
@@ -84,6 +100,35 @@ def test_sharded_pass_ranks_share_one_gpu(world, kw):
         np.testing.assert_array_equal(k, ora["count"].astype(np.int64))
         hits, sampled, valid, _ = counters
         assert (sampled, valid) == (ora["sampled"], ora["valid"])
+
+
+@pytest.mark.parametrize("world,umi_max,kw", [
+    (2, 16, dict(n=150_000, n_bar=210_000, n_gene=70_000, rate_depth=0.9, umi_len=16, umi_pool=4096, p_n_umi=0.01)),       # 71 key bits
+    (3, 24, dict(n=200_000, n_bar=2000, n_gene=900, rate_cell=0.7, rate_depth=0.8, umi_len=20, dup_factor=3.0, p_no_cb=0.03,
+                 p_unlisted_cb=0.05, p_bad_xf=0.1, p_n_umi=0.02)),
+    (2, 32, dict(n=120_000, n_bar=300, n_gene=100, umi_len=30, umi_pool=256, rate_depth=0.7, p_n_umi=0.05)),
+])
+def test_sharded_pass_with_keys_wider_than_64_bits(world, umi_max, kw):
+    """what the single-GPU engine takes, the sharded host path takes too (hashtable.c:70-115, bam2db_ds.c:417-419: any list size,
+    any UMI length): fastf_dev_probe_pack_wide -> two exchanges -> fastf_dev_adopt_wide + fastf_engine_finish per rank"""
+    ora = Case(**kw).oracle()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kw, 2, q, umi_max)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, f, c, k, counters, owners_ok, err in res:
+        assert owners_ok
+        np.testing.assert_array_equal(f, ora["feature"].astype(np.int64))
+        np.testing.assert_array_equal(c, ora["cell"].astype(np.int64))
+        np.testing.assert_array_equal(k, ora["count"].astype(np.int64))
+        hits, sampled, valid, errbits = counters
+        assert (sampled, valid, errbits) == (ora["sampled"], ora["valid"], 0)
 
 
 @pytest.mark.parametrize("fixed", [False, True], ids=["exact_protocol", "fixed_capacity_rows"])

@@ -449,14 +449,28 @@ def test_mixed_umi_lengths_0_to_32():
         eng.close()
 
 
-def test_wide_keys_are_refused_by_the_device_level_calls_only():
-    """a sharded engine driven through the fastf_dev_* calls takes keys of at most 64 bits: a clear refusal, not a wrong matrix
-    (the multi-device engine takes them: tests/test_gpu_multi.py::test_multi_device_wide_keys_match_oracle)"""
+def test_wide_keys_are_refused_by_the_64_bit_device_calls_only():
+    """a sharded engine may have keys wider than 64 bits (tests/test_gpu_dist.py::test_sharded_pass_with_keys_wider_than_64_bits,
+    tests/test_gpu_multi.py::test_multi_device_wide_keys_match_oracle); the fastf_dev_* calls that move ONE word per key refuse it
+    with a message, and the wide calls refuse an engine whose keys fit"""
     case = Case(n=10, n_bar=70_000, n_gene=70_000)
     lists = case.lists()
-    with pytest.raises(F.FastfError) as ei:
-        F.Engine.from_lists(lists, umi_max_bases=16, n_shards=2, shard_rank=0)
-    assert "64 bits" in str(ei.value)
+    eng = F.Engine.from_lists(lists, umi_max_bases=16, n_shards=2, shard_rank=0)
+    try:
+        assert eng.wide and eng.key_bits > 64
+        with pytest.raises(F.FastfError) as ei:
+            eng.dev_probe_pack(0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0)
+        assert "64 bits" in str(ei.value)
+    finally:
+        eng.close()
+    small = Case(n=10, n_bar=20, n_gene=10)
+    eng = F.Engine.from_lists(small.lists(), umi_max_bases=12)
+    try:
+        assert not eng.wide
+        with pytest.raises(F.FastfError):
+            eng.dev_adopt_wide(0, 0, 0)
+    finally:
+        eng.close()
 
 
 # ---- the resident single-GPU pass (what bench.py times): streaming K1b -> segmented keys -> sort through the region map ----
