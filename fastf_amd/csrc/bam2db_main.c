@@ -205,15 +205,17 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
      * shared between the host threads and the device (host_io.c: hybrid inflate, every block CRC-checked on the host) */
     /* ONE device ordinal for the reader's device side and the engine (several devices: the first of them): FASTF_DEVICES
      * ("0,1,2,3", or a count = devices 0..count-1), else FASTF_DEVICE, else device 0 */
-    int dev0 = 0;
+    int dev0 = 0, dev_second = -1;         /* dev_second: the engine's second device, for the reader's second inflate context (host_io.c) */
     {   const char *dvs = getenv("FASTF_DEVICES"), *dv1 = getenv("FASTF_DEVICE");
         if (dvs && *dvs) dev0 = strchr(dvs, ',') ? (int)strtol(dvs, NULL, 10) : 0;
+        if (dvs && *dvs) { const char *c = strchr(dvs, ','); dev_second = c ? (int)strtol(c + 1, NULL, 10) : (atoi(dvs) >= 2 ? 1 : -1); }
+        if (dev_second < 0 || dev_second > 254 || dev_second == dev0) dev_second = -1;
         else if (dv1) dev0 = atoi(dv1);
         if (dvs && *dvs && !strchr(dvs, ',') && atoi(dvs) == 1 && dv1) dev0 = atoi(dv1);      /* FASTF_DEVICES=1: one device, FASTF_DEVICE says which */
         if (dev0 < 0 || dev0 > 254) dev0 = 0; }
     {   /* | 4: the device-side parse will be asked for (below, once the lists are known) unless it is switched off */
         const char *gp = getenv("FASTF_GPU_PARSE");
-        bam = fastf_bam_open2(bam_file, 0, 1 | ((gp && gp[0] == '0') ? 0 : 4) | ((dev0 + 1) << 8));
+        bam = fastf_bam_open2(bam_file, 0, 1 | ((gp && gp[0] == '0') ? 0 : 4) | ((dev0 + 1) << 8) | ((dev_second + 1) << 16));
     }
     if (!bam) { fprintf(stderr, "Fail to open BAM file %s (%s)\n", bam_file, fastf_last_error()); goto done; }
     fprintf(stderr, "Opened BAM file %s successfully\n", bam_file);

@@ -81,7 +81,9 @@ void fastf_bam_print_profile(const fastf_bam_t *b);   /* FASTF_BAM_PROFILE=1: st
 fastf_bam_t *fastf_bam_open(const char *path, int n_threads);
 /* gpu_inflate: what to do when FASTF_GPU_INFLATE is unset — 0/-1 host threads only, 1 inflate shared with the device, 2 wait for
  * the device; | 4: the caller will call fastf_bam_enable_device_parse (nothing is pinned for copy-back windows up front);
- * | (ordinal + 1) << 8: the device the reader's device side runs on (0 in those bits: FASTF_DEVICE, else device 0) */
+ * | (ordinal + 1) << 8: the device the reader's device side runs on (0 in those bits: FASTF_DEVICE, else device 0);
+ * | (ordinal + 1) << 16: a SECOND device — the reader then keeps an inflate/parse context on each and deals its windows to them
+ *   by turns (two windows in flight; 0 in those bits: FASTF_BAM_DEVICE2, else one device) */
 fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate);
 /* Decodes up to cap records into packed SoA; returns the count, 0 at EOF, -1 on error. */
 long fastf_bam_read_batch(fastf_bam_t *b, const fastf_keydict_t *cells, const fastf_keydict_t *feats,
