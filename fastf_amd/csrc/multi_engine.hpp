@@ -39,6 +39,7 @@ struct MultiDev {
     // (mt_fill_kernel on its compute stream: a few hundred microseconds per chunk), into a ring of decisions addressed by absolute hit rank,
     // so the draws of its own chunks are there when its K1b runs and nothing about them crosses PCIe or waits for a host loop
     DevBuf d_mt, d_ring, d_mtwords; u64 ring_len = 0;
+    u32 mt_idx = MT_N;                         // where in its 624-word block this device's copy of the stream stands (launch_mt_decisions_par)
     u64* h_base[2] = {nullptr, nullptr};       // pinned: absolute hit-rank base of the chunk in that slot (copied beside the K1b launch)
     u64* h_cnt[2] = {nullptr, nullptr};        // pinned snapshot of the sub-engine's d_small behind that slot's K1a
     int next_slot = 0;
@@ -279,8 +280,11 @@ static int multi_retire_chunk(fastf_multi* m) {
                 mg.ring_len = r;
                 HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
                 HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)
+                mg.mt_idx = (u32)m->mt.idx;
             }
-            if (launch_mt_decisions(mg.e->s_compute, (u32*)mg.d_mt.p, mg.d_mtwords, (u32*)mg.d_ring.p, base, hits, mg.ring_len - 1, mg.e->threshold)) return 1;
+            // (a chunk with many hits: sub-streams seated by jump-ahead, generated by many workgroups — the device's serial
+            //  2.5 G draws/s no longer caps this form; few hits: the one-workgroup kernel)
+            if (launch_mt_decisions_par(mg.e, mg.e->s_compute, (u32*)mg.d_mt.p, &mg.mt_idx, mg.d_mtwords, (u32*)mg.d_ring.p, base, hits, mg.ring_len - 1, mg.e->threshold)) return 1;
             HIP_OK(hipGetLastError());
         }
         if (hits) m->mt_uploaded = true;

@@ -90,6 +90,21 @@ def test_multi_device_wide_keys_match_oracle(name, G):
         eng.close()
 
 
+def test_multi_device_chunks_with_millions_of_hits_use_the_parallel_generator():
+    """a chunk with more than 4 x 624 x 512 CB hits: every device continues the one MT19937 stream by jump-ahead on many
+    workgroups (launch_mt_decisions_par) — the decisions must still be the serial stream's, draw for draw (bam2db_ds.c:385)"""
+    case = Case(n=3_300_000, n_bar=500, n_gene=200, rate_cell=1.0, rate_depth=0.5, umi_pool=4096, p_bad_xf=0.05)
+    ora = case.oracle()
+    lists = case.lists()
+    cbk, gxk, umi, meta = case.packed(lists)
+    eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, umi_max_bases=12, batch_records=1_600_000, devices=[0, 0])
+    try:
+        eng.push(cbk, gxk, umi, meta)                       # two chunks of 1.6 M hits, a third of 0.1 M (the serial kernel)
+        assert_matches_oracle(eng.finish(), ora)
+    finally:
+        eng.close()
+
+
 def test_multi_device_empty_and_tiny():
     case = Case(n=10, n_bar=4, n_gene=3)
     lists = case.lists()
