@@ -26,6 +26,23 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+// rows on the host: three arrays of `cap` u32 in one allocation of 2 MiB-aligned, huge-page backed memory (fastf_big_alloc: no
+// zero fill, a page fault per 2 MiB) — what the single-device engine's own row buffer is
+struct HostRows {
+    u32* p = nullptr; u64 cap = 0;
+    int ensure(u64 n) {
+        if (n <= cap) return 0;
+        release();
+        const u64 c = n + n / 8 + 1024;
+        p = (u32*)fastf_big_alloc((size_t)c * 12);
+        if (!p) return set_err("out of memory (%llu matrix rows)", (unsigned long long)n);
+        cap = c;
+        return 0;
+    }
+    void release() { if (p) fastf_big_free(p, (size_t)cap * 12); p = nullptr; cap = 0; }
+    u32* f() const { return p; } u32* c() const { return p + cap; } u32* k() const { return p + 2 * cap; }
+};
+
 struct MultiDev {
     fastf_engine* e = nullptr;                 // sub-engine on this device: tables, workspace, streams (n_shards = G, shard_rank = g)
     int dev = 0;
@@ -52,7 +69,8 @@ struct MultiDev {
     // receive side
     DevBuf d_recv, d_tmp, d_f, d_c, d_k, d_ukeys, d_ncopy;
     u64 n_recv = 0; int sorted_in_tmp = 0; bool fully_sorted = false;
-    std::vector<u32> f, c, k;                  // this shard's rows, ascending (cell, feature)
+    HostRows rows;                             // this shard's rows, ascending (cell, feature): pf/pc/pk[0 .. nnz) — in `rows`, or
+    const u32 *pf = nullptr, *pc = nullptr, *pk = nullptr; u64 nnz = 0;     // (wide keys) the sub-engine's own row buffer
     std::vector<u64> ukeys; std::vector<u32> ncopy;
 };
 
@@ -76,7 +94,7 @@ struct fastf_multi {
     bool finished = false, aliased = false;
     bool keycount_lent = false;                                  // wide keys: the sub-engines' key-count words hold what they received (multi_finish_wide)
     int use_rccl = 0; RcclApi rccl; std::vector<ncclComm_t> comms;
-    std::vector<u32> feature, cell, count;                       // merged rows
+    HostRows merged; u64 merged_n = 0;                           // merged rows
     std::vector<u32> ufeature, ucell, uumi, ncopy; std::vector<uint8_t> unonnull;
 };
 
@@ -135,8 +153,10 @@ static void multi_destroy(fastf_engine* e) {
         multi_free_old_shards(md);
         DevBuf* all[] = {&md.d_shard, &md.d_recv, &md.d_tmp, &md.d_f, &md.d_c, &md.d_k, &md.d_ukeys, &md.d_ncopy, &md.d_mt, &md.d_ring, &md.d_mtwords};
         for (DevBuf* b : all) b->release();
+        md.rows.release();
         if (md.e) fastf_engine_destroy(md.e);
     }
+    m->merged.release();
     delete m;
     e->multi = nullptr;
 }
@@ -541,7 +561,7 @@ static int multi_finish_wide(fastf_multi* m) {
         MultiDev& mh = m->d[h];
         fastf_coo_t part;
         if (fastf_engine_finish(mh.e, &part, nullptr)) return 1;
-        mh.f.assign(part.feature, part.feature + part.nnz); mh.c.assign(part.cell, part.cell + part.nnz); mh.k.assign(part.count, part.count + part.nnz);
+        mh.pf = part.feature; mh.pc = part.cell; mh.pk = part.count; mh.nnz = part.nnz;       // (the sub-engine's buffer: valid until its reset)
     }
     m->keycount_lent = true;           // (-u rows read the same word; the next push puts K1b's count back: multi_return_keycount)
     return 0;
@@ -582,30 +602,33 @@ static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3])
             MultiDev& mh = m->d[h];
             if (mh.h_info[SM_COUNTERS + 3]) return set_err("%s", err_bits_text(mh.h_info[SM_COUNTERS + 3]));
             const u64 nnz = mh.n_recv ? mh.h_info[SM_NNZ] : 0;
-            mh.f.resize(nnz); mh.c.resize(nnz); mh.k.resize(nnz);
+            if (mh.rows.ensure(std::max<u64>(nnz, 1))) return 1;
+            mh.pf = mh.rows.f(); mh.pc = mh.rows.c(); mh.pk = mh.rows.k(); mh.nnz = nnz;
             if (nnz) {
                 HIP_OK(hipSetDevice(mh.dev));
-                HIP_OK(hipMemcpy(mh.f.data(), mh.d_f.p, nnz * 4, hipMemcpyDeviceToHost));
-                HIP_OK(hipMemcpy(mh.c.data(), mh.d_c.p, nnz * 4, hipMemcpyDeviceToHost));
-                HIP_OK(hipMemcpy(mh.k.data(), mh.d_k.p, nnz * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(mh.rows.f(), mh.d_f.p, nnz * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(mh.rows.c(), mh.d_c.p, nnz * 4, hipMemcpyDeviceToHost));
+                HIP_OK(hipMemcpy(mh.rows.k(), mh.d_k.p, nnz * 4, hipMemcpyDeviceToHost));
             }
         }
         }
         u64 total = 0;
         std::vector<const u32*> cells(G); std::vector<u64> ns(G);
-        for (u32 h = 0; h < G; ++h) { cells[h] = m->d[h].c.data(); ns[h] = m->d[h].c.size(); total += ns[h]; }
-        m->feature.resize(total); m->cell.resize(total); m->count.resize(total);
+        for (u32 h = 0; h < G; ++h) { cells[h] = m->d[h].pc; ns[h] = m->d[h].nnz; total += ns[h]; }
+        if (m->merged.ensure(std::max<u64>(total, 1))) return 1;
+        u32 *of = m->merged.f(), *oc = m->merged.c(), *ok = m->merged.k();
         u64 w = 0;
         multi_merge_by_cell(G, cells, ns, [&](u32 g, u64 a, u64 b) {
             const MultiDev& mg = m->d[g];
-            memcpy(m->feature.data() + w, mg.f.data() + a, (b - a) * 4);
-            memcpy(m->cell.data() + w, mg.c.data() + a, (b - a) * 4);
-            memcpy(m->count.data() + w, mg.k.data() + a, (b - a) * 4);
+            memcpy(of + w, mg.pf + a, (b - a) * 4);
+            memcpy(oc + w, mg.pc + a, (b - a) * 4);
+            memcpy(ok + w, mg.pk + a, (b - a) * 4);
             w += b - a;
         });
+        m->merged_n = total;
         m->finished = true;
     }
-    coo->feature = m->feature.data(); coo->cell = m->cell.data(); coo->count = m->count.data(); coo->nnz = m->feature.size();
+    coo->feature = m->merged.f(); coo->cell = m->merged.c(); coo->count = m->merged.k(); coo->nnz = m->merged_n;
     if (counters) { counters[0] = m->total_records; counters[1] = m->c_sampled; counters[2] = m->c_valid; }
     return 0;
 }

@@ -20,13 +20,15 @@ w = []
 for l in sys.stdin:
     m = re.match(r'\[bam\] ([0-9.]+) window (\d+): (\d+) blocks, (\d+) on the device in ([0-9.]+) ms(?: \(queued a window ago\))?, (\d+) on the host in ([0-9.]+) ms', l)
     if m: w.append((float(m.group(1)), int(m.group(3)), int(m.group(4)), float(m.group(5)), float(m.group(7))))
-    if l.startswith('[bam2db] lists'): tot = l.split('total so far')[1].strip()
+    if l.startswith('[bam2db] lists'): tot = l.split('total so far')[1].strip(); stages = l.strip()
+    if l.startswith('[bam2db] phases'): phases = l.strip()
     if 'device side ready' in l: ready = l.split()[1]
 if len(w) > 3:
     full = w[1:-1]                                  # between the first shared window and the last (partial) one
     blocks = sum(x[1] for x in full); span = full[-1][0] - w[0][0]
     print('   device ready %s, %d shared windows, steady state %d blocks in %.1f ms = %.0f blocks/ms (device %.0f%% of them, %.1f ms per window; host %.1f ms), total %s' % (
           ready, len(w), blocks, span * 1e3, blocks / (span * 1e3), 100.0 * sum(x[2] for x in full) / blocks, sum(x[3] for x in full) / len(full), sum(x[4] for x in full) / len(full), tot))
+    print('      ' + stages); print('      ' + phases)
 "
   done
 done
