@@ -217,7 +217,7 @@ struct fastf_gpuinf {
     hipStream_t s_parse = nullptr;
     DevBuf d_seg, d_offs, d_result, d_soa[2]; u64 soa_cap[2] = {0, 0};
     u64* h_result = nullptr;
-    u64 n_parsed_windows = 0, n_parse_fallbacks = 0;
+    u64 n_parsed_windows = 0, n_parse_fallbacks = 0, n_parse_repairs = 0;      // (repairs: segments whose chain gr_repair_kernel walked again)
 };
 
 extern "C" fastf_gpuinf_t* fastf_gpuinf_create(int device) FASTF_TRY {
@@ -490,6 +490,16 @@ extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned 
     HIP_OK(hipStreamSynchronize(s));
     g->n_parsed_windows++;
     if (g->h_result[0]) {
+        // chains that do not meet (a guessed start inside a record, a record longer than a segment): walked again from where the
+        // chain in front ends, then stitched again — the window stays on the device
+        hipLaunchKernelGGL(gr_repair_kernel, dim3(1), dim3(64), 0, s, (const uint8_t*)win, start, end, (GrSeg*)g->d_seg.p, (u32*)g->d_offs.p, n_seg, (u64*)g->d_result.p + 5);
+        hipLaunchKernelGGL(gr_stitch_kernel, dim3(1), dim3(1024), 0, s, (GrSeg*)g->d_seg.p, n_seg, end, (u64*)g->d_result.p);
+        HIP_OK(hipMemcpyAsync(g->h_result, g->d_result.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(s));
+        g->n_parse_repairs += g->h_result[5];
+    }
+    if (g->h_result[0]) {
         out->status = 1; g->n_parse_fallbacks++;
         const char* pv = getenv("FASTF_BAM_PROFILE");
         if (pv && pv[0] == '2') {                                      // where the chains parted
@@ -528,6 +538,7 @@ extern "C" int fastf_gpurec_fetch(fastf_gpuinf_t* g, int parity, unsigned char* 
     return 0;
 } FASTF_CATCH_INT
 
+extern "C" uint64_t fastf_gpurec_repairs(const fastf_gpuinf_t* g) { return g ? g->n_parse_repairs : 0; }
 extern "C" void fastf_gpurec_stats(const fastf_gpuinf_t* g, uint64_t* windows, uint64_t* fallbacks) FASTF_TRY {
     if (windows) *windows = g ? g->n_parsed_windows : 0;
     if (fallbacks) *fallbacks = g ? g->n_parse_fallbacks : 0;

@@ -372,6 +372,49 @@ __global__ __launch_bounds__(1024) void gr_stitch_kernel(GrSeg* __restrict__ seg
     }
 }
 
+// repair: one wavefront, run when the stitch found chains that do not meet.  A segment whose guessed chain start is not where
+// the chain in front of it ends (bytes inside a record that look like three records in a row; a record longer than a segment,
+// inside which no start can be guessed at all) is walked again from that end — the true chain, by induction from segment 0,
+// whose chain begins at `start` — until a segment's own guess is met again.  The scan for the next such segment takes 64
+// segments a step; the walk itself is lane 0's, serial like the chain.  gr_stitch_kernel then runs again (bases, status).
+__global__ __launch_bounds__(64) void gr_repair_kernel(const uint8_t* __restrict__ buf, uint64_t start, uint64_t end, GrSeg* __restrict__ seg,
+                                                       uint32_t* __restrict__ offs, uint32_t n_seg, unsigned long long* __restrict__ n_repaired) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t s = 1, repaired = 0;
+    while (s < n_seg) {
+        const uint32_t idx = s + (uint32_t)lane;
+        bool bad = false;
+        if (idx < n_seg) { const uint64_t f = seg[idx].first; bad = f == GR_NONE || seg[idx - 1].exit_off != f; }
+        const uint64_t m = __ballot(bad);
+        if (!m) { s += 64; continue; }
+        uint32_t sb = s + (uint32_t)__builtin_ctzll(m);
+        uint32_t next = 0;                                            // (lane 0) where the scan goes on
+        if (lane == 0) {
+            uint64_t o = seg[sb - 1].exit_off;                        // the true chain enters segment sb here
+            for (;;) {
+                const uint64_t lo = start + (uint64_t)sb * GR_SEG, hi = lo + GR_SEG < end ? lo + GR_SEG : end;
+                uint32_t* out = offs + (size_t)sb * GR_SEG_RECS;
+                const uint64_t first = o;
+                uint32_t n = 0;
+                while (o >= lo && o < hi) {                            // (o >= hi: a record that began earlier runs through the whole segment)
+                    const uint64_t e = gr::rec_end(buf, o, end);
+                    if (!e) break;
+                    out[n++] = (uint32_t)(o - lo);
+                    o = e;
+                }
+                seg[sb].first = first; seg[sb].exit_off = o; seg[sb].n = n; seg[sb].base = 0;
+                ++repaired;
+                ++sb;
+                if (sb >= n_seg || seg[sb].first == o) break;          // the next segment's own chain starts where this one ends: in step again
+            }
+            next = sb + 1;
+        }
+        s = (uint32_t)__shfl((int)next, 0, 64);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");            // lane 0's table entries, before the other lanes read them
+    }
+    if (lane == 0) *n_repaired = repaired;
+}
+
 // pack: one wavefront per segment, a lane per record
 __global__ __launch_bounds__(64) void gr_pack_kernel(const uint8_t* __restrict__ buf, uint64_t start, const GrSeg* __restrict__ seg,
                                                      const uint32_t* __restrict__ offs, gr::Dict cells, gr::Dict feats,

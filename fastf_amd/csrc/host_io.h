@@ -73,6 +73,7 @@ int  fastf_gpurec_parse(fastf_gpuinf_t *g, int parity, const unsigned char *tail
                         fastf_gpurec_result_t *out);
 int  fastf_gpurec_fetch(fastf_gpuinf_t *g, int parity, unsigned char *dst, uint64_t from, uint64_t to);
 void fastf_gpurec_stats(const fastf_gpuinf_t *g, uint64_t *windows, uint64_t *fallbacks);
+uint64_t fastf_gpurec_repairs(const fastf_gpuinf_t *g);   /* hop segments whose guessed chain did not meet the one before and were walked again on the device */
 void *fastf_pinned_alloc(size_t bytes);
 void fastf_pinned_free(void *p);
 int  fastf_pinned_register(void *p, size_t bytes);

@@ -21,6 +21,7 @@ void fastf_gpuinf_stats(const fastf_gpuinf_t *g, uint64_t *a, uint64_t *b) { (vo
 int fastf_gpurec_parse(fastf_gpuinf_t *g, int p, const unsigned char *t, size_t tl, uint64_t d, uint64_t e, uint32_t nr, const fastf_keydict_view_t *c, const fastf_keydict_view_t *f, fastf_gpurec_result_t *o) { (void)g; (void)p; (void)t; (void)tl; (void)d; (void)e; (void)nr; (void)c; (void)f; (void)o; return 1; }
 int fastf_gpurec_fetch(fastf_gpuinf_t *g, int p, unsigned char *d, uint64_t a, uint64_t b) { (void)g; (void)p; (void)d; (void)a; (void)b; return 1; }
 void fastf_gpurec_stats(const fastf_gpuinf_t *g, uint64_t *a, uint64_t *b) { (void)g; if (a) *a = 0; if (b) *b = 0; }
+uint64_t fastf_gpurec_repairs(const fastf_gpuinf_t *g) { (void)g; return 0; }
 void *fastf_pinned_alloc(size_t n) { return malloc(n); }
 void fastf_pinned_free(void *p) { free(p); }
 int fastf_pinned_register(void *p, size_t n) { (void)p; (void)n; return SAN_PINNED_REGISTER_RC; }
