@@ -153,13 +153,14 @@ typedef struct {
     uint64_t no_xf, no_gx; double t_release;
 } rel_ctx;
 
-/* the pin thread has stopped: unregister what it registered (but the first slot if it is on loan), free the slab (if not) */
+/* the pin thread has stopped: unregister what it registered (but the first keep_first slots: on loan), free the slab (if none is) */
 static void slab_release(dec_ctx *d, int keep_first)
 {
-    for (int k = keep_first ? 1 : 0; k < d->n_slots; k++)
+    for (int k = keep_first; k < d->n_slots; k++)
         if (d->pinned[k] == 1) { fastf_pinned_unregister(d->slab + (size_t)k * d->slot_bytes); d->pinned[k] = 0; }
     if (!keep_first) { fastf_big_free(d->slab, (size_t)d->n_slots * d->slot_bytes); d->slab = NULL; }
-    else fastf_big_drop(d->slab + d->slot_bytes, (size_t)(d->n_slots - 1) * d->slot_bytes);      /* the other slots' pages, at least */
+    else if (keep_first < d->n_slots)
+        fastf_big_drop(d->slab + (size_t)keep_first * d->slot_bytes, (size_t)(d->n_slots - keep_first) * d->slot_bytes);      /* the other slots' pages, at least */
 }
 static void pin_thread_stop(dec_ctx *d, pthread_t th)
 {
@@ -174,7 +175,7 @@ static void *release_main(void *vp)
     pthread_join(r->dec_thread, NULL);                  /* it has delivered its end-of-file batch and is on its way out */
     fastf_bam_stats(r->bam, NULL, &r->no_xf, &r->no_gx);
     fastf_bam_close(r->bam);                            /* prints the reader's profile lines first */
-    /* keep_first: the first slot is on loan to the engine as its row buffer until the outputs are written (bam2db() below) */
+    /* keep_first: that many slots at the front of the slab are on loan to the engine as its row buffer until the outputs are written (bam2db() below) */
     if (r->pin_started) pin_thread_stop(r->dec, r->pin_thread);
     slab_release(r->dec, r->keep_first);
     r->t_release = now_s() - t0;
@@ -336,12 +337,15 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
      * the rows at PCIe rate.  A matrix that does not fit takes the engine's own buffer. */
     const char *lr = getenv("FASTF_LEND_ROWS");                                  /* "0": the engine's own row buffer (A/B) */
     pthread_mutex_lock(&dec.mu);
-    const int first_pinned = dec.pinned[0] == 1;
+    /* (every slot the decoder reached is pinned and idle by now: all of them from the front of the slab — 12 bytes a row; a matrix
+     * of 40 M rows in pageable memory came over at 1-10 GB/s, its page faults behind the release thread's unmapping) */
+    int n_lend = 0;
+    while (n_lend < dec.n_slots && dec.pinned[n_lend] == 1) n_lend++;
     pthread_mutex_unlock(&dec.mu);
-    const int lend = first_pinned && !(lr && lr[0] == '0') && fastf_engine_lend_rows(eng, dec.slab, dec.slot_bytes) == 0;
+    const int lend = (n_lend > 0 && !(lr && lr[0] == '0') && fastf_engine_lend_rows(eng, dec.slab, (size_t)n_lend * dec.slot_bytes) == 0) ? n_lend : 0;
     rel.dec_thread = dec_thread; rel.pin_thread = pin_thread; rel.pin_started = pin_started; rel.dec = &dec; rel.bam = bam; rel.keep_first = lend;
     if (pthread_create(&rel_thread, NULL, release_main, &rel) == 0) {
-        /* the release thread stops the pin thread and gives the slab back, but for the first slot if that is on loan */
+        /* the release thread stops the pin thread and gives the slab back, but for the slots on loan */
         rel_started = 1; dec_started = 0; pin_started = 0; bam = NULL;
     }
     fastf_coo_t coo; uint64_t counters[3];
