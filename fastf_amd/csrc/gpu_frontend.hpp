@@ -43,7 +43,10 @@ __device__ __forceinline__ u32 gi_l2_load32(const uint8_t* p) {
 #endif
 constexpr int GI2_LPW = FASTF_GI2_LPW;
 static_assert(GI2_LPW >= 1 && GI2_LPW <= 64 && sizeof(gi2::Work) * GI2_LPW <= 40 * 1024, "blocks per wave: four waves' working sets share a CU's LDS");
-constexpr size_t GI2_LDS_BYTES = sizeof(gi2::Work) * GI2_LPW;
+#ifndef FASTF_GI2_LDS_MULT
+#define FASTF_GI2_LDS_MULT 1                 // (probe builds: 2 asks for twice the LDS a workgroup needs — half the blocks in flight per CU, same code)
+#endif
+constexpr size_t GI2_LDS_BYTES = sizeof(gi2::Work) * GI2_LPW * FASTF_GI2_LDS_MULT;
 #if defined(FASTF_EXPERIMENT) && defined(FASTF_X_GI2_STAMPS)
 __device__ unsigned long long gi2_stamp_acc[8];
 #endif
@@ -518,7 +521,7 @@ extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned 
     const u64 n_rec = g->h_result[1];
     if (n_rec > sc) return set_err("internal: %llu records in a window sized for %llu", (unsigned long long)n_rec, (unsigned long long)sc);
     if (n_rec) {
-        hipLaunchKernelGGL(gr_pack_kernel, dim3(n_seg), dim3(64), 0, s, (const uint8_t*)win, start, (const GrSeg*)g->d_seg.p, (const u32*)g->d_offs.p,
+        hipLaunchKernelGGL(gr_pack_kernel, dim3(n_seg), dim3(GR_PACK_THREADS), 0, s, (const uint8_t*)win, start, end, (const GrSeg*)g->d_seg.p, (const u32*)g->d_offs.p,
                            dc, df, cb, gx, umi, meta, sc, (u64*)g->d_result.p);
         HIP_OK(hipMemcpyAsync(g->h_result, g->d_result.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipGetLastError());

@@ -415,23 +415,39 @@ __global__ __launch_bounds__(64) void gr_repair_kernel(const uint8_t* __restrict
     if (lane == 0) *n_repaired = repaired;
 }
 
-// pack: one wavefront per segment, a lane per record
-__global__ __launch_bounds__(64) void gr_pack_kernel(const uint8_t* __restrict__ buf, uint64_t start, const GrSeg* __restrict__ seg,
+// pack: one workgroup (two wavefronts) per segment, a lane per record.  The segment's bytes — and GR_STAGE_OVER beyond it, for
+// the records that begin in it and end behind it — are staged in LDS with 16-byte loads first: a record is then parsed byte by
+// byte out of LDS (a lane walks ~15 tags, a few hundred dependent byte reads: from memory they were the kernel's whole time,
+// 120 GB/s of a 3 GB window).  A record that reaches beyond what is staged (longer than GR_STAGE_OVER) is read from memory.
+constexpr uint32_t GR_STAGE_OVER = 4096, GR_STAGE = GR_SEG + GR_STAGE_OVER + 16, GR_PACK_THREADS = 128;
+__global__ __launch_bounds__(GR_PACK_THREADS) void gr_pack_kernel(const uint8_t* __restrict__ buf, uint64_t start, uint64_t end, const GrSeg* __restrict__ seg,
                                                      const uint32_t* __restrict__ offs, gr::Dict cells, gr::Dict feats,
                                                      unsigned long long* __restrict__ cb_key, unsigned long long* __restrict__ gx_key,
                                                      uint32_t* __restrict__ umi, uint32_t* __restrict__ meta, uint64_t cap,
                                                      unsigned long long* __restrict__ result) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[GR_STAGE];
     const uint32_t s = blockIdx.x;
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const GrSeg g = seg[s];
+    if (g.n == 0) return;                                             // (workgroup-uniform: a segment inside one long record)
     const uint64_t lo = start + (uint64_t)s * GR_SEG;
+    // staged: [a0, a0 + n_stage) of the window, a0 = lo rounded down to 16 bytes (buf itself is an allocation's start)
+    const uint64_t a0 = lo & ~15ull;
+    const uint32_t shift = (uint32_t)(lo - a0);
+    const uint64_t want_end = lo + GR_SEG + GR_STAGE_OVER < end ? lo + GR_SEG + GR_STAGE_OVER : end;
+    const uint32_t n_stage = (uint32_t)(want_end - a0);               // <= GR_STAGE - 1
+    for (uint32_t i = threadIdx.x * 16u; i < n_stage; i += GR_PACK_THREADS * 16u)      // (the last 16 bytes may run past `end`: inside the allocation, never parsed)
+        *reinterpret_cast<uint4*>(s_buf + i) = *reinterpret_cast<const uint4*>(buf + a0 + i);
+    __syncthreads();
     const uint32_t* in = offs + (size_t)s * GR_SEG_RECS;
     uint32_t no_xf = 0, no_gx = 0;
-    for (uint32_t k = (uint32_t)lane; k < g.n; k += 64) {
+    for (uint32_t k = threadIdx.x; k < g.n; k += GR_PACK_THREADS) {
         const uint64_t i = (uint64_t)g.base + k;
         if (i >= cap) break;
         uint64_t c, x; uint32_t u, m;
-        gr::pack_record(buf + lo + in[k], cells, feats, &c, &x, &u, &m, &no_xf, &no_gx);
+        const uint32_t at = shift + in[k];                            // the record's block_size field in s_buf
+        const uint32_t bs = gr::rd32(s_buf + at);
+        if ((uint64_t)at + 4u + bs <= n_stage) gr::pack_record(s_buf + at, cells, feats, &c, &x, &u, &m, &no_xf, &no_gx);
+        else gr::pack_record(buf + lo + in[k], cells, feats, &c, &x, &u, &m, &no_xf, &no_gx);
         cb_key[i] = c; gx_key[i] = x; umi[i] = u; meta[i] = m;
     }
     if (no_xf) atomicAdd(&result[3], (unsigned long long)no_xf);
