@@ -523,7 +523,7 @@ static void copy_worker(void *vp, int widx)
 
 /* map the pages of a window's compressed bytes, every thread a stripe: the block walk that follows is serial, and on a
  * freshly mapped file it would take the window's 9 000 first-touch faults one by one (10 ms of a 25 ms window period) */
-typedef struct { const unsigned char *base; size_t len, next; unsigned sink[64]; } touch_job;
+typedef struct { const unsigned char *base; size_t len, next; unsigned sink[64]; int helpers; } touch_job;
 static void touch_worker(void *vp, int widx)
 {
     touch_job *j = (touch_job *)vp;
@@ -621,6 +621,7 @@ struct scout {
     size_t clen, pos, utotal, nblk; int eof, bad;            /* the answer */
     bgzf_blk *blk; size_t blkcap;
 };
+static void *scout_touch_main(void *vp) { touch_worker(vp, 1 + __atomic_fetch_add(&((touch_job *)vp)->helpers, 1, __ATOMIC_RELAXED)); return NULL; }
 static void *scout_main(void *vp)
 {
     struct scout *sc = (struct scout *)vp;
@@ -633,10 +634,26 @@ static void *scout_main(void *vp)
         const unsigned char *cbuf = sc->map + sc->start;
         const size_t clen = sc->map_len - sc->start < sc->wcap ? sc->map_len - sc->start : sc->wcap;
         unsigned acc = 0;
-        for (size_t o = 0; o < clen; o += 4096) acc += *(const volatile unsigned char *)(cbuf + o);
+        const double ts0 = now_s();
+        {   /* the window's pages into this process's page tables, a byte touched per page — by this thread and three helpers, a
+             * stripe each (one thread took 36-48 ms for a 190 MB window: the ceiling of a window period once the device holds 90 %
+             * of the blocks; MADV_POPULATE_READ does it in one call but keeps the address space locked meanwhile: the staging
+             * copy of the window in front went from 7 to 40-60 ms behind it: profiles/r5_notes/window_period_at_high_share.txt) */
+            enum { HELPERS = 3 };
+            touch_job tj; memset(&tj, 0, sizeof tj); tj.base = cbuf; tj.len = clen;
+            pthread_t th[HELPERS]; int started[HELPERS];
+            for (int i = 0; i < HELPERS; i++) started[i] = clen >= ((size_t)8 << 20) && pthread_create(&th[i], NULL, scout_touch_main, &tj) == 0;
+            touch_worker(&tj, 0);
+            for (int i = 0; i < HELPERS; i++) if (started[i]) pthread_join(th[i], NULL);
+            acc = tj.sink[0];
+        }
+        const double ts1 = now_s();
         const char *why = NULL;
         size_t nblk = 0, pos = 0, utotal = 0;
         const int bad = walk_blocks(cbuf, clen, &sc->blk, &sc->blkcap, &nblk, &pos, &utotal, &why) != 0;
+        { const char *pv = getenv("FASTF_BAM_PROFILE");
+          if (pv && pv[0] == '2') fprintf(stderr, "[bam] scout: %zu blocks of the window at %zu: pages mapped in %.1f ms, blocks walked in %.1f ms\n",
+                                          nblk, (size_t)sc->start, (ts1 - ts0) * 1e3, (now_s() - ts1) * 1e3); }
         pthread_mutex_lock(&sc->mu);
         sc->clen = clen; sc->pos = pos; sc->utotal = utotal; sc->nblk = nblk; sc->bad = bad + (int)(acc & 0);
         sc->eof = sc->start + clen == sc->map_len;
@@ -1134,9 +1151,10 @@ fastf_bam_t *fastf_bam_open2(const char *path, int n_threads, int gpu_inflate)
         if (b->gpu_share_max > 1.0) b->gpu_share_max = 1.0;
         b->gpu_share = sh2 ? atof(sh2) : b->gpu_share_max;
         if (b->gpu_share > b->gpu_share_max) b->gpu_share = b->gpu_share_max;
-        /* keep mode (the device parses its share too): the host threads also hop and pack beside their inflate, and the
-         * shares settle at 0.65-0.72 on the files measured — start there */
-        if (b->parse_expected && !sh2 && !sh3) b->gpu_share = 0.68; }
+        /* keep mode (the device parses its share too): the host threads also hop and pack beside their inflate.  With round 4's
+         * decoder the shares settled at 0.65-0.72; the lane decoder's time for a share barely depends on it (a block's serial
+         * latency) and the shares now settle at 0.85-0.93 — a run of a dozen windows should not spend three of them getting there */
+        if (b->parse_expected && !sh2 && !sh3) b->gpu_share = 0.85; }
     const char *w = getenv("FASTF_BAM_WINDOW");
     /* device inflate wants many blocks per launch (the chip holds 5 120 of them at once): 128 MiB windows, about 8 000
      * blocks, of which the device takes its share, unless told otherwise */
