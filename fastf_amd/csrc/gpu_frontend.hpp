@@ -481,7 +481,7 @@ extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned 
     if (gpurec_parse_buffers(g, parity, end - start)) return 1;
     hipStream_t s = g->s_parse;
     uint8_t* win = (uint8_t*)g->d_win[parity].p;
-    if (tail_len) HIP_OK(hipMemcpyAsync(win + start, tail, tail_len, hipMemcpyHostToDevice, s));
+    if (tail_len && copy_h2d_on(win + start, tail, tail_len, s)) return 1;       // (the tail lies in the reader's host window: ordinary memory)
     const u32 n_seg = (u32)((end - start + GR_SEG - 1) / GR_SEG);
     const u64 sc = g->soa_cap[parity];
     u64* cb = (u64*)g->d_soa[parity].p; u64* gx = cb + sc; u32* umi = (u32*)(gx + sc); u32* meta = umi + sc;
@@ -507,7 +507,7 @@ extern "C" int fastf_gpurec_parse(fastf_gpuinf_t* g, int parity, const unsigned 
         const char* pv = getenv("FASTF_BAM_PROFILE");
         if (pv && pv[0] == '2') {                                      // where the chains parted
             std::vector<GrSeg> hs(n_seg);
-            if (hipMemcpy(hs.data(), g->d_seg.p, (size_t)n_seg * sizeof(GrSeg), hipMemcpyDeviceToHost) == hipSuccess)
+            if (copy_d2h(hs.data(), g->d_seg.p, (size_t)n_seg * sizeof(GrSeg)) == 0)
                 for (u32 i = 0; i < n_seg; ++i)
                     if (hs[i].first == GR_NONE || (i > 0 && hs[i - 1].exit_off != hs[i].first)) {
                         fprintf(stderr, "[bam] device parse: window [%llu, %llu), %u segments: segment %u begins at %lld (lo %llu), the chain before it ends at %llu\n",
@@ -537,7 +537,7 @@ extern "C" int fastf_gpurec_fetch(fastf_gpuinf_t* g, int parity, unsigned char* 
     if (!g || parity < 0 || parity > 1 || to < from || !g->d_win[parity].p || g->d_win[parity].bytes < to) return set_err("bad fastf_gpurec_fetch arguments");
     if (to == from) return 0;
     HIP_OK(hipSetDevice(g->device));
-    HIP_OK(hipMemcpy(dst, (const uint8_t*)g->d_win[parity].p + from, (size_t)(to - from), hipMemcpyDeviceToHost));
+    if (copy_d2h(dst, (const uint8_t*)g->d_win[parity].p + from, (size_t)(to - from))) return 1;       // (dst: the reader's host window, pinned or not)
     return 0;
 } FASTF_CATCH_INT
 

@@ -298,8 +298,7 @@ static int multi_retire_chunk(fastf_multi* m) {
                 u64 r = 1024; while (r < 2 * cap) r <<= 1;
                 if (mg.d_mt.ensure(sizeof(fastf_mt_t)) || mg.d_ring.ensure(r / 8) || mg.d_mtwords.ensure(cap * 4)) return 1;   // the decision stream: one bit per rank
                 mg.ring_len = r;
-                HIP_OK(hipMemcpyAsync(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice, mg.e->s_compute));
-                HIP_OK(hipStreamSynchronize(mg.e->s_compute));                   // (m->mt is ordinary memory; once per stream position)
+                if (copy_h2d_on(mg.d_mt.p, &m->mt, sizeof(fastf_mt_t), mg.e->s_compute)) return 1;       // (m->mt is ordinary memory; once per stream position)
                 mg.mt_idx = (u32)m->mt.idx;
             }
             // (a chunk with many hits: sub-streams seated by jump-ahead, generated by many workgroups — the device's serial
@@ -606,9 +605,7 @@ static int multi_finish(fastf_engine* e, fastf_coo_t* coo, uint64_t counters[3])
             mh.pf = mh.rows.f(); mh.pc = mh.rows.c(); mh.pk = mh.rows.k(); mh.nnz = nnz;
             if (nnz) {
                 HIP_OK(hipSetDevice(mh.dev));
-                HIP_OK(hipMemcpy(mh.rows.f(), mh.d_f.p, nnz * 4, hipMemcpyDeviceToHost));
-                HIP_OK(hipMemcpy(mh.rows.c(), mh.d_c.p, nnz * 4, hipMemcpyDeviceToHost));
-                HIP_OK(hipMemcpy(mh.rows.k(), mh.d_k.p, nnz * 4, hipMemcpyDeviceToHost));
+                if (copy_d2h(mh.rows.f(), mh.d_f.p, nnz * 4) || copy_d2h(mh.rows.c(), mh.d_c.p, nnz * 4) || copy_d2h(mh.rows.k(), mh.d_k.p, nnz * 4)) return 1;
             }
         }
         }
@@ -687,8 +684,7 @@ static int multi_umi_rows(fastf_engine* e, fastf_umi_rows_t* rows) {
         const u64 nr = mh.h_info[SM_NROWS_U];
         mh.ukeys.resize(nr); mh.ncopy.resize(nr);
         if (nr) {
-            HIP_OK(hipMemcpy(mh.ukeys.data(), mh.d_ukeys.p, nr * 8, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(mh.ncopy.data(), mh.d_ncopy.p, nr * 4, hipMemcpyDeviceToHost));
+            if (copy_d2h(mh.ukeys.data(), mh.d_ukeys.p, nr * 8) || copy_d2h(mh.ncopy.data(), mh.d_ncopy.p, nr * 4)) return 1;
         }
         ucell[h].resize(nr);
         for (u64 i = 0; i < nr; ++i) ucell[h][i] = (u32)(mh.ukeys[i] >> e->L.cell_shift);

@@ -277,10 +277,10 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
         HIP_OK(hipMemcpyAsync(&m1, d_m1, sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         h->h_key1.resize(m1); h->h_count1.resize(m1); h->h_first1.resize(m1); h->h_tmp32.resize(m1);
-        HIP_OK(hipMemcpy(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64), hipMemcpyDeviceToHost));
-        HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_c1.p, m1 * sizeof(u32), hipMemcpyDeviceToHost));
+        if (copy_d2h(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64))) return 1;
+        if (copy_d2h(h->h_tmp32.data(), h->d_c1.p, m1 * sizeof(u32))) return 1;
         { u64* dst = h->h_count1.data(); const u32* src = h->h_tmp32.data(); th_par_for(m1, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
-        HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_first.p, m1 * sizeof(u32), hipMemcpyDeviceToHost));
+        if (copy_d2h(h->h_tmp32.data(), h->d_first.p, m1 * sizeof(u32))) return 1;
         { u64* dst = h->h_first1.data(); const u32* src = h->h_tmp32.data(); th_par_for(m1, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
         // the absent records were counted under the fill key
         const u64 n_absent = n - h->n_present1;
@@ -317,14 +317,14 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
     HIP_OK(hipMemcpyAsync(&mp, d_mp, sizeof(u64), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     h->h_key1.resize(m1); h->h_u2.resize(m2); h->h_up.resize(mp);
-    HIP_OK(hipMemcpy(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(h->h_u2.data(), h->d_u2.p, m2 * sizeof(u64), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(h->h_up.data(), h->d_up.p, mp * sizeof(u64), hipMemcpyDeviceToHost));
+    if (copy_d2h(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64))) return 1;
+    if (copy_d2h(h->h_u2.data(), h->d_u2.p, m2 * sizeof(u64))) return 1;
+    if (copy_d2h(h->h_up.data(), h->d_up.p, mp * sizeof(u64))) return 1;
     h->h_pair_count.resize(mp); h->h_pair_first.resize(mp); h->h_pair_k1.resize(mp); h->h_pair_key2.resize(mp);
     h->h_tmp32.resize(mp);
-    HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_cp.p, mp * sizeof(u32), hipMemcpyDeviceToHost));
+    if (copy_d2h(h->h_tmp32.data(), h->d_cp.p, mp * sizeof(u32))) return 1;
     { u64* dst = h->h_pair_count.data(); const u32* src = h->h_tmp32.data(); th_par_for(mp, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
-    HIP_OK(hipMemcpy(h->h_tmp32.data(), h->d_first.p, mp * sizeof(u32), hipMemcpyDeviceToHost));
+    if (copy_d2h(h->h_tmp32.data(), h->d_first.p, mp * sizeof(u32))) return 1;
     { u64* dst = h->h_pair_first.data(); const u32* src = h->h_tmp32.data(); th_par_for(mp, [=](u64 lo, u64 hi) { for (u64 i = lo; i < hi; ++i) dst[i] = src[i]; }); }
     const u64 n_invalid = n - h->n_valid;
     if (n_invalid) {

@@ -108,6 +108,60 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// ---- pageable host memory and the HIP runtime ----
+// Host memory the runtime has not been told about (malloc, std::vector, the caller's arrays) is never handed to hipMemcpy*: it
+// goes through a pinned bounce buffer of the library's own.  For such memory the runtime pins the range on the fly and KEEPS the
+// pin in a small per-queue cache keyed by address; it does not hear about free(), and when the allocator hands the same addresses
+// out again a later copy finds the stale pin: a device-to-host copy into memory that had once been the SOURCE of a host-to-device
+// copy died with "Memory access fault ... Write access to a read-only page" at a heap address (round 5, twice in a row in
+// test_engine_matches_oracle[c5_like] — the barcode table of 100 k entries uploaded from a std::vector at create, the rows copied
+// into the recycled chunk at finish; the same suite with GPU_PINNED_MIN_XFER_SIZE raised so that nothing is pinned on the fly:
+// green.  profiles/r5_notes/stale_pin_fault.txt).  These copies are off the hot path: tables at create, rows of a first finish
+// into a buffer that is not pinned yet, -u rows, the carried-over tail of a reader window.
+struct HostBounce {
+    static constexpr size_t BYTES = (size_t)8 << 20;
+    std::mutex mu; void* p = nullptr;
+    int ready() {                                       // (caller holds mu)
+        if (p) return 0;
+        if (hipHostMalloc(&p, BYTES, hipHostMallocPortable) != hipSuccess) { p = nullptr; return set_err("hipHostMalloc(bounce buffer) failed: %s", hipGetErrorString(hipGetLastError())); }
+        return 0;
+    }
+};
+static HostBounce g_bounce;
+// synchronous; the current device must be the one d_dst / d_src lives on
+static int copy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_bounce.mu);
+    if (g_bounce.ready()) return 1;
+    for (size_t o = 0; o < bytes; o += HostBounce::BYTES) {
+        const size_t n = std::min(bytes - o, HostBounce::BYTES);
+        memcpy(g_bounce.p, (const char*)h_src + o, n);
+        HIP_OK(hipMemcpy((char*)d_dst + o, g_bounce.p, n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+static int copy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_bounce.mu);
+    if (g_bounce.ready()) return 1;
+    for (size_t o = 0; o < bytes; o += HostBounce::BYTES) {
+        const size_t n = std::min(bytes - o, HostBounce::BYTES);
+        HIP_OK(hipMemcpy(g_bounce.p, (const char*)d_src + o, n, hipMemcpyDeviceToHost));
+        memcpy((char*)h_dst + o, g_bounce.p, n);
+    }
+    return 0;
+}
+// the same onto stream s (and waited for: the bounce buffer is free again when this returns)
+static int copy_h2d_on(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_bounce.mu);
+    if (g_bounce.ready()) return 1;
+    for (size_t o = 0; o < bytes; o += HostBounce::BYTES) {
+        const size_t n = std::min(bytes - o, HostBounce::BYTES);
+        memcpy(g_bounce.p, (const char*)h_src + o, n);
+        HIP_OK(hipMemcpyAsync((char*)d_dst + o, g_bounce.p, n, hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 struct KernelTimer {           // optional per-kernel HIP-event timing (bench roofline leg)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -258,7 +312,7 @@ static int build_table(const u64* keys, u32 n, DevBuf& buf, Table& t, const char
         }
     }
     if (buf.ensure((size_t)cap * sizeof(uint4))) return 1;
-    HIP_OK(hipMemcpy(buf.p, slots.data(), (size_t)cap * sizeof(uint4), hipMemcpyHostToDevice));
+    if (copy_h2d(buf.p, slots.data(), (size_t)cap * sizeof(uint4))) return 1;
     t.slots = (const uint4*)buf.p;
     t.mask = cap - 1;
     return 0;
@@ -278,7 +332,7 @@ static int build_cell_filter(fastf_engine* e, const u64* keys, u32 n) {
     std::vector<u32> w(bits / 32, 0u);
     for (u32 i = 0; i < n; ++i) { const u32 b = h_filter_bit(keys[i]) & (bits - 1); w[b >> 5] |= 1u << (b & 31); }
     if (e->d_cell_filter.ensure(bits / 8)) return 1;
-    HIP_OK(hipMemcpy(e->d_cell_filter.p, w.data(), bits / 8, hipMemcpyHostToDevice));
+    if (copy_h2d(e->d_cell_filter.p, w.data(), bits / 8)) return 1;
     e->cell_filter.bits = (const u32*)e->d_cell_filter.p; e->cell_filter.mask = bits - 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_filtered_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(bits / 8)) != hipSuccess) { e->cell_filter.bits = nullptr; }
@@ -360,7 +414,7 @@ static int build_cell_lds(fastf_engine* e, const u64* keys, u32 n) {
     CellImage ci;
     if (!make_cell_image(keys, n, ci)) return 0;
     if (e->img_cells.ensure(ci.img.size())) return 1;
-    HIP_OK(hipMemcpy(e->img_cells.p, ci.img.data(), ci.img.size(), hipMemcpyHostToDevice));
+    if (copy_h2d(e->img_cells.p, ci.img.data(), ci.img.size())) return 1;
     e->lds_cells.image = (const u32*)e->img_cells.p; e->lds_cells.slot_bits = ci.slot_bits; e->lds_cells.bucket_mask = ci.bucket_mask;
     e->lds_cells.family = ci.family; e->lds_cells.bytes = ci.bytes; e->lds_cells.seed = ci.seed;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(probe_cells_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -424,7 +478,7 @@ static int build_gene_lds(fastf_engine* e, const u64* keys, u32 n) {
         for (u32 w = 0; w < words; ++w) { rank[w] = (unsigned short)acc; acc += (u32)__builtin_popcount(bitmap[w]); }
     }
     if (e->img_genes.ensure(bytes)) return 1;
-    HIP_OK(hipMemcpy(e->img_genes.p, img.data(), bytes, hipMemcpyHostToDevice));
+    if (copy_h2d(e->img_genes.p, img.data(), bytes)) return 1;
     e->lds_genes.image = (const u32*)e->img_genes.p; e->lds_genes.words = words; e->lds_genes.n_perm = (u32)best_n;
     e->lds_genes.family = (u32)best; e->lds_genes.vmin = vmin; e->lds_genes.range = range; e->lds_genes.bytes = (u32)bytes; e->lds_genes.direct = direct ? 1u : 0u;
     {
@@ -855,7 +909,7 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
     if (!e->d_mtpoly.p) {                                      // the polynomials: constants of the generator (mt_jump.c), once per engine
         static_assert(MT_POLY_WORDS == FASTF_MT_POLY_WORDS && MT_SUB_DRAWS == FASTF_MT_SUB_DRAWS, "kernel and table agree");
         if (e->d_mtpoly.ensure((size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64))) return 1;
-        HIP_OK(hipMemcpy(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64), hipMemcpyHostToDevice));
+        if (copy_h2d(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64))) return 1;
         HIP_OK(hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_JUMP_LDS_WORDS * sizeof(u32))));
     }
     u32* const w = (u32*)words.p;
@@ -893,8 +947,7 @@ extern "C" int fastf_dev_mt_decisions(fastf_engine_t* e, uint32_t seed, uint64_t
     fastf_mt_t mt; fastf_mt_seed(&mt, seed); fastf_mt_skip(&mt, skip);
     // (the seated state goes into the first slot of the sub-stream array's tail: a buffer the engine keeps)
     if (e->d_mtseat.ensure(sizeof mt)) return 1;
-    HIP_OK(hipMemcpyAsync(e->d_mtseat.p, &mt, sizeof mt, hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_OK(hipStreamSynchronize((hipStream_t)stream));                    // (mt is on this stack)
+    if (copy_h2d_on(e->d_mtseat.p, &mt, sizeof mt, (hipStream_t)stream)) return 1;
     u32 idx = (u32)mt.idx;
     if (launch_mt_decisions_par(e, (hipStream_t)stream, (u32*)e->d_mtseat.p, &idx, e->d_mtwords, d_bits_out, 0, n_draws, ~0ull, e->threshold)) return 1;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return set_err("the generator kernels failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1646,8 +1699,8 @@ static int rebase_store(fastf_engine* e) {
     if (grow_regions(e, R)) return 1;
     std::vector<u64> phys(R), cnt(R);
     for (u32 i = 0; i < R; ++i) { phys[i] = (u64)i * RUN; cnt[i] = std::min<u64>(RUN, n - phys[i]); }
-    HIP_OK(hipMemcpy(e->d_rgn_phys.p, phys.data(), R * sizeof(u64), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(e->d_segcount.p, cnt.data(), R * sizeof(u64), hipMemcpyHostToDevice));
+    if (copy_h2d(e->d_rgn_phys.p, phys.data(), R * sizeof(u64))) return 1;
+    if (copy_h2d(e->d_segcount.p, cnt.data(), R * sizeof(u64))) return 1;
     hipLaunchKernelGGL(rgn_hist_kernel, dim3(std::min<u32>(R, 8 * g_cu_count)), dim3(256), 0, e->s_compute, (const u64*)e->d_keys.p, (const u64*)e->d_rgn_phys.p,
                        (const u64*)e->d_segcount.p, R, e->skip_bits, (u32*)e->d_rgn_hist.p);
     HIP_OK(hipGetLastError());
@@ -1697,7 +1750,7 @@ static int push_impl(fastf_engine_t* e, const fastf_batch_t* batch, const uint32
             // (the generator's scratch for the most ranks one launch can be asked for — everything the ring holds — so that no
             //  push stops to grow it)
             if (e->d_mt.ensure(sizeof(fastf_mt_t)) || e->d_mtwords.ensure(e->ring_len * 4)) return 1;
-            HIP_OK(hipMemcpy(e->d_mt.p, &e->mt, sizeof(fastf_mt_t), hipMemcpyHostToDevice));
+            if (copy_h2d(e->d_mt.p, &e->mt, sizeof(fastf_mt_t))) return 1;
             e->mt_dev_idx = (u32)e->mt.idx;
             e->mt_on_device = true;
         }
@@ -1728,14 +1781,14 @@ extern "C" int fastf_debug_mt_fill(int device, uint32_t seed, uint64_t skip, con
     int rc = 0;
     do {
         if (st.ensure(sizeof mt) || buf.ensure(std::max<u64>(total, 1) * 4)) { rc = 1; break; }
-        if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess) { rc = set_err("copy failed"); break; }
+        if (copy_h2d(st.p, &mt, sizeof mt)) { rc = 1; break; }
         u64 at = 0;
         for (u32 i = 0; i < n_calls; ++i) {
             hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, (hipStream_t)0, (u32*)st.p, (u32*)buf.p, at, counts[i], ~0ull);
             at += counts[i];
         }
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
-        if (total && hipMemcpy(out, buf.p, total * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy back failed"); break; }
+        if (total && copy_d2h(out, buf.p, total * 4)) { rc = 1; break; }
     } while (0);
     st.release(); buf.release();
     return rc;
@@ -1753,14 +1806,14 @@ extern "C" int fastf_debug_mt_fill_bits(int device, uint32_t seed, uint64_t skip
     int rc = 0;
     do {
         if (st.ensure(sizeof mt) || buf.ensure(ring_bits / 8)) { rc = 1; break; }
-        if (hipMemcpy(st.p, &mt, sizeof mt, hipMemcpyHostToDevice) != hipSuccess || hipMemset(buf.p, 0xFF, ring_bits / 8) != hipSuccess) { rc = set_err("copy failed"); break; }
+        if (copy_h2d(st.p, &mt, sizeof mt) || hipMemset(buf.p, 0xFF, ring_bits / 8) != hipSuccess) { rc = set_err("copy failed"); break; }
         u64 at = first;
         for (u32 i = 0; i < n_calls; ++i) {
             if (launch_mt_decisions((hipStream_t)0, (u32*)st.p, words, (u32*)buf.p, at, counts[i], ring_bits - 1, threshold)) { rc = 1; break; }
             at += counts[i];
         }
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { rc = set_err("mt_fill_kernel failed"); break; }
-        if (hipMemcpy(out, buf.p, ring_bits / 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy back failed"); break; }
+        if (copy_d2h(out, buf.p, ring_bits / 8)) { rc = 1; break; }
     } while (0);
     st.release(); buf.release(); words.release();
     return rc;
@@ -1930,9 +1983,8 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
                 if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, h_f, h_c, h_k, nullptr, s)) return 1;
             } else {
                 if (launch_rows_gather<false>(e, small + SM_KEYCOUNT, (u32*)e->d_feature.p, (u32*)e->d_cell.p, (u32*)e->d_count.p, nullptr, s)) return 1;
-                HIP_OK(hipMemcpyAsync(h_f, e->d_feature.p, nnz * 4, hipMemcpyDeviceToHost, s));
-                HIP_OK(hipMemcpyAsync(h_c, e->d_cell.p, nnz * 4, hipMemcpyDeviceToHost, s));
-                HIP_OK(hipMemcpyAsync(h_k, e->d_count.p, nnz * 4, hipMemcpyDeviceToHost, s));
+                HIP_OK(hipStreamSynchronize(s));               // (the gather; the row buffer is ordinary memory: through the bounce buffer)
+                if (copy_d2h(h_f, e->d_feature.p, nnz * 4) || copy_d2h(h_c, e->d_cell.p, nnz * 4) || copy_d2h(h_k, e->d_count.p, nnz * 4)) return 1;
             }
             HIP_OK(hipStreamSynchronize(s));
         }
@@ -1990,9 +2042,7 @@ static int umi_rows_wide(fastf_engine* e, fastf_umi_rows_t* rows) {
             if (nrows > n) { rc = set_err("internal error: %llu -u rows out of %llu keys", (unsigned long long)nrows, (unsigned long long)n); break; }
             uk.resize(nrows); uv.resize(nrows); e->h_ncopy.resize(nrows);
             if (nrows) {
-                if (hipMemcpy(uk.data(), e->d_ukeys.p, nrows * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                    hipMemcpy(uv.data(), uvals, nrows * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                    hipMemcpy(e->h_ncopy.data(), e->d_ncopy.p, nrows * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = set_err("copy of the -u rows failed"); break; }
+                if (copy_d2h(uk.data(), e->d_ukeys.p, nrows * 8) || copy_d2h(uv.data(), uvals, nrows * 8) || copy_d2h(e->h_ncopy.data(), e->d_ncopy.p, nrows * 4)) { rc = 1; break; }
             }
         } while (0);
         cnt.release(); base.release();
@@ -2056,8 +2106,7 @@ extern "C" int fastf_engine_umi_rows(fastf_engine_t* e, fastf_umi_rows_t* rows) 
         ukeys.resize(nrows);
         e->h_ncopy.resize(nrows);
         if (nrows) {
-            HIP_OK(hipMemcpy(ukeys.data(), e->d_ukeys.p, nrows * 8, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(e->h_ncopy.data(), e->d_ncopy.p, nrows * 4, hipMemcpyDeviceToHost));
+            if (copy_d2h(ukeys.data(), e->d_ukeys.p, nrows * 8) || copy_d2h(e->h_ncopy.data(), e->d_ncopy.p, nrows * 4)) return 1;
         }
     } else {
         e->h_ncopy.clear();
