@@ -312,7 +312,7 @@ static int gpuinf_crc_table(fastf_gpuinf_t* g) {
     if (g->d_crctab.p) return 0;
     uint32_t t[288]; gr_crc_tables(t);
     if (g->d_crctab.ensure(sizeof t)) return 1;
-    HIP_OK(hipMemcpy(g->d_crctab.p, t, sizeof t, hipMemcpyHostToDevice));
+    if (copy_h2d(g->d_crctab.p, t, sizeof t)) return 1;
     return 0;
 }
 static int gpurec_parse_buffers(fastf_gpuinf_t* g, int parity, u64 bytes) {       // for a parse over `bytes` of window
@@ -447,8 +447,18 @@ extern "C" int fastf_gpuinf_wait(fastf_gpuinf_t* g, uint8_t* status, double* dev
 
 extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, const fastf_gpuinf_blk_t* blk, size_t n,
                                 unsigned char* out, uint8_t* status) FASTF_TRY {
-    if (fastf_gpuinf_submit(g, comp, blk, n, out)) return 1;
-    return fastf_gpuinf_wait(g, status, nullptr);
+    // (tests and tools call this with ordinary memory; the reader's own buffers are pinned.  Registered for the call: the runtime
+    //  is told about the ranges instead of pinning them on the fly behind our back — umi_engine.hip, "pageable host memory")
+    size_t cend = 0, uend = 0;
+    for (size_t i = 0; i < n; ++i) { cend = std::max<size_t>(cend, blk[i].coff + blk[i].clen); uend = std::max<size_t>(uend, blk[i].uoff + blk[i].isize); }
+    const bool reg_c = g && n && cend && hipHostRegister((void*)comp, cend, hipHostRegisterDefault) == hipSuccess;
+    const bool reg_u = g && n && uend && hipHostRegister((void*)out, uend, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();                                            // (already registered by the caller: fine)
+    int rc = fastf_gpuinf_submit(g, comp, blk, n, out);
+    if (!rc) rc = fastf_gpuinf_wait(g, status, nullptr);
+    if (reg_c) (void)hipHostUnregister((void*)comp);
+    if (reg_u) (void)hipHostUnregister((void*)out);
+    return rc;
 } FASTF_CATCH_INT
 
 // ---- second stage: record hop + tag extraction + key packing on the window buffer of `parity` (keep mode) ----
