@@ -568,9 +568,17 @@ extern "C" int fastf_engine_create(const fastf_engine_config_t* cfg, fastf_engin
 
     int rc = 0;
     do {
-        if (hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&e->s_copy, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&e->s_mt, hipStreamNonBlocking) != hipSuccess ||
+        // (FASTF_STREAM_PRIORITY=1: the engine's streams at the device's highest priority, so that a push's K1 kernels get the next free
+        //  CU in front of the reader's queued inflate workgroups.  Measured twice on the 80 M-record file: 1022 against 933 blocks/ms
+        //  in one session, 1007 against 1018 in the next, the device side ready 0.1 s later — a knob, off:
+        //  profiles/r5_notes/window_period_at_high_share.txt)
+        int prio_lo = 0, prio_hi = 0;
+        const char* sp = getenv("FASTF_STREAM_PRIORITY");
+        const bool high = sp && sp[0] == '1' && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_hi != prio_lo;
+        auto mk = [&](hipStream_t* s) { return high ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(s, hipStreamNonBlocking); };
+        if (mk(&e->s_compute) != hipSuccess ||
+            mk(&e->s_copy) != hipSuccess ||
+            mk(&e->s_mt) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_mt, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->slot[0].ev_copy, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->slot[1].ev_copy, hipEventDisableTiming) != hipSuccess ||
