@@ -40,7 +40,7 @@ import torch  # noqa: E402  (before fastf_amd: one shared HIP runtime)
 import torch.distributed as dist  # noqa: E402
 
 import fastf_amd as F  # noqa: E402
-from fastf_amd import workload  # noqa: E402
+from fastf_amd import hostmem, workload  # noqa: E402
 from fastf_amd.dist import HipStages, ShardedPass  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -128,7 +128,7 @@ def main():
     job._pool = None
     torch.cuda.empty_cache()
     draws_h = F.mt_draws(workload.SEED, lists.mt_skip, N_total)      # job-wide draw stream: draw i belongs to the i-th CB hit
-    d_draws = torch.from_numpy(draws_h.view(np.int32)).to(dev)
+    d_draws = hostmem.to_device(draws_h, dev)                         # (pinned staging: fastf_amd/hostmem.py)
     torch.cuda.synchronize()
     if rank == 0:
         log("bench: job generated in %.1f s (%d records per rank)" % (time.perf_counter() - t_gen, n_local))
@@ -399,7 +399,7 @@ def cpu_leg(job, dev, local, n_seg):
     pack_ok = True
     for s_ in range(n_seg):
         a, b = s_ * job.seg_len, (s_ + 1) * job.seg_len
-        c, g, u, m = (t.cpu().numpy() for t in job.segment_packed(s_, dev))
+        c, g, u, m = (hostmem.to_host(t) for t in job.segment_packed(s_, dev))
         nn = (meta[a:b] & 4) != 0
         pack_ok = pack_ok and (np.array_equal(cbk[a:b].view(np.int64), c) and np.array_equal(gxk[a:b].view(np.int64), g)
                                and np.array_equal(meta[a:b].view(np.int32), m) and np.array_equal(umi[a:b].view(np.int32)[nn], u[nn]))

@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "fastf_keydict_pack_many",
     "fastf_engine_create", "fastf_engine_destroy", "fastf_engine_push", "fastf_engine_push_draws",
     "fastf_engine_push_pinned", "fastf_engine_wait_input",
-    "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister",
+    "fastf_pinned_alloc", "fastf_pinned_free", "fastf_pinned_register", "fastf_pinned_unregister", "fastf_debug_live_registrations", "fastf_pick_devices",
     "fastf_engine_finish", "fastf_engine_lend_rows", "fastf_engine_umi_rows", "fastf_engine_reset", "fastf_engine_key_bits",
     "fastf_engine_skip_bits", "fastf_engine_sort_passes", "fastf_engine_table_modes", "fastf_engine_cell_scratch_bytes",
     "fastf_dev_count_hits", "fastf_dev_count_hits_blocked", "fastf_dev_block_bytes", "fastf_dev_block_records", "fastf_dev_set_regions", "fastf_dev_draw_bits", "fastf_dev_mt_decisions", "fastf_dev_probe_pack", "fastf_dev_probe_pack_wide", "fastf_dev_adopt_wide", "fastf_engine_is_wide", "fastf_dev_probe_capacity", "fastf_dev_sort", "fastf_dev_reduce", "fastf_dev_rows_gather", "fastf_engine_device_records",
@@ -105,15 +105,43 @@ ABI_SYMBOLS = [
 ]
 
 
+def _one_hip_runtime():
+    """ONE HIP runtime per process.  The torch wheel bundles its own libamdhip64.so (soname libamdhip64.so.7, the soname this
+    library needs too): whichever of the two is loaded first decides which runtime the OTHER gets — torch first, and this
+    library binds to torch's copy by soname; this library first, and it brings in /opt/rocm's copy, after which `import torch`
+    loads its bundled one BESIDE it (torch asks for the file name libamdhip64.so, which no loaded soname matches): two HIP
+    runtimes, two HSA runtimes, one GPU address space.  So: if torch is installed but not imported yet, its runtime is loaded
+    here first (the file only — torch itself is not imported), and the order of imports stops mattering."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FASTF_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
+def hip_runtimes_loaded():
+    """paths of every libamdhip64 mapped into this process (one, if all is well)"""
+    with open("/proc/self/maps") as f:
+        return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+
+
 def lib():
-    """Load the shared library.  torch (if it is going to be used in this process) must be
-    imported BEFORE this call so both share one HIP runtime (same libamdhip64 soname)."""
+    """Load the shared library (one HIP runtime per process: _one_hip_runtime)."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(_LIB):
         raise FastfError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(there is no Python/CPU fallback for the engine)" % _LIB)
+    _one_hip_runtime()
     L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
     vp, u64, u32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t
     L.fastf_last_error.restype = C.c_char_p

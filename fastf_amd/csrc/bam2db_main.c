@@ -182,6 +182,26 @@ static void *release_main(void *vp)
     return NULL;
 }
 
+/* Which device(s) a run uses.  FASTF_DEVICES = "a,b,.." (explicit ordinals: the first is the engine's and the reader's device, the
+ * second the one a second inflate context may use) or a count n (devices 0..n-1; n == 1: one device, FASTF_DEVICE says which);
+ * without FASTF_DEVICES, FASTF_DEVICE; without both, device 0.  Exported for the host-only test of the parsing. */
+void fastf_pick_devices(const char *devices, const char *device, int *dev0, int *dev_second)
+{
+    int d0 = 0, d2 = -1;
+    if (devices && *devices) {
+        const char *c = strchr(devices, ',');
+        if (c) { d0 = (int)strtol(devices, NULL, 10); d2 = (int)strtol(c + 1, NULL, 10); }
+        else {
+            const int n = atoi(devices);
+            if (n >= 2) d2 = 1;                                    /* devices 0..n-1 */
+            else if (device) d0 = atoi(device);                    /* one device: FASTF_DEVICE says which */
+        }
+    } else if (device) d0 = atoi(device);
+    if (d0 < 0 || d0 > 254) d0 = 0;
+    if (d2 < 0 || d2 > 254 || d2 == d0) d2 = -1;
+    *dev0 = d0; *dev_second = d2;
+}
+
 static uint32_t bits_for(uint64_t v) { uint32_t b = 0; while (b < 64 && (v >> b)) b++; return b ? b : 1; }
 
 /* umi_bases: 0 = choose (16 bases if the packed key then fits 64 bits, else 12 with a second run at 16 — keys wider than 64
@@ -208,12 +228,7 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
      * ("0,1,2,3", or a count = devices 0..count-1), else FASTF_DEVICE, else device 0 */
     int dev0 = 0, dev_second = -1;         /* dev_second: the engine's second device, for the reader's second inflate context (host_io.c) */
     {   const char *dvs = getenv("FASTF_DEVICES"), *dv1 = getenv("FASTF_DEVICE");
-        if (dvs && *dvs) dev0 = strchr(dvs, ',') ? (int)strtol(dvs, NULL, 10) : 0;
-        if (dvs && *dvs) { const char *c = strchr(dvs, ','); dev_second = c ? (int)strtol(c + 1, NULL, 10) : (atoi(dvs) >= 2 ? 1 : -1); }
-        if (dev_second < 0 || dev_second > 254 || dev_second == dev0) dev_second = -1;
-        else if (dv1) dev0 = atoi(dv1);
-        if (dvs && *dvs && !strchr(dvs, ',') && atoi(dvs) == 1 && dv1) dev0 = atoi(dv1);      /* FASTF_DEVICES=1: one device, FASTF_DEVICE says which */
-        if (dev0 < 0 || dev0 > 254) dev0 = 0; }
+        fastf_pick_devices(dvs, dv1, &dev0, &dev_second); }
     {   /* | 4: the device-side parse will be asked for (below, once the lists are known) unless it is switched off */
         const char *gp = getenv("FASTF_GPU_PARSE");
         bam = fastf_bam_open2(bam_file, 0, 1 | ((gp && gp[0] == '0') ? 0 : 4) | ((dev0 + 1) << 8) | ((dev_second + 1) << 16));
@@ -244,7 +259,7 @@ static int bam2db_run(char *bam_file, char *path_out, char *barcodes_file, char 
      * it, so that the engine copies the packed records to the device straight from where the decoder wrote them */
     /* UMIs beyond 16 bases (the third attempt of bam2db(), or FASTF_UMI_MAX_BASES): the slots carry a fifth array, the host packs */
     const int long_umis = umi_bases > 16 || (getenv("FASTF_UMI_MAX_BASES") && atoi(getenv("FASTF_UMI_MAX_BASES")) > 16);
-    dec.n_slots = DEC_SLOTS; dec.slot_bytes = cap * (long_umis ? 28 : 24);
+    dec.n_slots = DEC_SLOTS; dec.slot_bytes = (cap * (long_umis ? 28 : 24) + 4095) & ~(size_t)4095;     /* whole pages: two slots' registrations never share one */
     if (!(dec.slab = (unsigned char *)fastf_big_alloc((size_t)dec.n_slots * dec.slot_bytes))) { fprintf(stderr, "out of memory\n"); goto done; }
     for (int k = 0; k < dec.n_slots; k++) {
         unsigned char *base = dec.slab + (size_t)k * dec.slot_bytes;

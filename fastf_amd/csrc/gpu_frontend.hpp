@@ -451,13 +451,12 @@ extern "C" int fastf_gpuinf_run(fastf_gpuinf_t* g, const unsigned char* comp, co
     //  is told about the ranges instead of pinning them on the fly behind our back — umi_engine.hip, "pageable host memory")
     size_t cend = 0, uend = 0;
     for (size_t i = 0; i < n; ++i) { cend = std::max<size_t>(cend, blk[i].coff + blk[i].clen); uend = std::max<size_t>(uend, blk[i].uoff + blk[i].isize); }
-    const bool reg_c = g && n && cend && hipHostRegister((void*)comp, cend, hipHostRegisterDefault) == hipSuccess;
-    const bool reg_u = g && n && uend && hipHostRegister((void*)out, uend, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();                                            // (already registered by the caller: fine)
+    const bool reg_c = g && n && cend && pin_reg((void*)comp, cend + 64) == 0;   // (+ 64: the submit copies the readable slack behind the last block too)
+    const bool reg_u = g && n && uend && pin_reg((void*)out, uend) == 0;
     int rc = fastf_gpuinf_submit(g, comp, blk, n, out);
     if (!rc) rc = fastf_gpuinf_wait(g, status, nullptr);
-    if (reg_c) (void)hipHostUnregister((void*)comp);
-    if (reg_u) (void)hipHostUnregister((void*)out);
+    if (reg_c) pin_unreg((void*)comp);
+    if (reg_u) pin_unreg((void*)out);
     return rc;
 } FASTF_CATCH_INT
 

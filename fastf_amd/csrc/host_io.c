@@ -290,24 +290,99 @@ static inline uint32_t rd16(const unsigned char *p) { return (uint32_t)p[0] | (u
 
 #define NX_RESERVE ((size_t)1 << 20)
 
-/* Big, short-lived host buffers (the reader's window buffers, the decoder's SoA slab) are 2 MiB aligned and ask for
- * transparent huge pages: a window buffer is 640 MB that 16 threads touch for the first time while they inflate into it
- * (0.13 s of 4 KiB page faults per GB, 0.04 s with huge pages) and that the process gives back at its end (0.06-0.13 s per
- * GB against 0.04 s) — tools/thp_probe.c.  Released with free().  FASTF_THP=0: ordinary pages. */
+/* Big host buffers (the reader's window buffers, the decoder's SoA slab, the engines' row buffers) are mappings of their own,
+ * never pieces of the malloc heap:
+ *  - they are the host memory the GPU gets to see (hipHostRegister pins them in place; the row gather writes them); a range
+ *    that goes back to malloc is handed out again to somebody else — a numpy array, a torch CPU tensor — at the same address,
+ *    and whatever the runtime still believed about that address would then be about the wrong memory.  A private mapping is
+ *    unmapped when it is released and its addresses stay out of malloc's hands;
+ *  - they ask for transparent huge pages (a window buffer is 640 MB that 16 threads touch for the first time while they
+ *    inflate into it: 0.13 s of 4 KiB page faults per GB, 0.04 s with huge pages; tools/thp_probe.c), and MADV_HUGEPAGE is a
+ *    property of the ADDRESS RANGE that outlives free(): on heap memory it made every later tenant of those addresses a
+ *    candidate for khugepaged's collapses (each one stalls the GPU queues of the process for tens of ms when the range is
+ *    GPU-visible: tools/pin_probe.hip collapse).  On a mapping of its own the mark goes with the mapping.
+ * 2 MiB aligned, page-granular, zero filled by the kernel on first touch.  FASTF_THP=0: ordinary pages. */
+/* ---- ledger of the host ranges the HIP runtime has been told about (hipHostRegister through umi_engine.hip's pin_reg) ----
+ * A registration must end before its memory does: a range that is unmapped (or whose pages are dropped) while registered leaves the
+ * runtime with an entry for addresses that the next mapping there inherits — hipPointerGetAttributes still calls them registered
+ * (tools/pin_probe.hip facts, step 3), and a copy into them is then issued against a GPU mapping that no longer has pages.  Every
+ * release of a big buffer is checked against the ledger; FASTF_DEBUG_PINS=1 turns a violation into abort(). */
+typedef struct { uintptr_t a, b; } pin_range;
+static pin_range g_pins[256];
+static pthread_mutex_t g_pins_mu = PTHREAD_MUTEX_INITIALIZER;
+static int pins_debug(void) { static int v = -1; if (v < 0) { const char *e = getenv("FASTF_DEBUG_PINS"); v = e && e[0] == '1'; } return v; }
+void fastf_pin_ledger_add(const void *p, size_t bytes)
+{
+    pthread_mutex_lock(&g_pins_mu);
+    for (int i = 0; i < (int)(sizeof g_pins / sizeof g_pins[0]); i++) if (!g_pins[i].a) { g_pins[i].a = (uintptr_t)p; g_pins[i].b = (uintptr_t)p + bytes; break; }
+    pthread_mutex_unlock(&g_pins_mu);
+}
+int fastf_pin_ledger_remove(const void *p)
+{
+    int found = 0;
+    pthread_mutex_lock(&g_pins_mu);
+    for (int i = 0; i < (int)(sizeof g_pins / sizeof g_pins[0]); i++) if (g_pins[i].a == (uintptr_t)p) { g_pins[i].a = g_pins[i].b = 0; found = 1; break; }
+    pthread_mutex_unlock(&g_pins_mu);
+    if (!found && pins_debug()) { fprintf(stderr, "fastf: INTERNAL ERROR: unregistering %p, which the ledger does not hold\n", p); abort(); }
+    return found;
+}
+int fastf_pin_ledger_live(void)
+{
+    int n = 0;
+    pthread_mutex_lock(&g_pins_mu);
+    for (int i = 0; i < (int)(sizeof g_pins / sizeof g_pins[0]); i++) n += g_pins[i].a != 0;
+    pthread_mutex_unlock(&g_pins_mu);
+    return n;
+}
+/* [p, p + bytes) is about to be unmapped / dropped: no live registration may touch one of its pages */
+static void pin_ledger_check_release(const void *p, size_t bytes, const char *what)
+{
+    const uintptr_t a = (uintptr_t)p & ~(uintptr_t)4095, b = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+    uintptr_t ra = 0, rb = 0;
+    pthread_mutex_lock(&g_pins_mu);
+    for (int i = 0; i < (int)(sizeof g_pins / sizeof g_pins[0]); i++)
+        if (g_pins[i].a && (g_pins[i].a & ~(uintptr_t)4095) < b && a < ((g_pins[i].b + 4095) & ~(uintptr_t)4095)) { ra = g_pins[i].a; rb = g_pins[i].b; break; }
+    pthread_mutex_unlock(&g_pins_mu);
+    if (!ra) return;
+    fprintf(stderr, "fastf: INTERNAL ERROR: %s of [%p, +%zu) while [%#lx, %#lx) inside it is still registered with the HIP runtime\n", what, p, bytes, (unsigned long)ra, (unsigned long)rb);
+    if (pins_debug()) abort();
+}
+
+typedef struct { void *p; void *base; size_t len; } big_map;
+static big_map g_big[128];
+static pthread_mutex_t g_big_mu = PTHREAD_MUTEX_INITIALIZER;
+
 void *fastf_big_alloc(size_t bytes)
 {
-    void *p = NULL;
-    if (bytes < ((size_t)4 << 20)) return malloc(bytes);
-    if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) return NULL;
-    const char *t = getenv("FASTF_THP");
-    if (!(t && t[0] == '0')) (void)madvise(p, bytes, MADV_HUGEPAGE);
+    if (!bytes) bytes = 1;
+    const size_t huge = (size_t)2 << 20;
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    const size_t pad = want >= huge ? huge : 0;                      /* small buffers: page aligned is all they need */
+    void *m = mmap(NULL, want + pad, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return NULL;
+    char *p = (char *)m;
+    if (pad) {
+        p = (char *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
+        /* the unaligned head and what is left of the pad behind the buffer go back right away */
+        if (p > (char *)m) (void)munmap(m, (size_t)(p - (char *)m));
+        char *end = p + want, *mend = (char *)m + want + pad;
+        if (mend > end) (void)munmap(end, (size_t)(mend - end));
+        const char *t = getenv("FASTF_THP");
+        if (!(t && t[0] == '0')) (void)madvise(p, want, MADV_HUGEPAGE);
+    }
+    pthread_mutex_lock(&g_big_mu);
+    int slot = -1;
+    for (int i = 0; i < (int)(sizeof g_big / sizeof g_big[0]); i++) if (!g_big[i].p) { slot = i; break; }
+    if (slot >= 0) { g_big[slot].p = p; g_big[slot].base = p; g_big[slot].len = want; }
+    pthread_mutex_unlock(&g_big_mu);
+    if (slot < 0) { (void)munmap(p, want); return NULL; }
     return p;
 }
 
-/* Give such a buffer back.  free() alone is one munmap that holds the address-space lock for writing while a gigabyte of
- * pages is returned (13 ms per 640 MB window buffer): every page fault and every malloc of the other threads — the gzip
- * writers run beside the reader's release — waits for it.  MADV_DONTNEED returns the pages under the READ lock, slice by
- * slice; the munmap behind it finds nothing left to do. */
+/* Give such a buffer back.  One munmap of a gigabyte holds the address-space lock for writing while the pages are returned
+ * (13 ms per 640 MB window buffer): every page fault and every malloc of the other threads — the gzip writers run beside the
+ * reader's release — waits for it.  MADV_DONTNEED returns the pages under the READ lock, slice by slice; the munmap behind it
+ * finds nothing left to do. */
 typedef struct { char *p; size_t bytes, next; } zap_job;
 static void *zap_main(void *vp)
 {
@@ -320,29 +395,35 @@ static void *zap_main(void *vp)
     }
     return NULL;
 }
-/* the pages of [p, p + bytes) go back, the range stays allocated (part of a bigger buffer that is still in use elsewhere) */
-void fastf_big_drop(void *p, size_t bytes)
+static void zap_pages(void *p, size_t bytes)
 {
-    if (!p || ((uintptr_t)p & 4095) != 0) return;
     zap_job j = { (char *)p, bytes & ~(size_t)4095, 0 };
     pthread_t th[3]; int n = 0;
+    /* (the read lock lets several threads return pages at once: four of them for the big buffers) */
     if (bytes >= ((size_t)128 << 20)) for (; n < 3; n++) if (pthread_create(&th[n], NULL, zap_main, &j) != 0) break;
     zap_main(&j);
     for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
 }
+/* the pages of [p, p + bytes) go back, the range stays allocated (part of a bigger buffer that is still in use elsewhere) */
+void fastf_big_drop(void *p, size_t bytes)
+{
+    if (!p || ((uintptr_t)p & 4095) != 0) return;
+    pin_ledger_check_release(p, bytes & ~(size_t)4095, "fastf_big_drop");
+    zap_pages(p, bytes);
+}
+/* bytes: what the caller asked fastf_big_alloc for (kept for the callers' sake; the mapping's own length decides) */
 void fastf_big_free(void *p, size_t bytes)
 {
+    (void)bytes;
     if (!p) return;
-    if (bytes >= ((size_t)4 << 20) && ((uintptr_t)p & 4095) == 0) {
-        /* (the read lock lets several threads return pages at once: four of them for the big buffers) */
-        /* whole pages inside the buffer only: madvise rounds a length UP, and the page behind a heap chunk is not ours */
-        zap_job j = { (char *)p, bytes & ~(size_t)4095, 0 };
-        pthread_t th[3]; int n = 0;
-        if (bytes >= ((size_t)128 << 20)) for (; n < 3; n++) if (pthread_create(&th[n], NULL, zap_main, &j) != 0) break;
-        zap_main(&j);
-        for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
-    }
-    free(p);
+    size_t len = 0;
+    pthread_mutex_lock(&g_big_mu);
+    for (int i = 0; i < (int)(sizeof g_big / sizeof g_big[0]); i++) if (g_big[i].p == p) { len = g_big[i].len; g_big[i].p = NULL; break; }
+    pthread_mutex_unlock(&g_big_mu);
+    if (len) pin_ledger_check_release(p, len, "fastf_big_free");
+    if (!len) { free(p); return; }                                   /* not one of ours: ordinary heap memory (the host-only reader's small window) */
+    if (len >= ((size_t)4 << 20)) zap_pages(p, len);
+    (void)munmap(p, len);
 }
 
 static int host_threads(int asked)
@@ -484,13 +565,12 @@ static void *gpu_init_main(void *vp)
      * steady state gains 4-8 % (750-772 against 691-745 blocks/ms) and the start-up loses 0.2 s, because this context's
      * reservations (hipMalloc of two window buffers and the parse buffers) hold the runtime's lock against the first shared
      * windows' submits; the gain is what a 10 GB file would keep and a 1 GB file does not. */
-    /* A second DEVICE (bam2db() with FASTF_DEVICES=a,b,..: the flags' bits 16..23) gets the second context: the windows then
-     * alternate between two GPUs — each inflates, checks and parses every other window in its own memory, the packed records
-     * go to the engine's devices from there (device-to-device).  Unmeasured on two GPUs (one-GPU boxes here); with both
-     * contexts on one device it is the path above. */
+    /* With FASTF_BAM_EARLY=1 and a second DEVICE (bam2db() with FASTF_DEVICES=a,b,..: the flags' bits 16..23, or FASTF_BAM_DEVICE2)
+     * the second context lives there: the windows then alternate between two GPUs — each inflates, checks and parses every other
+     * window in its own memory, the packed records go to the engine's devices from there (device-to-device).  Opt-in only: it
+     * has never run on two GPUs (one-GPU boxes here); with both contexts on one device it is the path above. */
     { const char *ev = getenv("FASTF_BAM_EARLY");
-      const int second_dev = b->gpu_device2 >= 0 && b->gpu_device2 != b->gpu_device;
-      if (g && b->parse_expected && b->map && ((ev && ev[0] == '1') || (second_dev && !(ev && ev[0] == '0')))) {
+      if (g && b->parse_expected && b->map && ev && ev[0] == '1') {
           fastf_gpuinf_t *g2 = fastf_gpuinf_create(b->gpu_device2 >= 0 ? b->gpu_device2 : b->gpu_device);
           if (g2) {
               b->gcomp2 = (unsigned char *)fastf_pinned_alloc(b->ccap + 4096);
@@ -858,7 +938,7 @@ static int fill_next(fastf_bam_t *b)
         }
         if (NX_RESERVE + utotal > b->ncap) {
             gpu_quiesce(b);
-            b->ncap = (NX_RESERVE + utotal) * 5 / 4 + (1 << 20); pin_drop(b, b->nbuf); free(b->nbuf); b->nbuf = (unsigned char *)fastf_big_alloc(b->ncap);
+            b->ncap = (NX_RESERVE + utotal) * 5 / 4 + (1 << 20); pin_drop(b, b->nbuf); fastf_big_free(b->nbuf, 0); b->nbuf = (unsigned char *)fastf_big_alloc(b->ncap);
             if (!b->nbuf) { b->ncap = 0; io_err("out of memory (inflate window of %zu bytes)", NX_RESERVE + utotal); return -1; }
         }
         if (b->map && !b->file_eof) {
@@ -1077,7 +1157,7 @@ static int bam_fill(fastf_bam_t *b)
         memcpy(nb, b->ubuf + b->upos, tail);
         memcpy(nb + tail, b->nbuf + NX_RESERVE, data);
         gpu_quiesce(b);
-        pin_drop(b, b->nbuf); free(b->nbuf); b->nbuf = nb; b->ncap = tail + data + (1 << 20); b->nlen = tail + data;
+        pin_drop(b, b->nbuf); fastf_big_free(b->nbuf, 0); b->nbuf = nb; b->ncap = tail + data + (1 << 20); b->nlen = tail + data;
         start = 0;
     }
     unsigned char *tb = b->ubuf; size_t tc = b->ucap;

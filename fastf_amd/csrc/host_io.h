@@ -143,11 +143,16 @@ void fastf_pack_records(const fastf_keydict_t *cells, const fastf_keydict_t *fea
 #ifdef __cplusplus
 }
 #endif
-/* 2 MiB-aligned allocation that asks for transparent huge pages (big short-lived buffers); release with free() */
+/* host buffers the GPU may get to see, and big short-lived ones: private mappings (never malloc heap), page granular, 2 MiB aligned
+ * with transparent huge pages from 2 MiB on; release with fastf_big_free() only (host_io.c) */
 void fastf_par_run(int n_threads, void (*fn)(void *, int), void *arg);   /* fn(arg, worker index) on n_threads threads, joined */
 int  fastf_host_thread_count(void);                                      /* FASTF_HOST_THREADS, else the cores (at most 16) */
+/* ledger of live hipHostRegister ranges (host_io.c): every release of a big buffer is checked against it */
+void  fastf_pin_ledger_add(const void *p, size_t bytes);
+int   fastf_pin_ledger_remove(const void *p);     /* 1 if the ledger held it */
+int   fastf_pin_ledger_live(void);
 void *fastf_big_alloc(size_t bytes);
 void  fastf_big_drop(void *p, size_t bytes);      /* pages back, range stays allocated */
-void  fastf_big_free(void *p, size_t bytes);      /* pages back slice by slice (MADV_DONTNEED), then free() */
+void  fastf_big_free(void *p, size_t bytes);      /* pages back slice by slice (MADV_DONTNEED), then munmap; heap memory passed here is free()d */
 
 #endif

@@ -108,16 +108,42 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
-// ---- pageable host memory and the HIP runtime ----
-// Host memory the runtime has not been told about (malloc, std::vector, the caller's arrays) is never handed to hipMemcpy*: it
-// goes through a pinned bounce buffer of the library's own.  For such memory the runtime pins the range on the fly and KEEPS the
-// pin in a small per-queue cache keyed by address; it does not hear about free(), and when the allocator hands the same addresses
-// out again a later copy finds the stale pin: a device-to-host copy into memory that had once been the SOURCE of a host-to-device
-// copy died with "Memory access fault ... Write access to a read-only page" at a heap address (round 5, twice in a row in
-// test_engine_matches_oracle[c5_like] — the barcode table of 100 k entries uploaded from a std::vector at create, the rows copied
-// into the recycled chunk at finish; the same suite with GPU_PINNED_MIN_XFER_SIZE raised so that nothing is pinned on the fly:
-// green.  profiles/r5_notes/stale_pin_fault.txt).  These copies are off the hot path: tables at create, rows of a first finish
-// into a buffer that is not pinned yet, -u rows, the carried-over tail of a reader window.
+// ---- host memory and the HIP runtime ----
+// Three rules, each with its own mechanism:
+//  1. Host memory the runtime has not been told about (malloc, std::vector, the caller's arrays) is never handed to hipMemcpy*: it
+//     goes through a pinned bounce buffer of the library's own.  For unknown memory of a megabyte or more the runtime pins the range
+//     on the fly, has the GPU read or write the caller's pages directly and lets go again; all three GPU memory faults of rounds
+//     5/6 were GPU writes to heap addresses while such a copy was running (profiles/r6_notes/gpu_fault_chain.md).  Off the hot
+//     path: tables at create, rows of a first finish into a buffer that is not pinned yet, -u rows, a reader window's tail.
+//  2. Every hipHostRegister / hipHostUnregister of the library goes through pin_reg / pin_unreg below and so through the ledger
+//     of host_io.c: a registered range is never released (fastf_big_free / fastf_big_drop check), the ledger is empty when the
+//     last handle is gone (tests/test_gpu_parity.py::test_no_registration_outlives_its_buffer).
+//  3. Registered memory is a mapping of its own (fastf_big_alloc), never a piece of the malloc heap.
+// FASTF_DEBUG_PINS=1: a ledger violation aborts, and every ABI entry that takes pinned host pointers (fastf_engine_push_pinned,
+// fastf_engine_lend_rows, fastf_dev_rows_gather) asks the runtime whether it knows the memory (hipPointerGetAttributes).
+static int pin_reg(void* p, size_t bytes) {
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    fastf_pin_ledger_add(p, bytes);
+    return 0;
+}
+static void pin_unreg(void* p) {
+    if (!p) return;
+    (void)fastf_pin_ledger_remove(p);
+    if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+}
+static bool pins_debug() { static const bool v = [] { const char* e = getenv("FASTF_DEBUG_PINS"); return e && e[0] == '1'; }(); return v; }
+// debug builds of a run: [p, p + bytes) must be memory the runtime knows (pinned host or device memory)
+static int debug_known_memory(const void* p, size_t bytes, const char* what) {
+    if (!pins_debug() || !p || !bytes) return 0;
+    for (const char* q : {(const char*)p, (const char*)p + bytes - 1}) {
+        hipPointerAttribute_t a; memset(&a, 0, sizeof a);
+        if (hipPointerGetAttributes(&a, q) != hipSuccess || a.type == hipMemoryTypeUnregistered) {
+            (void)hipGetLastError();
+            return set_err("FASTF_DEBUG_PINS: %s: %p (+%zu) is host memory the HIP runtime has not been told about", what, p, bytes);
+        }
+    }
+    return 0;
+}
 struct HostBounce {
     static constexpr size_t BYTES = (size_t)8 << 20;
     std::mutex mu; void* p = nullptr;
@@ -637,7 +663,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
         if (e->t_ev[i]) (void)hipEventDestroy(e->t_ev[i]);
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
-    if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
+    if (e->h_coo) { if (e->h_coo_pinned) pin_unreg(e->h_coo); fastf_big_free(e->h_coo, (size_t)e->h_coo_cap * 12); }
     e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release(); e->d_mtsub.release(); e->d_mtpoly.release(); e->d_mtseat.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
@@ -1381,6 +1407,7 @@ extern "C" int fastf_dev_rows_gather(fastf_engine_t* e, const uint64_t* d_n, uin
     if (!e) return set_err("null engine");
     if (e->multi) return set_err("fastf_dev_rows_gather: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
+    if (debug_known_memory(feature, 4, "fastf_dev_rows_gather feature") || debug_known_memory(cell, 4, "fastf_dev_rows_gather cell") || debug_known_memory(count, 4, "fastf_dev_rows_gather count")) return 1;
     return launch_rows_gather<false>(e, (const u64*)d_n, feature, cell, count, nullptr, (hipStream_t)stream);
 } FASTF_CATCH_INT
 
@@ -1837,6 +1864,9 @@ extern "C" int fastf_engine_push_draws(fastf_engine_t* e, const fastf_batch_t* b
 } FASTF_CATCH_INT
 
 extern "C" int fastf_engine_push_pinned(fastf_engine_t* e, const fastf_batch_t* batch) FASTF_TRY {
+    if (batch && batch->n && (debug_known_memory(batch->cb_key, batch->n * 8, "fastf_engine_push_pinned cb_key") || debug_known_memory(batch->gx_key, batch->n * 8, "fastf_engine_push_pinned gx_key") ||
+                              debug_known_memory(batch->umi, batch->n * 4, "fastf_engine_push_pinned umi") || debug_known_memory(batch->meta, batch->n * 4, "fastf_engine_push_pinned meta")))
+        return 1;
     return push_impl(e, batch, nullptr, 0, true);
 } FASTF_CATCH_INT
 
@@ -1855,10 +1885,11 @@ extern "C" void* fastf_pinned_alloc(size_t bytes) FASTF_TRY {
 } FASTF_CATCH_ZERO
 extern "C" void fastf_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 extern "C" int fastf_pinned_register(void* p, size_t bytes) FASTF_TRY {
-    HIP_OK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    if (pin_reg(p, bytes)) return set_err("hipHostRegister of %zu bytes at %p failed", bytes, p);
     return 0;
 } FASTF_CATCH_INT
-extern "C" void fastf_pinned_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
+extern "C" void fastf_pinned_unregister(void* p) { pin_unreg(p); }
+extern "C" int fastf_debug_live_registrations(void) { return fastf_pin_ledger_live(); }
 
 // Engines with sub-groups (umi_max_bases > 24): K3's rows are one per (cell, feature, first bases of the UMI), the sorted word split
 // into two halves at row_split, ascending.  One row per (cell, feature), the counts summed: UMIs of different sub-groups differ.
@@ -1972,14 +2003,14 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             e->rows_at = e->lent_rows; e->rows_stride = e->lent_cap;
         } else {
             if (nnz > e->h_coo_cap) {
-                if (e->h_coo) { if (e->h_coo_pinned) (void)hipHostUnregister(e->h_coo); free(e->h_coo); }
+                if (e->h_coo) { if (e->h_coo_pinned) pin_unreg(e->h_coo); fastf_big_free(e->h_coo, (size_t)e->h_coo_cap * 12); }
                 e->h_coo = nullptr; e->h_coo_cap = 0; e->h_coo_pinned = false; e->h_coo_uses = 0;
                 const u64 cap = nnz + nnz / 8 + 1024;
                 void* m = fastf_big_alloc((size_t)cap * 12);               // 2 MiB aligned, transparent huge pages (host_io.c)
                 if (!m) return set_err("out of memory (%llu matrix rows)", (unsigned long long)nnz);
                 e->h_coo = (u32*)m; e->h_coo_cap = cap;
             }
-            if (!e->h_coo_pinned && e->h_coo && e->h_coo_uses++ >= 1 && hipHostRegister(e->h_coo, (size_t)e->h_coo_cap * 12, hipHostRegisterDefault) == hipSuccess)
+            if (!e->h_coo_pinned && e->h_coo && e->h_coo_uses++ >= 1 && pin_reg(e->h_coo, (size_t)e->h_coo_cap * 12) == 0)
                 e->h_coo_pinned = true;
             e->rows_at = e->h_coo; e->rows_stride = e->h_coo_cap;
         }
@@ -2185,6 +2216,7 @@ extern "C" int fastf_engine_lend_rows(fastf_engine_t* e, void* pinned, size_t by
     if (e->multi) return 0;                                  // the multi-device merge writes its own buffer
     if (e->finished) return set_err("fastf_engine_lend_rows: the rows of this pass are out already (reset first)");
     if (!pinned || bytes < 12 || ((uintptr_t)pinned & 3u)) { e->lent_rows = nullptr; e->lent_cap = 0; return pinned ? set_err("fastf_engine_lend_rows: needs 4-byte aligned memory of at least 12 bytes") : 0; }
+    if (debug_known_memory(pinned, bytes, "fastf_engine_lend_rows")) return 1;
     e->lent_rows = (u32*)pinned; e->lent_cap = bytes / 12;
     return 0;
 } FASTF_CATCH_INT

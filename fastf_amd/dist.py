@@ -45,6 +45,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .hostmem import copy_into, to_device, to_host, to_host_tensor
+
 
 def owner_of_cell(cell_index: np.ndarray, n_shards: int) -> np.ndarray:
     """host mirror of shard_of() in umi_kernels.hpp (murmur3 finaliser, top 32 bits, mod G)"""
@@ -278,11 +280,11 @@ class ShardedPass:
             st.count_hits(cb, n, self.hits)
         if self.pipelined and self.host_small:                               # gloo: host integers
             all_h = torch.empty(G, dtype=torch.int64)
-            self._gather_small(all_h, self.hits.cpu())
+            self._gather_small(all_h, to_host_tensor(self.hits))
             self.draw_base.fill_(int(all_h[:self.rank].sum()))
             st.probe_pack(cb, gx, umi, meta, n, draws, self.draw_base, self.keys_out, self.stride,
                           self.key_counts, self.counters, reuse_hits=True)
-            send = self.key_counts.cpu()
+            send = to_host_tensor(self.key_counts)
             recv = torch.empty(G, dtype=torch.int64)
             self._exchange_small(recv, send)
             return send.tolist(), recv.tolist()
@@ -486,9 +488,9 @@ class ShardedPass:
     def _all_gather(self, out, inp):
         self.n_collectives += 1
         if self.host_staged:
-            o = out.cpu()
-            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
-            out.copy_(o)
+            o = to_host_tensor(out)
+            dist.all_gather_into_tensor(o, to_host_tensor(inp), group=self.group)
+            copy_into(out, o)
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 
@@ -496,8 +498,8 @@ class ShardedPass:
         self.n_collectives += 1
         if self.host_staged:
             o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
-            out.copy_(o)
+            dist.all_to_all_single(o, to_host_tensor(inp), out_splits, in_splits, group=self.group)
+            copy_into(out, o)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
@@ -505,9 +507,9 @@ class ShardedPass:
         self.n_collectives += 1
         op = dist.ReduceOp.SUM if op is None else op
         if self.host_staged:
-            h = t.cpu()
+            h = to_host_tensor(t)
             dist.all_reduce(h, op=op, group=self.group)
-            t.copy_(h)
+            copy_into(t, h)
         else:
             dist.all_reduce(t, op=op, group=self.group)
 
@@ -553,8 +555,8 @@ class ShardedPass:
             return self._wide_rows
         self.gather_rows()
         z = int(self.nnz.item())
-        return (self.feature[:z].cpu().numpy().astype(np.int64), self.cell[:z].cpu().numpy().astype(np.int64),
-                self.count[:z].cpu().numpy().astype(np.int64))
+        return (to_host(self.feature[:z]).astype(np.int64), to_host(self.cell[:z]).astype(np.int64),
+                to_host(self.count[:z]).astype(np.int64))
 
     def gather_coo(self):
         """All shards' rows on every rank, merged into the reference order (cell, feature)."""
@@ -566,12 +568,12 @@ class ShardedPass:
         self._all_gather(zs, z)
         zmax = int(zs.max().item())
         pad = torch.zeros((3, zmax), dtype=torch.int64, device=self.dev)
-        pad[0, :len(f)] = torch.from_numpy(f).to(self.dev)
-        pad[1, :len(f)] = torch.from_numpy(c).to(self.dev)
-        pad[2, :len(f)] = torch.from_numpy(k).to(self.dev)
+        pad[0, :len(f)] = to_device(f, self.dev)
+        pad[1, :len(f)] = to_device(c, self.dev)
+        pad[2, :len(f)] = to_device(k, self.dev)
         allp = torch.zeros((self.G, 3, zmax), dtype=torch.int64, device=self.dev)
         self._all_gather(allp.view(-1), pad.view(-1))
-        allp, zs = allp.cpu().numpy(), zs.cpu().numpy()
+        allp, zs = to_host(allp), to_host(zs)
         F = np.concatenate([allp[g, 0, :zs[g]] for g in range(self.G)])
         Cc = np.concatenate([allp[g, 1, :zs[g]] for g in range(self.G)])
         K = np.concatenate([allp[g, 2, :zs[g]] for g in range(self.G)])
@@ -584,5 +586,5 @@ class ShardedPass:
         if self.G > 1 and not self._counters_reduced:
             self._all_reduce(self.counters[:3])
             self._counters_reduced = True
-        c = self.counters.cpu().numpy()
+        c = to_host(self.counters)
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])

@@ -60,7 +60,8 @@ class C3:
         import torch
         if self._pool is None:
             g = torch.Generator(device=dev); g.manual_seed(1000 + self.pool_seed)
-            ccdf = torch.from_numpy(self.cell_cdf).to(dev); gcdf = torch.from_numpy(self.gene_cdf).to(dev)
+            from .hostmem import to_device
+            ccdf = to_device(self.cell_cdf, dev); gcdf = to_device(self.gene_cdf, dev)
             u = torch.rand(self.n_mol, device=dev, dtype=torch.float64, generator=g)
             cell = torch.searchsorted(ccdf, u).clamp_(max=N_BARCODES - 1).to(torch.int32)
             u = torch.rand(self.n_mol, device=dev, dtype=torch.float64, generator=g)
@@ -92,8 +93,9 @@ class C3:
         """packed SoA of a segment on the device: cb_key i64, gx_key i64, umi i32, meta i32 (bit patterns of u64/u32)"""
         import torch
         c, g, u, kind, alt = self.segment_indices(seg, dev, n)
-        ck = torch.from_numpy(self.all_lists.cell_keys.view(np.int64)).to(dev)
-        fk = torch.from_numpy(self.all_lists.feature_keys.view(np.int64)).to(dev)
+        from .hostmem import to_device
+        ck = to_device(self.all_lists.cell_keys, dev)
+        fk = to_device(self.all_lists.feature_keys, dev)
         cb = ck[c.long()]
         cb = torch.where((kind & 2) != 0, (alt << 16) | self.cb_family, cb)
         cb = torch.where((kind & 1) != 0, torch.zeros_like(cb), cb)
@@ -107,7 +109,8 @@ class C3:
     # ---- the same records as strings (CPU oracle sample) ----
     def segment_strings(self, seg, dev, n):
         """(flags u8, xf i32, cb S, gx S, ub S) of the first n records of a segment, as oracle/fastf_oracle.c takes them"""
-        c, g, u, kind, alt = (t.cpu().numpy() for t in self.segment_indices(seg, dev, n))
+        from .hostmem import to_host
+        c, g, u, kind, alt = (to_host(t) for t in self.segment_indices(seg, dev, n))
         cb = self.bar[c].copy()
         un = (kind & 2) != 0
         if un.any():
@@ -153,8 +156,8 @@ class C2:
         import torch
         n = self.seg_len if n is None else int(n)
         cbk, gxk, umi, meta = self._seg(seg)[1]
-        return (torch.from_numpy(cbk[:n].view(np.int64)).to(dev), torch.from_numpy(gxk[:n].view(np.int64)).to(dev),
-                torch.from_numpy(umi[:n].view(np.int32)).to(dev), torch.from_numpy(meta[:n].view(np.int32)).to(dev))
+        from .hostmem import to_device
+        return (to_device(cbk[:n], dev), to_device(gxk[:n], dev), to_device(umi[:n], dev), to_device(meta[:n], dev))
 
     def segment_strings(self, seg, dev, n):
         return tuple(a[:n] for a in self._seg(seg)[0])

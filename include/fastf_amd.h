@@ -51,6 +51,9 @@ int bam2db(char *bam_file, char *db_file, char *path_out, char *barcodes_file,
 
 /* main.c:288-362; argv[0] == "bam2db". */
 int cmd_bam2db(int argc, const char **argv);
+/* which device(s) bam2db() uses, from the values of FASTF_DEVICES ("a,b,.." or a count) and FASTF_DEVICE (either may be NULL):
+ * *dev0 = the engine's and the reader's device, *dev_second = the second listed device or -1 */
+void fastf_pick_devices(const char *devices, const char *device, int *dev0, int *dev_second);
 
 /* --- crb / extract: src/extract.c.  The tree types are the reference's (filter.h:28-34, extract.h:8-13); they are
  * declared here under guards so that this header can be included next to the reference's own. --- */
@@ -214,8 +217,13 @@ int  fastf_engine_push_pinned(fastf_engine_t *e, const fastf_batch_t *batch);
 int  fastf_engine_wait_input(fastf_engine_t *e);   /* every host-to-device copy queued so far has completed */
 void *fastf_pinned_alloc(size_t bytes);            /* hipHostMalloc; NULL on failure */
 void  fastf_pinned_free(void *p);
-int   fastf_pinned_register(void *p, size_t bytes);/* pin memory the caller allocated (hipHostRegister) */
+/* pin memory the caller allocated (hipHostRegister).  The caller MUST unregister before the memory is freed, unmapped or its pages
+ * dropped: the runtime keeps its entry for the addresses otherwise, and the next owner of those addresses inherits it (a later copy
+ * into them faults on the GPU).  Prefer memory that is a mapping of its own over malloc heap memory.  The library keeps a ledger of
+ * its registrations; FASTF_DEBUG_PINS=1 makes a violation abort and checks the pointers of the *_pinned / lend / gather entries. */
+int   fastf_pinned_register(void *p, size_t bytes);
 void  fastf_pinned_unregister(void *p);
+int   fastf_debug_live_registrations(void);        /* registrations made through this library that are still live (tests) */
 /* Sort + segmented unique/reduce over everything pushed; results stay valid until
  * reset/destroy.  counters = {total, sampled, sampled_valid} (bam2db_ds.c:342-344). */
 int  fastf_engine_finish(fastf_engine_t *e, fastf_coo_t *coo, uint64_t counters[3]);

@@ -5,6 +5,8 @@ import os
 import socket
 
 import numpy as np
+
+from fastf_amd import hostmem
 import pytest
 import torch.multiprocessing as mp
 
@@ -39,7 +41,7 @@ def _worker(rank, world, port, case_kw, steps, q, umi_max=12):
         cuts = [n * i // world for i in range(world + 1)]
         cuts[1] = int(cuts[1] * 0.7)                      # uneven slices
         a, b = cuts[rank], cuts[rank + 1]
-        t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+        t = lambda x: hostmem.to_device(x, dev)
         draws = t(F.mt_draws(case.seed, lists.mt_skip, n))
         eng = F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, n_shards=world, shard_rank=rank, device=0,
                                   umi_max_bases=umi_max)
@@ -180,7 +182,7 @@ def test_pipelined_pass_with_asynchronous_loopback_exchange(fixed):
     cases[1].cb, cases[1].gx, cases[1].ub = synth.as_cstr(cb), synth.as_cstr(gx), synth.as_cstr(ub)
     lists = cases[0].lists()
     oras = [c.oracle() for c in cases]
-    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+    t = lambda x: hostmem.to_device(x, dev)
     packed = [[t(a) for a in c.packed(lists)] for c in cases]
     n = cases[0].n
     draws = t(F.mt_draws(cases[0].seed, lists.mt_skip, n))

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import fastf_amd as F
+from fastf_amd import hostmem
 from fastf_amd import synth, _lib
 from fastf_amd import workload as workload_mod
 from fastf_amd.dist import owner_of_cell
@@ -194,6 +195,7 @@ def test_reference_main_drives_the_engine(tmp_path):
     assert _read_gz(out / "umi.tsv.gz") == ora["umi"]
 
 
+@pytest.mark.own_process
 def test_bam2db_symbol_in_process(tmp_path):
     """the drop-in C symbol itself (what the reference's main.c would call)"""
     import torch  # noqa: F401
@@ -208,11 +210,14 @@ def test_bam2db_symbol_in_process(tmp_path):
     assert rc == 0
     assert _read_gz(tmp_path / "matrix.mtx.gz") == ora["matrix"]
     assert not (tmp_path / "umi.tsv.gz").exists()
+    L.fastf_debug_live_registrations.restype = int
+    assert L.fastf_debug_live_registrations() == 0          # window buffers, decoder slab, lent rows: all unregistered before release
     # error convention: 1 + message, no crash
     assert L.bam2db(b"/nonexistent.bam", None, str(tmp_path).encode(), str(b).encode(), str(f).encode(),
                     C.c_float(1.0), C.c_float(1.0), 926) == 1
 
 
+@pytest.mark.own_process
 @pytest.mark.parametrize("G", [2, 4, 8])
 def test_sharded_device_path_on_one_gpu(G):
     """n_shards = G engines on one device: slices → K1a/K1b with a draw-rank base → per-shard buffers →
@@ -225,7 +230,7 @@ def test_sharded_device_path_on_one_gpu(G):
     cbk, gxk, umi, meta = case.packed(lists)
     n = case.n
     dev = torch.device("cuda")
-    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32)).to(dev)
+    t = lambda a: hostmem.to_device(a, dev)
     draws = t(F.mt_draws(case.seed, lists.mt_skip, n))
     engs = [F.Engine.from_lists(lists, rate_depth=case.rate_depth, seed=case.seed, n_shards=G, shard_rank=r) for r in range(G)]
     s = torch.cuda.current_stream().cuda_stream
@@ -254,8 +259,8 @@ def test_sharded_device_path_on_one_gpu(G):
                                    draws.data_ptr(), n, keys_out[r].data_ptr(), stride, kc[r].data_ptr(), counters[r].data_ptr(), s,
                                    d_draw_base=db.data_ptr())
         torch.cuda.synchronize()
-        kc_h = kc.cpu().numpy()
-        tot = counters.sum(0).cpu().numpy()
+        kc_h = hostmem.to_host(kc)
+        tot = hostmem.to_host(counters.sum(0))
         assert (int(tot[1]), int(tot[2]), int(tot[3])) == (ora["sampled"], ora["valid"], 0)
         F_, C_, K_ = [], [], []
         for sh in range(G):
@@ -270,9 +275,9 @@ def test_sharded_device_path_on_one_gpu(G):
             engs[sh].dev_reduce(src.data_ptr(), d_n.data_ptr(), m, f.data_ptr(), c.data_ptr(), k.data_ptr(), nnz.data_ptr(), s)
             torch.cuda.synchronize()
             z = int(nnz.item())
-            cc = c[:z].cpu().numpy().astype(np.int64)
+            cc = hostmem.to_host(c[:z]).astype(np.int64)
             assert (owner_of_cell(cc, G) == sh).all()           # host mirror of the device ownership hash
-            F_.append(f[:z].cpu().numpy().astype(np.int64)); C_.append(cc); K_.append(k[:z].cpu().numpy().astype(np.int64))
+            F_.append(hostmem.to_host(f[:z]).astype(np.int64)); C_.append(cc); K_.append(hostmem.to_host(k[:z]).astype(np.int64))
         Fa, Ca, Ka = np.concatenate(F_), np.concatenate(C_), np.concatenate(K_)
         order = np.lexsort((Fa, Ca))
         np.testing.assert_array_equal(Fa[order], ora["feature"].astype(np.int64))
@@ -283,6 +288,7 @@ def test_sharded_device_path_on_one_gpu(G):
             e.close()
 
 
+@pytest.mark.own_process
 def test_full_size_properties_config2():
     """BASELINE configs[1] at full size (10 M records): size-independent properties instead of the oracle:
     sortedness of rows, row-count/sum invariants, idempotence, and equality with a 2-batch push."""
@@ -328,7 +334,7 @@ def _expected_matrix_torch(job, dev, cb, gx, umi, meta, draws_h):
     route to COUNT(DISTINCT umi) GROUP BY cell, feature with the reference's draw-per-hit rule (bam2db_ds.c:374-435)"""
     import torch
     lists = job.lists
-    skeys = torch.from_numpy(lists.cell_keys.view(np.int64)).to(dev)            # cell_index i+1 <-> skeys[i]
+    skeys = hostmem.to_device(lists.cell_keys, dev)            # cell_index i+1 <-> skeys[i]
     sk, order = torch.sort(skeys)
     pos = torch.searchsorted(sk, cb).clamp_(max=len(sk) - 1)
     hit = (cb != 0) & (sk[pos] == cb)
@@ -336,10 +342,10 @@ def _expected_matrix_torch(job, dev, cb, gx, umi, meta, draws_h):
     rank = torch.cumsum(hit.to(torch.int64), 0) - 1
     n_hits = int(hit.sum().item())
     T = F.draw_threshold(workload_mod.RATE_DEPTH)
-    keep_by_rank = torch.from_numpy((draws_h[:n_hits].astype(np.int64) < T)).to(dev)
+    keep_by_rank = hostmem.to_device(draws_h[:n_hits].astype(np.int64) < T, dev)
     kept = hit.clone()
     kept[hit] = keep_by_rank[rank[hit]]
-    fkeys = torch.from_numpy(lists.feature_keys.view(np.int64)).to(dev)
+    fkeys = hostmem.to_device(lists.feature_keys, dev)
     fs, forder = torch.sort(fkeys)
     fpos = torch.searchsorted(fs, gx).clamp_(max=len(fs) - 1)
     feat_ok = (gx != 0) & (fs[fpos] == gx)
@@ -352,9 +358,10 @@ def _expected_matrix_torch(job, dev, cb, gx, umi, meta, draws_h):
     grp, inv = torch.unique_consecutive(ucode >> 26, return_inverse=True)
     cnt = torch.zeros(len(grp), dtype=torch.int64, device=dev).index_add_(0, inv, (ucode >> 25) & 1)
     return dict(hits=n_hits, sampled=int(kept.sum().item()), valid=int(valid.sum().item()),
-                cell=(grp >> 16).cpu().numpy(), feature=(grp & 0xFFFF).cpu().numpy(), count=cnt.cpu().numpy())
+                cell=hostmem.to_host(grp >> 16), feature=hostmem.to_host(grp & 0xFFFF), count=hostmem.to_host(cnt))
 
 
+@pytest.mark.own_process
 def test_full_size_config3_exact():
     """BASELINE configs[2] at full size on one GPU (fastf_amd/workload.py: 200 M records, 50 k barcodes x 36 601 genes,
     --cell 0.5 --depth 0.5, log-normal cells, Zipf genes, 12-bp UMIs, 5 % without CB, 5 % unlisted CB, 15 % bad xf,
@@ -386,7 +393,7 @@ def test_full_size_config3_exact():
     # 1. the resident pass (streaming K1b -> segmented sort -> reduce), twice on the same buffers
     eng = F.Engine.from_lists(lists, rate_depth=workload_mod.RATE_DEPTH, seed=workload_mod.SEED, umi_max_bases=12)
     try:
-        d_draws = torch.from_numpy(draws_h.view(np.int32)).to(dev)
+        d_draws = hostmem.to_device(draws_h, dev)
         sp = ShardedPass(HipStages(eng, dev), N, dev)
         for _ in range(2):
             sp.run(cb, gx, umi, meta, N, d_draws)
@@ -419,6 +426,7 @@ def test_full_size_config3_exact():
         pb.close()
 
 
+@pytest.mark.own_process
 def test_adversarial_share_of_config5():
     """One GPU's share of BASELINE configs[4] (1 B records / 8 GPUs = 125 M, 12 500 of the 100 k barcodes), keep-all,
     UMIs Zipf(1.5)-drawn from a 4 096-value pool per gene: most keys are duplicates and a few radix digits dominate.
@@ -457,6 +465,7 @@ def test_adversarial_share_of_config5():
         eng.close()
 
 
+@pytest.mark.own_process
 def test_adversarial_config5_whole_on_one_gpu():
     """BASELINE configs[4] WHOLE on one GPU (tools/config5_whole.py): 1 B records, all 100 k barcodes (the L2 cell table),
     keep-all, Zipf-skewed UMI reuse; records generated on the device and pushed as device-resident batches, 1 B keys through

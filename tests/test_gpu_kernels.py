@@ -1,6 +1,8 @@
 """Device-level entry points (fastf_dev_*) on HBM-resident buffers, checked against numpy
 restatements of sort / group-by (bit-exact; integer work)."""
 import numpy as np
+
+from fastf_amd import hostmem
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -19,7 +21,7 @@ def env():
 
 
 def _t(torch, a):
-    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a.view(np.int32)).cuda()
+    return hostmem.to_device(a, "cuda")
 
 
 @pytest.mark.parametrize("n,bits", [(1, 8), (63, 17), (8192, 24), (8193, 33), (100_003, 47), (1_000_000, 56), (300_000, 64)])
@@ -35,7 +37,7 @@ def test_dev_sort_matches_numpy(env, n, bits):
     s = torch.cuda.current_stream().cuda_stream
     in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), n, key_bits=bits, stream=s)
     torch.cuda.synchronize()
-    got = (d_tmp if in_tmp else d_keys).cpu().numpy().view(np.uint64)
+    got = hostmem.to_host(d_tmp if in_tmp else d_keys).view(np.uint64)
     np.testing.assert_array_equal(got, np.sort(keys))
     assert eng.dev_error_bits() == 0
 
@@ -50,7 +52,7 @@ def test_dev_sort_respects_device_side_n(env):
     in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), 50_000, key_bits=40,
                           stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    got = (d_tmp if in_tmp else d_keys).cpu().numpy().view(np.uint64)[:12_345]
+    got = hostmem.to_host(d_tmp if in_tmp else d_keys).view(np.uint64)[:12_345]
     np.testing.assert_array_equal(got, np.sort(keys[:12_345]))
 
 
@@ -84,9 +86,9 @@ def test_dev_reduce_matches_numpy(env, n, n_groups, seed):
     uk = np.unique(keys[(keys >> np.uint64(26)) & np.uint64(1) == 1])
     want = np.zeros(len(ug), dtype=np.int64)
     np.add.at(want, np.searchsorted(ug, uk >> np.uint64(fs)), 1)
-    np.testing.assert_array_equal(d_c.cpu().numpy()[:nnz].astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64))
-    np.testing.assert_array_equal(d_f.cpu().numpy()[:nnz].astype(np.int64), (ug & np.uint64((1 << 9) - 1)).astype(np.int64))
-    np.testing.assert_array_equal(d_k.cpu().numpy()[:nnz].astype(np.int64), want)
+    np.testing.assert_array_equal(hostmem.to_host(d_c)[:nnz].astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64))
+    np.testing.assert_array_equal(hostmem.to_host(d_f)[:nnz].astype(np.int64), (ug & np.uint64((1 << 9) - 1)).astype(np.int64))
+    np.testing.assert_array_equal(hostmem.to_host(d_k)[:nnz].astype(np.int64), want)
     assert eng.dev_error_bits() == 0
 
 
@@ -129,7 +131,7 @@ def _group_only_case(torch, eng, mode, n, n_groups, low_values, seed):
     s = torch.cuda.current_stream().cuda_stream
     in_tmp = eng.dev_sort(d_keys.data_ptr(), d_tmp.data_ptr(), d_n.data_ptr(), n, stream=s, skip_low=True)
     src = d_tmp if in_tmp else d_keys
-    got_keys = src.cpu().numpy().view(np.uint64)
+    got_keys = hostmem.to_host(src).view(np.uint64)
     assert (np.diff((got_keys >> np.uint64(skip)).astype(np.int64)) >= 0).all()           # sorted on the high bits
     np.testing.assert_array_equal(np.sort(got_keys), np.sort(keys))                       # a permutation
     d_f = torch.empty(n, dtype=torch.int32, device="cuda"); d_c = torch.empty_like(d_f); d_k = torch.empty_like(d_f)
@@ -154,8 +156,8 @@ def _group_only_case(torch, eng, mode, n, n_groups, low_values, seed):
     uk = np.unique(keys[(keys >> np.uint64(26)) & np.uint64(1) == 1])
     want = np.zeros(len(ug), dtype=np.int64)
     np.add.at(want, np.searchsorted(ug, uk >> np.uint64(fs)), 1)
-    np.testing.assert_array_equal(d_k.cpu().numpy()[:nnz].astype(np.int64), want)
-    np.testing.assert_array_equal(d_c.cpu().numpy()[:nnz].astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64))
+    np.testing.assert_array_equal(hostmem.to_host(d_k)[:nnz].astype(np.int64), want)
+    np.testing.assert_array_equal(hostmem.to_host(d_c)[:nnz].astype(np.int64), (ug >> np.uint64(cs - fs)).astype(np.int64))
 
 
 def _want_rows(keys, fs=27, cs=36):
@@ -201,9 +203,9 @@ def test_reduce_windows_groups_longer_than_a_window_and_regions(env, sizes, seed
     assert int(d_nnz.item()) == len(f)
     eng.dev_rows_gather(d_n.data_ptr(), d_f.data_ptr(), d_c.data_ptr(), d_k.data_ptr(), stream=s)
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(d_f.cpu().numpy()[:len(f)].astype(np.int64), f)
-    np.testing.assert_array_equal(d_c.cpu().numpy()[:len(f)].astype(np.int64), c)
-    np.testing.assert_array_equal(d_k.cpu().numpy()[:len(f)].astype(np.int64), k)
+    np.testing.assert_array_equal(hostmem.to_host(d_f)[:len(f)].astype(np.int64), f)
+    np.testing.assert_array_equal(hostmem.to_host(d_c)[:len(f)].astype(np.int64), c)
+    np.testing.assert_array_equal(hostmem.to_host(d_k)[:len(f)].astype(np.int64), k)
     # (2) the same regions straight into pinned host memory
     h = [torch.empty(len(f) + 1, dtype=torch.int32).pin_memory() for _ in range(3)]
     for t in h:
@@ -263,9 +265,9 @@ def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypat
             assert eng.dev_error_bits() == 0
         f, c, k = _want_rows(keys)
         assert int(d_nnz.item()) == len(f)
-        np.testing.assert_array_equal(d_f.cpu().numpy()[:len(f)].astype(np.int64), f)
-        np.testing.assert_array_equal(d_c.cpu().numpy()[:len(f)].astype(np.int64), c)
-        np.testing.assert_array_equal(d_k.cpu().numpy()[:len(f)].astype(np.int64), k)
+        np.testing.assert_array_equal(hostmem.to_host(d_f)[:len(f)].astype(np.int64), f)
+        np.testing.assert_array_equal(hostmem.to_host(d_c)[:len(f)].astype(np.int64), c)
+        np.testing.assert_array_equal(hostmem.to_host(d_k)[:len(f)].astype(np.int64), k)
     finally:
         eng.close()
 
@@ -353,14 +355,14 @@ def test_parallel_mt_decisions_are_the_reference_stream(env, seed, skip, n, rate
         words = torch.full(((max(n, 4 * J_SUB + 99) + 63) // 64 * 2 + 2,), -1, dtype=torch.int32, device="cuda")
         eng.dev_mt_decisions(seed, skip, n, words.data_ptr())
         torch.cuda.synchronize()
-        got = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+        got = np.unpackbits(hostmem.to_host(words).view(np.uint8), bitorder="little")
         want = (F.mt_draws(seed, skip, n).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
         np.testing.assert_array_equal(got[:n], want)
         assert not got[n:(n + 63) // 64 * 64].any()    # the tail of the last 64-bit word is zero
         # a second call on the same engine (the polynomials and the sub-stream states are in place) from another position
         eng.dev_mt_decisions(seed + 1, skip + 17, 4 * J_SUB + 99, words.data_ptr())
         torch.cuda.synchronize()
-        got = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+        got = np.unpackbits(hostmem.to_host(words).view(np.uint8), bitorder="little")
         want = (F.mt_draws(seed + 1, skip + 17, 4 * J_SUB + 99).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
         np.testing.assert_array_equal(got[:4 * J_SUB + 99], want)
     finally:

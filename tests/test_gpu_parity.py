@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import fastf_amd as F
+from fastf_amd import hostmem
 from helpers import Case, assert_matches_oracle
 
 pytestmark = pytest.mark.gpu
@@ -215,6 +216,7 @@ def test_engine_reuse_cycles_grow_the_row_buffer():
     big = Case(n=200_000, n_bar=60, n_gene=40, umi_pool=4096, data_seed=3)      # the same lists (they follow data_seed), ten times the records
     lists = small.lists()
     assert big.bt == small.bt and big.ft == small.ft
+    live0 = _live_registrations()
     eng = F.Engine.from_lists(lists, rate_depth=small.rate_depth, seed=small.seed, batch_records=16_384)
     try:
         for case in (small, small, big, small, big):
@@ -226,8 +228,45 @@ def test_engine_reuse_cycles_grow_the_row_buffer():
             for k in ("feature", "cell", "count"):
                 np.testing.assert_array_equal(res[k], again[k])
             assert_matches_oracle(res, case.oracle(), eng, case, lists, eng.umi_rows())
+        assert _live_registrations() == live0 + 1            # the row buffer, pinned in place since its second use
     finally:
         eng.close()
+    assert _live_registrations() == live0                    # ... and unregistered before it was unmapped
+
+
+def _live_registrations():
+    from fastf_amd import _lib
+    L = _lib.lib()
+    L.fastf_debug_live_registrations.restype = int
+    return L.fastf_debug_live_registrations()
+
+
+def test_tables_from_heap_arrays_that_are_recycled_before_the_rows_come_back():
+    """Round 5's fault, as a sequence: a multi-megabyte barcode table uploaded from heap memory at create (100 k barcodes: the L2
+    table), that memory freed and the same sizes allocated again, then the rows of a FIRST finish copied into a row buffer that is
+    not pinned yet, and the -u rows into the caller's arrays.  None of these copies hands heap memory to the runtime (bounce
+    buffer), the row buffer is a mapping of its own, and nothing stays registered."""
+    import gc
+    live0 = _live_registrations()
+    case = Case(n=600_000, n_bar=100_000, n_gene=3000, umi_pool=4096, data_seed=5, rate_depth=0.9)
+    ora = case.oracle()
+    lists = case.lists()
+    ck, fk = lists.cell_keys.copy(), lists.feature_keys.copy()          # heap arrays of 0.8 MB and 24 KB
+    eng = F.Engine(ck, fk, rate_depth=case.rate_depth, seed=case.seed, mt_skip=lists.mt_skip)
+    try:
+        eng._cell_keys = eng._feature_keys = None
+        del ck, fk
+        gc.collect()
+        junk = [np.full(100_000, i, dtype=np.uint64) for i in range(8)]          # the allocator hands the freed chunks out again
+        eng.push(*case.packed(lists))
+        res = eng.finish()
+        rows = eng.umi_rows()
+        assert_matches_oracle(res, ora, eng, case, lists, rows)
+        assert all(int(j[0]) == i for i, j in enumerate(junk))
+        assert _live_registrations() == live0                            # a first finish pins nothing
+    finally:
+        eng.close()
+    assert _live_registrations() == live0
 
 
 def test_empty_input():
@@ -504,7 +543,7 @@ def test_resident_pass_streaming_k1b_matches_oracle(name):
     lists = case.lists()
     cbk, gxk, umi, meta = case.packed(lists)
     dev = torch.device("cuda", 0)
-    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+    t = lambda x: hostmem.to_device(x, dev)
     d = [t(x) for x in (cbk, gxk, umi, meta)]
     draws = t(F.mt_draws(case.seed, lists.mt_skip, case.n))
     for form in ("blocked", "soa", "tile"):
@@ -557,7 +596,7 @@ def test_streaming_k1b_record_counts_around_its_unit_tile_and_round_sizes(n):
     lists = case.lists()
     cbk, gxk, umi, meta = case.packed(lists)
     dev = torch.device("cuda", 0)
-    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x.view(np.int32)).to(dev)
+    t = lambda x: hostmem.to_device(x, dev)
     d = [t(x) for x in (cbk, gxk, umi, meta)]
     draws = t(F.mt_draws(case.seed, lists.mt_skip, ora["total"]))       # exactly as many draws as there can be hits
     for form in ("blocked", "soa"):

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def read_all_dev(path, lists, cap=1000, threads=0, gpu=2):
     """(cb, gx, umi, meta, records that came packed from the device)"""
     L = _lib.lib()
-    hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL(_lib.hip_runtimes_loaded()[0])           # the ONE runtime of this process (by path: no second copy)
     L.fastf_bam_open2.restype = C.c_void_p
     L.fastf_bam_open2.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.fastf_bam_enable_device_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -1,5 +1,6 @@
 """Host-side C of the product (libfastf_amd.so, no GPU needed) against the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -8,6 +9,8 @@ import fastf_amd as F
 from fastf_amd import engine, synth, _lib
 from oracle import oracle as O
 from helpers import Case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed,skip", [(926, 0), (926, 500), (1, 623), (1, 624), (77, 100000)])
@@ -235,3 +238,78 @@ def test_mt_jump_polynomials_are_the_generator_advanced():
             want, _ = array_after(seed, 5 + stride // 624)
             np.testing.assert_array_equal(out[1:], want[1:])
             assert (int(out[0]) ^ int(want[0])) >> 31 == 0                # word 0 lends only its top bit
+
+
+@pytest.mark.parametrize("devices,device,want", [
+    (None, None, (0, -1)), (None, "3", (3, -1)), ("", "2", (2, -1)),
+    ("1", "5", (5, -1)),                   # one device: FASTF_DEVICE says which
+    ("1", None, (0, -1)),
+    ("4", "5", (0, 1)),                    # a count: devices 0..3; FASTF_DEVICE is not consulted
+    ("2,3", "7", (2, 3)),                  # an explicit list wins over FASTF_DEVICE
+    ("2,2", None, (2, -1)),                # the second entry aliases the first: no second device
+    ("3", None, (0, 1)), ("0,1,2,3", None, (0, 1)), ("5,300", None, (5, -1)), ("-1,2", None, (0, 2)),
+])
+def test_device_selection_from_the_environment_values(devices, device, want):
+    """bam2db()'s device choice (FASTF_DEVICES / FASTF_DEVICE): round 5's dangling else made FASTF_DEVICE alone a no-op"""
+    L = _lib.lib()
+    L.fastf_pick_devices.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fastf_pick_devices.restype = None
+    d0, d2 = C.c_int(-9), C.c_int(-9)
+    L.fastf_pick_devices(None if devices is None else devices.encode(), None if device is None else device.encode(), C.byref(d0), C.byref(d2))
+    assert (d0.value, d2.value) == want
+
+
+def test_big_buffers_are_private_mappings_and_the_pin_ledger_guards_their_release():
+    """fastf_big_alloc: page-aligned (2 MiB from 2 MiB on) mappings of their own, never malloc heap; the ledger of registered
+    ranges knows what is live; releasing unknown (heap) memory through fastf_big_free still frees it"""
+    L = _lib.lib()
+    L.fastf_big_alloc.restype = C.c_void_p; L.fastf_big_alloc.argtypes = [C.c_size_t]
+    L.fastf_big_free.argtypes = [C.c_void_p, C.c_size_t]; L.fastf_big_free.restype = None
+    L.fastf_pin_ledger_add.argtypes = [C.c_void_p, C.c_size_t]; L.fastf_pin_ledger_add.restype = None
+    L.fastf_pin_ledger_remove.argtypes = [C.c_void_p]; L.fastf_pin_ledger_live.restype = C.c_int
+
+    def mapping_of(addr):
+        for ln in open("/proc/self/maps"):
+            lo, hi = (int(x, 16) for x in ln.split()[0].split("-"))
+            if lo <= addr < hi:
+                return ln
+        return ""
+    small, big = L.fastf_big_alloc(100), L.fastf_big_alloc(5 << 20)
+    assert small and big and small % 4096 == 0 and big % (2 << 20) == 0
+    for a in (small, big):
+        assert "[heap]" not in mapping_of(a)
+    C.memset(big, 7, 5 << 20); C.memset(small, 7, 100)
+    base = L.fastf_pin_ledger_live()
+    L.fastf_pin_ledger_add(big + 4096, 8192)
+    assert L.fastf_pin_ledger_live() == base + 1
+    assert L.fastf_pin_ledger_remove(big + 4096) == 1 and L.fastf_pin_ledger_live() == base
+    L.fastf_big_free(big, 5 << 20); L.fastf_big_free(small, 100)
+    libc = C.CDLL(None); libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    L.fastf_big_free(libc.malloc(64), 64)                               # heap memory: passed on to free()
+
+
+def test_releasing_a_registered_buffer_is_caught(tmp_path):
+    """FASTF_DEBUG_PINS=1: fastf_big_free of a range the ledger holds aborts the process (a child process here)"""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from fastf_amd import _lib\nL = _lib.lib()\n"
+            "L.fastf_big_alloc.restype = C.c_void_p; L.fastf_big_alloc.argtypes = [C.c_size_t]\n"
+            "L.fastf_big_free.argtypes = [C.c_void_p, C.c_size_t]; L.fastf_pin_ledger_add.argtypes = [C.c_void_p, C.c_size_t]\n"
+            "p = L.fastf_big_alloc(1 << 20); L.fastf_pin_ledger_add(p + 4096, 4096); L.fastf_big_free(p, 1 << 20); print('survived')\n") % ROOT
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, FASTF_DEBUG_PINS="1"))
+    assert r.returncode == -6 and "still registered with the HIP runtime" in r.stderr and "survived" not in r.stdout
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, FASTF_DEBUG_PINS="0"))
+    assert r.returncode == 0 and "INTERNAL ERROR" in r.stderr and "survived" in r.stdout
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """fastf_amd loaded BEFORE torch used to bring in /opt/rocm's libamdhip64 and torch then its bundled copy beside it: two HIP
+    runtimes in one process.  _lib.lib() now loads torch's copy first when torch is installed."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom fastf_amd import _lib\n_lib.lib()\nimport torch\n"
+            "print(len(_lib.hip_runtimes_loaded()), _lib.hip_runtimes_loaded())\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[0] == "1", r.stdout

@@ -13,6 +13,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
+
+from fastf_amd import hostmem
 import torch
 
 import fastf_amd as F
@@ -24,8 +26,8 @@ def run(N=1_000_000_000, B=25_000_000, n_cells=100_000, n_genes=36_601, log=prin
     dev = torch.device("cuda", 0)
     bt, ft, _, _ = synth.make_lists(n_cells, n_genes, seed=99)
     lists = F.Lists(bt, ft, 1.0, 926)
-    cell_keys = torch.from_numpy(lists.cell_keys.view(np.int64)).to(dev)
-    feat_keys = torch.from_numpy(lists.feature_keys.view(np.int64)).to(dev)
+    cell_keys = hostmem.to_device(lists.cell_keys, dev)
+    feat_keys = hostmem.to_device(lists.feature_keys, dev)
     gcdf = torch.cumsum(1.0 / torch.arange(1, n_genes + 1, dtype=torch.float64, device=dev) ** 1.1, 0)
     ucdf = torch.cumsum(1.0 / torch.arange(1, 4097, dtype=torch.float64, device=dev) ** 1.5, 0)
     gcdf /= gcdf[-1].clone(); ucdf /= ucdf[-1].clone()
@@ -64,7 +66,7 @@ def run(N=1_000_000_000, B=25_000_000, n_cells=100_000, n_genes=36_601, log=prin
         del uq
         assert res["nnz"] == len(grp)
         for name, want in (("cell", (grp >> 16) + 1), ("feature", (grp & 0xFFFF) + 1), ("count", cnt)):
-            got = torch.from_numpy(res[name].view(np.int32)).to(dev).to(torch.int64)
+            got = hostmem.to_device(res[name], dev).to(torch.int64)
             assert torch.equal(got, want), name
             del got
         return dict(records=N, push_s=t_push, finish_s=t_finish, rows=int(res["nnz"]))
