@@ -35,6 +35,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# (no on-the-fly pinning of pageable host memory by the HIP runtime in this process: DESIGN section 14; the transfers of this
+#  script go through pinned staging anyway — fastf_amd/hostmem.py — this covers what torch copies by itself)
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (before fastf_amd: one shared HIP runtime)
 import torch.distributed as dist  # noqa: E402
