@@ -931,7 +931,7 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
     if (count == 0) return 0;
     static const bool no_par = getenv("FASTF_MT_SERIAL") != nullptr;
     const u64 head = *idx < MT_N ? std::min<u64>(count, MT_N - *idx) : 0;          // to the next block boundary
-    if (count < MT_PAR_MIN || no_par || count - head > ((u64)MT_SUB_DRAWS << FASTF_MT_JUMP_LEVELS)) {
+    if (count < MT_PAR_MIN || no_par) {
         if (launch_mt_decisions(s, d_mt, words, d_ring, first, count, ring_mask, threshold)) return 1;
         *idx = mt_idx_after(*idx, count);
         return 0;
@@ -941,33 +941,39 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
         if (words.ensure(std::max<u64>(count * 4, 1u << 20))) return 1;
     }
     if (!e->d_mtpoly.p) {                                      // the polynomials: constants of the generator (mt_jump.c), once per engine
-        static_assert(MT_POLY_WORDS == FASTF_MT_POLY_WORDS && MT_SUB_DRAWS == FASTF_MT_SUB_DRAWS, "kernel and table agree");
-        if (e->d_mtpoly.ensure((size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64))) return 1;
-        if (copy_h2d(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_LEVELS * MT_POLY_WORDS * sizeof(u64))) return 1;
+        static_assert(MT_POLY_WORDS == FASTF_MT_POLY_WORDS && MT_SUB_DRAWS == FASTF_MT_SUB_DRAWS && MT_JUMP_R == FASTF_MT_JUMP_R, "kernel and table agree");
+        if (e->d_mtpoly.ensure((size_t)FASTF_MT_JUMP_POLYS * MT_POLY_WORDS * sizeof(u64))) return 1;
+        if (copy_h2d(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_POLYS * MT_POLY_WORDS * sizeof(u64))) return 1;
         HIP_OK(hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_JUMP_LDS_WORDS * sizeof(u32))));
     }
     u32* const w = (u32*)words.p;
     if (head) {                                                // the rest of the block the stream stands in
         hipLaunchKernelGGL(mt_fill_kernel, dim3(1), dim3(256), 0, s, d_mt, w, 0ull, head, ~0ull);
     }
-    const u64 body = count - head;
-    const u32 S = (u32)((body + MT_SUB_DRAWS - 1) / MT_SUB_DRAWS);
-    if (e->d_mtsub.bytes < (size_t)S * MT_STATE_WORDS * 4) {
-        if (e->d_mtsub.p) HIP_OK(hipStreamSynchronize(s));
-        if (e->d_mtsub.ensure((size_t)std::max<u32>(S, 64) * MT_STATE_WORDS * 4)) return 1;
+    // rounds of at most R^2 sub-streams: a round's last sub-stream, generated to its end, is where the next round starts
+    constexpr u64 ROUND_DRAWS = (u64)MT_JUMP_R * MT_JUMP_R * MT_SUB_DRAWS;
+    u64 at = head, last = 0;
+    while (at < count) {
+        const u64 body = std::min<u64>(count - at, ROUND_DRAWS);
+        const u32 S = (u32)((body + MT_SUB_DRAWS - 1) / MT_SUB_DRAWS);
+        if (e->d_mtsub.bytes < (size_t)S * MT_STATE_WORDS * 4) {
+            if (e->d_mtsub.p) HIP_OK(hipStreamSynchronize(s));
+            if (e->d_mtsub.ensure((size_t)std::max<u32>(S, 64) * MT_STATE_WORDS * 4)) return 1;
+        }
+        u32* const sub = (u32*)e->d_mtsub.p;
+        HIP_OK(hipMemcpyAsync(sub, d_mt, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
+        const u32 n_coarse = (S + MT_JUMP_R - 1) / MT_JUMP_R;            // sub-streams 0, R, 2R, ..
+        if (n_coarse > 1)
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(n_coarse - 1), dim3(1024), MT_JUMP_LDS_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p, 1u, S);
+        if (S > 1)
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(n_coarse * (MT_JUMP_R - 1)), dim3(1024), MT_JUMP_LDS_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p, 0u, S);
+        hipLaunchKernelGGL(mt_fill_multi_kernel, dim3(S), dim3(256), 0, s, sub, w + at, 0ull, body, ~0ull);
+        HIP_OK(hipMemcpyAsync(d_mt, sub + (size_t)(S - 1) * MT_STATE_WORDS, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipGetLastError());
+        last = body - (u64)(S - 1) * MT_SUB_DRAWS;               // draws of the round's last sub-stream
+        at += body;
     }
-    u32* const sub = (u32*)e->d_mtsub.p;
-    HIP_OK(hipMemcpyAsync(sub, d_mt, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
-    u32 levels = 0;
-    while ((1u << levels) < S) ++levels;
-    for (u32 l = levels; l-- > 0;) {                           // sub-streams 2^l apart from those 2^(l+1) apart
-        const u32 stride = 1u << l, grid = (S + 2 * stride - 1) / (2 * stride);
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(grid), dim3(1024), MT_JUMP_LDS_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p + (size_t)l * MT_POLY_WORDS, stride, S);
-    }
-    hipLaunchKernelGGL(mt_fill_multi_kernel, dim3(S), dim3(256), 0, s, sub, w + head, 0ull, body, ~0ull);
-    HIP_OK(hipMemcpyAsync(d_mt, sub + (size_t)(S - 1) * MT_STATE_WORDS, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
-    HIP_OK(hipGetLastError());
-    *idx = mt_idx_after(MT_N, body - (u64)(S - 1) * MT_SUB_DRAWS);
+    *idx = mt_idx_after(MT_N, last);
     return launch_draw_bits(threshold, (const u32*)w, count, d_ring, s, first, ring_mask);
 }
 

@@ -203,20 +203,27 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u
 //                         as a flat word sequence X_{t+624} = X_{t+397} ^ mix(X_t, X_{t+1}) for 19 937 words more, in LDS (83 KB;
 //                         sweeps of 227 words, a barrier each), and the array J words on is the XOR of the windows X[k .. k+623]
 //                         over the set coefficients k of g: thread i XORs X[k + i], the polynomial's bits walk in scalar registers.
-//                         Level l of a call seats the sub-streams 2^l apart from those 2^(l+1) apart (polynomial l of the table
-//                         the library carries): log2(S) launches for S sub-streams.
+//                         Two launches seat up to R^2 = 1024 sub-streams: sub-streams R, 2R, .. straight from the stream's
+//                         state (polynomials x^(i R J)), then the R - 1 behind every one of those (x^(i J)) — every workgroup
+//                         of a launch depends on the launch before only.  (Round 5 doubled: sub-streams 2^l apart from those
+//                         2^(l+1) apart, nine dependent launches of 105 us for 283 sub-streams, 0.94 of the 1.37 ms a job's draws cost.)
 //   mt_fill_multi_kernel  workgroup j continues sub-stream j by its share of the call's draws (mt_fill_body above).
-// 90 M draws (one configs[2] job): 283 sub-streams, nine jump launches, one fill launch.
+// 90 M draws (one configs[2] job): 283 sub-streams, two jump launches (8 and 274 workgroups), one fill launch.
 // ------------------------------------------------------------------------------------
 constexpr u32 MT_SUB_DRAWS = 624u * 512u, MT_POLY_WORDS = 312, MT_DEG = 19937, MT_STATE_WORDS = MT_N + 1;
 constexpr u32 MT_JUMP_SWEEPS = 88, MT_SEQ_WORDS = MT_N + MT_JUMP_SWEEPS * (MT_N - MT_M);   // 20 600 words >= 624 + 19 936: every window of the convolution
 static_assert(MT_SEQ_WORDS >= MT_N + MT_DEG + 16, "the sequence covers the windows of every coefficient (and the sixteen outputs beyond 624 a lane reads along)");
 constexpr u32 MT_JUMP_LDS_WORDS = MT_SEQ_WORDS + 16 * 640;      // + the sixteen waves' partial arrays
-__global__ __launch_bounds__(1024) void mt_jump_kernel(u32* __restrict__ states, const u64* __restrict__ poly, u32 stride, u32 n_sub) {
+// coarse == true: workgroup b seats sub-stream (b + 1) R from sub-stream 0 (polynomial x^((b + 1) R J): the table's second half);
+// coarse == false: workgroup b = c (R - 1) + (i - 1) seats sub-stream c R + i from sub-stream c R (polynomial x^(i J))
+constexpr u32 MT_JUMP_R = 32;
+__global__ __launch_bounds__(1024) void mt_jump_kernel(u32* __restrict__ states, const u64* __restrict__ polys, u32 coarse, u32 n_sub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mtj_smem[];
     u32* const X = reinterpret_cast<u32*>(mtj_smem);
-    const u32 src = blockIdx.x * 2u * stride, dst = src + stride;
+    const u32 c = coarse ? 0u : blockIdx.x / (MT_JUMP_R - 1u), i = coarse ? blockIdx.x + 1u : blockIdx.x % (MT_JUMP_R - 1u) + 1u;
+    const u32 src = c * MT_JUMP_R, dst = coarse ? i * MT_JUMP_R : src + i;
     if (dst >= n_sub) return;                                  // (block-uniform)
+    const u64* const poly = polys + (u64)((coarse ? MT_JUMP_R - 1u : 0u) + i - 1u) * MT_POLY_WORDS;
     const u32 tid = threadIdx.x;
     const u32* const a = states + (u64)src * MT_STATE_WORDS;
     for (u32 i = tid; i < MT_N; i += 1024) X[i] = a[i];

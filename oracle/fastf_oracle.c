@@ -68,6 +68,17 @@ uint32_t oracle_genrand_int32(void)
     return y;
 }
 
+/* test convenience, no algorithm of its own: init_genrand(seed), `skip` draws thrown away, then n calls of genrand_int32() into
+ * out[] (what a Python loop over oracle_genrand_int32() returns, without its million ctypes calls); state[0..623] (if not NULL):
+ * the generator's array afterwards */
+void oracle_mt_draws(uint32_t seed, uint64_t skip, uint64_t n, uint32_t *out, uint32_t *state)
+{
+    oracle_init_genrand(seed);
+    for (uint64_t i = 0; i < skip; i++) (void)oracle_genrand_int32();
+    for (uint64_t i = 0; i < n; i++) out[i] = oracle_genrand_int32();
+    if (state) for (int i = 0; i < MT_N; i++) state[i] = g_mt[i];
+}
+
 /* mt19937ar.c:149-153 */
 double oracle_genrand_real1(void)
 {

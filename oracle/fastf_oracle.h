@@ -87,6 +87,7 @@ void oracle_result_free(oracle_result_t *r);
 void     oracle_init_genrand(uint32_t s);            /* mt19937ar.c:60-73   */
 uint32_t oracle_genrand_int32(void);                 /* mt19937ar.c:105-140 */
 double   oracle_genrand_real1(void);                 /* mt19937ar.c:149-153 */
+void     oracle_mt_draws(uint32_t seed, uint64_t skip, uint64_t n, uint32_t *out, uint32_t *state);  /* loop over the two above */
 /* SampleInt(iota(n_total), n_total, n_sample, 0, seed) then qsort; utils.c:29-75,
  * bam2db_ds.c:240-244.  out must hold n_sample entries (n_total if equal). */
 int      oracle_sample_cells(size_t n_total, size_t n_sample, unsigned int seed, uint64_t *out);

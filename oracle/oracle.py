@@ -159,10 +159,16 @@ def ref_lib():
     return R
 
 
-def mt_stream(seed, n):
+def mt_stream(seed, n, skip=0, state=False):
+    """n draws of genrand_int32() after init_genrand(seed) and `skip` draws thrown away (oracle_mt_draws: the loop in C);
+    state=True: also the generator's 624-word array afterwards"""
     L = lib()
-    L.oracle_init_genrand(seed)
-    return np.array([L.oracle_genrand_int32() for _ in range(n)], dtype=np.uint32)
+    L.oracle_mt_draws.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.oracle_mt_draws.restype = None
+    out = np.zeros(max(int(n), 1), dtype=np.uint32)
+    st = np.zeros(624, dtype=np.uint32)
+    L.oracle_mt_draws(seed, int(skip), int(n), out.ctypes.data, st.ctypes.data)
+    return (out[:n], st) if state else out[:n]
 
 
 def sample_cells(n_total, n_sample, seed):

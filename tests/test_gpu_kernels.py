@@ -3,6 +3,7 @@ restatements of sort / group-by (bit-exact; integer work)."""
 import numpy as np
 
 from fastf_amd import hostmem
+from oracle import oracle as O
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -279,8 +280,9 @@ def test_hash_dedup_reduce_on_group_sorted_keys(sizes, too_long, seed, monkeypat
     (1, 623, [2_000_000]),
 ])
 def test_device_mt19937_is_the_reference_stream(env, seed, skip, counts):
-    """mt_fill_kernel (three sweeps per 624-word block) against the host generator, which tests/test_oracle_pins.py pins to the
-    reference's own mt19937ar.c: launches of every size across block boundaries, continued from a host-side skip"""
+    """mt_fill_kernel (three sweeps per 624-word block) against the ORACLE's generator (oracle/fastf_oracle.c: mt19937ar.c:105-140
+    restated, pinned to the reference's own file by tests/test_oracle_pins.py): launches of every size across block boundaries,
+    continued from a host-side skip"""
     import ctypes as C
     torch, F, eng = env
     from fastf_amd import _lib
@@ -290,7 +292,7 @@ def test_device_mt19937_is_the_reference_stream(env, seed, skip, counts):
     out = np.zeros(max(n, 1), np.uint32)
     cs = np.asarray(counts, np.uint64)
     assert L.fastf_debug_mt_fill(0, seed, skip, cs.ctypes.data, len(counts), out.ctypes.data) == 0, L.fastf_last_error()
-    np.testing.assert_array_equal(out[:n], F.mt_draws(seed, skip, n))
+    np.testing.assert_array_equal(out[:n], O.mt_stream(seed, n, skip=skip))
 
 
 @pytest.mark.parametrize("seed,skip,first,counts,rate,ring_bits", [
@@ -317,7 +319,7 @@ def test_device_decision_stream(env, seed, skip, first, counts, rate, ring_bits)
     cs = np.asarray(counts, np.uint64)
     assert L.fastf_debug_mt_fill_bits(0, seed, skip, first, cs.ctypes.data, len(counts), thr, ring_bits, out.ctypes.data) == 0, L.fastf_last_error()
     got = np.unpackbits(out.view(np.uint8), bitorder="little")
-    want = (F.mt_draws(seed, skip, n).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
+    want = (O.mt_stream(seed, n, skip=skip).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
     keep = min(n, ring_bits - 64)                      # the newest ranks; older ones may have been overwritten by the wrap
     r = np.arange(first + n - keep, first + n, dtype=np.uint64)
     np.testing.assert_array_equal(got[(r % np.uint64(ring_bits)).astype(np.int64)], want[n - keep:])
@@ -336,13 +338,16 @@ J_SUB = 624 * 512                                      # draws per sub-stream of
     (926, 0, 5 * J_SUB + 1234, 0.5),                   # a stream that starts at a block boundary (seeded: the first draw regenerates)
     (926, 100, 4 * J_SUB, 0.3),                        # ... in the middle of a block: the rest of it goes out first; the smallest parallel call
     (7, 7, 4 * J_SUB + 1, 0.7),
-    (5489, 624 * 3 + 5, 20_000_000, 0.5),              # 63 sub-streams, six levels of jumps
+    (5489, 624 * 3 + 5, 20_000_000, 0.5),              # 63 sub-streams: one coarse jump (sub-stream 32), then the fine ones behind 0 and 32
     (1, 623, 9 * J_SUB - 623, 1.0),                    # ends exactly on a sub-stream boundary
+    (926, 11, 33 * J_SUB + 5, 0.5),                    # sub-stream 32 is seated by the coarse launch and has one fine sub-stream behind it
+    (3, 0, 1027 * J_SUB + 77, 0.25),                   # more than R^2 = 1024 sub-streams: a second round continues the first's last sub-stream
 ])
 def test_parallel_mt_decisions_are_the_reference_stream(env, seed, skip, n, rate):
     """fastf_dev_mt_decisions: the MT19937 stream (mt19937ar.c:105-140) from many workgroups at once — sub-streams 624 x 512 draws
-    apart, seated by jump-ahead (mt_jump_kernel: the state J draws on is g(F) applied to the state now, g = x^J mod the
-    characteristic polynomial) and generated side by side — must be the stream one generator produces, decision for decision"""
+    apart, seated by jump-ahead in two launches (mt_jump_kernel: the state J draws on is g(F) applied to the state now, g = x^J mod
+    the characteristic polynomial; sub-streams 32, 64, .. from the stream's state, then the 31 behind each) and generated side by
+    side — must be the stream the ORACLE's one generator produces, decision for decision"""
     torch, F, eng0 = env
     from fastf_amd import _lib
     from helpers import Case
@@ -356,14 +361,14 @@ def test_parallel_mt_decisions_are_the_reference_stream(env, seed, skip, n, rate
         eng.dev_mt_decisions(seed, skip, n, words.data_ptr())
         torch.cuda.synchronize()
         got = np.unpackbits(hostmem.to_host(words).view(np.uint8), bitorder="little")
-        want = (F.mt_draws(seed, skip, n).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
+        want = (O.mt_stream(seed, n, skip=skip).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
         np.testing.assert_array_equal(got[:n], want)
         assert not got[n:(n + 63) // 64 * 64].any()    # the tail of the last 64-bit word is zero
         # a second call on the same engine (the polynomials and the sub-stream states are in place) from another position
         eng.dev_mt_decisions(seed + 1, skip + 17, 4 * J_SUB + 99, words.data_ptr())
         torch.cuda.synchronize()
         got = np.unpackbits(hostmem.to_host(words).view(np.uint8), bitorder="little")
-        want = (F.mt_draws(seed + 1, skip + 17, 4 * J_SUB + 99).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
+        want = (O.mt_stream(seed + 1, 4 * J_SUB + 99, skip=skip + 17).astype(np.uint64) < np.uint64(thr)).astype(np.uint8)
         np.testing.assert_array_equal(got[:4 * J_SUB + 99], want)
     finally:
         eng.close()

@@ -209,33 +209,42 @@ def test_pack_umi_long_matches_the_codec_up_to_32_bases():
 
 
 def test_mt_jump_polynomials_are_the_generator_advanced():
-    """mt_jump.c: x^J mod the characteristic polynomial of MT19937 (Berlekamp-Massey on its own output, then squarings), applied
-    to a block-boundary array as a convolution with the generated sequence, must give the array fastf_mt_skip reaches by
-    generating J draws — for the table the library carries (strides of 624 x 512 x 2^l draws) and for polynomials computed here"""
+    """mt_jump.c: x^J mod the characteristic polynomial of MT19937 (Berlekamp-Massey on its own output, squarings, products mod
+    phi), applied to a block-boundary array as a convolution with the generated sequence, must give the array the generator reaches
+    by generating J draws — for the table the library carries (the two-level seating: x^(i J) and x^(i R J), J = 624 x 512 draws,
+    R = 32) and for polynomials computed here.  The reference is the ORACLE's generator (oracle.mt_stream: mt19937ar.c restated),
+    continued draw by draw."""
     import ctypes as C
     L = _lib.lib()
-    NW, J = 312, 624 * 512
+    NW, J, R = 312, 624 * 512, 32
     L.fastf_mt_jump_table.restype = C.POINTER(C.c_uint64)
     L.fastf_mt_jump_polys.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+    L.fastf_mt_jump_table_compute.argtypes = [C.c_uint64, C.c_void_p]
     L.fastf_mt_jump_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    table = np.ctypeslib.as_array(L.fastf_mt_jump_table(), shape=(12 * NW,)).copy()
-    fresh = np.zeros(3 * NW, np.uint64)
-    assert L.fastf_mt_jump_polys(J, 3, fresh.ctypes.data) == 0
-    np.testing.assert_array_equal(fresh, table[:3 * NW])                 # the build tool's table is what the code computes
+    table = np.ctypeslib.as_array(L.fastf_mt_jump_table(), shape=(2 * (R - 1) * NW,)).copy()
+    fresh = np.zeros(2 * (R - 1) * NW, np.uint64)
+    assert L.fastf_mt_jump_table_compute(J, fresh.ctypes.data) == 0
+    np.testing.assert_array_equal(fresh, table)                          # the build tool's table is what the code computes
+    direct = np.zeros(NW, np.uint64)
+    for i in (1, 2, 5, 31):                                              # products mod phi agree with square-and-multiply on the exponent
+        assert L.fastf_mt_jump_polys(i * J, 1, direct.ctypes.data) == 0
+        np.testing.assert_array_equal(direct, table[(i - 1) * NW:i * NW])
+    assert L.fastf_mt_jump_polys(3 * R * J, 1, direct.ctypes.data) == 0
+    np.testing.assert_array_equal(direct, table[(R - 1 + 2) * NW:(R - 1 + 3) * NW])
     odd = np.zeros(2 * NW, np.uint64)
     assert L.fastf_mt_jump_polys(624 * 33, 2, odd.ctypes.data) == 0      # another stride (odd part 39 * 33 > 624: square-and-multiply)
 
     def array_after(seed, blocks):
-        from fastf_amd.engine import MT
-        mt = MT(); L.fastf_mt_seed(C.byref(mt), seed); L.fastf_mt_skip(C.byref(mt), 624 * blocks)
-        return np.array(mt.s[:], dtype=np.uint32), mt
+        """the ORACLE generator's 624-word array after `blocks` whole blocks of draws"""
+        return O.mt_stream(seed, 0, skip=624 * blocks, state=True)[1]
 
     for seed in (926, 1):
-        a, mt = array_after(seed, 5)
-        for poly, stride in ((table[:NW], J), (table[NW:2 * NW], 2 * J), (table[5 * NW:6 * NW], 32 * J), (odd[:NW], 624 * 33), (odd[NW:], 624 * 66)):
+        a = array_after(seed, 5)
+        cases = ((table[:NW], J), (table[NW:2 * NW], 2 * J), ((table[(R - 1) * NW:R * NW]), R * J), (odd[:NW], 624 * 33), (odd[NW:], 624 * 66))
+        for poly, stride in cases:
             out = np.zeros(624, np.uint32)
             L.fastf_mt_jump_apply(a.ctypes.data, np.ascontiguousarray(poly).ctypes.data, out.ctypes.data)
-            want, _ = array_after(seed, 5 + stride // 624)
+            want = array_after(seed, 5 + stride // 624)
             np.testing.assert_array_equal(out[1:], want[1:])
             assert (int(out[0]) ^ int(want[0])) >> 31 == 0                # word 0 lends only its top bit
 
