@@ -478,6 +478,8 @@ def e2e_leg(job, sizes):
                     # BAM, the pinned slab and the GPU context of the exiting process) is reported next to it, not in it
                     done = (closed[-1] - w0) if closed else wall
                     md5 = subprocess.run("zcat %s/matrix.mtx.gz | md5sum" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()[0]
+                    # (the header names the BAM's path: the rows alone compare runs on copies of the file)
+                    body_md5 = subprocess.run("zcat %s/matrix.mtx.gz | grep -v '^%%' | md5sum" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()[0]
                     dims = subprocess.run("zcat %s/matrix.mtx.gz | grep -v '^%%' -m 1" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()
                     # the clock a user lives with: process start -> process exit.  "outputs closed" (SURVEY 8d's end-to-end
                     # scope) is kept beside it
@@ -489,7 +491,7 @@ def e2e_leg(job, sizes):
                             ph = {k: float(v) for k, v in (kv.split("=") for kv in l.split(":", 1)[1].split())}
                     if best is None or wall < best["seconds"]:
                         best = {"value": n / wall, "unit": "records/s", "seconds": wall, "scope": "process start -> process exit",
-                                "seconds_to_outputs_closed": done, "records_per_s_to_outputs_closed": n / done, "matrix_md5": md5,
+                                "seconds_to_outputs_closed": done, "records_per_s_to_outputs_closed": n / done, "matrix_md5": md5, "matrix_rows_md5": body_md5,
                                 "matrix_rows": int(dims[2]) if len(dims) == 3 else None,
                                 "start_up_s": ph.get("decoder_saw_engine_s"), "records_decoded_during_start_up": ph.get("records_before"),
                                 "steady_state_records_per_s": (ph["steady_records"] / ph["steady_s"]) if ph.get("steady_s") else None,
@@ -501,8 +503,90 @@ def e2e_leg(job, sizes):
             if v:
                 out[label]["value"] = max(x["value"] for x in v); out[label]["unit"] = "records/s"
                 out[label]["same_matrix"] = len({x["matrix_md5"] for x in v}) == 1
+            if bodies > 1 and v and not os.environ.get("FASTF_E2E_NO_COLD"):
+                # every line above reads its BAM from /dev/shm (page cache: "read 0.000 s").  ONE line with the read in it: the
+                # same file on a disk-backed directory, its pages dropped from the page cache before the run
+                out[label + "_cold"] = _cold_run(cli, bam, td, n, threads, out[label]["hybrid_inflate"].get("matrix_rows_md5"))
             os.unlink(bam)
     return out
+
+
+def _disk_dir(need_bytes):
+    """a directory on a disk-backed filesystem with room for need_bytes (FASTF_E2E_DISK_DIR first), or None"""
+    fstype = {}
+    try:
+        for ln in open("/proc/mounts"):
+            f = ln.split()
+            fstype[f[1]] = f[2]
+    except OSError:
+        pass
+
+    def fs_of(path):
+        path = os.path.realpath(path)
+        best = ""
+        for m in fstype:
+            if (path == m or path.startswith(m.rstrip("/") + "/")) and len(m) > len(best):
+                best = m
+        return fstype.get(best, "?")
+    for d in [os.environ.get("FASTF_E2E_DISK_DIR"), os.path.join(ROOT, "build"), "/var/tmp", "/tmp"]:
+        if not d or not os.path.isdir(d):
+            continue
+        if fs_of(d) in ("tmpfs", "ramfs", "devtmpfs"):
+            continue
+        st = os.statvfs(d)
+        if st.f_bavail * st.f_frsize >= need_bytes + (2 << 30):
+            return d, fs_of(d)
+    return None, None
+
+
+def _cold_run(cli, bam, td, n, threads, want_md5):
+    import shutil
+    size = os.path.getsize(bam)
+    d, fs = _disk_dir(size)
+    if d is None:
+        return {"skipped": "no disk-backed directory with %.1f GB free (set FASTF_E2E_DISK_DIR)" % (size / 1e9)}
+    cold = os.path.join(d, "fastf_cold_%d.bam" % os.getpid())
+    try:
+        t0 = time.perf_counter()
+        shutil.copyfile(bam, cold)
+        fd = os.open(cold, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)           # clean pages of the file leave the page cache
+        finally:
+            os.close(fd)
+        t_copy = time.perf_counter() - t0
+        resident = None
+        try:                                                             # how much of it is still cached (util-linux fincore, if there)
+            r = subprocess.run(["fincore", "--bytes", "--noheadings", "--output", "RES", cold], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            if r.returncode == 0:
+                resident = int(r.stdout.decode().split()[0]) / size
+        except (OSError, ValueError, IndexError):
+            pass
+        od = os.path.join(td, "out_cold"); os.makedirs(od, exist_ok=True)
+        env = dict(os.environ, FASTF_HOST_THREADS=str(threads), FASTF_PROFILE="1", FASTF_BAM_PROFILE="1", FASTF_GPU_INFLATE="1")
+        t0 = time.perf_counter(); w0 = time.time()
+        p = subprocess.run([cli, "bam2db", "-b", cold, "-a", os.path.join(td, "bar.tsv"), "-f", os.path.join(td, "feat.tsv"),
+                            "-o", od, "-c", "0.5", "-r", "0.5", "-s", "926"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": p.stderr.decode(errors="replace")[-400:]}
+        lines = p.stderr.decode(errors="replace").splitlines()
+        closed = [float(l.split(" at ")[1].split()[0]) for l in lines if l.startswith("[bam2db] outputs closed at")]
+        done = (closed[-1] - w0) if closed else wall
+        md5 = subprocess.run("zcat %s/matrix.mtx.gz | grep -v '^%%' | md5sum" % od, shell=True, stdout=subprocess.PIPE).stdout.decode().split()[0]
+        rdr = [l for l in lines if l.startswith("[bam] ") and "read " in l]
+        return {"value": n / wall, "unit": "records/s", "seconds": wall, "scope": "process start -> process exit, the BAM on a disk-backed "
+                "filesystem with its pages dropped from the page cache before the run (posix_fadvise DONTNEED after fsync)",
+                "seconds_to_outputs_closed": done, "records_per_s_to_outputs_closed": n / done, "bam_bytes": size,
+                "bam_bytes_per_s": size / wall, "filesystem": fs, "directory": d, "copied_and_dropped_in_s": t_copy,
+                "cached_fraction_before_the_run": resident, "matrix_rows_md5": md5, "same_matrix_rows_as_the_cached_run": md5 == want_md5,
+                "reader": " | ".join(rdr[:1])}
+    finally:
+        try:
+            os.unlink(cold)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

@@ -156,7 +156,9 @@ GI2_FN void refill(Bits& b) {
 GI2_FN uint32_t peek(const Bits& b, int n) { return (uint32_t)b.buf & ((1u << n) - 1u); }
 GI2_FN void drop(Bits& b, uint32_t n) { b.buf >>= n; b.cnt -= n; }
 GI2_FN uint32_t take(Bits& b, int n) { const uint32_t v = peek(b, n); drop(b, (uint32_t)n); return v; }
-// `in` readable from its 16-byte-aligned floor to 192 bytes past in + in_len
+// `in` readable from its 16-byte-aligned floor to 192 bytes past in + in_len.  (What is read at most: every loop that consumes
+// input stops once pos has passed n_words = the block's words + 2, a header in front of the first check is 9 bytes, and the three
+// stages reach 3 x QW words ahead of pos — 124 bytes past the end with QW = 8.)
 GI2_FN uint32_t bits_open(Bits& b, const uint8_t* in, uint32_t in_len) {
     const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u);     // bytes in front of `in` inside its first quad
     b.in32 = reinterpret_cast<const uint32_t*>(in - lead);
@@ -194,9 +196,10 @@ GI2_FN uint32_t rev32(uint32_t c) {                          // all 32 bits in r
 struct Canon { uint32_t v[15]; };
 
 // the code lengths w.lens[at .. at + n_sym) -> the sorted symbol list (LIT: lit_lo / lit_hi, else dist_sorted) and the fifteen
-// words.  0, or E_LENS for an over-subscribed set (or an incomplete one with more than one code).
+// words.  0, or E_LENS for an over-subscribed set, or an incomplete one — which zlib (inftrees.c) accepts in one form only: a
+// literal/length or distance alphabet holding a single code of length 1 (never for the code-length alphabet: `complete_only`).
 template <bool LIT>
-GI2_FN int build(Work& w, uint32_t at0, int n_sym, Canon& c) {
+GI2_FN int build(Work& w, uint32_t at0, int n_sym, Canon& c, bool complete_only = false) {
     for (int l = 0; l < 16; ++l) w.count[l] = 0;
     for (int s = 0; s < n_sym; ++s) w.count[get_len(w, at0 + (uint32_t)s)]++;
     const uint32_t n_codes = (uint32_t)n_sym - w.count[0];
@@ -213,7 +216,8 @@ GI2_UNROLL
         c.v[l - 1] = (((first + n) << (15 - l)) << 16) | ((uint32_t)l << 12) | cum;
         prev = n;
     }
-    if (bad || (left > 0 && n_codes > 1)) return E_LENS;
+    if (bad) return E_LENS;
+    if (left > 0 && (complete_only || n_codes > 1 || (n_codes == 1 && w.count[1] != 1))) return E_LENS;
     if (LIT) for (int i = 0; i < 9; ++i) w.lit_hi[i] = 0;
     for (int s = 0; s < n_sym; ++s) {
         const uint32_t l = get_len(w, at0 + (uint32_t)s);
@@ -355,11 +359,13 @@ GI2_FN int inflate_tokens(Work& w, const uint8_t* in, uint32_t in_len, uint8_t* 
                 // the code-length code: its symbols sorted in the distance list's space (rebuilt right after)
                 for (uint32_t i = 0; i < 19; ++i) set_len(w, 300u + i, 0);
                 for (int i = 0; i < n_cl; ++i) { refill(b); set_len(w, 300u + CLORD[i], take(b, 3)); }
-                if (!err && build<false>(w, 300, 19, cl)) err = E_LENS;
+                if (b.pos > b.n_words) err = E_INPUT;                      // (a header that runs on past its block)
+                if (!err && build<false>(w, 300, 19, cl, true)) err = E_LENS;
                 uint32_t prev = 0;
                 int i = 0;
                 const int n_all = n_lit + n_dist;                          // (<= 316: the 19 entries at 300.. are dead by the time they are overwritten — the code is built)
                 while (i < n_all && !err) {
+                    if (b.pos > b.n_words) { err = E_INPUT; break; }       // every loop that consumes input checks: the over-read stays within the slack
                     refill(b);
                     const int cs = decode<false>(b, cl, w);
                     if (cs < 0) { err = E_LENS; break; }

@@ -241,7 +241,7 @@ static int th_distinct(fastf_taghist* h, const u64* src, u64 fill_idx, u64 varyi
     fastf_engine* e = h->ws;
     const u64 n = h->n;
     u64* d_nn = (u64*)h->d_small.p + 7;
-    HIP_OK(hipMemcpyAsync(d_nn, &h->n, sizeof(u64), hipMemcpyHostToDevice, s));
+    if (copy_h2d_on(d_nn, &h->n, sizeof(u64), s)) return 1;      // (a word of the handle: through the bounce buffer, like every host word)
     const u32 grid = (u32)std::min<u64>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(th_fill_copy_kernel, dim3(grid), dim3(256), 0, s, src, (u64*)h->d_a.p, n, fill_idx);
     int in_tmp = 0;
@@ -274,8 +274,8 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
         hipLaunchKernelGGL(th_first_index_kernel, dim3(grid), dim3(256), 0, s, (const u64*)h->d_k1.p, n, (const u64*)h->d_u1.p,
                            (const u64*)d_m1, (u32*)h->d_first.p);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpyAsync(&m1, d_m1, sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        if (copy_d2h(&m1, d_m1, sizeof(u64))) return 1;
         h->h_key1.resize(m1); h->h_count1.resize(m1); h->h_first1.resize(m1); h->h_tmp32.resize(m1);
         if (copy_d2h(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64))) return 1;
         if (copy_d2h(h->h_tmp32.data(), h->d_c1.p, m1 * sizeof(u32))) return 1;
@@ -286,7 +286,7 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
         const u64 n_absent = n - h->n_present1;
         if (n_absent) {
             u64 fill = 0;
-            HIP_OK(hipMemcpy(&fill, (const u64*)h->d_k1.p + h->first_present1, sizeof(u64), hipMemcpyDeviceToHost));
+            if (copy_d2h(&fill, (const u64*)h->d_k1.p + h->first_present1, sizeof(u64))) return 1;
             const size_t at = (size_t)(std::lower_bound(h->h_key1.begin(), h->h_key1.end(), fill) - h->h_key1.begin());
             if (at >= m1 || h->h_key1[at] != fill || h->h_count1[at] <= n_absent) return set_err("tag histogram: fill key lost");
             h->h_count1[at] -= n_absent;
@@ -303,9 +303,8 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
                        (const u64*)h->d_u1.p, (const u64*)d_m1, (const u64*)h->d_u2.p, (const u64*)d_m2, (u64*)h->d_code.p);
     HIP_OK(hipGetLastError());
     u64 m2 = 0;
-    HIP_OK(hipMemcpyAsync(&m1, d_m1, sizeof(u64), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(&m2, d_m2, sizeof(u64), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    if (copy_d2h(&m1, d_m1, sizeof(u64)) || copy_d2h(&m2, d_m2, sizeof(u64))) return 1;
     // digits of the pair code that can vary: rank2 in the low word, rank1 + 1 in the high word
     const u64 varying = ((1ull << bits_for(m2 ? m2 - 1 : 0)) - 1) | (((1ull << bits_for(m1)) - 1) << 32);
     if (th_distinct(h, (const u64*)h->d_code.p, h->first_valid_pair, varying, (u64*)h->d_up.p, (u32*)h->d_cp.p, d_mp, s)) return 1;
@@ -314,8 +313,8 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
                        (const u64*)d_mp, (u32*)h->d_first.p);
     HIP_OK(hipGetLastError());
     u64 mp = 0;
-    HIP_OK(hipMemcpyAsync(&mp, d_mp, sizeof(u64), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    if (copy_d2h(&mp, d_mp, sizeof(u64))) return 1;
     h->h_key1.resize(m1); h->h_u2.resize(m2); h->h_up.resize(mp);
     if (copy_d2h(h->h_key1.data(), h->d_u1.p, m1 * sizeof(u64))) return 1;
     if (copy_d2h(h->h_u2.data(), h->d_u2.p, m2 * sizeof(u64))) return 1;
@@ -329,7 +328,7 @@ extern "C" int fastf_taghist_finish(fastf_taghist_t* h, fastf_taghist_result_t* 
     const u64 n_invalid = n - h->n_valid;
     if (n_invalid) {
         u64 fill = 0;
-        HIP_OK(hipMemcpy(&fill, (const u64*)h->d_code.p + h->first_valid_pair, sizeof(u64), hipMemcpyDeviceToHost));
+        if (copy_d2h(&fill, (const u64*)h->d_code.p + h->first_valid_pair, sizeof(u64))) return 1;
         const size_t at = (size_t)(std::lower_bound(h->h_up.begin(), h->h_up.end(), fill) - h->h_up.begin());
         if (at >= mp || h->h_up[at] != fill || h->h_pair_count[at] <= n_invalid) return set_err("tag histogram: fill pair lost");
         h->h_pair_count[at] -= n_invalid;

@@ -1432,7 +1432,7 @@ extern "C" int fastf_dev_error_bits(fastf_engine_t* e, uint64_t* bits) FASTF_TRY
     if (e->multi) return set_err("fastf_dev_error_bits: device-level calls take a single-device engine");
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpy(bits, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64), hipMemcpyDeviceToHost));
+    if (copy_d2h(bits, (u64*)e->d_small.p + SM_COUNTERS + 3, sizeof(u64))) return 1;
     return 0;
 } FASTF_CATCH_INT
 
@@ -1986,7 +1986,7 @@ extern "C" int fastf_engine_finish(fastf_engine_t* e, fastf_coo_t* coo, uint64_t
             u64* other = e->sorted_in_tmp ? (u64*)e->d_keys.p : (u64*)e->d_tmp.p;
             int in_other = 0;
             const u64 keep = e->h_small[SM_COUNTERS + 3] & ~ERR_RUN_TOO_LONG;
-            HIP_OK(hipMemcpyAsync(small + SM_COUNTERS + 3, &keep, sizeof(u64), hipMemcpyHostToDevice, s));
+            if (copy_h2d_on(small + SM_COUNTERS + 3, &keep, sizeof(u64), s)) return 1;
             if (launch_sort(e, from, other, small + SM_KEYCOUNT, n, e->L.total_bits, 0, &in_other, s)) return 1;
             if (in_other) e->sorted_in_tmp = !e->sorted_in_tmp;
             e->fully_sorted = true; e->store_regions = false;
@@ -2191,7 +2191,7 @@ extern "C" int fastf_dev_adopt_wide(fastf_engine_t* e, const uint64_t* d_keys, c
         HIP_OK(hipMemcpyAsync(e->d_vals.p, d_vals, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
     }
     const u64 cnt = n;
-    HIP_OK(hipMemcpyAsync((u64*)e->d_small.p + SM_KEYCOUNT, &cnt, sizeof(u64), hipMemcpyHostToDevice, s));
+    if (copy_h2d_on((u64*)e->d_small.p + SM_KEYCOUNT, &cnt, sizeof(u64), s)) return 1;
     HIP_OK(hipStreamSynchronize(s));                       // (fastf_engine_finish works on the engine's own stream; cnt is a local)
     e->keys_so_far = n; e->finished = false; e->finish_queued = false; e->fully_sorted = false; e->sorted_in_tmp = 0;
     return 0;

@@ -147,3 +147,34 @@ def test_token_decoder_rejects_malformed_input_without_crashing(gi2):
     for _ in range(200):                                              # garbage
         g = rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8).tobytes()
         gi2(g, int(rng.integers(0, 65537)))
+
+
+def _bits(*fields):
+    """(value, width) fields, LSB first, into bytes (DEFLATE's bit order)"""
+    acc = n = 0
+    for v, w in fields:
+        acc |= v << n; n += w
+    return acc.to_bytes((n + 7) // 8 + 8, "little")
+
+
+def test_token_decoder_rejects_the_incomplete_code_sets_zlib_rejects(gi2):
+    """zlib (inftrees.c) takes an incomplete Huffman set in ONE form only: a literal/length or distance alphabet with a single code
+    of length 1.  An incomplete code-length alphabet, or a single code of another length, is "invalid code lengths set" there
+    and must not decode here either (this decoder used to accept a single code of any length, in any alphabet)."""
+    # BFINAL=1, BTYPE=2, HLIT=0 (257), HDIST=0 (1), HCLEN=0 (4 code-length codes: symbols 16, 17, 18, 0)
+    # the code-length code: only symbol 0, with length 2 -> incomplete
+    bad_cl = _bits((1, 1), (2, 2), (0, 5), (0, 5), (0, 4), (0, 3), (0, 3), (0, 3), (2, 3))
+    assert zlib_rejects(bad_cl)
+    assert gi2(bad_cl, 16)[0] != 0
+    # ... with length 1: still incomplete, still rejected for THIS alphabet
+    bad_cl1 = _bits((1, 1), (2, 2), (0, 5), (0, 5), (0, 4), (0, 3), (0, 3), (0, 3), (1, 3))
+    assert zlib_rejects(bad_cl1)
+    assert gi2(bad_cl1, 16)[0] != 0
+
+
+def zlib_rejects(raw):
+    try:
+        zlib.decompressobj(-15).decompress(raw)
+    except zlib.error:
+        return True
+    return False

@@ -19,4 +19,6 @@ cp $(find $out/stats -name "*kernel_stats.csv" | head -1) profiles/${tag}_rocpro
 # (kernels run a few per cent slower under the tracer than in the plain run below)
 grep '^{"metric"' $out/stats.log | tail -1 > profiles/${tag}_bench_line_under_rocprofv3.json
 python3 bench.py --steps 100 --warmup 3 > profiles/${tag}_bench_line.json 2> $out/bench.err
-echo "profiles/${tag}_* written"
+# (only gpurun_out/ travels back from the GPU box: a copy of everything this script put under profiles/)
+mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/
+echo "profiles/${tag}_* written (copies under $out/profiles/)"
