@@ -349,7 +349,7 @@ static void pin_ledger_check_release(const void *p, size_t bytes, const char *wh
 }
 
 typedef struct { void *p; void *base; size_t len; } big_map;
-static big_map g_big[128];
+static big_map g_big[1024];
 static pthread_mutex_t g_big_mu = PTHREAD_MUTEX_INITIALIZER;
 
 void *fastf_big_alloc(size_t bytes)
