@@ -216,7 +216,7 @@ def main():
         with_draws = {"ms_per_step": t_with * 1e3, "records_per_s": N_total / t_with, "steps": n_gen_steps,
                       "draw_generation_ms": t_gen_only * 1e3, "draws_per_step": hits, "draws_per_s": hits / t_gen_only,
                       "same_counters_as_the_resident_stream": (h2, s2, v2) == (hits, sampled, valid) and int(sp.d_n.item()) == K_ref,
-                      "scope": "fastf_dev_mt_decisions (host seeds and skips the stream, the device seats 624 x 512-draw sub-streams by jump-ahead and generates them side by side, draw_bits packs the decisions; the call synchronises) + the step above"}
+                      "scope": "fastf_dev_mt_decisions (host seeds and skips the stream, the device seats 624 x 256-draw sub-streams by jump-ahead and generates them side by side, draw_bits packs the decisions; the call synchronises) + the step above"}
     K_local = int(sp.d_n.item())
     Z_local = int(sp.nnz.item())
     tot = torch.tensor([K_local, Z_local], dtype=torch.int64, device=dev)

@@ -6,10 +6,10 @@
 extern "C" {
 #endif
 #define FASTF_MT_POLY_WORDS 312            /* 19937 coefficients, bit k of word k >> 6 = coefficient of x^k */
-#define FASTF_MT_SUB_BLOCKS 512            /* a sub-stream of the parallel generator: 512 blocks of 624 draws */
+#define FASTF_MT_SUB_BLOCKS 256            /* a sub-stream of the parallel generator: 256 blocks of 624 draws */
 #define FASTF_MT_SUB_DRAWS (624u * FASTF_MT_SUB_BLOCKS)
 #define FASTF_MT_JUMP_R 32                 /* two-level seating: sub-streams 0, R, 2R, .. from the stream's state, then the R - 1 behind each */
-#define FASTF_MT_JUMP_POLYS (2 * (FASTF_MT_JUMP_R - 1))   /* x^(iJ), i = 1..R-1, then x^(iRJ), i = 1..R-1: up to R^2 = 1024 sub-streams (327 M draws) per round */
+#define FASTF_MT_JUMP_POLYS (2 * (FASTF_MT_JUMP_R - 1))   /* x^(iJ), i = 1..R-1, then x^(iRJ), i = 1..R-1: up to R^2 = 1024 sub-streams (163 M draws) per round */
 /* out[l * 312 ..]: x^(stride_words * 2^l) mod phi for l = 0 .. n_levels-1 (computed: Berlekamp-Massey once per process, then
  * squarings, a few ms each).  0 on success. */
 int fastf_mt_jump_polys(uint64_t stride_words, uint32_t n_levels, uint64_t *out);

@@ -223,7 +223,7 @@ struct fastf_engine {
     DevBuf d_mtwords;                    // the generator's words of one launch, between mt_fill_kernel and draw_bits_kernel
     DevBuf d_mt; bool mt_on_device = false;  // the engine-owned stream continues on the device (mt_fill_kernel): state words + read index
     u32 mt_dev_idx = MT_N;                   // ... and where in its block that stream stands, as the host knows it (the parallel generator starts at a block boundary)
-    DevBuf d_mtsub, d_mtpoly, d_mtseat;      // parallel generator (jump-ahead): the sub-streams' states; the jump polynomials; the state fastf_dev_mt_decisions seats
+    DevBuf d_mtsub, d_mtpoly, d_mtseat, d_mtseq;   // parallel generator (jump-ahead): the sub-streams' states; the jump polynomials; the state fastf_dev_mt_decisions seats; the sources' sequences
     u64 draws_up = 0;                    // absolute ranks below this are (being) uploaded
     u64 draws_valid = 0;                 // ranks below this carry a real draw (caller-supplied streams can run short)
     // staging: chunks in flight, double buffered
@@ -664,7 +664,7 @@ extern "C" void fastf_engine_destroy(fastf_engine_t* e) FASTF_TRY {
     }
     if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->h_coo) { if (e->h_coo_pinned) pin_unreg(e->h_coo); fastf_big_free(e->h_coo, (size_t)e->h_coo_cap * 12); }
-    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release(); e->d_mtsub.release(); e->d_mtpoly.release(); e->d_mtseat.release();
+    e->d_ring.release(); e->d_mt.release(); e->d_dbits.release(); e->d_mtwords.release(); e->d_mtsub.release(); e->d_mtpoly.release(); e->d_mtseat.release(); e->d_mtseq.release();
     DevBuf* all[] = {&e->tab_cells, &e->tab_feats, &e->img_cells, &e->img_genes, &e->d_cell_filter, &e->d_keys, &e->d_tmp, &e->d_small, &e->d_feature, &e->d_cell,
                      &e->d_count, &e->d_ukeys, &e->d_ncopy, &e->d_cellidx, &e->d_tilecnt, &e->d_tilebase, &e->d_binbase, &e->d_cnt, &e->d_rg_feature, &e->d_rg_cell, &e->d_rg_count, &e->d_rg_ukeys, &e->d_spanrows, &e->d_spanbase, &e->d_giant, &e->d_scanblk,
                      &e->d_halfhits, &e->d_segcount, &e->d_segprefix, &e->d_tileseg, &e->d_segkeys, &e->d_vals, &e->d_vtmp,
@@ -921,7 +921,7 @@ static u32 mt_idx_after(u32 idx, u64 n) {
     if (idx + n <= MT_N) return (u32)(idx + n);
     return (u32)((idx + n - 1) % MT_N) + 1u;
 }
-// The same as launch_mt_decisions, by MANY workgroups (mt_jump_kernel / mt_fill_multi_kernel: jump-ahead).  *idx: the read index of
+// The same as launch_mt_decisions, by MANY workgroups (mt_seq_kernel + mt_conv_kernel / mt_fill_multi_kernel: jump-ahead).  *idx: the read index of
 // the stream in d_mt as the host knows it (the jumps start at a block boundary: the rest of the block the stream stands in is
 // handed out by the one-workgroup kernel first); updated.  Calls below MT_PAR_MIN draws take the one-workgroup kernel: seating
 // the sub-streams costs a handful of launches.
@@ -944,7 +944,9 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
         static_assert(MT_POLY_WORDS == FASTF_MT_POLY_WORDS && MT_SUB_DRAWS == FASTF_MT_SUB_DRAWS && MT_JUMP_R == FASTF_MT_JUMP_R, "kernel and table agree");
         if (e->d_mtpoly.ensure((size_t)FASTF_MT_JUMP_POLYS * MT_POLY_WORDS * sizeof(u64))) return 1;
         if (copy_h2d(e->d_mtpoly.p, fastf_mt_jump_table(), (size_t)FASTF_MT_JUMP_POLYS * MT_POLY_WORDS * sizeof(u64))) return 1;
-        HIP_OK(hipFuncSetAttribute((const void*)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_JUMP_LDS_WORDS * sizeof(u32))));
+        HIP_OK(hipFuncSetAttribute((const void*)mt_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_SEQ_WORDS * sizeof(u32))));
+        HIP_OK(hipFuncSetAttribute((const void*)mt_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MT_CONV_LDS_WORDS * sizeof(u32))));
+        if (e->d_mtseq.ensure((size_t)MT_JUMP_R * MT_SEQ_STRIDE * sizeof(u32))) return 1;      // the sequences of up to R sources
     }
     u32* const w = (u32*)words.p;
     if (head) {                                                // the rest of the block the stream stands in
@@ -961,12 +963,18 @@ static int launch_mt_decisions_par(fastf_engine* e, hipStream_t s, u32* d_mt, u3
             if (e->d_mtsub.ensure((size_t)std::max<u32>(S, 64) * MT_STATE_WORDS * 4)) return 1;
         }
         u32* const sub = (u32*)e->d_mtsub.p;
+        u32* const seq = (u32*)e->d_mtseq.p;
         HIP_OK(hipMemcpyAsync(sub, d_mt, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
+        if (S > 1) HIP_OK(hipMemsetAsync(sub + MT_STATE_WORDS, 0, (size_t)(S - 1) * MT_STATE_WORDS * 4, s));   // the halves of a jump XOR into zeros
         const u32 n_coarse = (S + MT_JUMP_R - 1) / MT_JUMP_R;            // sub-streams 0, R, 2R, ..
-        if (n_coarse > 1)
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(n_coarse - 1), dim3(1024), MT_JUMP_LDS_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p, 1u, S);
-        if (S > 1)
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(n_coarse * (MT_JUMP_R - 1)), dim3(1024), MT_JUMP_LDS_WORDS * sizeof(u32), s, sub, (const u64*)e->d_mtpoly.p, 0u, S);
+        if (n_coarse > 1) {
+            hipLaunchKernelGGL(mt_seq_kernel, dim3(1), dim3(256), MT_SEQ_WORDS * sizeof(u32), s, (const u32*)sub, seq, 1u, S);
+            hipLaunchKernelGGL(mt_conv_kernel, dim3(2 * (n_coarse - 1)), dim3(512), MT_CONV_LDS_WORDS * sizeof(u32), s, sub, (const u32*)seq, (const u64*)e->d_mtpoly.p, 1u, S);
+        }
+        if (S > 1) {
+            hipLaunchKernelGGL(mt_seq_kernel, dim3(n_coarse), dim3(256), MT_SEQ_WORDS * sizeof(u32), s, (const u32*)sub, seq, MT_JUMP_R, S);
+            hipLaunchKernelGGL(mt_conv_kernel, dim3(2 * n_coarse * (MT_JUMP_R - 1)), dim3(512), MT_CONV_LDS_WORDS * sizeof(u32), s, sub, (const u32*)seq, (const u64*)e->d_mtpoly.p, 0u, S);
+        }
         hipLaunchKernelGGL(mt_fill_multi_kernel, dim3(S), dim3(256), 0, s, sub, w + at, 0ull, body, ~0ull);
         HIP_OK(hipMemcpyAsync(d_mt, sub + (size_t)(S - 1) * MT_STATE_WORDS, MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, s));
         HIP_OK(hipGetLastError());

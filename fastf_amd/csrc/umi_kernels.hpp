@@ -198,71 +198,133 @@ __global__ __launch_bounds__(256) void mt_fill_kernel(u32* __restrict__ state, u
 // ------------------------------------------------------------------------------------
 // The same stream from MANY workgroups: jump-ahead (mt_jump.c has the algebra).  The stream's state is linear over GF(2), so
 // the state J draws on is g(F) applied to the state now, with g = x^J mod the characteristic polynomial — a constant of the
-// generator, no seed in it.  Sub-stream j of a call starts J = 624 x 512 draws behind sub-stream j - 1:
-//   mt_jump_kernel        one workgroup per jump: the source array (a block boundary: all 624 words handed out) is continued
-//                         as a flat word sequence X_{t+624} = X_{t+397} ^ mix(X_t, X_{t+1}) for 19 937 words more, in LDS (83 KB;
-//                         sweeps of 227 words, a barrier each), and the array J words on is the XOR of the windows X[k .. k+623]
-//                         over the set coefficients k of g: thread i XORs X[k + i], the polynomial's bits walk in scalar registers.
-//                         Two launches seat up to R^2 = 1024 sub-streams: sub-streams R, 2R, .. straight from the stream's
+// generator, no seed in it.  Sub-stream j of a call starts J = 624 x 256 draws behind sub-stream j - 1:
+//   mt_seq_kernel         one workgroup per SOURCE: its array (a block boundary: all 624 words handed out) is continued as a flat
+//                         word sequence X_{t+624} = X_{t+397} ^ mix(X_t, X_{t+1}) for 19 976 words more, in LDS (sweeps of 227
+//                         words, a barrier each), and written out (82 KB)
+//   mt_conv_kernel        two workgroups per JUMP, half the polynomial each: the array J words on is the XOR of the windows
+//                         X[k .. k+623] over the set coefficients k of g — a lane keeps ten outputs, the polynomial's bits walk in
+//                         scalar registers, eight waves split the half's words, the halves meet in the destination by atomic XOR
+//                         Two rounds of these seat up to R^2 = 1024 sub-streams: sub-streams R, 2R, .. straight from the stream's
 //                         state (polynomials x^(i R J)), then the R - 1 behind every one of those (x^(i J)) — every workgroup
 //                         of a launch depends on the launch before only.  (Round 5 doubled: sub-streams 2^l apart from those
 //                         2^(l+1) apart, nine dependent launches of 105 us for 283 sub-streams, 0.94 of the 1.37 ms a job's draws cost.)
 //   mt_fill_multi_kernel  workgroup j continues sub-stream j by its share of the call's draws (mt_fill_body above).
-// 90 M draws (one configs[2] job): 283 sub-streams, two jump launches (8 and 274 workgroups), one fill launch.
+// 90 M draws (one configs[2] job): 566 sub-streams; sequences: 1 + 18 workgroups, convolutions: 34 + 1 096 half-jumps; one fill launch.
 // ------------------------------------------------------------------------------------
-constexpr u32 MT_SUB_DRAWS = 624u * 512u, MT_POLY_WORDS = 312, MT_DEG = 19937, MT_STATE_WORDS = MT_N + 1;
+constexpr u32 MT_SUB_DRAWS = 624u * 256u, MT_POLY_WORDS = 312, MT_DEG = 19937, MT_STATE_WORDS = MT_N + 1;
 constexpr u32 MT_JUMP_SWEEPS = 88, MT_SEQ_WORDS = MT_N + MT_JUMP_SWEEPS * (MT_N - MT_M);   // 20 600 words >= 624 + 19 936: every window of the convolution
 static_assert(MT_SEQ_WORDS >= MT_N + MT_DEG + 16, "the sequence covers the windows of every coefficient (and the sixteen outputs beyond 624 a lane reads along)");
-constexpr u32 MT_JUMP_LDS_WORDS = MT_SEQ_WORDS + 16 * 640;      // + the sixteen waves' partial arrays
-// coarse == true: workgroup b seats sub-stream (b + 1) R from sub-stream 0 (polynomial x^((b + 1) R J): the table's second half);
-// coarse == false: workgroup b = c (R - 1) + (i - 1) seats sub-stream c R + i from sub-stream c R (polynomial x^(i J))
+constexpr u32 MT_SEQ_STRIDE = 20736;                             // words between two sequences in memory (a half's bulk load reads a few words past 20 600: never used)
 constexpr u32 MT_JUMP_R = 32;
-__global__ __launch_bounds__(1024) void mt_jump_kernel(u32* __restrict__ states, const u64* __restrict__ polys, u32 coarse, u32 n_sub) {
+// Round 6, second step: the SEQUENCE of a source is computed once (mt_seq_kernel: one workgroup per source, 88 barrier sweeps in
+// LDS, then out to memory — 82 KB) instead of by every jump that starts there (31 of them per source), and a jump's CONVOLUTION is
+// split in two halves of the polynomial (mt_conv_kernel): a half needs 10 624 words of the sequence, 63 KB of LDS with its eight
+// waves' partial arrays — two workgroups per CU where the whole jump (123 KB) allowed one — and XORs its 624 words into the
+// zeroed destination with atomics.  274 jumps = 548 halves over 512 places instead of 274 workgroups over 256.
+constexpr u32 MT_HALF_PW = MT_POLY_WORDS / 2, MT_HALF_X = MT_HALF_PW * 64u + 640u, MT_CONV_WAVES = 8;    // 156 polynomial words, 10 624 sequence words per half
+constexpr u32 MT_CONV_LDS_WORDS = MT_HALF_X + 16u + MT_CONV_WAVES * 640u;
+static_assert(MT_POLY_WORDS % 2 == 0 && MT_HALF_PW * 64u + MT_HALF_X <= MT_SEQ_STRIDE, "a half's bulk load stays inside its sequence's stride");
+// workgroup b: the sequence of sub-stream b * src_stride (a block boundary: all 624 words handed out) continued as a flat word
+// sequence X_{t+624} = X_{t+397} ^ mix(X_t, X_{t+1}) for 19 976 words more, to seq + b * MT_SEQ_STRIDE
+__global__ __launch_bounds__(256) void mt_seq_kernel(const u32* __restrict__ states, u32* __restrict__ seq, u32 src_stride, u32 n_sub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mtj_smem[];
     u32* const X = reinterpret_cast<u32*>(mtj_smem);
-    const u32 c = coarse ? 0u : blockIdx.x / (MT_JUMP_R - 1u), i = coarse ? blockIdx.x + 1u : blockIdx.x % (MT_JUMP_R - 1u) + 1u;
-    const u32 src = c * MT_JUMP_R, dst = coarse ? i * MT_JUMP_R : src + i;
-    if (dst >= n_sub) return;                                  // (block-uniform)
-    const u64* const poly = polys + (u64)((coarse ? MT_JUMP_R - 1u : 0u) + i - 1u) * MT_POLY_WORDS;
+    const u32 src = blockIdx.x * src_stride;
+    if (src >= n_sub) return;                                  // (block-uniform)
     const u32 tid = threadIdx.x;
     const u32* const a = states + (u64)src * MT_STATE_WORDS;
-    for (u32 i = tid; i < MT_N; i += 1024) X[i] = a[i];
+    for (u32 i = tid; i < MT_N; i += 256) X[i] = a[i];
     __syncthreads();
-    // the sequence: words t + 624 for t in [base, base + 227) need nothing beyond X[base + 623]
+    // words t + 624 for t in [base, base + 227) need nothing beyond X[base + 623]
     for (u32 sw = 0; sw < MT_JUMP_SWEEPS; ++sw) {
         if (tid < MT_N - MT_M) { const u32 t = sw * (MT_N - MT_M) + tid; X[t + MT_N] = X[t + MT_M] ^ mt_mix(X[t], X[t + 1]); }
         __syncthreads();
     }
-    // W_J[i] = XOR over the set coefficients k of X[k + i].  All sixteen waves work: wave w takes the polynomial's words w, w + 16,
-    // ... (a sixteenth of the coefficients), every lane ten of the 624 outputs (i = lane + 64 q), and the sixteen partial arrays
-    // meet in LDS.  (One output per thread — 624 threads, each walking all 10 000 coefficients — took 0.53 ms a jump: ten waves
-    // waiting on one LDS read stream each; profiles/r5_notes/mt_jump.txt.)
-    u32* const part = X + MT_SEQ_WORDS;                            // [16][640]
-    {
-        const u32 lane = tid & 63u, w = tid >> 6;
-        u32 acc[10];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) acc[q] = 0;
-        for (u32 pw = w; pw < MT_POLY_WORDS; pw += 16) {
-            u64 bits = uniform64(poly[pw]);
-            const u32* const xw = X + (pw << 6) + lane;
-            while (bits) {                                         // (uniform inside the wave)
-                const u32 k = (u32)__builtin_ctzll(bits); bits &= bits - 1;
-#pragma unroll
-                for (int q = 0; q < 10; ++q) acc[q] ^= xw[k + 64 * q];     // (outputs 624..639 read on into the sequence: never stored)
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 10; ++q) part[w * 640u + lane + 64u * q] = acc[q];
+    u32* const out = seq + (u64)blockIdx.x * MT_SEQ_STRIDE;
+    for (u32 i = tid; i < MT_SEQ_WORDS; i += 256) out[i] = X[i];
+}
+// One HALF of a jump.  coarse: job g seats sub-stream (g + 1) R from sub-stream 0 (sequence 0, polynomial x^((g + 1) R J): the
+// table's second half); else job g = c (R - 1) + (i - 1) seats sub-stream c R + i from sub-stream c R (sequence c, polynomial x^(i J)).
+// W_J[i] = XOR over the set coefficients k of X[k + i]: wave w takes the half's polynomial words w, w + 8, .., every lane ten of the 624
+// outputs (i = lane + 64 q), the eight partial arrays meet in LDS, and the half's 624 words go into the destination by atomic XOR
+// (the destinations were zeroed; the other half adds its own).
+__global__ __launch_bounds__(512, 2) void mt_conv_kernel(u32* __restrict__ states, const u32* __restrict__ seq, const u64* __restrict__ polys, u32 coarse, u32 n_sub) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mtj_smem[];
+    u32* const X = reinterpret_cast<u32*>(mtj_smem);
+    const u32 job = blockIdx.x >> 1, half = blockIdx.x & 1u;
+    const u32 c = coarse ? 0u : job / (MT_JUMP_R - 1u), i = coarse ? job + 1u : job % (MT_JUMP_R - 1u) + 1u;
+    const u32 dst = coarse ? i * MT_JUMP_R : c * MT_JUMP_R + i;
+    if (dst >= n_sub) return;                                  // (block-uniform)
+    const u64* const poly = polys + (u64)((coarse ? MT_JUMP_R - 1u : 0u) + i - 1u) * MT_POLY_WORDS + (u64)half * MT_HALF_PW;
+    const u32 tid = threadIdx.x;
+    {   // this half's stretch of the sequence: 16-byte loads (the stride and the half's offset are multiples of four words)
+        const uint4* const g = reinterpret_cast<const uint4*>(seq + (u64)c * MT_SEQ_STRIDE + (u64)half * MT_HALF_PW * 64u);
+        uint4* const l = reinterpret_cast<uint4*>(X);
+        for (u32 q = tid; q < MT_HALF_X / 4u; q += 512) l[q] = g[q];
     }
     __syncthreads();
-    if (tid < MT_N) {
+    u32* const part = X + MT_HALF_X + 16u;                        // [8][640]
+    {
+        // A lane keeps five PAIRS of outputs and reads them with ds_read_b64 — 256 bytes a clock from the LDS where ds_read_b32
+        // moves 128 (MI355X_MICROARCH.md, LDS) — which wants 8-byte aligned addresses: for an even coefficient k the pairs are the
+        // outputs (2m, 2m + 1), for an odd one (2m - 1, 2m), so that the first word read, X[k + i], always has an even index
+        // (X[k - 1 + 2m] for odd k: pair 0's first word belongs to no output).  Two sets of accumulators; the odd set is moved
+        // down by one output when the wave is done (a DPP shift and four readlanes).
+        const u32 lane = tid & 63u, w = tid >> 6;
+        u64 ae[5], ao[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { ae[q] = 0; ao[q] = 0; }
+        const u64* const X64 = reinterpret_cast<const u64*>(X);
+        // the even coefficients of a polynomial word, then the odd ones, two coefficients a turn: ten 8-byte reads in flight per lane
+        auto walk = [&](u64 bits, const u64* const base, u64 (&acc)[5]) {
+            while (bits) {                                         // (uniform inside the wave)
+                const u32 k0 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+                const u64* const x0 = base + (k0 >> 1);
+                if (bits) {
+                    const u32 k1 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+                    const u64* const x1 = base + (k1 >> 1);
+                    u64 t0[5], t1[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { t0[q] = x0[64 * q]; t1[q] = x1[64 * q]; }
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {                  // a ^ b ^ c in one instruction per 32 bits (v_bitop3, truth table 0x96): the kernel is bound by its XORs
+                        const u32 lo = __builtin_amdgcn_bitop3_b32((u32)acc[q], (u32)t0[q], (u32)t1[q], 0x96);
+                        const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(acc[q] >> 32), (u32)(t0[q] >> 32), (u32)(t1[q] >> 32), 0x96);
+                        acc[q] = (u64)lo | ((u64)hi << 32);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) acc[q] ^= x0[64 * q];
+                }
+            }
+        };
+        for (u32 pw = w; pw < MT_HALF_PW; pw += MT_CONV_WAVES) {
+            const u64 bits = uniform64(poly[pw]);
+            const u64* const base = X64 + (pw << 5) + lane;          // X[64 pw + 2m ..]: even k reads X[k + 2m ..], odd k X[k - 1 + 2m ..]
+            walk(bits & 0x5555555555555555ull, base, ae);
+            walk(bits & 0xAAAAAAAAAAAAAAAAull, base, ao);
+        }
+        // output 2m = ae[m].lo ^ ao[m].hi, output 2m + 1 = ae[m].hi ^ ao[m + 1].lo  (pair m = lane + 64 q; beyond pair 319: 0)
+        u32 carry = 0;
+#pragma unroll
+        for (int q = 4; q >= 0; --q) {
+            const u32 o_lo = (u32)ao[q];
+            // lane l: ao.lo of pair m + 1 (lane 63: pair 0 of the turn above) — DPP wave_shl:1
+            const u32 from_above = (u32)__builtin_amdgcn_update_dpp((int)carry, (int)o_lo, 0x130, 0xF, 0xF, false);
+            carry = (u32)__builtin_amdgcn_readlane((int)o_lo, 0);
+            const u32 v_lo = (u32)ae[q] ^ (u32)(ao[q] >> 32), v_hi = (u32)(ae[q] >> 32) ^ from_above;
+            *reinterpret_cast<u64*>(part + w * 640u + 2u * (lane + 64u * q)) = (u64)v_lo | ((u64)v_hi << 32);
+        }
+    }
+    __syncthreads();
+    for (u32 t = tid; t < MT_N; t += 512) {
         u32 v = 0;
 #pragma unroll
-        for (u32 w = 0; w < 16; ++w) v ^= part[w * 640u + tid];
-        states[(u64)dst * MT_STATE_WORDS + tid] = v;
+        for (u32 w = 0; w < MT_CONV_WAVES; ++w) v ^= part[w * 640u + t];
+        if (v) atomicXor(&states[(u64)dst * MT_STATE_WORDS + t], v);
     }
-    if (tid == 0) states[(u64)dst * MT_STATE_WORDS + MT_N] = MT_N;   // a block boundary: the next draw regenerates
+    if (tid == 0 && half == 0) states[(u64)dst * MT_STATE_WORDS + MT_N] = MT_N;   // a block boundary: the next draw regenerates
 }
 // sub-stream j: draws [j * MT_SUB_DRAWS, ...) of the call's `count`, to out[(first + that) & mask]
 __global__ __launch_bounds__(256) void mt_fill_multi_kernel(u32* __restrict__ states, u32* __restrict__ out, u64 first, u64 count, u64 mask) {

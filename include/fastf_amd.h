@@ -333,7 +333,7 @@ int fastf_dev_count_hits_blocked(fastf_engine_t *e, const uint64_t *d_cb_key, ui
 int fastf_dev_draw_bits(fastf_engine_t *e, const uint32_t *d_draws, uint64_t n_draws, uint32_t *d_bits_out, void *stream);
 /* The decision stream from the DEVICE's generator: bit i of d_bits_out = draw i of init_genrand(seed) advanced by `skip` draws is
  * below the engine's threshold (mt19937ar.c:105-140 + bam2db_ds.c:385-390) — same layout and size rule as fastf_dev_draw_bits.
- * Large counts run on many workgroups at once: the stream's state is linear, sub-streams 624 x 512 draws apart are seated by
+ * Large counts run on many workgroups at once: the stream's state is linear, sub-streams 624 x 256 draws apart are seated by
  * jump-ahead (mt_jump.c) and generated side by side.  Synchronises the stream. */
 int fastf_dev_mt_decisions(fastf_engine_t *e, uint32_t seed, uint64_t skip, uint64_t n_draws, uint32_t *d_bits_out, void *stream);
 

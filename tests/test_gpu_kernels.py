@@ -331,7 +331,7 @@ def test_device_decision_stream(env, seed, skip, first, counts, rate, ring_bits)
         assert got[beyond.astype(np.int64)].all()                                    # the word after it: untouched
 
 
-J_SUB = 624 * 512                                      # draws per sub-stream of the parallel generator (mt_jump.h)
+J_SUB = 624 * 256                                      # draws per sub-stream of the parallel generator (mt_jump.h)
 
 
 @pytest.mark.parametrize("seed,skip,n,rate", [
@@ -344,7 +344,7 @@ J_SUB = 624 * 512                                      # draws per sub-stream of
     (3, 0, 1027 * J_SUB + 77, 0.25),                   # more than R^2 = 1024 sub-streams: a second round continues the first's last sub-stream
 ])
 def test_parallel_mt_decisions_are_the_reference_stream(env, seed, skip, n, rate):
-    """fastf_dev_mt_decisions: the MT19937 stream (mt19937ar.c:105-140) from many workgroups at once — sub-streams 624 x 512 draws
+    """fastf_dev_mt_decisions: the MT19937 stream (mt19937ar.c:105-140) from many workgroups at once — sub-streams 624 x 256 draws
     apart, seated by jump-ahead in two launches (mt_jump_kernel: the state J draws on is g(F) applied to the state now, g = x^J mod
     the characteristic polynomial; sub-streams 32, 64, .. from the stream's state, then the 31 behind each) and generated side by
     side — must be the stream the ORACLE's one generator produces, decision for decision"""

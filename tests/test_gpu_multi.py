@@ -91,7 +91,7 @@ def test_multi_device_wide_keys_match_oracle(name, G):
 
 
 def test_multi_device_chunks_with_millions_of_hits_use_the_parallel_generator():
-    """a chunk with more than 4 x 624 x 512 CB hits: every device continues the one MT19937 stream by jump-ahead on many
+    """a chunk with more than 4 x 624 x 256 CB hits: every device continues the one MT19937 stream by jump-ahead on many
     workgroups (launch_mt_decisions_par) — the decisions must still be the serial stream's, draw for draw (bam2db_ds.c:385)"""
     case = Case(n=3_300_000, n_bar=500, n_gene=200, rate_cell=1.0, rate_depth=0.5, umi_pool=4096, p_bad_xf=0.05)
     ora = case.oracle()

@@ -211,12 +211,12 @@ def test_pack_umi_long_matches_the_codec_up_to_32_bases():
 def test_mt_jump_polynomials_are_the_generator_advanced():
     """mt_jump.c: x^J mod the characteristic polynomial of MT19937 (Berlekamp-Massey on its own output, squarings, products mod
     phi), applied to a block-boundary array as a convolution with the generated sequence, must give the array the generator reaches
-    by generating J draws — for the table the library carries (the two-level seating: x^(i J) and x^(i R J), J = 624 x 512 draws,
+    by generating J draws — for the table the library carries (the two-level seating: x^(i J) and x^(i R J), J = 624 x 256 draws,
     R = 32) and for polynomials computed here.  The reference is the ORACLE's generator (oracle.mt_stream: mt19937ar.c restated),
     continued draw by draw."""
     import ctypes as C
     L = _lib.lib()
-    NW, J, R = 312, 624 * 512, 32
+    NW, J, R = 312, 624 * 256, 32
     L.fastf_mt_jump_table.restype = C.POINTER(C.c_uint64)
     L.fastf_mt_jump_polys.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
     L.fastf_mt_jump_table_compute.argtypes = [C.c_uint64, C.c_void_p]
