@@ -153,3 +153,20 @@ def test_no_result_changing_build_knob_in_the_product():
                 assert "FASTF_EXPERIMENT" in line, "%s:%d: FASTF_X_ knob outside FASTF_EXPERIMENT" % (fn, i)
             # the names round 3's verdict listed must not come back under another guard
             assert not re.search(r"FASTF_K3_(NOHASH|HASH_NOFLAG|DEBUG)\b", line) or line.lstrip().startswith("//"), "%s:%d" % (fn, i)
+
+
+def test_no_pageable_transfers_in_the_python_layer():
+    """DESIGN section 14, rule 1: no code of the repo hands pageable host memory to the HIP runtime — torch's `.cpu()` and
+    `torch.from_numpy(x).to(device)` / `.cuda()` of arrays are spelled fastf_amd.hostmem.to_host / to_device (pinned staging)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py"), os.path.join(root, "tools", "config5_whole.py")]
+    for d in ("fastf_amd", "tests"):
+        files += [os.path.join(root, d, f) for f in os.listdir(os.path.join(root, d)) if f.endswith(".py")]
+    bad = []
+    for f in files:
+        if f.endswith(os.path.join("fastf_amd", "hostmem.py")) or f.endswith("test_abi.py"):
+            continue
+        for i, ln in enumerate(open(f), 1):
+            if re.search(r"\.cpu\(\)|from_numpy\([^)]*\)\s*\.(to|cuda)\(", ln):
+                bad.append("%s:%d: %s" % (os.path.relpath(f, root), i, ln.strip()))
+    assert not bad, "\n".join(bad)
