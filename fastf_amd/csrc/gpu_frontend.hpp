@@ -360,6 +360,10 @@ static int gpuinf_submit_impl(fastf_gpuinf_t* g, const unsigned char* comp, cons
     if (n == 0) return 0;
     HIP_OK(hipSetDevice(g->device));
     const bool keep = keep_parity >= 0;
+    // FASTF_DEBUG_PINS: the compressed bytes go to the device straight from `comp`, the inflated ones come back straight into
+    // `out` (copy-back mode): both must be memory the runtime has been told about (the reader's pinned staging / pinned window front)
+    if (debug_known_memory(comp + blk[0].coff, blk[0].clen, "fastf_gpuinf_submit comp") ||
+        (!keep && out && debug_known_memory(out + blk[0].uoff, blk[0].isize ? blk[0].isize : 1, "fastf_gpuinf_submit out"))) return 1;
     if (keep) {
         u64 wend = 0;
         for (size_t i = 0; i < n; ++i) wend = std::max<u64>(wend, blk[i].uoff + blk[i].isize);

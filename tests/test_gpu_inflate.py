@@ -58,6 +58,16 @@ def test_device_inflate_matches_zlib(kernel, monkeypatch):
             for c, d in blocks:
                 assert out[o:o + len(d)] == d
                 o += len(d)
+        # ordinary (heap) memory on both sides: fastf_gpuinf_run registers the ranges for the call — the compressed bytes with the
+        # 64 bytes of slack the submit copies along — and unregisters them; nothing stays in the ledger
+        L.fastf_debug_live_registrations.restype = int
+        live0 = L.fastf_debug_live_registrations()
+        h_comp = np.frombuffer(bytes(comp_all), dtype=np.uint8).copy()
+        h_out = np.zeros(max(uoff, 1), dtype=np.uint8)
+        st2 = (C.c_uint8 * len(blocks))()
+        assert L.fastf_gpuinf_run(g, h_comp.ctypes.data, desc, len(blocks), h_out.ctypes.data, st2) == 0, L.fastf_last_error()
+        assert bytes(st2) == bytes(len(blocks)) and h_out.tobytes() == b"".join(d for _, d in blocks)
+        assert L.fastf_debug_live_registrations() == live0
         # a corrupted block is declined (or its CRC will differ), the others are untouched
         bad = bytearray(comp_all); bad[desc[5].coff + 3] ^= 0x5A
         C.memmove(cbuf, bytes(bad), len(bad))
