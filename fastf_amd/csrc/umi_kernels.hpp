@@ -244,6 +244,13 @@ __global__ __launch_bounds__(256) void mt_seq_kernel(const u32* __restrict__ sta
     u32* const out = seq + (u64)blockIdx.x * MT_SEQ_STRIDE;
     for (u32 i = tid; i < MT_SEQ_WORDS; i += 256) out[i] = X[i];
 }
+// one 8-byte LDS read that the compiler cannot pair with a neighbour (its 32-bit LDS address passes through an empty asm)
+__device__ __forceinline__ u64 lds_read_u64_alone(const u64* p) {
+    typedef __attribute__((address_space(3))) const u64 lds_u64;
+    u32 a = (u32)(uintptr_t)(lds_u64*)p;
+    asm volatile("" : "+v"(a));
+    return *(lds_u64*)(uintptr_t)a;
+}
 // One HALF of a jump.  coarse: job g seats sub-stream (g + 1) R from sub-stream 0 (sequence 0, polynomial x^((g + 1) R J): the
 // table's second half); else job g = c (R - 1) + (i - 1) seats sub-stream c R + i from sub-stream c R (sequence c, polynomial x^(i J)).
 // W_J[i] = XOR over the set coefficients k of X[k + i]: wave w takes the half's polynomial words w, w + 8, .., every lane ten of the 624
@@ -276,24 +283,35 @@ __global__ __launch_bounds__(512, 2) void mt_conv_kernel(u32* __restrict__ state
 #pragma unroll
         for (int q = 0; q < 5; ++q) { ae[q] = 0; ao[q] = 0; }
         const u64* const X64 = reinterpret_cast<const u64*>(X);
-        // the even coefficients of a polynomial word, then the odd ones, two coefficients a turn: ten 8-byte reads in flight per lane
+        // the even coefficients of a polynomial word, then the odd ones, FOUR coefficients a turn: twenty 8-byte reads in flight per
+        // lane (a lone half-jump took 56 us at two a turn — 215 cycles per coefficient and wave: the wave waited for each turn's reads)
+        auto xor3 = [](u64 a, u64 b, u64 c) -> u64 {              // a ^ b ^ c in one instruction per 32 bits (v_bitop3, truth table 0x96)
+            const u32 lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, 0x96);
+            const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), 0x96);
+            return (u64)lo | ((u64)hi << 32);
+        };
         auto walk = [&](u64 bits, const u64* const base, u64 (&acc)[5]) {
             while (bits) {                                         // (uniform inside the wave)
-                const u32 k0 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
-                const u64* const x0 = base + (k0 >> 1);
-                if (bits) {
+                const u32 n = (u32)__builtin_popcountll(bits);
+                if (n >= 4) {
+                    const u32 k0 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
                     const u32 k1 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
-                    const u64* const x1 = base + (k1 >> 1);
-                    u64 t0[5], t1[5];
+                    const u32 k2 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+                    const u32 k3 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+                    const u64 *x0 = base + (k0 >> 1), *x1 = base + (k1 >> 1), *x2 = base + (k2 >> 1), *x3 = base + (k3 >> 1);
+                    u64 t0[5], t1[5], t2[5], t3[5];
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) { t0[q] = x0[64 * q]; t1[q] = x1[64 * q]; }
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {                  // a ^ b ^ c in one instruction per 32 bits (v_bitop3, truth table 0x96): the kernel is bound by its XORs
-                        const u32 lo = __builtin_amdgcn_bitop3_b32((u32)acc[q], (u32)t0[q], (u32)t1[q], 0x96);
-                        const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(acc[q] >> 32), (u32)(t0[q] >> 32), (u32)(t1[q] >> 32), 0x96);
-                        acc[q] = (u64)lo | ((u64)hi << 32);
+                    // (every address made opaque: separate ds_read_b64 — 256 bytes a clock — instead of the ds_read2st64_b64
+                    //  pairs the compiler merges neighbours into, which the LDS serves at 128)
+                    for (int q = 0; q < 5; ++q) {
+                        t0[q] = lds_read_u64_alone(x0 + 64 * q); t1[q] = lds_read_u64_alone(x1 + 64 * q);
+                        t2[q] = lds_read_u64_alone(x2 + 64 * q); t3[q] = lds_read_u64_alone(x3 + 64 * q);
                     }
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) acc[q] = xor3(xor3(acc[q], t0[q], t1[q]), t2[q], t3[q]);
                 } else {
+                    const u32 k0 = (u32)__builtin_ctzll(bits); bits &= bits - 1;
+                    const u64* const x0 = base + (k0 >> 1);
 #pragma unroll
                     for (int q = 0; q < 5; ++q) acc[q] ^= x0[64 * q];
                 }
