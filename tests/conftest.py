@@ -4,7 +4,7 @@ GPU tests run in CHILD processes, one per test file (and one per test for the te
 200 M / 1 B-record jobs): `pytest -m gpu` in the parent collects, orders and reports as usual, but the parent never touches
 the GPU — each unit's tests run in a fresh `python -m pytest <node ids>` child that the parent starts (an ordinary child
 process, never an exec of a process that has initialised the GPU) and whose per-test reports it replays.  A GPU fault, a
-hang or a leaked pin in one unit ends that unit's child; the other files' results are still there (rounds 5's single
+hang or a leaked pin in one unit ends that unit's child; the other files' results are still there (round 5's single
 process lost 69 tests behind one fault).  The files run in the order of SURVEY section 8: the 8a parity tests first.
 
 FASTF_TEST_INPROCESS=1: everything in this process, as before (debugging one test under a tool).
